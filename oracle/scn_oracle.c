@@ -1,0 +1,533 @@
+/*
+ * scn_oracle.c -- CPU restatement of the reference's sparse-3D hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path
+ * (automatic-as-built-reconstruction_amd/, include/) may link, import or call this file.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
+ * there only as the checker / the timed CPU comparator.
+ *
+ * Each function cites the reference file:line (under /root/reference) whose
+ * algorithm it restates.  Nothing here is copied from the reference: data
+ * structures are flat C arrays (the reference uses google::dense_hash_map +
+ * std::vector<std::vector<int>> + at::Tensor).
+ *
+ * PARITY PINNING STATUS (see DESIGN.md "Oracle"):
+ *   - Region geometry (offset enumeration, input/output region arithmetic) is
+ *     pinned against the reference's own RectangularRegions.h compiled from
+ *     /root/reference into oracle/_ref/ (tests/test_oracle_ref_regions.py).
+ *   - Voxel/rule counts are pinned against the reference-run statistics the
+ *     survey recorded in BASELINE.md (V0=66,094 / R3=243,374 for S80k seed 0).
+ *   - The SparseConvNet C++ compute path itself is UNBUILDABLE here (needs
+ *     google sparsehash, absent, and no stand-in headers are allowed), and the
+ *     reference holds no golden vectors for it: the numerical half of this
+ *     oracle is "parity unpinned" against reference outputs; it is cross-checked
+ *     against independent dense torch conv3d / closed-form BN in tests.
+ *
+ * Site-order convention: the reference numbers input-layer sites in first-seen
+ * order of the point list (IOLayersRules.h:86-91) -- reproduced exactly.
+ * Strided-convolution output sites are numbered by the reference in
+ * dense_hash_map iteration order (ConvolutionRules.h:18-30), which is an
+ * artefact of the hash implementation; this restatement uses insertion order
+ * (input rows ascending, then region order), i.e. what the reference does with
+ * an insertion-ordered map.  Parity on those is modulo per-sample permutation.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef int32_t Int; /* 32bits.h:11 */
+
+/* ------------------------------------------------------------------------- */
+/* A minimal insertion-ordered open-addressing map (b,x,y,z) -> Int.          */
+/* Plays the role of SparseGrid::mp (Metadata.h:24-33), one map for the batch */
+/* with the batch index folded into the key (the reference keeps one map per  */
+/* sample; keys of different samples never collide either way).               */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int64_t *keys; /* packed key, -1 = empty */
+  Int *vals;
+  uint64_t mask;
+} omap;
+
+static inline int64_t pack_key(int64_t b, int64_t x, int64_t y, int64_t z) {
+  /* 16 bits each; coordinates are biased by 1 so that -1 (a neighbour probe just
+   * outside the grid) still packs to a valid non-colliding key */
+  return ((b & 0xffff) << 48) | (((x + 1) & 0xffff) << 32) |
+         (((y + 1) & 0xffff) << 16) | ((z + 1) & 0xffff);
+}
+static inline int coord_ok(int64_t v) { return v >= -1 && v < 65534; }
+
+static inline uint64_t mix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k;
+}
+static int omap_init(omap *m, int64_t n) {
+  uint64_t cap = 16;
+  while (cap < (uint64_t)(2 * n + 2)) cap <<= 1;
+  m->keys = (int64_t *)malloc(cap * sizeof(int64_t));
+  m->vals = (Int *)malloc(cap * sizeof(Int));
+  if (!m->keys || !m->vals) return -1;
+  memset(m->keys, 0xff, cap * sizeof(int64_t));
+  m->mask = cap - 1;
+  return 0;
+}
+static void omap_free(omap *m) { free(m->keys); free(m->vals); }
+static inline Int omap_find(const omap *m, int64_t key) {
+  uint64_t h = mix64((uint64_t)key) & m->mask;
+  while (m->keys[h] != -1) {
+    if (m->keys[h] == key) return m->vals[h];
+    h = (h + 1) & m->mask;
+  }
+  return -1;
+}
+/* insert if absent; returns existing or new value */
+static inline Int omap_insert(omap *m, int64_t key, Int val) {
+  uint64_t h = mix64((uint64_t)key) & m->mask;
+  while (m->keys[h] != -1) {
+    if (m->keys[h] == key) return m->vals[h];
+    h = (h + 1) & m->mask;
+  }
+  m->keys[h] = key; m->vals[h] = val;
+  return val;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A2: inputLayerRules (IOLayersRules.h:18-125), modes 1..4.                  */
+/* coords: int64 [n, ncols] (ncols = 3 or 4; last column = batch index).      */
+/* Outputs: point_voxel[n] (output row of every input row), out_coords[V,4]    */
+/* int64 (x,y,z,b) in first-seen order, counts[V].  Returns V; *max_active.    */
+/* ------------------------------------------------------------------------- */
+int64_t oracle_input_layer_sites(const int64_t *coords, int64_t n, int ncols,
+                                 Int *point_voxel, int64_t *out_coords,
+                                 Int *counts, Int *max_active) {
+  omap m;
+  if (omap_init(&m, n)) return -1;
+  Int nActive = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t *c = coords + i * ncols;
+    int64_t b = (ncols == 4) ? c[3] : 0;
+    if (!coord_ok(c[0]) || !coord_ok(c[1]) || !coord_ok(c[2]) || c[0] < 0 ||
+        c[1] < 0 || c[2] < 0 || b < 0 || b > 65534) {
+      omap_free(&m);
+      return -2;
+    }
+    int64_t key = pack_key(b, c[0], c[1], c[2]);
+    Int v = omap_find(&m, key);
+    if (v < 0) { /* IOLayersRules.h:86-91: sg.mp[p] = nActive++ */
+      v = nActive++;
+      omap_insert(&m, key, v);
+      out_coords[4 * v + 0] = c[0]; out_coords[4 * v + 1] = c[1];
+      out_coords[4 * v + 2] = c[2]; out_coords[4 * v + 3] = b;
+      counts[v] = 0;
+    }
+    point_voxel[i] = v;
+    counts[v]++;
+  }
+  Int ma = 0;
+  for (Int v = 0; v < nActive; ++v) if (counts[v] > ma) ma = counts[v];
+  *max_active = ma;
+  omap_free(&m);
+  return nActive;
+}
+
+/* The reference's padded rule table rules[1]: V x (1+maxActive) rows of
+ * (count, idx...) (IOLayersRules.h:112-124 for modes 3/4; :100-111 for 1/2,
+ * where maxActive is 1 and the kept point is front()/back()).
+ * mode 1 keeps outputRows.front() ("mode==1" branch :100-104) and mode 2
+ * keeps .back() (:106-110) exactly as written in the reference. */
+void oracle_input_layer_rules(const Int *point_voxel, int64_t n, int64_t V,
+                              Int mode, Int max_active, Int *rules) {
+  Int w = ((mode == 3 || mode == 4) ? max_active : 1) + 1;
+  memset(rules, 0, (size_t)V * w * sizeof(Int));
+  for (int64_t i = 0; i < n; ++i) {
+    Int *r = rules + (int64_t)point_voxel[i] * w;
+    if (mode == 3 || mode == 4) {
+      r[0]++; r[r[0]] = (Int)i;
+    } else if (mode == 1) { /* front() */
+      if (r[0] == 0) { r[0] = 1; r[1] = (Int)i; }
+    } else { /* mode 2: back() */
+      r[0] = 1; r[1] = (Int)i;
+    }
+  }
+}
+
+/* CPU/IOLayers.cpp:11-29 InputLayer_ForwardPass (output pre-zeroed here). */
+void oracle_input_layer_fwd(const float *in, float *out, int64_t nRows,
+                            Int maxActive, Int nPlanes, const Int *rules,
+                            int average) {
+  memset(out, 0, (size_t)nRows * nPlanes * sizeof(float));
+#pragma omp parallel for
+  for (int64_t row = 0; row < nRows; ++row) {
+    const Int *r = rules + row * (1 + maxActive);
+    Int nA = r[0];
+    float mult = (average && nA > 0) ? (float)1 / nA : (float)1;
+    float *o = out + row * nPlanes;
+    for (Int i = 1; i <= nA; ++i) {
+      const float *f = in + (int64_t)r[i] * nPlanes;
+      for (Int p = 0; p < nPlanes; ++p) {
+        volatile float prod = mult * f[p]; /* no FMA contraction */
+        o[p] = o[p] + prod;
+      }
+    }
+  }
+}
+/* CPU/IOLayers.cpp:30-47 InputLayer_BackwardPass (d_in pre-zeroed here). */
+void oracle_input_layer_bwd(float *d_in, const float *d_out, int64_t nInRows,
+                            int64_t nRows, Int maxActive, Int nPlanes,
+                            const Int *rules, int average) {
+  memset(d_in, 0, (size_t)nInRows * nPlanes * sizeof(float));
+  for (int64_t row = 0; row < nRows; ++row) {
+    const Int *r = rules + row * (1 + maxActive);
+    Int nA = r[0];
+    float mult = (average && nA > 0) ? (float)1 / nA : (float)1;
+    const float *o = d_out + row * nPlanes;
+    for (Int i = 1; i <= nA; ++i) {
+      float *f = d_in + (int64_t)r[i] * nPlanes;
+      for (Int p = 0; p < nPlanes; ++p) {
+        volatile float prod = mult * o[p];
+        f[p] = f[p] + prod;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Geometry helpers restating RectangularRegions.h                            */
+/* ------------------------------------------------------------------------- */
+/* RectangularRegion::offset (RectangularRegions.h:30-38): last dim fastest.  */
+static inline Int region_offset(const int64_t *p, const int64_t *lb,
+                                const int64_t *ub) {
+  Int of = 0, mm = 1;
+  for (int i = 2; i >= 0; --i) {
+    of += mm * (Int)(p[i] - lb[i]);
+    mm *= (Int)(ub[i] - lb[i] + 1);
+  }
+  return of;
+}
+static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
+static inline int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
+
+/* exported for the _ref pinning test */
+void oracle_input_region(const int64_t *out_pt, const int64_t *size,
+                         const int64_t *stride, int64_t *lb, int64_t *ub) {
+  /* RectangularRegions.h:95-105 InputRegionCalculator */
+  for (int i = 0; i < 3; ++i) {
+    lb[i] = out_pt[i] * stride[i];
+    ub[i] = out_pt[i] * stride[i] + size[i] - 1;
+  }
+}
+void oracle_output_region(const int64_t *in_pt, const int64_t *size,
+                          const int64_t *stride, const int64_t *out_sz,
+                          int64_t *lb, int64_t *ub) {
+  /* RectangularRegions.h:109-119 OutputRegionCalculator (C integer division) */
+  for (int i = 0; i < 3; ++i) {
+    lb[i] = imax(0, (in_pt[i] - size[i] + stride[i]) / stride[i]);
+    ub[i] = imin(out_sz[i] - 1, in_pt[i] / stride[i]);
+  }
+}
+void oracle_submanifold_region(const int64_t *out_pt, const int64_t *size,
+                               int64_t *lb, int64_t *ub) {
+  /* SubmanifoldConvolutionRules.h:11-21 */
+  for (int i = 0; i < 3; ++i) {
+    int64_t pad = size[i] / 2;
+    lb[i] = out_pt[i] - pad;
+    ub[i] = out_pt[i] + size[i] - 1 - pad;
+  }
+}
+Int oracle_region_offset(const int64_t *p, const int64_t *lb,
+                         const int64_t *ub) {
+  return region_offset(p, lb, ub);
+}
+/* iterate a region in RectangularRegionIterator order (:56-71); writes the
+ * visited points, returns the count (0 when lb[i] > ub[i] for some i). */
+int64_t oracle_region_points(const int64_t *lb, const int64_t *ub,
+                             int64_t *pts) {
+  for (int i = 0; i < 3; ++i) if (lb[i] > ub[i]) return 0;
+  int64_t n = 0, p[3] = {lb[0], lb[1], lb[2]};
+  for (;;) {
+    pts[3 * n] = p[0]; pts[3 * n + 1] = p[1]; pts[3 * n + 2] = p[2]; ++n;
+    int i = 2;
+    for (;;) {
+      p[i]++;
+      if (p[i] <= ub[i]) break;
+      p[i] = lb[i];
+      if (--i < 0) return n;
+    }
+  }
+}
+
+/* build the coordinate map of a grid: site_coords int64 [V,4] (x,y,z,b) */
+static int build_grid_map(omap *m, const int64_t *sc, int64_t V) {
+  if (omap_init(m, V)) return -1;
+  for (int64_t v = 0; v < V; ++v)
+    omap_insert(m, pack_key(sc[4 * v + 3], sc[4 * v], sc[4 * v + 1],
+                            sc[4 * v + 2]), (Int)v);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A4: SubmanifoldConvolution_SgToRules (SubmanifoldConvolutionRules.h:26-45) */
+/* For every active site (row order) and every filter offset (region order)   */
+/* append (in_row, out_row) to rules[offset].  rules: int32 [vol][cap][2] with */
+/* cap = V (each output appears at most once per offset); counts[vol].        */
+/* Returns the total rule count (countActiveInputs).                          */
+/* ------------------------------------------------------------------------- */
+int64_t oracle_submanifold_rules(const int64_t *site_coords, int64_t V,
+                                 const int64_t *size, Int *rules,
+                                 int64_t *counts) {
+  omap m;
+  if (build_grid_map(&m, site_coords, V)) return -1;
+  int64_t vol = size[0] * size[1] * size[2], total = 0;
+  memset(counts, 0, (size_t)vol * sizeof(int64_t));
+  for (int64_t v = 0; v < V; ++v) {
+    const int64_t *o = site_coords + 4 * v;
+    int64_t lb[3], ub[3];
+    oracle_submanifold_region(o, size, lb, ub);
+    Int off = 0;
+    for (int64_t x = lb[0]; x <= ub[0]; ++x)
+      for (int64_t y = lb[1]; y <= ub[1]; ++y)
+        for (int64_t z = lb[2]; z <= ub[2]; ++z, ++off) {
+          if (!coord_ok(x) || !coord_ok(y) || !coord_ok(z)) continue;
+          Int u = omap_find(&m, pack_key(o[3], x, y, z));
+          if (u >= 0) {
+            Int *r = rules + ((int64_t)off * V + counts[off]) * 2;
+            r[0] = u; r[1] = (Int)v;
+            counts[off]++; total++;
+          }
+        }
+  }
+  omap_free(&m);
+  return total;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A5: Convolution_InputSgToRulesAndOutputSg (ConvolutionRules.h:11-34) with  */
+/* insertion-ordered output numbering.  rules: int32 [vol][cap][2], cap =     */
+/* rule_cap (>= V_in * max outputs per input); out_coords int64 [V_out,4].    */
+/* Returns V_out.                                                             */
+/* ------------------------------------------------------------------------- */
+int64_t oracle_convolution_rules(const int64_t *in_coords, int64_t V_in,
+                                 const int64_t *size, const int64_t *stride,
+                                 const int64_t *out_spatial, int64_t rule_cap,
+                                 Int *rules, int64_t *counts,
+                                 int64_t *out_coords) {
+  omap om;
+  int64_t maxout = 1;
+  for (int i = 0; i < 3; ++i) maxout *= (size[i] + stride[i] - 1) / stride[i];
+  if (omap_init(&om, V_in * maxout)) return -1;
+  int64_t vol = size[0] * size[1] * size[2];
+  memset(counts, 0, (size_t)vol * sizeof(int64_t));
+  Int nOut = 0;
+  for (int64_t u = 0; u < V_in; ++u) {
+    const int64_t *ip = in_coords + 4 * u;
+    int64_t lb[3], ub[3];
+    oracle_output_region(ip, size, stride, out_spatial, lb, ub);
+    for (int64_t x = lb[0]; x <= ub[0]; ++x)
+      for (int64_t y = lb[1]; y <= ub[1]; ++y)
+        for (int64_t z = lb[2]; z <= ub[2]; ++z) {
+          int64_t j[3] = {x, y, z}, ilb[3], iub[3];
+          oracle_input_region(j, size, stride, ilb, iub);
+          Int off = region_offset(ip, ilb, iub);
+          int64_t key = pack_key(ip[3], x, y, z);
+          Int o = omap_find(&om, key);
+          if (o < 0) {
+            o = nOut++;
+            omap_insert(&om, key, o);
+            out_coords[4 * o] = x; out_coords[4 * o + 1] = y;
+            out_coords[4 * o + 2] = z; out_coords[4 * o + 3] = ip[3];
+          }
+          if (counts[off] >= rule_cap) { omap_free(&om); return -3; }
+          Int *r = rules + ((int64_t)off * rule_cap + counts[off]) * 2;
+          r[0] = (Int)u; r[1] = o;
+          counts[off]++;
+        }
+  }
+  omap_free(&om);
+  return nOut;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A7/A8/A9: gather - matmul - scatter-add per filter offset                  */
+/* (CPU/Convolution.cpp:8-43 rule_index_select / rule_index_add_, :62-79,     */
+/*  :101-114; Deconvolution = same with the rule columns swapped,             */
+/*  CPU/Deconvolution.cpp:34-37,68-75).  groups = 1 (FPN_Net never sets it).  */
+/* rules: int32 [vol][rule_cap][2]; in_col selects which column indexes the   */
+/* input rows (0 for Convolution / Submanifold, 1 for Deconvolution).         */
+/* Returns the reference's multiply-add count.                                */
+/* ------------------------------------------------------------------------- */
+double oracle_conv_fwd(const float *in, Int nIn, float *out, Int nOut,
+                       int64_t nOutRows, const float *W, const float *bias,
+                       const Int *rules, const int64_t *counts, int64_t vol,
+                       int64_t rule_cap, int in_col) {
+  double flops = 0;
+  for (int64_t r = 0; r < nOutRows; ++r)
+    for (Int j = 0; j < nOut; ++j) out[r * nOut + j] = bias ? bias[j] : 0.f;
+  for (int64_t k = 0; k < vol; ++k) {
+    int64_t nR = counts[k];
+    if (!nR) continue;
+    flops += (double)nR * nIn * nOut;
+    const float *w = W + k * nIn * nOut;
+    const Int *rk = rules + k * rule_cap * 2;
+    float *tmp = (float *)malloc((size_t)nR * nOut * sizeof(float));
+#pragma omp parallel for
+    for (int64_t i = 0; i < nR; ++i) {
+      const float *s = in + (int64_t)rk[2 * i + in_col] * nIn;
+      float *t = tmp + i * nOut;
+      for (Int j = 0; j < nOut; ++j) {
+        double acc = 0; /* at::matmul: accumulation order unspecified */
+        for (Int c = 0; c < nIn; ++c) acc += (double)s[c] * w[c * nOut + j];
+        t[j] = (float)acc;
+      }
+    }
+    /* rule_index_add_: within one offset every output row occurs once */
+#pragma omp parallel for
+    for (int64_t i = 0; i < nR; ++i) {
+      float *t = out + (int64_t)rk[2 * i + 1 - in_col] * nOut;
+      for (Int j = 0; j < nOut; ++j) t[j] += tmp[i * nOut + j];
+    }
+    free(tmp);
+  }
+  return flops;
+}
+
+/* CPU/Convolution.cpp:81-115 / :151-185 (d_input zeroed; dW[k] overwritten
+ * per offset by matmul_out; d_bias = column sums). */
+void oracle_conv_bwd(const float *in, float *d_in, int64_t nInRows, Int nIn,
+                     const float *d_out, int64_t nOutRows, Int nOut,
+                     const float *W, float *dW, float *d_bias,
+                     const Int *rules, const int64_t *counts, int64_t vol,
+                     int64_t rule_cap, int in_col) {
+  memset(d_in, 0, (size_t)nInRows * nIn * sizeof(float));
+  if (d_bias)
+    for (Int j = 0; j < nOut; ++j) {
+      double s = 0;
+      for (int64_t r = 0; r < nOutRows; ++r) s += d_out[r * nOut + j];
+      d_bias[j] = (float)s;
+    }
+  for (int64_t k = 0; k < vol; ++k) {
+    int64_t nR = counts[k];
+    if (!nR) continue; /* reference leaves dW[k] at its pre-zeroed value */
+    const float *w = W + k * nIn * nOut;
+    float *dw = dW + k * nIn * nOut;
+    const Int *rk = rules + k * rule_cap * 2;
+#pragma omp parallel for
+    for (Int c = 0; c < nIn; ++c)
+      for (Int j = 0; j < nOut; ++j) {
+        double acc = 0;
+        for (int64_t i = 0; i < nR; ++i)
+          acc += (double)in[(int64_t)rk[2 * i + in_col] * nIn + c] *
+                 d_out[(int64_t)rk[2 * i + 1 - in_col] * nOut + j];
+        dw[c * nOut + j] = (float)acc;
+      }
+    float *tmp = (float *)malloc((size_t)nR * nIn * sizeof(float));
+#pragma omp parallel for
+    for (int64_t i = 0; i < nR; ++i) {
+      const float *g = d_out + (int64_t)rk[2 * i + 1 - in_col] * nOut;
+      for (Int c = 0; c < nIn; ++c) {
+        double acc = 0;
+        for (Int j = 0; j < nOut; ++j) acc += (double)g[j] * w[c * nOut + j];
+        tmp[i * nIn + c] = (float)acc;
+      }
+    }
+#pragma omp parallel for
+    for (int64_t i = 0; i < nR; ++i) {
+      float *t = d_in + (int64_t)rk[2 * i + in_col] * nIn;
+      for (Int c = 0; c < nIn; ++c) t[c] += tmp[i * nIn + c];
+    }
+    free(tmp);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A10: BatchNormalization_ForwardPass / _BackwardPass                        */
+/* (CPU/BatchNormalization.cpp:12-61, :63-107) -- sequential fp32, as written */
+/* ------------------------------------------------------------------------- */
+void oracle_bn_fwd(const float *in, float *out, Int nPlanes, int64_t nActive,
+                   float *saveMean, float *saveInvStd, float *runningMean,
+                   float *runningVar, const float *weight, const float *bias,
+                   float eps, float momentum, int train, float leakiness) {
+  if (train) {
+    memset(saveMean, 0, nPlanes * sizeof(float));
+    memset(saveInvStd, 0, nPlanes * sizeof(float));
+    for (int64_t row = 0; row < nActive; ++row)
+      for (Int p = 0; p < nPlanes; ++p) {
+        float v = in[row * nPlanes + p];
+        saveMean[p] += v;
+        saveInvStd[p] += v * v;
+      }
+    for (Int p = 0; p < nPlanes; ++p) {
+      saveMean[p] /= nActive;
+      runningMean[p] = momentum * runningMean[p] + (1 - momentum) * saveMean[p];
+      saveInvStd[p] -= saveMean[p] * saveMean[p] * nActive;
+      runningVar[p] = momentum * runningVar[p] +
+                      (1 - momentum) * saveInvStd[p] / (nActive - 1);
+      saveInvStd[p] = powf(saveInvStd[p] / nActive + eps, -0.5f);
+    }
+  } else {
+    for (Int p = 0; p < nPlanes; ++p) {
+      saveMean[p] = runningMean[p];
+      saveInvStd[p] = powf(runningVar[p] + eps, -0.5f);
+    }
+  }
+  float *w = (float *)malloc(nPlanes * sizeof(float));
+  float *b = (float *)malloc(nPlanes * sizeof(float));
+  for (Int p = 0; p < nPlanes; ++p) {
+    w[p] = saveInvStd[p] * (weight ? weight[p] : 1);
+    b[p] = -saveMean[p] * w[p] + (bias ? bias[p] : 0);
+  }
+#pragma omp parallel for
+  for (int64_t row = 0; row < nActive; ++row)
+    for (Int p = 0; p < nPlanes; ++p) {
+      float o = in[row * nPlanes + p] * w[p] + b[p];
+      float r = (o > 0) ? 1 : leakiness;
+      out[row * nPlanes + p] = o * r;
+    }
+  free(w); free(b);
+}
+
+void oracle_bn_bwd(const float *in, float *d_in, const float *out,
+                   float *d_out /* modified in place, :79-82 */, Int nPlanes,
+                   int64_t nActive, const float *saveMean,
+                   const float *saveInvStd, const float *weight,
+                   float *d_weight, float *d_bias, float leakiness) {
+  float *gradMean = (float *)calloc(nPlanes, sizeof(float));
+  float *dotp = (float *)calloc(nPlanes, sizeof(float));
+  float *kk = (float *)calloc(nPlanes, sizeof(float));
+  for (int64_t row = 0; row < nActive; ++row)
+    for (Int p = 0; p < nPlanes; ++p) {
+      int64_t i = row * nPlanes + p;
+      float d = d_out[i];
+      float r = (out[i] > 0) ? 1 : leakiness;
+      d *= r;
+      d_out[i] = d;
+      gradMean[p] += d;
+      dotp[p] += (in[i] - saveMean[p]) * d;
+    }
+  for (Int p = 0; p < nPlanes; ++p) {
+    if (d_bias) d_bias[p] = gradMean[p];
+    gradMean[p] /= nActive;
+    kk[p] = dotp[p] * saveInvStd[p] * saveInvStd[p] / nActive;
+  }
+#pragma omp parallel for
+  for (int64_t row = 0; row < nActive; ++row)
+    for (Int p = 0; p < nPlanes; ++p) {
+      int64_t i = row * nPlanes + p;
+      d_in[i] = (d_out[i] - gradMean[p] - (in[i] - saveMean[p]) * kk[p]) *
+                saveInvStd[p] * (weight ? weight[p] : 1);
+    }
+  if (d_weight)
+    for (Int p = 0; p < nPlanes; ++p) d_weight[p] = dotp[p] * saveInvStd[p];
+  free(gradMean); free(dotp); free(kk);
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
