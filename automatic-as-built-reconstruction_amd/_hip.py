@@ -1,0 +1,107 @@
+"""ctypes binding of lib/libaabr_hip.so (C ABI: include/aabr_hip.h).
+
+PyTorch is used only for device memory and streams; every compute call goes through this
+module.  Loading fails loudly when the library is missing -- there is no fallback path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaabr_hip.so")
+
+_lib = None
+META_WORDS = 8
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+
+_SIGS = {
+    "aabr_version": (C.c_int, []),
+    "aabr_last_error": (C.c_char_p, []),
+    "aabr_input_layer_sites": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aabr_input_layer_forward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "aabr_input_layer_backward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "aabr_input_layer_rule_table": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "aabr_submanifold_table": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32p, _vp, _vp, _vp]),
+    "aabr_convolution_sites": (C.c_int, [_vp, _i64, _i32p, _i32p, _i32p, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "aabr_convolution_tables": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32p, _i32p,
+                                          _i32p, _vp, _vp, _vp, _vp]),
+    "aabr_table_to_rulebook": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "aabr_spatial_locations": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "aabr_conv_wpack_floats": (C.c_int64, [_i32, _i32, _i32]),
+    "aabr_conv_forward": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "aabr_conv_dw_scratch_floats": (C.c_int64, [_i64, _i32, _i32, _i32]),
+    "aabr_conv_backward_weight": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "aabr_bn_scratch_floats": (C.c_int64, [_i32]),
+    "aabr_bn_forward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32,
+                                  _vp, _vp]),
+    "aabr_bn_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
+    "aabr_rotate_iou_eval": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "aabr_boxes_iou_3d": (C.c_int, [_vp, _i64, _vp, _i64, _f32p, _i32, _i32, _vp, _vp]),
+    "aabr_rotate_nms_sorted": (C.c_int, [_vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "aabr_nms_sorted": (C.c_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
+
+
+class AabrError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library (no GPU needed just to load it and resolve symbols)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AabrError(
+                "%s is missing: build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require_gpu(t=None):
+    if not torch.cuda.is_available():
+        raise AabrError("the MI355X hot path needs a GPU (torch.cuda.is_available() is False); "
+                        "there is no CPU fallback")
+    if t is not None and not t.is_cuda:
+        raise AabrError("expected a tensor in device memory, got %s" % t.device)
+
+
+def check(rc):
+    if rc != 0:
+        raise AabrError("libaabr_hip: rc=%d: %s" % (rc, load().aabr_last_error().decode()))
+
+
+def ptr(t):
+    """device pointer of a tensor, None -> NULL"""
+    if t is None or t.numel() == 0:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i32x3(v):
+    return (C.c_int32 * 3)(*[int(x) for x in v])
+
+
+def f32x4(v):
+    return (C.c_float * 4)(*[float(x) for x in v])
+
+
+def next_pow2(n):
+    c = 64
+    while c < n:
+        c <<= 1
+    return c

@@ -1,0 +1,223 @@
+// bn.hip -- BatchNormalization + leaky ReLU, forward and backward (gfx950).
+//
+// Replaces SCN/CPU/BatchNormalization.cpp:12-157 and SCN/CUDA/BatchNormalization.cu:14-238.
+// HBM-bound streaming: forward = 2 reads + 1 write of [rows, planes] fp32, backward = 5 passes
+// (x, out, d_out twice each for the statistics and the apply, 1 write).  The reference's CUDA
+// launch uses <= 16 blocks (BatchNormalization.cu:111); here the statistics pass fills the
+// chip with up to kMaxParts blocks and combines their partial sums in a fixed order, so the
+// result is bit-reproducible.  Partial sums are kept in fp64 (the reference accumulates
+// sum and sum-of-squares sequentially in fp32; fp64 partials are strictly closer to the
+// exact statistics).
+#include "common.h"
+
+namespace aabr {
+
+constexpr int kMaxParts = 256;
+
+// two-quantity column reduction: for every plane p,
+//   A[p] = sum_rows fa(row,p),  B[p] = sum_rows fb(row,p)
+// MODE 0: fa = x, fb = x*x            (forward statistics)
+// MODE 1: fa = d*r, fb = (x-mean)*d*r (backward statistics, r = out>0 ? 1 : leakiness)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bn_partials(const float *__restrict__ x, const float *__restrict__ out,
+                                                     const float *__restrict__ d_out,
+                                                     const float *__restrict__ mean, float leak, int64_t rows,
+                                                     int planes, double *__restrict__ part) {
+  __shared__ double ra[256], rb[256];
+  const int tpr = planes < 256 ? planes : 256; // threads per row
+  const int rpi = 256 / tpr;                   // rows per iteration
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
+  for (int p0 = 0; p0 < planes; p0 += tpr) {
+    const int p = p0 + tx;
+    double a = 0.0, b = 0.0;
+    if (p < planes && ty < rpi) {
+      const float mu = (MODE == 1) ? mean[p] : 0.0f;
+      for (int64_t r = (int64_t)blockIdx.x * rpi + ty; r < rows; r += (int64_t)gridDim.x * rpi) {
+        const int64_t i = r * planes + p;
+        if (MODE == 0) {
+          float v = x[i];
+          a += (double)v;
+          b += (double)v * (double)v;
+        } else {
+          float d = d_out[i];
+          d = (out[i] > 0.0f) ? d : d * leak;
+          a += (double)d;
+          b += (double)(x[i] - mu) * (double)d;
+        }
+      }
+    }
+    ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+    __syncthreads();
+    if (ty == 0 && p < planes) {
+      for (int j = 1; j < rpi; ++j) { a += ra[j * tpr + tx]; b += rb[j * tpr + tx]; }
+      part[((int64_t)blockIdx.x * 2 + 0) * planes + p] = a;
+      part[((int64_t)blockIdx.x * 2 + 1) * planes + p] = b;
+    }
+    __syncthreads();
+  }
+}
+
+// forward finalize, one thread per plane (CPU/BatchNormalization.cpp:33-48): coef[p] = {w, b}
+// with y = x*w + b.
+__global__ void k_bn_fwd_finalize(const double *__restrict__ part, int nparts, int64_t rows, int planes,
+                                  float *save_mean, float *save_invstd, float *running_mean,
+                                  float *running_var, const float *weight, const float *bias, float eps,
+                                  float momentum, int train, float *coef) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= planes) return;
+  float mean, invstd;
+  if (train) {
+    double s = 0.0, ss = 0.0;
+    for (int j = 0; j < nparts; ++j) {
+      s += part[((int64_t)j * 2 + 0) * planes + p];
+      ss += part[((int64_t)j * 2 + 1) * planes + p];
+    }
+    double m = s / (double)rows;
+    double var_n = ss - m * m * (double)rows; // == sum (x-mean)^2
+    mean = (float)m;
+    running_mean[p] = momentum * running_mean[p] + (1 - momentum) * mean;
+    running_var[p] = momentum * running_var[p] + (1 - momentum) * (float)(var_n / (double)(rows - 1));
+    invstd = powf((float)(var_n / (double)rows) + eps, -0.5f);
+  } else {
+    mean = running_mean[p];
+    invstd = powf(running_var[p] + eps, -0.5f);
+  }
+  save_mean[p] = mean;
+  save_invstd[p] = invstd;
+  float w = invstd * (weight ? weight[p] : 1.0f);
+  coef[p] = w;
+  coef[planes + p] = -mean * w + (bias ? bias[p] : 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_bn_fwd_apply(const float *__restrict__ x, float *__restrict__ y,
+                                                      int64_t total, int planes,
+                                                      const float *__restrict__ coef, float leak) {
+  // planes % 4 == 0 path: float4 per thread
+  int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = i4 * 4;
+  if (i >= total) return;
+  int p = (int)(i % planes);
+  float4 v = *reinterpret_cast<const float4 *>(x + i);
+  float4 w = *reinterpret_cast<const float4 *>(coef + p);
+  float4 b = *reinterpret_cast<const float4 *>(coef + planes + p);
+  float4 o;
+  o.x = v.x * w.x + b.x; o.y = v.y * w.y + b.y; o.z = v.z * w.z + b.z; o.w = v.w * w.w + b.w;
+  o.x = o.x > 0.0f ? o.x : o.x * leak; o.y = o.y > 0.0f ? o.y : o.y * leak;
+  o.z = o.z > 0.0f ? o.z : o.z * leak; o.w = o.w > 0.0f ? o.w : o.w * leak;
+  *reinterpret_cast<float4 *>(y + i) = o;
+}
+__global__ __launch_bounds__(256) void k_bn_fwd_apply1(const float *__restrict__ x, float *__restrict__ y,
+                                                       int64_t total, int planes,
+                                                       const float *__restrict__ coef, float leak) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int p = (int)(i % planes);
+  float o = x[i] * coef[p] + coef[planes + p];
+  y[i] = o > 0.0f ? o : o * leak;
+}
+
+// backward finalize (CPU/BatchNormalization.cpp:85-90,103-106): coef = {gradMean, k, invstd*w}
+__global__ void k_bn_bwd_finalize(const double *__restrict__ part, int nparts, int64_t rows, int planes,
+                                  const float *save_invstd, const float *weight, float *d_weight,
+                                  float *d_bias, float *coef) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= planes) return;
+  double s = 0.0, dp = 0.0;
+  for (int j = 0; j < nparts; ++j) {
+    s += part[((int64_t)j * 2 + 0) * planes + p];
+    dp += part[((int64_t)j * 2 + 1) * planes + p];
+  }
+  float is = save_invstd[p];
+  if (d_bias) d_bias[p] = (float)s;
+  if (d_weight) d_weight[p] = (float)dp * is;
+  coef[p] = (float)(s / (double)rows);
+  coef[planes + p] = (float)dp * is * is / (float)rows;
+  coef[2 * planes + p] = is * (weight ? weight[p] : 1.0f);
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, float *__restrict__ d_in,
+                                                      const float *__restrict__ out,
+                                                      const float *__restrict__ d_out, int64_t total,
+                                                      int planes, const float *__restrict__ mean,
+                                                      const float *__restrict__ coef, float leak) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int p = (int)(i % planes);
+  float d = d_out[i];
+  d = (out[i] > 0.0f) ? d : d * leak;
+  d_in[i] = (d - coef[p] - (x[i] - mean[p]) * coef[planes + p]) * coef[2 * planes + p];
+}
+
+static int bn_parts(int64_t rows, int planes) {
+  int tpr = planes < 256 ? planes : 256, rpi = 256 / tpr;
+  int64_t want = ceil_div(rows, (int64_t)rpi * 8); // >= 8 rows per thread
+  if (want < 1) want = 1;
+  if (want > kMaxParts) want = kMaxParts;
+  return (int)want;
+}
+
+} // namespace aabr
+using namespace aabr;
+
+extern "C" int64_t aabr_bn_scratch_floats(int planes) {
+  return (int64_t)kMaxParts * 2 * planes * 2 /* doubles */ + 4 * (int64_t)planes + 8;
+}
+
+extern "C" int aabr_bn_forward(const float *in, float *out, int64_t rows, int planes, float *save_mean,
+                               float *save_invstd, float *running_mean, float *running_var,
+                               const float *weight, const float *bias, float eps, float momentum, int train,
+                               float leakiness, float *scratch, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(rows >= 0 && planes > 0, "bad sizes");
+  AABR_CHECK_ARG(save_mean && save_invstd && running_mean && running_var && scratch, "null pointer");
+  AABR_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
+  if (rows == 0) return AABR_OK; // reference: nActive == 0 leaves everything untouched
+  AABR_CHECK_ARG(in && out, "null pointer");
+  double *part = reinterpret_cast<double *>(scratch);
+  float *coef = scratch + (int64_t)kMaxParts * 2 * planes * 2;
+  int nparts = 0;
+  if (train) {
+    nparts = bn_parts(rows, planes);
+    hipLaunchKernelGGL(k_bn_partials<0>, dim3(nparts), dim3(256), 0, st, in, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
+  }
+  hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((unsigned)ceil_div(planes, 256)), dim3(256), 0, st, part, nparts,
+                     rows, planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps,
+                     momentum, train, coef);
+  int64_t total = rows * planes;
+  if ((planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(k_bn_fwd_apply, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, out,
+                       total, planes, coef, leakiness);
+  else
+    hipLaunchKernelGGL(k_bn_fwd_apply1, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, out, total,
+                       planes, coef, leakiness);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, const float *d_out,
+                                int64_t rows, int planes, const float *save_mean, const float *save_invstd,
+                                const float *weight, float *d_weight, float *d_bias, float leakiness,
+                                float *scratch, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(rows >= 0 && planes > 0, "bad sizes");
+  AABR_CHECK_ARG(save_mean && save_invstd && scratch, "null pointer");
+  if (rows == 0) {
+    if (d_weight) hipMemsetAsync(d_weight, 0, planes * sizeof(float), st);
+    if (d_bias) hipMemsetAsync(d_bias, 0, planes * sizeof(float), st);
+    return AABR_OK;
+  }
+  AABR_CHECK_ARG(in && d_in && out && d_out, "null pointer");
+  double *part = reinterpret_cast<double *>(scratch);
+  float *coef = scratch + (int64_t)kMaxParts * 2 * planes * 2;
+  int nparts = bn_parts(rows, planes);
+  hipLaunchKernelGGL(k_bn_partials<1>, dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean, leakiness,
+                     rows, planes, part);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, 256)), dim3(256), 0, st, part, nparts,
+                     rows, planes, save_invstd, weight, d_weight, d_bias, coef);
+  int64_t total = rows * planes;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, d_in, out,
+                     d_out, total, planes, save_mean, coef, leakiness);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}

@@ -1,0 +1,69 @@
+// common.h -- shared host/device helpers of libaabr_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/aabr_hip.h"
+
+namespace aabr {
+
+void set_error(const char *fmt, ...);
+
+#define AABR_CHECK_ARG(cond, msg)                                   \
+  do {                                                              \
+    if (!(cond)) { aabr::set_error("%s: %s", __func__, msg); return AABR_EINVAL; } \
+  } while (0)
+
+#define AABR_CHECK_LAUNCH()                                                   \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      aabr::set_error("%s: HIP error %s", __func__, hipGetErrorString(e__));  \
+      return AABR_ELAUNCH;                                                    \
+    }                                                                         \
+  } while (0)
+
+constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kMaxCoord = 65534;
+
+// (b,x,y,z) -> 64-bit key, 16 bits each, spatial coordinates biased by +1 so a probe one
+// cell outside the grid (-1) is still a valid, never-inserted key.
+__host__ __device__ inline uint64_t pack_key(int b, int x, int y, int z) {
+  return ((uint64_t)(uint32_t)(b & 0xffff) << 48) | ((uint64_t)(uint32_t)((x + 1) & 0xffff) << 32) |
+         ((uint64_t)(uint32_t)((y + 1) & 0xffff) << 16) | (uint64_t)(uint32_t)((z + 1) & 0xffff);
+}
+__host__ __device__ inline bool coord_in_range(int v) { return v >= -1 && v <= kMaxCoord; }
+
+__host__ __device__ inline uint64_t mix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return k;
+}
+
+// read-only probe of a finished table
+__device__ inline int grid_find(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                                uint64_t mask, uint64_t key) {
+  uint64_t h = mix64(key) & mask;
+  for (;;) {
+    uint64_t k = keys[h];
+    if (k == key) return vals[h];
+    if (k == kEmptyKey) return -1;
+    h = (h + 1) & mask;
+  }
+}
+
+// insert-or-find; returns the slot
+__device__ inline uint32_t grid_insert(uint64_t *keys, uint64_t mask, uint64_t key) {
+  uint64_t h = mix64(key) & mask;
+  for (;;) {
+    unsigned long long prev = atomicCAS((unsigned long long *)&keys[h], (unsigned long long)kEmptyKey,
+                                       (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) return (uint32_t)h;
+    h = (h + 1) & mask;
+  }
+}
+
+inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+} // namespace aabr

@@ -1,0 +1,616 @@
+// geometry.hip -- on-device sparse-grid state for the SparseConvNet hot path (gfx950).
+//
+// Replaces the host-side hash grids and rule-book builders of the reference
+// (SparseConvNet/sparseconvnet/SCN/Metadata/{Metadata.cpp,IOLayersRules.h,
+//  SubmanifoldConvolutionRules.h,ConvolutionRules.h,RectangularRegions.h}) with device
+// kernels: the hash grid, the site numbering and every rule table live in HBM and never
+// visit the host.  Integer work, HBM/latency bound: coalesced key/coord streams, random
+// probes into a table that sits in L2 / Infinity Cache.
+//
+// Site numbering contract (DESIGN.md §Row order):
+//   input layer  : first-seen order of the point list  == IOLayersRules.h:86-91 (exact)
+//   strided conv : first-seen order over input rows ascending, then output-region order
+//                  (the reference's order is dense_hash_map iteration order, an artefact;
+//                   parity there is modulo a per-sample permutation)
+#include "common.h"
+
+namespace aabr {
+
+// ------------------------------------------------------------------ block-wide 2-lane scan
+template <int NT>
+__device__ inline void block_exscan2(int a, int b, int &ea, int &eb, int &ta, int &tb) {
+  __shared__ int sa[NT / 64], sb[NT / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int ia = a, ib = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
+    if (lane >= d) { ia += ua; ib += ub; }
+  }
+  if (lane == 63) { sa[w] = ia; sb[w] = ib; }
+  __syncthreads();
+  int pa = 0, pb = 0, xa = 0, xb = 0;
+#pragma unroll
+  for (int j = 0; j < NT / 64; ++j) {
+    int va = sa[j], vb = sb[j];
+    if (j < w) { pa += va; pb += vb; }
+    xa += va; xb += vb;
+  }
+  ea = pa + ia - a; eb = pb + ib - b; ta = xa; tb = xb;
+  __syncthreads();
+}
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanThreads * kScanItems; // 1024 items per block
+
+// "first" flag of encounter e: it won the atomicMin on its slot.
+__device__ inline void first_flag(const int32_t *slot, const uint32_t *minidx, const uint32_t *slotcnt,
+                                  int64_t e, int64_t n, int &f, int &c) {
+  f = 0; c = 0;
+  if (e < n) {
+    int s = slot[e];
+    if (s >= 0 && minidx[s] == (uint32_t)e) {
+      f = 1;
+      c = slotcnt ? (int)(slotcnt[s] + 1u) : 1; // slotcnt starts at 0xFFFFFFFF
+    }
+  }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_blocksums(
+    const int32_t *__restrict__ slot, const uint32_t *__restrict__ minidx,
+    const uint32_t *__restrict__ slotcnt, int64_t n, int32_t *__restrict__ blocksums) {
+  int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int a = 0, b = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    int f, c;
+    first_flag(slot, minidx, slotcnt, base + j, n, f, c);
+    a += f; b += c;
+  }
+  int ea, eb, ta, tb;
+  block_exscan2<kScanThreads>(a, b, ea, eb, ta, tb);
+  if (threadIdx.x == 0) { blocksums[2 * blockIdx.x] = ta; blocksums[2 * blockIdx.x + 1] = tb; }
+}
+
+// single block: exclusive scan of the per-block sums; totals -> meta[0], meta[3]
+__global__ __launch_bounds__(1024) void k_scan_blockprefix(const int32_t *__restrict__ blocksums,
+                                                          int64_t nblk, int32_t *__restrict__ prefix,
+                                                          int32_t *__restrict__ meta,
+                                                          int32_t *__restrict__ site_off) {
+  int ca = 0, cb = 0;
+  for (int64_t base = 0; base < nblk; base += 1024) {
+    int64_t i = base + threadIdx.x;
+    int a = 0, b = 0;
+    if (i < nblk) { a = blocksums[2 * i]; b = blocksums[2 * i + 1]; }
+    int ea, eb, ta, tb;
+    block_exscan2<1024>(a, b, ea, eb, ta, tb);
+    if (i < nblk) { prefix[2 * i] = ca + ea; prefix[2 * i + 1] = cb + eb; }
+    ca += ta; cb += tb;
+  }
+  if (threadIdx.x == 0) {
+    meta[0] = ca;
+    meta[3] = cb;
+    if (site_off) site_off[ca] = cb; // CSR terminator: offsets[V] = number of valid points
+  }
+}
+
+struct ConvGeom {
+  int size[3], stride[3], out_sp[3];
+  int maxout;
+};
+
+// l-th point (region order, z fastest) of the output region of input point p
+// (OutputRegionCalculator, RectangularRegions.h:109-119).  Returns false if l is past the end.
+__device__ inline bool output_region_lth(const ConvGeom &g, const int p[3], int l, int j[3]) {
+  int lb[3], n[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int num = p[i] - g.size[i] + g.stride[i];
+    int q = num / g.stride[i]; // C division (toward zero), then clamp at 0 like std::max(0L, ..)
+    lb[i] = q > 0 ? q : 0;
+    int ub = p[i] / g.stride[i];
+    if (ub > g.out_sp[i] - 1) ub = g.out_sp[i] - 1;
+    n[i] = ub - lb[i] + 1;
+    if (n[i] <= 0) return false;
+  }
+  if (l >= n[0] * n[1] * n[2]) return false;
+  j[2] = lb[2] + l % n[2]; l /= n[2];
+  j[1] = lb[1] + l % n[1]; l /= n[1];
+  j[0] = lb[0] + l;
+  return true;
+}
+
+// MODE 0: input layer (items = points); MODE 1: strided-conv output sites (items = encounters)
+template <int MODE>
+__global__ __launch_bounds__(kScanThreads) void k_assign_sites(
+    const int32_t *__restrict__ slot, const uint32_t *__restrict__ minidx,
+    const uint32_t *__restrict__ slotcnt, int64_t n, const int32_t *__restrict__ prefix,
+    int32_t *__restrict__ vals, int32_t *__restrict__ site_coords, int32_t *__restrict__ site_off,
+    int32_t *__restrict__ meta, const int64_t *__restrict__ coords64, int ncols,
+    const int32_t *__restrict__ in_coords, ConvGeom g) {
+  int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int f[kScanItems], c[kScanItems], a = 0, b = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    first_flag(slot, minidx, slotcnt, base + j, n, f[j], c[j]);
+    a += f[j]; b += c[j];
+  }
+  int ea, eb, ta, tb;
+  block_exscan2<kScanThreads>(a, b, ea, eb, ta, tb);
+  int ra = prefix[2 * blockIdx.x] + ea, rb = prefix[2 * blockIdx.x + 1] + eb;
+  int maxc = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    if (f[j]) {
+      int64_t e = base + j;
+      vals[slot[e]] = ra;
+      if (MODE == 0) {
+        const int64_t *cp = coords64 + e * ncols;
+        int4 sc = make_int4((int)cp[0], (int)cp[1], (int)cp[2], ncols == 4 ? (int)cp[3] : 0);
+        *reinterpret_cast<int4 *>(site_coords + 4 * (int64_t)ra) = sc;
+        site_off[ra] = rb;
+        maxc = c[j] > maxc ? c[j] : maxc;
+      } else {
+        int64_t u = e / g.maxout;
+        int l = (int)(e % g.maxout);
+        int4 ic = *reinterpret_cast<const int4 *>(in_coords + 4 * u);
+        int p[3] = {ic.x, ic.y, ic.z}, jj[3];
+        output_region_lth(g, p, l, jj);
+        *reinterpret_cast<int4 *>(site_coords + 4 * (int64_t)ra) = make_int4(jj[0], jj[1], jj[2], ic.w);
+      }
+      ra += 1; rb += c[j];
+    }
+  }
+  if (MODE == 0 && maxc > 0) atomicMax(&meta[1], maxc);
+}
+
+// ------------------------------------------------------------------ input layer
+__global__ __launch_bounds__(256) void k_insert_points(const int64_t *__restrict__ coords, int64_t n,
+                                                       int ncols, uint64_t *keys, uint64_t mask,
+                                                       uint32_t *minidx, uint32_t *slotcnt,
+                                                       int32_t *__restrict__ slot, int32_t *meta) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t *c = coords + i * ncols;
+  int64_t x = c[0], y = c[1], z = c[2], b = ncols == 4 ? c[3] : 0;
+  if (x < 0 || y < 0 || z < 0 || b < 0 || x > kMaxCoord || y > kMaxCoord || z > kMaxCoord ||
+      b > kMaxCoord) {
+    slot[i] = -1;
+    atomicOr(&meta[2], 1);
+    return;
+  }
+  uint32_t h = grid_insert(keys, mask, pack_key((int)b, (int)x, (int)y, (int)z));
+  atomicMin(&minidx[h], (uint32_t)i);
+  atomicAdd(&slotcnt[h], 1u);
+  slot[i] = (int32_t)h;
+}
+
+__global__ __launch_bounds__(256) void k_point_site_fill(const int32_t *__restrict__ slot, int64_t n,
+                                                         const int32_t *__restrict__ vals,
+                                                         uint32_t *slotcnt,
+                                                         const int32_t *__restrict__ site_off,
+                                                         int32_t *__restrict__ point_site,
+                                                         int32_t *__restrict__ seg) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int s = slot[i];
+  if (s < 0) { point_site[i] = -1; return; }
+  int v = vals[s];
+  point_site[i] = v;
+  // slotcnt holds count-1 after the inserts; hand out positions count-1 .. 0
+  uint32_t pos = atomicAdd(&slotcnt[s], 0xFFFFFFFFu);
+  seg[site_off[v] + (int)pos] = (int32_t)i;
+}
+
+// order every site's point list by ascending point index (rank by counting: the lists are
+// tiny -- mean N/V ~ 1.2 -- and the quadratic cost is spread over the points themselves).
+__global__ __launch_bounds__(256) void k_rank_points(const int32_t *__restrict__ point_site, int64_t n,
+                                                     const int32_t *__restrict__ site_off,
+                                                     const int32_t *__restrict__ seg,
+                                                     int32_t *__restrict__ site_pts) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int v = point_site[i];
+  if (v < 0) return;
+  int s = site_off[v], e = site_off[v + 1], r = 0;
+  for (int j = s; j < e; ++j) r += (seg[j] < (int32_t)i) ? 1 : 0;
+  site_pts[s + r] = (int32_t)i;
+}
+
+// out[v] = sum_j mult * in[pts[j]] in ascending point order, separate multiply and add
+// (no FMA contraction) so the fp32 result is bit-identical to InputLayer_ForwardPass
+// (CPU/IOLayers.cpp:18-27: `out_f[plane] += multiplier * in_f[plane]`).
+__global__ __launch_bounds__(256) void k_input_forward(const float *__restrict__ in, float *__restrict__ out,
+                                                       int64_t V, int planes,
+                                                       const int32_t *__restrict__ site_off,
+                                                       const int32_t *__restrict__ site_pts, int mode) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= V * planes) return;
+  int64_t v = idx / planes;
+  int p = (int)(idx - v * planes);
+  int s = site_off[v], e = site_off[v + 1];
+  float acc = 0.0f;
+  if (mode == 1) {
+    acc = __fadd_rn(0.0f, in[(int64_t)site_pts[s] * planes + p]);
+  } else if (mode == 2) {
+    acc = __fadd_rn(0.0f, in[(int64_t)site_pts[e - 1] * planes + p]);
+  } else {
+    float mult = (mode == 4 && e > s) ? __fdiv_rn(1.0f, (float)(e - s)) : 1.0f;
+    for (int j = s; j < e; ++j)
+      acc = __fadd_rn(acc, __fmul_rn(mult, in[(int64_t)site_pts[j] * planes + p]));
+  }
+  out[idx] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_input_backward(float *__restrict__ d_in,
+                                                        const float *__restrict__ d_out, int64_t n,
+                                                        int planes, const int32_t *__restrict__ point_site,
+                                                        const int32_t *__restrict__ site_off,
+                                                        const int32_t *__restrict__ site_pts, int mode) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * planes) return;
+  int64_t i = idx / planes;
+  int p = (int)(idx - i * planes);
+  int v = point_site[i];
+  float g = 0.0f;
+  if (v >= 0) {
+    int s = site_off[v], e = site_off[v + 1];
+    bool take = true;
+    if (mode == 1) take = (site_pts[s] == (int32_t)i);
+    if (mode == 2) take = (site_pts[e - 1] == (int32_t)i);
+    if (take) {
+      float mult = (mode == 4) ? __fdiv_rn(1.0f, (float)(e - s)) : 1.0f;
+      g = __fadd_rn(0.0f, __fmul_rn(mult, d_out[(int64_t)v * planes + p]));
+    }
+  }
+  d_in[idx] = g;
+}
+
+__global__ __launch_bounds__(256) void k_input_rule_table(const int32_t *__restrict__ site_off,
+                                                          const int32_t *__restrict__ site_pts, int64_t V,
+                                                          int width, int mode, int32_t *__restrict__ rules) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  int s = site_off[v], e = site_off[v + 1];
+  int32_t *r = rules + v * width;
+  if (mode == 3 || mode == 4) {
+    r[0] = e - s;
+    for (int j = 1; j < width; ++j) r[j] = (s + j - 1 < e) ? site_pts[s + j - 1] : 0;
+  } else {
+    r[0] = 1;
+    r[1] = (mode == 1) ? site_pts[s] : site_pts[e - 1];
+  }
+}
+
+// ------------------------------------------------------------------ rule tables
+struct Filter3 { int size[3]; };
+
+__global__ __launch_bounds__(256) void k_submanifold_table(const int32_t *__restrict__ site_coords,
+                                                           int64_t V, const uint64_t *__restrict__ keys,
+                                                           const int32_t *__restrict__ vals, uint64_t mask,
+                                                           Filter3 fs, int32_t *__restrict__ table,
+                                                           int32_t *__restrict__ counts) {
+  const int k = blockIdx.y;
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int hit = 0;
+  if (v < V) {
+    int dz = k % fs.size[2], t = k / fs.size[2];
+    int dy = t % fs.size[1], dx = t / fs.size[1];
+    int4 c = *reinterpret_cast<const int4 *>(site_coords + 4 * v);
+    // InputRegionCalculator_Submanifold: lb = p - size/2
+    int x = c.x + dx - fs.size[0] / 2, y = c.y + dy - fs.size[1] / 2, z = c.z + dz - fs.size[2] / 2;
+    int r = -1;
+    if (coord_in_range(x) && coord_in_range(y) && coord_in_range(z))
+      r = grid_find(keys, vals, mask, pack_key(c.w, x, y, z));
+    table[(int64_t)k * V + v] = r;
+    hit = r >= 0;
+  }
+  if (counts) {
+    unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], (int)__popcll(m));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_conv_insert_sites(const int32_t *__restrict__ in_coords,
+                                                           int64_t V_in, ConvGeom g, uint64_t *keys,
+                                                           uint64_t mask, uint32_t *minidx,
+                                                           int32_t *__restrict__ slot) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= V_in) return;
+  int4 ic = *reinterpret_cast<const int4 *>(in_coords + 4 * u);
+  int p[3] = {ic.x, ic.y, ic.z}, j[3];
+  for (int l = 0; l < g.maxout; ++l) {
+    int64_t e = u * g.maxout + l;
+    if (output_region_lth(g, p, l, j)) {
+      uint32_t h = grid_insert(keys, mask, pack_key(ic.w, j[0], j[1], j[2]));
+      atomicMin(&minidx[h], (uint32_t)e);
+      slot[e] = (int32_t)h;
+    } else {
+      slot[e] = -1;
+    }
+  }
+}
+
+// table_out[k][o]: input row at o*stride + koff (InputRegionCalculator, :95-105)
+__global__ __launch_bounds__(256) void k_conv_table_out(const int32_t *__restrict__ out_coords,
+                                                        int64_t V_out, const uint64_t *__restrict__ in_keys,
+                                                        const int32_t *__restrict__ in_vals,
+                                                        uint64_t in_mask, ConvGeom g,
+                                                        int32_t *__restrict__ table,
+                                                        int32_t *__restrict__ counts) {
+  const int k = blockIdx.y;
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int hit = 0;
+  if (o < V_out) {
+    int dz = k % g.size[2], t = k / g.size[2];
+    int dy = t % g.size[1], dx = t / g.size[1];
+    int4 c = *reinterpret_cast<const int4 *>(out_coords + 4 * o);
+    int x = c.x * g.stride[0] + dx, y = c.y * g.stride[1] + dy, z = c.z * g.stride[2] + dz;
+    int r = -1;
+    if (coord_in_range(x) && coord_in_range(y) && coord_in_range(z))
+      r = grid_find(in_keys, in_vals, in_mask, pack_key(c.w, x, y, z));
+    table[(int64_t)k * V_out + o] = r;
+    hit = r >= 0;
+  }
+  if (counts) {
+    unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], (int)__popcll(m));
+  }
+}
+
+// table_in[k][u]: the output row whose window holds input u at offset k, if that output cell
+// is inside [0, out_spatial) (OutputRegionCalculator clamps, :109-119)
+__global__ __launch_bounds__(256) void k_conv_table_in(const int32_t *__restrict__ in_coords, int64_t V_in,
+                                                       const uint64_t *__restrict__ out_keys,
+                                                       const int32_t *__restrict__ out_vals,
+                                                       uint64_t out_mask, ConvGeom g,
+                                                       int32_t *__restrict__ table) {
+  const int k = blockIdx.y;
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= V_in) return;
+  int d[3];
+  d[2] = k % g.size[2];
+  int t = k / g.size[2];
+  d[1] = t % g.size[1];
+  d[0] = t / g.size[1];
+  int4 c = *reinterpret_cast<const int4 *>(in_coords + 4 * u);
+  int p[3] = {c.x, c.y, c.z}, j[3];
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int q = p[i] - d[i];
+    if (q < 0 || q % g.stride[i] != 0) { ok = false; break; }
+    j[i] = q / g.stride[i];
+    if (j[i] > g.out_sp[i] - 1) { ok = false; break; }
+  }
+  int r = -1;
+  if (ok) r = grid_find(out_keys, out_vals, out_mask, pack_key(c.w, j[0], j[1], j[2]));
+  table[(int64_t)k * V_in + u] = r;
+}
+
+// one block per filter offset: ordered compaction of the table row into (entry, row) pairs
+__global__ __launch_bounds__(1024) void k_table_to_rulebook(const int32_t *__restrict__ table, int64_t V,
+                                                            int32_t *__restrict__ rules,
+                                                            int32_t *__restrict__ counts) {
+  const int k = blockIdx.x;
+  int run = 0;
+  for (int64_t base = 0; base < V; base += 1024) {
+    int64_t v = base + threadIdx.x;
+    int t = (v < V) ? table[(int64_t)k * V + v] : -1;
+    int f = t >= 0, ea, eb, ta, tb;
+    block_exscan2<1024>(f, 0, ea, eb, ta, tb);
+    if (f) {
+      int32_t *r = rules + ((int64_t)k * V + run + ea) * 2;
+      r[0] = t; r[1] = (int32_t)v;
+    }
+    run += ta;
+  }
+  if (threadIdx.x == 0) counts[k] = run;
+}
+
+__global__ __launch_bounds__(256) void k_spatial_locations(const int32_t *__restrict__ sc, int64_t n4,
+                                                           int64_t *__restrict__ loc) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) loc[i] = sc[i];
+}
+
+static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)ceil_div(n > 0 ? n : 1, bs)); }
+
+} // namespace aabr
+
+using namespace aabr;
+
+extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys,
+                                      int32_t *vals, int64_t cap, int32_t *scratch, int32_t *point_site,
+                                      int32_t *site_coords, int32_t *site_off, int32_t *site_pts,
+                                      int32_t *meta, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(n >= 0 && (ncols == 3 || ncols == 4), "n >= 0 and ncols in {3,4} required");
+  AABR_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "cap must be a power of two >= max(64, 2n)");
+  AABR_CHECK_ARG(keys && vals && scratch && point_site && site_coords && site_off && site_pts && meta,
+                 "null pointer");
+  AABR_CHECK_ARG(n == 0 || coords, "null coords");
+  int64_t nblk = ceil_div(n > 0 ? n : 1, kScanTile);
+  uint32_t *minidx = (uint32_t *)scratch;
+  uint32_t *slotcnt = minidx + cap;
+  int32_t *slot = (int32_t *)(slotcnt + cap);
+  int32_t *seg = slot + n;
+  int32_t *blocksums = seg + n;
+  int32_t *prefix = blocksums + 2 * nblk;
+  hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st);
+  hipMemsetAsync(minidx, 0xFF, 2 * cap * sizeof(uint32_t), st);
+  hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st);
+  ConvGeom g = {};
+  if (n > 0)
+    hipLaunchKernelGGL(k_insert_points, grid1(n, 256), dim3(256), 0, st, coords, n, ncols, keys,
+                       (uint64_t)(cap - 1), minidx, slotcnt, slot, meta);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx, slotcnt,
+                     n, blocksums);
+  hipLaunchKernelGGL(k_scan_blockprefix, dim3(1), dim3(1024), 0, st, blocksums, nblk, prefix, meta, site_off);
+  hipLaunchKernelGGL(k_assign_sites<0>, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx, slotcnt,
+                     n, prefix, vals, site_coords, site_off, meta, coords, ncols, (const int32_t *)nullptr, g);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_point_site_fill, grid1(n, 256), dim3(256), 0, st, slot, n, vals, slotcnt, site_off,
+                       point_site, seg);
+    hipLaunchKernelGGL(k_rank_points, grid1(n, 256), dim3(256), 0, st, point_site, n, site_off, seg, site_pts);
+  }
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_input_layer_forward(const float *in_feats, float *out_feats, int64_t V, int planes,
+                                        const int32_t *site_off, const int32_t *site_pts, int mode,
+                                        void *stream_) {
+  AABR_CHECK_ARG(V >= 0 && planes > 0 && mode >= 1 && mode <= 4, "bad V/planes/mode");
+  if (V == 0) return AABR_OK;
+  AABR_CHECK_ARG(in_feats && out_feats && site_off && site_pts, "null pointer");
+  hipLaunchKernelGGL(k_input_forward, grid1(V * planes, 256), dim3(256), 0, (hipStream_t)stream_, in_feats,
+                     out_feats, V, planes, site_off, site_pts, mode);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_input_layer_backward(float *d_in_feats, const float *d_out_feats, int64_t n, int planes,
+                                         const int32_t *point_site, const int32_t *site_off,
+                                         const int32_t *site_pts, int mode, void *stream_) {
+  AABR_CHECK_ARG(n >= 0 && planes > 0 && mode >= 1 && mode <= 4, "bad n/planes/mode");
+  if (n == 0) return AABR_OK;
+  AABR_CHECK_ARG(d_in_feats && d_out_feats && point_site && site_off && site_pts, "null pointer");
+  hipLaunchKernelGGL(k_input_backward, grid1(n * planes, 256), dim3(256), 0, (hipStream_t)stream_, d_in_feats,
+                     d_out_feats, n, planes, point_site, site_off, site_pts, mode);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_input_layer_rule_table(const int32_t *site_off, const int32_t *site_pts, int64_t V,
+                                           int max_active, int mode, int32_t *rules, void *stream_) {
+  AABR_CHECK_ARG(V >= 0 && max_active >= 0 && mode >= 1 && mode <= 4, "bad V/max_active/mode");
+  if (V == 0) return AABR_OK;
+  AABR_CHECK_ARG(site_off && site_pts && rules, "null pointer");
+  int width = ((mode == 3 || mode == 4) ? max_active : 1) + 1;
+  hipLaunchKernelGGL(k_input_rule_table, grid1(V, 256), dim3(256), 0, (hipStream_t)stream_, site_off,
+                     site_pts, V, width, mode, rules);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t *keys,
+                                      const int32_t *vals, int64_t cap, const int32_t *fs_host,
+                                      int32_t *table, int32_t *counts, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(V >= 0 && fs_host && is_pow2(cap), "bad V/filter/cap");
+  Filter3 fs;
+  int64_t vol = 1;
+  for (int i = 0; i < 3; ++i) {
+    AABR_CHECK_ARG(fs_host[i] >= 1 && fs_host[i] <= 64, "filter size out of range");
+    fs.size[i] = fs_host[i];
+    vol *= fs_host[i];
+  }
+  AABR_CHECK_ARG(vol <= 65535, "filter volume too large");
+  if (counts) hipMemsetAsync(counts, 0, vol * sizeof(int32_t), st);
+  if (V == 0) return AABR_OK;
+  AABR_CHECK_ARG(site_coords && keys && vals && table, "null pointer");
+  hipLaunchKernelGGL(k_submanifold_table, dim3((unsigned)ceil_div(V, 256), (unsigned)vol), dim3(256), 0, st,
+                     site_coords, V, keys, vals, (uint64_t)(cap - 1), fs, table, counts);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+static int make_geom(const int32_t *size, const int32_t *stride, const int32_t *out_sp, ConvGeom &g) {
+  g.maxout = 1;
+  for (int i = 0; i < 3; ++i) {
+    if (size[i] < 1 || size[i] > 64 || stride[i] < 1 || stride[i] > 64 || out_sp[i] < 1) return -1;
+    g.size[i] = size[i]; g.stride[i] = stride[i]; g.out_sp[i] = out_sp[i];
+    g.maxout *= (size[i] + stride[i] - 1) / stride[i];
+  }
+  return 0;
+}
+
+extern "C" int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, const int32_t *size_host,
+                                      const int32_t *stride_host, const int32_t *out_spatial_host,
+                                      uint64_t *out_keys, int32_t *out_vals, int64_t out_cap,
+                                      int32_t *scratch, int32_t *out_site_coords, int32_t *meta,
+                                      void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(V_in >= 0 && size_host && stride_host && out_spatial_host, "bad arguments");
+  ConvGeom g;
+  AABR_CHECK_ARG(make_geom(size_host, stride_host, out_spatial_host, g) == 0, "bad filter geometry");
+  int64_t E = V_in * g.maxout;
+  AABR_CHECK_ARG(E < (int64_t)0x7fffffff, "too many encounters");
+  AABR_CHECK_ARG(is_pow2(out_cap) && out_cap >= 2 * E && out_cap >= 64,
+                 "out_cap must be a power of two >= max(64, 2*V_in*max_out_per_in)");
+  AABR_CHECK_ARG(out_keys && out_vals && scratch && out_site_coords && meta, "null pointer");
+  int64_t nblk = ceil_div(E > 0 ? E : 1, kScanTile);
+  uint32_t *minidx = (uint32_t *)scratch;
+  int32_t *slot = (int32_t *)(minidx + out_cap);
+  int32_t *blocksums = slot + E;
+  int32_t *prefix = blocksums + 2 * nblk;
+  hipMemsetAsync(out_keys, 0xFF, out_cap * sizeof(uint64_t), st);
+  hipMemsetAsync(minidx, 0xFF, out_cap * sizeof(uint32_t), st);
+  hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st);
+  if (V_in > 0)
+    hipLaunchKernelGGL(k_conv_insert_sites, grid1(V_in, 256), dim3(256), 0, st, in_coords, V_in, g, out_keys,
+                       (uint64_t)(out_cap - 1), minidx, slot);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx,
+                     (const uint32_t *)nullptr, E, blocksums);
+  hipLaunchKernelGGL(k_scan_blockprefix, dim3(1), dim3(1024), 0, st, blocksums, nblk, prefix, meta,
+                     (int32_t *)nullptr);
+  hipLaunchKernelGGL(k_assign_sites<1>, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx,
+                     (const uint32_t *)nullptr, E, prefix, out_vals, out_site_coords, (int32_t *)nullptr, meta,
+                     (const int64_t *)nullptr, 0, in_coords, g);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
+                                       const int32_t *in_vals, int64_t in_cap, const int32_t *out_coords,
+                                       int64_t V_out, const uint64_t *out_keys, const int32_t *out_vals,
+                                       int64_t out_cap, const int32_t *size_host, const int32_t *stride_host,
+                                       const int32_t *out_spatial_host, int32_t *table_out, int32_t *table_in,
+                                       int32_t *counts, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(V_in >= 0 && V_out >= 0 && size_host && stride_host && out_spatial_host, "bad arguments");
+  AABR_CHECK_ARG(is_pow2(in_cap) && is_pow2(out_cap), "capacities must be powers of two");
+  ConvGeom g;
+  AABR_CHECK_ARG(make_geom(size_host, stride_host, out_spatial_host, g) == 0, "bad filter geometry");
+  int vol = g.size[0] * g.size[1] * g.size[2];
+  if (counts) hipMemsetAsync(counts, 0, vol * sizeof(int32_t), st);
+  if (V_out > 0 && table_out) {
+    AABR_CHECK_ARG(out_coords && in_keys && in_vals, "null pointer");
+    hipLaunchKernelGGL(k_conv_table_out, dim3((unsigned)ceil_div(V_out, 256), (unsigned)vol), dim3(256), 0, st,
+                       out_coords, V_out, in_keys, in_vals, (uint64_t)(in_cap - 1), g, table_out, counts);
+  }
+  if (V_in > 0 && table_in) {
+    AABR_CHECK_ARG(in_coords && out_keys && out_vals, "null pointer");
+    hipLaunchKernelGGL(k_conv_table_in, dim3((unsigned)ceil_div(V_in, 256), (unsigned)vol), dim3(256), 0, st,
+                       in_coords, V_in, out_keys, out_vals, (uint64_t)(out_cap - 1), g, table_in);
+  }
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_table_to_rulebook(const int32_t *table, int64_t V, int vol, int32_t *rules,
+                                      int32_t *counts, void *stream_) {
+  AABR_CHECK_ARG(V >= 0 && vol > 0 && counts, "bad arguments");
+  if (V == 0) {
+    hipMemsetAsync(counts, 0, vol * sizeof(int32_t), (hipStream_t)stream_);
+    return AABR_OK;
+  }
+  AABR_CHECK_ARG(table && rules, "null pointer");
+  hipLaunchKernelGGL(k_table_to_rulebook, dim3((unsigned)vol), dim3(1024), 0, (hipStream_t)stream_, table, V,
+                     rules, counts);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_spatial_locations(const int32_t *site_coords, int64_t V, int64_t *locations,
+                                      void *stream_) {
+  AABR_CHECK_ARG(V >= 0, "bad V");
+  if (V == 0) return AABR_OK;
+  AABR_CHECK_ARG(site_coords && locations, "null pointer");
+  hipLaunchKernelGGL(k_spatial_locations, grid1(4 * V, 256), dim3(256), 0, (hipStream_t)stream_, site_coords,
+                     4 * V, locations);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}

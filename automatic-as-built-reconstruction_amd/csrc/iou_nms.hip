@@ -1,0 +1,241 @@
+// iou_nms.hip -- rotated-box IoU matrix and greedy rotated / axis-aligned NMS (gfx950).
+//
+// Replaces the numba.cuda kernels rotate_iou_kernel_eval / rotate_nms_kernel
+// (second/core/non_max_suppression/nms_gpu.py:406-439,626-664), the host post-processing
+// (nms_postprocess :109-126, check_same_boxes :706-717) and the third-party CPU suppression
+// loop the reference's 3-D path ends in (nms_cpu.py:32-44 -> spconv rotate_non_max_suppression_cpu).
+// VALU / latency bound (56 KB of boxes, ~2 M branchy pair evaluations), not HBM bound.
+//   mask kernel : one wave per 64x64 tile of the upper triangle, boxes staged in LDS,
+//                 64-bit suppression words written straight from registers.
+//   scan kernel : one workgroup walks the 64-row blocks; the in-block dependency chain is
+//                 resolved on the diagonal 64x64 bit block by one wave in registers
+//                 (wavefront-level), then the kept rows' words are OR-reduced in parallel.
+// Everything stays on the device; the keep list never round-trips through the host.
+#include "common.h"
+#include "iou_math.h"
+
+namespace aabr {
+using namespace aabr_iou;
+
+__global__ __launch_bounds__(64) void k_rotate_iou_eval(const float *__restrict__ boxes, int64_t N,
+                                                        const float *__restrict__ query, int64_t K,
+                                                        int criterion, float *__restrict__ iou) {
+  __shared__ float sq[64 * 5], sb[64 * 5];
+  const int tx = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * 64, k0 = (int64_t)blockIdx.y * 64;
+  const int rows = (int)((N - n0) < 64 ? (N - n0) : 64), cols = (int)((K - k0) < 64 ? (K - k0) : 64);
+  for (int i = tx; i < cols * 5; i += 64) sq[i] = query[k0 * 5 + i];
+  for (int i = tx; i < rows * 5; i += 64) sb[i] = boxes[n0 * 5 + i];
+  __syncthreads();
+  if (tx < rows) {
+    float b[5];
+    for (int d = 0; d < 5; ++d) b[d] = sb[tx * 5 + d];
+    for (int j = 0; j < cols; ++j) {
+      float q[5];
+      for (int d = 0; d < 5; ++d) q[d] = sq[j * 5 + d];
+      iou[(n0 + tx) * K + k0 + j] = iou_eval_entry(b, q, criterion);
+    }
+  }
+}
+
+// [.,7] yx_zb -> 5-parameter 2-D box + z interval, with the reference's thickness clamps
+// (rotate_nms_3d_torch.py:59-66: columns [0,1,3,4,6], clamp col 3 and col 5)
+__global__ __launch_bounds__(256) void k_box7_to_2d(const float *__restrict__ b7, int64_t n, float minY,
+                                                    float minZ, float *__restrict__ b5,
+                                                    float *__restrict__ zz) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *b = b7 + 7 * i;
+  float th = b[3] < minY ? minY : b[3];
+  float h = b[5] < minZ ? minZ : b[5];
+  b5[5 * i] = b[0]; b5[5 * i + 1] = b[1]; b5[5 * i + 2] = th; b5[5 * i + 3] = b[4]; b5[5 * i + 4] = b[6];
+  if (zz) { zz[2 * i] = b[2]; zz[2 * i + 1] = b[2] + h; }
+}
+
+// iou_one_dim (rotate_nms_3d_torch.py:7-21) folded into the matrix
+__global__ __launch_bounds__(256) void k_scale_by_z(float *__restrict__ iou, int64_t M, int64_t K,
+                                                    const float *__restrict__ tz,
+                                                    const float *__restrict__ az) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * K) return;
+  int64_t i = idx / K, j = idx - i * K;
+  float t0 = tz[2 * i], t1 = tz[2 * i + 1], a0 = az[2 * j], a1 = az[2 * j + 1];
+  float overlap = fminf(a1, t1) - fmaxf(a0, t0);
+  float common = fmaxf(a1, t1) - fminf(a0, t0);
+  iou[idx] = iou[idx] * (overlap / common);
+}
+
+// KIND 0: rotated 3-D boxes [n,7] (2-D IoU, optionally times z-IoU); KIND 1: axis-aligned [n,4]
+template <int KIND>
+__global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes, int64_t n, float thresh,
+                                                 int only_xy, int colblocks,
+                                                 unsigned long long *__restrict__ mask) {
+  constexpr int W = KIND == 0 ? 7 : 4;
+  __shared__ float sc[64 * W];
+  const int tx = threadIdx.x;
+  const int cb = blockIdx.x, rb = blockIdx.y;
+  const int64_t i = (int64_t)rb * 64 + tx;
+  if (cb < rb) { // below the diagonal: nothing can be suppressed by a lower-scored box
+    if (i < n) mask[i * colblocks + cb] = 0ull;
+    return;
+  }
+  const int64_t c0 = (int64_t)cb * 64;
+  const int cols = (int)((n - c0) < 64 ? (n - c0) : 64);
+  for (int t = tx; t < cols * W; t += 64) sc[t] = boxes[c0 * W + t];
+  __syncthreads();
+  if (i >= n) return;
+  unsigned long long bits = 0ull;
+  if (KIND == 0) {
+    const float *b = boxes + i * 7;
+    const float bi[5] = {b[0], b[1], b[3], b[4], b[6]};
+    const float z0 = b[2], z1 = b[2] + b[5];
+    for (int j = (cb == rb ? tx + 1 : 0); j < cols; ++j) {
+      const float *c = sc + j * 7;
+      const float bj[5] = {c[0], c[1], c[3], c[4], c[6]};
+      // matrix entry [i][j] of boxes_iou_3d(dets, dets): box = i, query = j
+      float v = iou_eval_entry(bi, bj, -1);
+      if (!only_xy) {
+        const float a0 = c[2], a1 = c[2] + c[5];
+        v = v * ((fminf(a1, z1) - fmaxf(a0, z0)) / (fmaxf(a1, z1) - fminf(a0, z0)));
+      }
+      if (v > 0.0f && v >= thresh) bits |= 1ull << j;
+    }
+  } else {
+    const float *b = boxes + i * 4;
+    const float ix1 = b[0], iy1 = b[1], ix2 = b[2], iy2 = b[3];
+    const float iarea = (ix2 - ix1 + 1) * (iy2 - iy1 + 1);
+    for (int j = (cb == rb ? tx + 1 : 0); j < cols; ++j) {
+      const float *c = sc + j * 4;
+      const float xx1 = fmaxf(ix1, c[0]), yy1 = fmaxf(iy1, c[1]);
+      const float xx2 = fminf(ix2, c[2]), yy2 = fminf(iy2, c[3]);
+      const float w = fmaxf(0.0f, xx2 - xx1 + 1), h = fmaxf(0.0f, yy2 - yy1 + 1);
+      const float inter = w * h;
+      const float jarea = (c[2] - c[0] + 1) * (c[3] - c[1] + 1);
+      if (inter / (iarea + jarea - inter) >= thresh) bits |= 1ull << j;
+    }
+  }
+  mask[i * colblocks + cb] = bits;
+}
+
+// Greedy scan.  remv words live in LDS (colblocks <= 8192 -> n <= 524288).
+__global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long *__restrict__ mask, int64_t n,
+                                                  int colblocks, int64_t post_max,
+                                                  int64_t *__restrict__ keep, int32_t *__restrict__ meta) {
+  extern __shared__ unsigned long long remv[];
+  __shared__ unsigned long long s_kept;
+  __shared__ int s_nk;
+  const int tid = threadIdx.x;
+  for (int w = tid; w < colblocks; w += blockDim.x) remv[w] = 0ull;
+  if (tid == 0) s_nk = 0;
+  __syncthreads();
+  for (int rb = 0; rb < colblocks; ++rb) {
+    const int64_t r0 = (int64_t)rb * 64;
+    const int rows = (int)((n - r0) < 64 ? (n - r0) : 64);
+    if (tid < 64) { // first wave: resolve the chain inside the block on the diagonal bits
+      unsigned long long diag = (tid < rows) ? mask[(r0 + tid) * colblocks + rb] : 0ull;
+      unsigned long long cur = remv[rb], kept = 0ull;
+      for (int b = 0; b < rows; ++b) {
+        unsigned long long db = __shfl(diag, b); // wave-uniform trip
+        if (!((cur >> b) & 1ull)) { kept |= 1ull << b; cur |= db; }
+      }
+      if (tid == 0) {
+        int nk = s_nk;
+        for (int b = 0; b < rows; ++b)
+          if ((kept >> b) & 1ull) {
+            if (nk < post_max) keep[nk] = r0 + b;
+            ++nk;
+          }
+        s_nk = nk;
+        s_kept = kept;
+      }
+    }
+    __syncthreads();
+    const unsigned long long kept = s_kept;
+    if (s_nk >= post_max) break; // uniform
+    for (int w = rb + 1 + tid; w < colblocks; w += blockDim.x) {
+      unsigned long long acc = remv[w];
+      unsigned long long kb = kept;
+      while (kb) {
+        int b = __ffsll((long long)kb) - 1;
+        kb &= kb - 1;
+        acc |= mask[(r0 + b) * colblocks + w];
+      }
+      remv[w] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) meta[0] = (int32_t)(s_nk < post_max ? s_nk : post_max);
+}
+
+} // namespace aabr
+using namespace aabr;
+
+extern "C" int aabr_rotate_iou_eval(const float *boxes, int64_t N, const float *query, int64_t K,
+                                    int criterion, float *iou, void *stream_) {
+  AABR_CHECK_ARG(N >= 0 && K >= 0, "bad sizes");
+  if (N == 0 || K == 0) return AABR_OK;
+  AABR_CHECK_ARG(boxes && query && iou, "null pointer");
+  AABR_CHECK_ARG(ceil_div(K, 64) <= 65535, "too many query boxes");
+  hipLaunchKernelGGL(k_rotate_iou_eval, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(K, 64)), dim3(64), 0,
+                     (hipStream_t)stream_, boxes, N, query, K, criterion, iou);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_boxes_iou_3d(const float *targets, int64_t M, const float *anchors, int64_t K,
+                                 const float *aug_host, int criterion, int only_xy, float *iou,
+                                 void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(M >= 0 && K >= 0 && aug_host, "bad arguments");
+  if (M == 0 || K == 0) return AABR_OK;
+  AABR_CHECK_ARG(targets && anchors && iou, "null pointer");
+  AABR_CHECK_ARG(ceil_div(K, 64) <= 65535, "too many anchors");
+  // scratch carved from a stream-ordered allocation (small: 7 floats per box)
+  float *tmp = nullptr;
+  if (hipMallocAsync((void **)&tmp, (size_t)(M + K) * 7 * sizeof(float), st) != hipSuccess) {
+    set_error("aabr_boxes_iou_3d: hipMallocAsync failed");
+    return AABR_ELAUNCH;
+  }
+  float *t5 = tmp, *a5 = t5 + 5 * M, *tz = a5 + 5 * K, *az = tz + 2 * M;
+  hipLaunchKernelGGL(k_box7_to_2d, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, st, targets, M, aug_host[0],
+                     aug_host[1], t5, tz);
+  hipLaunchKernelGGL(k_box7_to_2d, dim3((unsigned)ceil_div(K, 256)), dim3(256), 0, st, anchors, K, aug_host[2],
+                     aug_host[3], a5, az);
+  hipLaunchKernelGGL(k_rotate_iou_eval, dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(K, 64)), dim3(64), 0,
+                     st, t5, M, a5, K, criterion, iou);
+  if (!only_xy)
+    hipLaunchKernelGGL(k_scale_by_z, dim3((unsigned)ceil_div(M * K, 256)), dim3(256), 0, st, iou, M, K, tz, az);
+  hipFreeAsync(tmp, st);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+template <int KIND>
+static int nms_sorted_impl(const float *boxes, int64_t n, float thresh, int only_xy, int64_t post_max,
+                           uint64_t *mask, int64_t *keep, int32_t *meta, hipStream_t st, const char *fn) {
+  if (n < 0 || !meta) { set_error("%s: bad arguments", fn); return AABR_EINVAL; }
+  if (post_max < 0) post_max = n;
+  hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st);
+  if (n == 0 || post_max == 0) return AABR_OK;
+  if (!boxes || !mask || !keep) { set_error("%s: null pointer", fn); return AABR_EINVAL; }
+  int64_t colblocks = ceil_div(n, 64);
+  if (colblocks > 8192) { set_error("%s: n too large (max 524288)", fn); return AABR_EINVAL; }
+  hipLaunchKernelGGL((k_nms_mask<KIND>), dim3((unsigned)colblocks, (unsigned)colblocks), dim3(64), 0, st, boxes,
+                     n, thresh, only_xy, (int)colblocks, (unsigned long long *)mask);
+  hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), (size_t)colblocks * 8, st,
+                     (const unsigned long long *)mask, n, (int)colblocks, post_max, keep, meta);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("%s: HIP error %s", fn, hipGetErrorString(e)); return AABR_ELAUNCH; }
+  return AABR_OK;
+}
+
+extern "C" int aabr_rotate_nms_sorted(const float *boxes7, int64_t n, float thresh, int only_xy,
+                                      int64_t post_max, uint64_t *mask, int64_t *keep, int32_t *meta,
+                                      void *stream_) {
+  return nms_sorted_impl<0>(boxes7, n, thresh, only_xy, post_max, mask, keep, meta, (hipStream_t)stream_,
+                            "aabr_rotate_nms_sorted");
+}
+extern "C" int aabr_nms_sorted(const float *dets4, int64_t n, float thresh, uint64_t *mask, int64_t *keep,
+                               int32_t *meta, void *stream_) {
+  return nms_sorted_impl<1>(dets4, n, thresh, 1, -1, mask, keep, meta, (hipStream_t)stream_, "aabr_nms_sorted");
+}

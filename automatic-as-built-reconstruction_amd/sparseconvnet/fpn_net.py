@@ -1,0 +1,141 @@
+"""FPN_Net -- the sparse ResNet-FPN backbone of the detector.
+
+Same 17-argument constructor, sub-module names (layers_in, m_downs, m_shortcuts, m_ups,
+m_mergeds, convs_pro2d ...) and forward contract as the reference
+(SparseConvNet/sparseconvnet/fpn_net.py:13-203), so reference checkpoints load by name
+(maskrcnn_benchmark/utils/checkpoint.py:105-106) and `SparseRCNN.forward`
+(modeling/detector/sparse_rcnn.py:53) can call it unchanged.  Debug printing and pdb hooks
+of the reference are not reproduced."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+import sparseconvnet as scn
+
+
+class FPN_Net(torch.nn.Module):
+    def __init__(self, full_scale, dimension, raw_elements, reps, nPlanesF, nPlaneM, residual_blocks,
+                 fpn_scales_from_top, roi_scales_from_top, downsample, rpn_map_sizes, rpn_3d_2d_selector,
+                 leakiness=0, voxel_scale=None, bn_momentum=0.9, track_running_stats=True):
+        nn.Module.__init__(self)
+        self.bn_momentum = bn_momentum
+        self.track_running_stats = track_running_stats
+        self.dimension = dimension
+        self.down_kernels = downsample[0]
+        self.down_strides = downsample[1]
+        self.fpn_scales_from_top = fpn_scales_from_top
+        self.roi_scales_from_top = roi_scales_from_top
+        scale_num = len(nPlanesF)
+        assert len(self.down_kernels) == scale_num - 1 == len(self.down_strides)
+        assert all(len(ks) == 3 for ks in self.down_kernels)
+        assert all(len(ss) == 3 for ss in self.down_strides)
+        self._merge = "add"
+
+        ele_channels = {"xyz": 3, "color": 3, "normal": 3}
+        in_channels = sum(ele_channels[e] for e in raw_elements)
+        bn = dict(momentum=bn_momentum, track_running_stats=track_running_stats)
+
+        self.layers_in_0 = scn.Sequential(scn.InputLayer(dimension, full_scale, mode=4))
+        self.layers_in = scn.Sequential(
+            scn.InputLayer(dimension, full_scale, mode=4),
+            scn.SubmanifoldConvolution(dimension, in_channels, nPlanesF[0], 3, False))
+        # the reference also owns layers_out (BatchNormReLU + OutputLayer) and a 20-way linear
+        # head it never calls in forward (fpn_net.py:46-50); kept by name, minus OutputLayer
+        self.layers_out = scn.Sequential(scn.BatchNormReLU(nPlanesF[0], **bn))
+        self.linear = nn.Linear(nPlanesF[0], 20)
+        self.voxel_scale = voxel_scale
+        self.rpn_map_sizes = np.array(rpn_map_sizes)
+        self.rpn_3d_2d_selector = rpn_3d_2d_selector
+
+        self.convs_pro2d = nn.ModuleList()
+        for zsize in self.rpn_map_sizes[:, -1]:
+            self.convs_pro2d.append(scn.Convolution(self.dimension, nPlaneM, nPlaneM, [1, 1, int(zsize)],
+                                                    [1, 1, 1], False))
+
+        def block(m, a, b):
+            if residual_blocks:  # ResNet style
+                m.add(scn.ConcatTable()
+                      .add(scn.Identity() if a == b else scn.NetworkInNetwork(a, b, False))
+                      .add(scn.Sequential()
+                           .add(scn.BatchNormLeakyReLU(a, leakiness=leakiness, **bn))
+                           .add(scn.SubmanifoldConvolution(dimension, a, b, 3, False))
+                           .add(scn.BatchNormLeakyReLU(b, leakiness=leakiness, **bn))
+                           .add(scn.SubmanifoldConvolution(dimension, b, b, 3, False)))
+                      ).add(scn.AddTable())
+            else:  # VGG style
+                m.add(scn.Sequential()
+                      .add(scn.BatchNormLeakyReLU(a, leakiness=leakiness, **bn))
+                      .add(scn.SubmanifoldConvolution(dimension, a, b, 3, False)))
+            return {"kernel": [1, 1, 1], "stride": [1, 1, 1]}
+
+        def down(m, nPlane_in, nPlane_downed, scale):
+            m.add(scn.Sequential()
+                  .add(scn.BatchNormLeakyReLU(nPlane_in, leakiness=leakiness, **bn))
+                  .add(scn.Convolution(dimension, nPlane_in, nPlane_downed, self.down_kernels[scale],
+                                       self.down_strides[scale], False)))
+            return {"kernel": self.down_kernels[scale], "stride": self.down_strides[scale]}
+
+        def up(m, nPlane_in, nPlane_uped, scale):
+            m.add(scn.BatchNormLeakyReLU(nPlane_in, leakiness=leakiness, **bn)).add(
+                scn.Deconvolution(dimension, nPlane_in, nPlane_uped, self.down_kernels[scale],
+                                  self.down_strides[scale], False))
+            return {"kernel": self.down_kernels[scale], "stride": self.down_strides[scale]}
+
+        scales_num = len(nPlanesF)
+        m_downs = nn.ModuleList()
+        m_shortcuts = nn.ModuleList()
+        operations_down = []
+        for k in range(scales_num):
+            m = scn.Sequential()
+            if k > 0:
+                operations_down.append(down(m, nPlanesF[k - 1], nPlanesF[k], k - 1))
+            for _ in range(reps):
+                op = block(m, nPlanesF[k], nPlanesF[k])
+                if k == 0:
+                    operations_down.append(op)
+            m_downs.append(m)
+            m_shortcuts.append(scn.SubmanifoldConvolution(dimension, nPlanesF[k], nPlaneM, 1, False))
+
+        m_ups = nn.ModuleList()
+        m_mergeds = nn.ModuleList()
+        operations_up = []
+        for k in range(scales_num - 1, 0, -1):
+            m = scn.Sequential()
+            operations_up.append(up(m, nPlaneM, nPlaneM, k - 1))
+            m_ups.append(m)
+            m_mergeds.append(scn.SubmanifoldConvolution(dimension, nPlaneM, nPlaneM, 3, False))
+
+        self.m_downs = m_downs
+        self.m_shortcuts = m_shortcuts
+        self.m_ups = m_ups
+        self.m_mergeds = m_mergeds
+        self.operations_down = operations_down
+        self.operations_up = operations_up
+
+    def forward(self, net0):
+        net1 = self.layers_in(net0)
+        return self.forward_fpn(net1)
+
+    def forward_fpn(self, net):
+        scales_num = len(self.m_downs)
+        downs = []
+        for m in self.m_downs:
+            net = m(net)
+            downs.append(net)
+        net = self.m_shortcuts[-1](net)
+        ups = [net]
+        for k in range(scales_num - 1):
+            j = scales_num - 1 - k - 1
+            net = self.m_ups[k](net)
+            shorcut = self.m_shortcuts[j](downs[j])
+            net = scn.add_feature_planes([net, shorcut])
+            ups.append(self.m_mergeds[k](net))
+
+        rpn_maps_3d = [ups[i] for i in self.fpn_scales_from_top]
+        rpn_maps_2d = [self.convs_pro2d[i](rpn_maps_3d[i]) for i in range(len(rpn_maps_3d))]
+        rpn_maps = rpn_maps_3d + rpn_maps_2d
+        rpn_maps = [rpn_maps[i] for i in self.rpn_3d_2d_selector]
+        roi_maps = [ups[i] for i in self.roi_scales_from_top]
+        for i in range(len(rpn_maps_3d)):
+            assert torch.all(rpn_maps_3d[i].spatial_size == torch.tensor(self.rpn_map_sizes[i]))
+        return rpn_maps, roi_maps

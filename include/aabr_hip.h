@@ -1,0 +1,184 @@
+/*
+ * aabr_hip.h -- C ABI of libaabr_hip.so, the MI355X (gfx950) implementation of the
+ * sparse-3D detection hot path of xuyongzhi/Automatic-As-built-Reconstruction:
+ * voxel scatter -> hash grid -> rule tables -> sparse conv (MFMA) -> BN -> rotated IoU/NMS.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless its name ends in `_host`;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *    synchronises unless stated;
+ *  - every entry point returns 0 on success or a negative AABR_E* code;
+ *    aabr_last_error() returns a static message for the calling thread;
+ *  - row-major, contiguous arrays; features are float32 [rows, planes];
+ *    site coordinates are int32 [rows,4] = (x, y, z, batch); rule tables are
+ *    int32 [filter_volume][rows] "gather tables" (entry = partner row, or -1).
+ *
+ * The reference binds this path through two pybind11 extension modules
+ * (SparseConvNet/sparseconvnet/SCN/pybind.cpp:11-235 `sparseconvnet.SCN`,
+ *  maskrcnn_benchmark/csrc/vision.cpp:9-20 `_C`) whose arguments are at::Tensor /
+ * Metadata<3>&.  Each function below cites the reference interface it replaces;
+ * INTEGRATION.md shows the ctypes binding that reproduces the reference names.
+ */
+#ifndef AABR_HIP_H
+#define AABR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AABR_OK 0
+#define AABR_EINVAL (-1)  /* bad argument (null pointer, negative size, unsupported shape) */
+#define AABR_ELAUNCH (-2) /* HIP launch / runtime error */
+#define AABR_ERANGE (-3)  /* coordinate outside the supported [0, 65534] range */
+
+const char *aabr_last_error(void);
+int aabr_version(void);
+/* number of int32 words of the `meta` block written by the geometry builders */
+#define AABR_META_WORDS 8
+/* meta[0] = number of active sites, meta[1] = max points per site (input layer only),
+ * meta[2] = error flag (non-zero: coordinate out of range), meta[3] = total of 2nd scan lane */
+
+/* ---- hash grid ---------------------------------------------------------------------------
+ * A grid is an open-addressing table: keys uint64[cap] (packed b,x,y,z), vals int32[cap]
+ * (row of the site).  cap must be a power of two >= 2 * (number of inserted keys).
+ * Replaces SparseGrid / SparseGridMap (SCN/Metadata/Metadata.h:24-33).                       */
+
+/* Voxel scatter, geometry half -- replaces Metadata<3>::inputLayer -> inputLayerRules
+ * (SCN/Metadata/Metadata.cpp:405-417, IOLayersRules.h:18-125), modes 1..4.
+ *   coords       int64 [n, ncols] (ncols 3 or 4; 4th column = batch index)   (API layout)
+ *   keys, vals   hash grid storage, capacity cap (contents overwritten)
+ *   scratch      int32 [3*cap + 2*n + 4*nblk + 16] where nblk = ceil(n/1024)
+ *   point_site   int32 [n]   out: output row of every input row
+ *   site_coords  int32 [n,4] out: first V rows valid, first-seen order
+ *   site_off     int32 [n+1] out: CSR offsets of the per-site point lists (first V+1 valid)
+ *   site_pts     int32 [n]   out: point indices grouped by site, ascending inside a site
+ *   meta         int32 [AABR_META_WORDS] out (device): V, maxActive, error flag            */
+int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys,
+                           int32_t *vals, int64_t cap, int32_t *scratch, int32_t *point_site,
+                           int32_t *site_coords, int32_t *site_off, int32_t *site_pts,
+                           int32_t *meta, void *stream);
+
+/* Voxel scatter, feature half -- replaces InputLayer_ForwardPass / InputLayer_fp_
+ * (SCN/CPU/IOLayers.cpp:11-29, SCN/CUDA/IOLayers.cu:14-41).  mode: 1 keep-first-listed,
+ * 2 keep-last-listed, 3 sum, 4 mean (exactly the reference's mode table, ioLayers.py:33-38). */
+int aabr_input_layer_forward(const float *in_feats, float *out_feats, int64_t V, int planes,
+                             const int32_t *site_off, const int32_t *site_pts, int mode,
+                             void *stream);
+/* replaces InputLayer_BackwardPass / InputLayer_bp_ (CPU/IOLayers.cpp:30-47, IOLayers.cu:43-70) */
+int aabr_input_layer_backward(float *d_in_feats, const float *d_out_feats, int64_t n, int planes,
+                              const int32_t *point_site, const int32_t *site_off,
+                              const int32_t *site_pts, int mode, void *stream);
+
+/* Reference-format input rule table rules[1] (IOLayersRules.h:112-124): int32 [V, 1+maxActive]. */
+int aabr_input_layer_rule_table(const int32_t *site_off, const int32_t *site_pts, int64_t V,
+                                int max_active, int mode, int32_t *rules, void *stream);
+
+/* Submanifold rule table -- replaces Metadata<3>::getSubmanifoldRuleBook ->
+ * SubmanifoldConvolution_SgToRules (Metadata.cpp:429-443, SubmanifoldConvolutionRules.h:11-45).
+ * table[k*V + v] = row of the site at coords[v] + offset_k (offset enumeration of
+ * RectangularRegion::offset, RectangularRegions.h:30-38: z fastest), or -1.
+ * counts (int32 [vol], optional) receives the per-offset rule counts.                        */
+int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t *keys,
+                           const int32_t *vals, int64_t cap, const int32_t *filter_size_host,
+                           int32_t *table, int32_t *counts, void *stream);
+
+/* Strided convolution geometry -- replaces Metadata<3>::getRuleBook ->
+ * Convolution_InputSgToRulesAndOutputSg (Metadata.cpp:484-510, ConvolutionRules.h:11-34,
+ * RectangularRegions.h:95-119).  Creates the output grid (sites numbered in first-seen order
+ * over input rows ascending, then output-region order) and reports V_out in meta[0].
+ *   scratch int32 [3*out_cap + 2*E + 4*ceil(E/1024) + 16], E = V_in * max_out_per_in,
+ *   max_out_per_in = prod(ceil(size/stride)); out_site_coords int32 [E,4].                  */
+int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, const int32_t *size_host,
+                           const int32_t *stride_host, const int32_t *out_spatial_host,
+                           uint64_t *out_keys, int32_t *out_vals, int64_t out_cap,
+                           int32_t *scratch, int32_t *out_site_coords, int32_t *meta,
+                           void *stream);
+/* table_out[k*V_out + o] = input row at offset k of output o's window (or -1);
+ * table_in [k*V_in  + u] = output row whose window holds input u at offset k (or -1).       */
+int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
+                            const int32_t *in_vals, int64_t in_cap,
+                            const int32_t *out_coords, int64_t V_out, const uint64_t *out_keys,
+                            const int32_t *out_vals, int64_t out_cap, const int32_t *size_host,
+                            const int32_t *stride_host, const int32_t *out_spatial_host,
+                            int32_t *table_out, int32_t *table_in, int32_t *counts,
+                            void *stream);
+
+/* Reference-format rule book from a gather table: for offset k the (in,out) pairs in
+ * ascending `out` order -- the layout of RuleBook = vector<vector<Int>> (Metadata.h:34).
+ * rules int32 [vol][V][2] (first counts[k] pairs of each slab valid); in_col selects which
+ * column receives the table entry (0: table entry = input row; 1: swapped / deconvolution).  */
+int aabr_table_to_rulebook(const int32_t *table, int64_t V, int vol, int32_t *rules,
+                           int32_t *counts, void *stream);
+
+/* Metadata<3>::getSpatialLocations (Metadata.cpp:147-168): int32 [V,4] -> int64 [V,4]. */
+int aabr_spatial_locations(const int32_t *site_coords, int64_t V, int64_t *locations,
+                           void *stream);
+
+/* ---- sparse convolution (fp32 features, fp32 MFMA) ----------------------------------------
+ * out[o] = bias + sum_k in[table[k][o]] @ W[wk(k)]      (rows with table == -1 contribute 0)
+ * Replaces {Submanifold,}Convolution_updateOutput / Deconvolution_updateOutput
+ * (SCN/sparseconvnet_cuda.cpp:281-310; CPU/Convolution.cpp:45-79,117-149;
+ *  CPU/Deconvolution.cpp:7-41; CUDA/Convolution.cu:57-233,444-521,618-642).
+ *   W        float32 [vol, nIn, nOut]  (the reference's [vol, groups=1, nIn, nOut])
+ *   flags    bit0: use W[k]^T (input-gradient pass: `in` has nOut planes, `out` nIn planes,
+ *            CPU/Convolution.cpp:108-112); bit1: weight index vol-1-k (submanifold
+ *            input-gradient through the forward table).
+ *   wpack    float32 scratch, aabr_conv_wpack_floats(vol,nIn,nOut) elements
+ * Returns the reference's multiply-add count through *macs_host when counts_host given.      */
+int64_t aabr_conv_wpack_floats(int vol, int n_in, int n_out);
+int aabr_conv_forward(const float *in_feats, int n_in, float *out_feats, int n_out,
+                      int64_t V_out, const int32_t *table, int vol, const float *W,
+                      const float *bias, int flags, float *wpack, void *stream);
+/* dW[k] = sum_o in[table[k][o]]^T (x) d_out[o]; partials scratch float32
+ * [aabr_conv_dw_scratch_floats(...)]; d_bias (optional) = column sums of d_out.
+ * Replaces the dW half of *_backward (CPU/Convolution.cpp:81-115,151-185;
+ * CUDA/Convolution.cu:249-441,526-667).                                                     */
+int64_t aabr_conv_dw_scratch_floats(int64_t V_out, int vol, int n_in, int n_out);
+int aabr_conv_backward_weight(const float *in_feats, int n_in, const float *d_out, int n_out,
+                              int64_t V_out, const int32_t *table, int vol, float *dW,
+                              float *d_bias, float *scratch, void *stream);
+
+/* ---- batch normalisation + leaky ReLU ------------------------------------------------------
+ * Replaces BatchNormalization_updateOutput / _backward (SCN/CPU/BatchNormalization.cpp:12-157,
+ * SCN/CUDA/BatchNormalization.cu:14-238).  weight/bias may be NULL.  scratch: float32
+ * [aabr_bn_scratch_floats(planes)].                                                         */
+int64_t aabr_bn_scratch_floats(int planes);
+int aabr_bn_forward(const float *in, float *out, int64_t rows, int planes, float *save_mean,
+                    float *save_invstd, float *running_mean, float *running_var,
+                    const float *weight, const float *bias, float eps, float momentum,
+                    int train, float leakiness, float *scratch, void *stream);
+int aabr_bn_backward(const float *in, float *d_in, const float *out, const float *d_out,
+                     int64_t rows, int planes, const float *save_mean, const float *save_invstd,
+                     const float *weight, float *d_weight, float *d_bias, float leakiness,
+                     float *scratch, void *stream);
+
+/* ---- rotated IoU / NMS ---------------------------------------------------------------------
+ * iou[n,k] = devRotateIoUEval(query k, box n, criterion), then forced to 1 where the five
+ * parameters differ by < 1e-6 -- rotate_iou_gpu_eval + check_same_boxes
+ * (second/core/non_max_suppression/nms_gpu.py:552-717).  boxes [N,5], query [K,5]
+ * = (xc, yc, size_a, size_b, yaw).                                                           */
+int aabr_rotate_iou_eval(const float *boxes, int64_t N, const float *query, int64_t K,
+                         int criterion, float *iou, void *stream);
+/* boxes_iou_3d (utils3d/rotate_nms_3d_torch.py:23-90) on [.,7] yx_zb boxes;
+ * aug_host[4] = {target_Y, target_Z, anchor_Y, anchor_Z}.                                    */
+int aabr_boxes_iou_3d(const float *targets, int64_t M, const float *anchors, int64_t K,
+                      const float *aug_host, int criterion, int only_xy, float *iou,
+                      void *stream);
+/* Greedy rotated NMS over boxes already sorted by descending score: rotate_nms_3d_cc
+ * (second/core/non_max_suppression/nms_cpu.py:32-44) with the suppression rule of
+ * spconv-1.x rotate_non_max_suppression_cpu (IoU(i,j) > 0 and >= thresh).
+ *   boxes7 [n,7]; mask scratch uint64 [n * ceil(n/64)]; keep int64 [n] out (indices into the
+ *   sorted list, ascending = descending score); meta[0] = number kept (<= post_max).         */
+int aabr_rotate_nms_sorted(const float *boxes7, int64_t n, float thresh, int only_xy,
+                           int64_t post_max, uint64_t *mask, int64_t *keep, int32_t *meta,
+                           void *stream);
+/* maskrcnn_benchmark `_C.nms` (csrc/nms.h:10-28, csrc/cpu/nms_cpu.cpp:5-75,
+ * csrc/cuda/nms.cu:23-131): axis-aligned, +1 pixel convention; dets [n,4] sorted by
+ * descending score by the caller; keep = indices into the sorted list.                       */
+int aabr_nms_sorted(const float *dets4, int64_t n, float thresh, uint64_t *mask, int64_t *keep,
+                    int32_t *meta, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

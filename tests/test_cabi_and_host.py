@@ -1,0 +1,135 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the header
+declares, the host logic (module surface, spatial-size arithmetic, parameter inventory) matches
+the reference's contract, operators fail loudly without a GPU, and the kernels' IoU arithmetic
+(compiled for the host from the same header) agrees with the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import synth_scenes as S
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import _hip
+    hdr = open(os.path.join(REPO, "include", "aabr_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(aabr_\w+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = C.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libaabr_hip.so does not export %s" % name
+    assert set(_hip.EXPORTED_SYMBOLS) == declared  # the Python binding covers the whole header
+    assert _hip.load().aabr_version() >= 100
+
+
+def test_argument_validation_without_gpu():
+    """entry points validate before touching the device (no compute happens here)"""
+    import _hip
+    lib = _hip.load()
+    assert lib.aabr_input_layer_sites(None, -1, 3, None, None, 64, None, None, None, None, None, None, None) == -1
+    assert b"ncols" in lib.aabr_last_error()
+    assert lib.aabr_conv_forward(None, 0, None, 4, 10, None, 27, None, None, 0, None, None) == -1
+    assert lib.aabr_conv_wpack_floats(27, 32, 32) == 27 * 1 * 2 * 512
+    assert lib.aabr_conv_wpack_floats(27, 9, 32) == 27 * 1 * 2 * 512
+    assert lib.aabr_bn_scratch_floats(32) > 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_operators_fail_loudly_without_gpu():
+    import sparseconvnet as scn
+    import _hip
+    layer = scn.InputLayer(3, [64, 64, 64], mode=4)
+    with pytest.raises(_hip.AabrError):
+        layer([torch.zeros(4, 3, dtype=torch.long), torch.zeros(4, 2)])
+    from second.core.non_max_suppression.nms_gpu import rotate_iou_gpu_eval
+    with pytest.raises((_hip.AabrError, RuntimeError, AssertionError)):
+        rotate_iou_gpu_eval(np.zeros((2, 5), np.float32), np.zeros((2, 5), np.float32))
+
+
+def test_operator_surface_matches_reference_names():
+    import sparseconvnet as scn
+    for name in ("InputLayer", "SubmanifoldConvolution", "Convolution", "Deconvolution", "BatchNormalization",
+                 "BatchNormReLU", "BatchNormLeakyReLU", "Sequential", "ConcatTable", "AddTable", "JoinTable",
+                 "Identity", "NetworkInNetwork", "SparseConvNetTensor", "Metadata", "add_feature_planes", "FPN_Net"):
+        assert hasattr(scn, name), name
+    for name in ("InputLayer_updateOutput", "InputLayer_updateGradInput", "SubmanifoldConvolution_updateOutput",
+                 "SubmanifoldConvolution_backward", "Convolution_updateOutput", "Convolution_backward",
+                 "Deconvolution_updateOutput", "Deconvolution_backward", "BatchNormalization_updateOutput",
+                 "BatchNormalization_backward", "Metadata_3", "n_rulebook_bits"):
+        assert hasattr(scn.SCN, name), name
+    assert scn.SCN.n_rulebook_bits() == 32
+    from maskrcnn_benchmark.layers import nms  # noqa: F401
+    from maskrcnn_benchmark.structures.boxlist_ops_3d import boxlist_nms_3d, boxlist_iou_3d  # noqa: F401
+    from second.pytorch.core.box_torch_ops import rotate_nms_3d  # noqa: F401
+    from second.core.non_max_suppression.nms_cpu import rotate_nms_3d_cc  # noqa: F401
+    from second.core.non_max_suppression.nms_gpu import rotate_iou_gpu_eval  # noqa: F401
+    from utils3d.rotate_nms_3d_torch import boxes_iou_3d, iou_one_dim  # noqa: F401
+
+
+def default_fpn():
+    import sparseconvnet as scn
+    return scn.FPN_Net([4096, 4096, 512], 3, ["xyz", "color", "normal"], 1,
+                       [32, 64, 64, 128, 128, 128, 256, 256, 256], 128, True, [4, 3, 2, 1], [4, 3, 2, 1],
+                       [[[2, 2, 2]] * 8, [[2, 2, 2]] * 8],
+                       [[256, 256, 32], [128, 128, 16], [64, 64, 8], [32, 32, 4]], [1, 2, 3, 4, 5, 6], leakiness=0,
+                       voxel_scale=20, bn_momentum=0.95)
+
+
+def test_fpn_net_inventory_matches_reference_probe():
+    """SURVEY.md §2.2 / §8 A12 [probe of the reference]: 21,212,660 parameters, 36 SubmConv +
+    12 Conv + 8 Deconv + 35 BN, weight layout [vol, groups, nIn, nOut]."""
+    import sparseconvnet as scn
+    net = default_fpn()
+    assert sum(p.numel() for p in net.parameters()) == 21212660
+    mods = list(net.modules())
+    # layers_in is counted once; layers_out's BN is the 35th
+    assert sum(isinstance(m, scn.SubmanifoldConvolution) for m in mods) == 36
+    assert sum(isinstance(m, scn.Convolution) for m in mods) == 12
+    assert sum(isinstance(m, scn.Deconvolution) for m in mods) == 8
+    assert sum(isinstance(m, scn.BatchNormalization) for m in mods) == 35
+    assert tuple(net.layers_in[1].weight.shape) == (27, 1, 9, 32)
+    assert tuple(net.convs_pro2d[0].weight.shape) == (32, 1, 128, 128)
+    names = dict(net.named_parameters())
+    assert "m_downs.1.0.1.weight" in names and "m_mergeds.7.weight" in names
+    assert "m_downs.0.0.1.0.running_mean" in dict(net.named_buffers())
+
+
+def test_spatial_size_arithmetic():
+    import sparseconvnet as scn
+    conv = scn.Convolution(3, 4, 4, [2, 2, 2], [2, 2, 2], False)
+    assert conv.input_spatial_size(torch.LongTensor([128, 128, 16])).tolist() == [256, 256, 32]
+    dec = scn.Deconvolution(3, 4, 4, [2, 2, 2], [2, 2, 2], False)
+    assert dec.input_spatial_size(torch.LongTensor([256, 256, 32])).tolist() == [128, 128, 16]
+    # the full-scale chain of the default backbone: 4096,4096,512 halved 8 times
+    s = torch.LongTensor([4096, 4096, 512])
+    for _ in range(8):
+        s = (s - 2) // 2 + 1
+    assert s.tolist() == [16, 16, 2]
+
+
+def test_kernel_iou_arithmetic_on_host_matches_oracle(tmp_path):
+    so = str(tmp_path / "libhostiou.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
+                           os.path.join(REPO, "tests", "iou_math_host_harness.cpp")])
+    L = C.CDLL(so)
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    L.host_iou_eval.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_int, f32p]
+    b7, _ = S.make_nms_boxes(400, 7)
+    b5 = np.ascontiguousarray(b7[:, [0, 1, 3, 4, 6]])
+    b5[5] = b5[4]  # an exact duplicate pair
+    for crit in (-1, 0, 1, 2, 3, 4, 5, 6):
+        got = np.zeros((400, 400), np.float32)
+        L.host_iou_eval(b5, 400, b5, 400, crit, got)
+        np.testing.assert_array_equal(got, O.rotate_iou_eval(b5, b5, crit))
+    g = np.load(os.path.join(REPO, "tests", "golden", "iou_golden.npz"))
+    got = np.zeros((4, 4), np.float32)
+    L.host_iou_eval(g["t_boxes"], 4, g["t_boxes"], 4, -1, got)
+    np.testing.assert_array_equal(got, g["t_iou"])

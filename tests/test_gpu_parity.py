@@ -1,0 +1,455 @@
+"""Parity of the HIP path (through the reference-shaped Python boundary and the C ABI) against
+the CPU oracle, on a real MI355X.  Integer structures are compared bit-exactly; floating point
+within the tolerance written at each assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import ref_net
+import synth_scenes as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _scn():
+    import sparseconvnet as scn
+    return scn
+
+
+def _t(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def _rand_scene(rng, n, size, batch, C):
+    coords = np.stack([rng.integers(0, s, n) for s in size] + [np.sort(rng.integers(0, batch, n))], 1)
+    return coords.astype(np.int64), rng.standard_normal((n, C)).astype(np.float32)
+
+
+def _input(scn, coords, feats, spatial, mode=4):
+    layer = scn.InputLayer(3, list(spatial), mode=mode)
+    f = _t(feats).requires_grad_(True)
+    return layer([_t(coords), f]), f
+
+
+# ------------------------------------------------------------------------------------ input layer
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_input_layer_sites_rules_and_features_exact(mode):
+    scn = _scn()
+    rng = np.random.default_rng(10 + mode)
+    coords, feats = _rand_scene(rng, 5000, (12, 10, 6), 3, 7)  # heavy duplication (~3 pts / voxel)
+    x, f = _input(scn, coords, feats, (16, 16, 8), mode)
+    ref = O.input_layer(coords, feats, mode)
+    md = x.metadata
+    assert md.input["V"] == ref["V"]
+    np.testing.assert_array_equal(md.getSpatialLocations(x.spatial_size).numpy(), ref["coords"])
+    np.testing.assert_array_equal(md.input["point_site"].cpu().numpy(), ref["point_voxel"])
+    hdr, rules = md.inputLayerRuleBook()
+    assert hdr == [mode, ref["max_active"], 5000, ref["V"]]
+    np.testing.assert_array_equal(rules.cpu().numpy(), ref["rules"])
+    # same operation order, no FMA contraction -> bit-exact fp32
+    np.testing.assert_array_equal(x.features.detach().cpu().numpy(), ref["out"])
+    g = rng.standard_normal(ref["out"].shape).astype(np.float32)
+    x.features.backward(_t(g))
+    np.testing.assert_array_equal(f.grad.cpu().numpy(), O.input_layer_bwd(ref, g))
+
+
+def test_input_layer_edge_cases():
+    scn = _scn()
+    import _hip
+    # 3-column coordinates (no batch column), single point, all points in one voxel
+    for coords in (np.array([[3, 4, 5]], np.int64), np.tile(np.array([[7, 7, 7]], np.int64), (1000, 1)),
+                   np.array([[0, 0, 0], [65534, 65534, 65534], [0, 0, 0]], np.int64)):
+        feats = np.arange(coords.shape[0] * 2, dtype=np.float32).reshape(-1, 2)
+        x, _ = _input(scn, coords, feats, (70000, 70000, 70000), 4)
+        ref = O.input_layer(coords, feats, 4)
+        np.testing.assert_array_equal(x.features.detach().cpu().numpy(), ref["out"])
+        np.testing.assert_array_equal(x.get_spatial_locations().numpy()[:, :3], ref["coords"][:, :3])
+    # empty input
+    x, _ = _input(scn, np.zeros((0, 4), np.int64), np.zeros((0, 3), np.float32), (8, 8, 8), 4)
+    assert tuple(x.features.shape) == (0, 3) and x.get_spatial_locations().shape == (0, 4)
+    # out-of-range coordinates are rejected loudly
+    with pytest.raises(_hip.AabrError):
+        _input(scn, np.array([[1, 2, -3, 0]], np.int64), np.zeros((1, 2), np.float32), (8, 8, 8), 4)
+    with pytest.raises(_hip.AabrError):
+        _input(scn, np.array([[1, 2, 70000, 0]], np.int64), np.zeros((1, 2), np.float32), (8, 8, 8), 4)
+
+
+# ------------------------------------------------------------------------------------ rule books
+def _pairs_set(p):
+    return {(int(a), int(b)) for a, b in p}
+
+
+def test_submanifold_rulebook_exact():
+    scn = _scn()
+    rng = np.random.default_rng(20)
+    coords, feats = _rand_scene(rng, 4000, (20, 18, 9), 2, 3)
+    x, _ = _input(scn, coords, feats, (32, 32, 16), 3)
+    ref_il = O.input_layer(coords, feats, 3)
+    for fs in ([3, 3, 3], [1, 1, 1], [3, 1, 5]):
+        tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor(fs))
+        rb = O.submanifold_rules(ref_il["coords"], fs)
+        np.testing.assert_array_equal(tb.counts.cpu().numpy(), rb.counts)
+        got = scn.SCN.Metadata_3.tableToRuleBook(tb.out)
+        for k in range(rb.vol):  # same order too: ascending output row within an offset
+            np.testing.assert_array_equal(got[k].cpu().numpy(), rb.pairs(k))
+
+
+@pytest.mark.parametrize("fs,st", [([2, 2, 2], [2, 2, 2]), ([3, 3, 3], [2, 2, 2]), ([1, 1, 8], [1, 1, 1]),
+                                   ([4, 4, 4], [2, 2, 2])])
+def test_strided_rulebook_and_output_sites_exact(fs, st):
+    scn = _scn()
+    rng = np.random.default_rng(21)
+    size = np.array([17, 15, 8]) if fs != [1, 1, 8] else np.array([12, 12, 8])
+    if fs == [2, 2, 2]:
+        size = np.array([16, 16, 8])
+    if fs == [4, 4, 4]:
+        size = np.array([18, 18, 10])
+    coords, feats = _rand_scene(rng, 3000, tuple(size), 3, 3)
+    x, _ = _input(scn, coords, feats, tuple(size), 3)
+    ref_il = O.input_layer(coords, feats, 3)
+    osz = (size - np.array(fs)) // np.array(st) + 1
+    tb = x.metadata.getRuleBook(x.spatial_size, torch.LongTensor(osz), torch.LongTensor(fs), torch.LongTensor(st))
+    rb, oc = O.convolution_rules(ref_il["coords"], fs, st, osz)
+    # output sites: same set, same (insertion) order, batch-contiguous
+    np.testing.assert_array_equal(x.metadata.getSpatialLocations(torch.LongTensor(osz)).numpy(), oc)
+    np.testing.assert_array_equal(tb.counts.cpu().numpy(), rb.counts)
+    t_out = scn.SCN.Metadata_3.tableToRuleBook(tb.out)   # (in, out) pairs
+    t_in = scn.SCN.Metadata_3.tableToRuleBook(tb.inn)    # (out, in) pairs
+    for k in range(rb.vol):
+        want = _pairs_set(rb.pairs(k))
+        assert _pairs_set(t_out[k].cpu().numpy()) == want
+        assert {(b, a) for a, b in _pairs_set(t_in[k].cpu().numpy())} == want
+
+
+# ------------------------------------------------------------------------------------ convolutions
+CONV_SHAPES = [(9, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (16, 8), (5, 40), (128, 256)]
+
+
+@pytest.mark.parametrize("nIn,nOut", CONV_SHAPES)
+def test_submanifold_conv_forward_backward(nIn, nOut):
+    scn = _scn()
+    rng = np.random.default_rng(nIn * 1000 + nOut)
+    coords, feats = _rand_scene(rng, 2500, (14, 12, 6), 2, nIn)
+    x, f = _input(scn, coords, feats, (16, 16, 8), 4)
+    conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, nIn == 16).to(DEV)
+    if nIn == 16:
+        conv.bias.data.normal_()
+    y = conv(x)
+    il = O.input_layer(coords, feats, 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    W = conv.weight.detach().cpu().numpy().reshape(27, nIn, nOut)
+    bias = conv.bias.detach().cpu().numpy() if nIn == 16 else None
+    ref, macs = O.conv_fwd(il["out"], W, rb, il["V"], bias)
+    scale = np.abs(ref).max()
+    # fp32 MFMA (k-ordered fmaf chain) vs double-accumulated oracle
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=2e-6 * scale * nIn)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(_t(g))
+    d_in, dW, db = O.conv_bwd(il["out"], g, W, rb, want_bias=bias is not None)
+    d_feats = O.input_layer_bwd(il, d_in)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), d_feats, rtol=1e-4, atol=2e-6 * np.abs(d_feats).max() * nOut)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(27, nIn, nOut), dW, rtol=1e-4,
+                               atol=1e-5 * np.abs(dW).max())
+    if bias is not None:
+        np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), db, rtol=1e-4, atol=1e-4)
+
+
+def test_multiply_add_counter_matches_reference_definition():
+    scn = _scn()
+    rng = np.random.default_rng(31)
+    coords, feats = _rand_scene(rng, 1500, (10, 10, 6), 1, 8)
+    scn.forward_pass_multiplyAdd_count = 0
+    x, _ = _input(scn, coords, feats, (16, 16, 8), 4)
+    conv = scn.SubmanifoldConvolution(3, 8, 16, 3, False).to(DEV)
+    conv(x)
+    il = O.input_layer(coords, feats, 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    assert scn.forward_pass_multiplyAdd_count == rb.total * 8 * 16  # CPU/Convolution.cpp:141
+
+
+@pytest.mark.parametrize("fs,st,nIn,nOut", [([2, 2, 2], [2, 2, 2], 32, 64), ([2, 2, 2], [2, 2, 2], 64, 64),
+                                            ([1, 1, 8], [1, 1, 1], 128, 128), ([3, 3, 3], [2, 2, 2], 16, 24)])
+def test_strided_conv_and_deconv_forward_backward(fs, st, nIn, nOut):
+    scn = _scn()
+    rng = np.random.default_rng(40 + nIn)
+    size = np.array([16, 16, 8]) if fs != [3, 3, 3] else np.array([17, 17, 9])
+    coords, feats = _rand_scene(rng, 2500, tuple(size), 2, nIn)
+    x, f = _input(scn, coords, feats, tuple(size), 4)
+    conv = scn.Convolution(3, nIn, nOut, fs, st, False).to(DEV)
+    dec = scn.Deconvolution(3, nOut, nIn, fs, st, False).to(DEV)
+    y = conv(x)
+    z = dec(y)
+    assert z.spatial_size.tolist() == list(size)
+    il = O.input_layer(coords, feats, 4)
+    osz = (size - np.array(fs)) // np.array(st) + 1
+    rb, oc = O.convolution_rules(il["coords"], fs, st, osz)
+    Wc = conv.weight.detach().cpu().numpy().reshape(rb.vol, nIn, nOut)
+    Wd = dec.weight.detach().cpu().numpy().reshape(rb.vol, nOut, nIn)
+    yr, _ = O.conv_fwd(il["out"], Wc, rb, oc.shape[0])
+    zr, _ = O.conv_fwd(yr, Wd, rb, il["V"], in_col=1)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), yr, rtol=1e-4, atol=1e-5 * np.abs(yr).max())
+    np.testing.assert_allclose(z.features.detach().cpu().numpy(), zr, rtol=1e-4, atol=1e-5 * np.abs(zr).max())
+    g = rng.standard_normal(zr.shape).astype(np.float32)
+    z.features.backward(_t(g))
+    d_y, dWd, _ = O.conv_bwd(yr, g, Wd, rb, in_col=1)
+    d_x, dWc, _ = O.conv_bwd(il["out"], d_y, Wc, rb)
+    np.testing.assert_allclose(dec.weight.grad.cpu().numpy().reshape(Wd.shape), dWd, rtol=1e-4,
+                               atol=1e-5 * np.abs(dWd).max())
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(Wc.shape), dWc, rtol=1e-4,
+                               atol=1e-5 * np.abs(dWc).max())
+    d_feats = O.input_layer_bwd(il, d_x)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), d_feats, rtol=1e-4, atol=1e-5 * np.abs(d_feats).max())
+
+
+# ------------------------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize("planes,leak", [(32, 0.0), (64, 0.333), (128, 0.0), (9, 0.1), (256, 0.0)])
+def test_batchnorm_forward_backward(planes, leak):
+    scn = _scn()
+    rng = np.random.default_rng(50 + planes)
+    coords, feats = _rand_scene(rng, 6000, (24, 24, 8), 2, planes)
+    feats = (feats * 1.7 + 0.4).astype(np.float32)
+    x, f = _input(scn, coords, feats, (32, 32, 8), 4)
+    bn = scn.BatchNormLeakyReLU(planes, momentum=0.95, leakiness=leak).to(DEV)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_()
+    w, b = bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy()
+    y = bn(x)
+    il = O.input_layer(coords, feats, 4)
+    out, sm, si, rm, rv = O.bn_fwd(il["out"], w, b, np.zeros(planes), np.ones(planes), 1e-4, 0.95, True, leak)
+    # fp64 partial sums on the device vs sequential fp32 on the host (reference restatement)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), out, rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), rm, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), rv, rtol=1e-3)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    y.features.backward(_t(g))
+    d_in, dw, db, _ = O.bn_bwd(il["out"], out, g, sm, si, w, leak)
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), dw, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), db, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.input_layer_bwd(il, d_in), rtol=2e-3, atol=5e-4)
+    # eval mode uses the running statistics (BatchNormalization.cpp:42-47)
+    bn.eval()
+    ye = bn(x).features.detach().cpu().numpy()
+    oe, *_ = O.bn_fwd(il["out"], w, b, bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy(), 1e-4, 0.95,
+                      False, leak)
+    np.testing.assert_allclose(ye, oe, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ 2-stage slice
+def _two_stage_modules(scn, c_in):
+    torch.manual_seed(0)
+    m = dict(conv1=scn.SubmanifoldConvolution(3, c_in, 32, 3, False), bn1=scn.BatchNormLeakyReLU(32, momentum=0.95, leakiness=0),
+             conv2=scn.SubmanifoldConvolution(3, 32, 32, 3, False), bn2=scn.BatchNormLeakyReLU(32, momentum=0.95, leakiness=0),
+             conv3=scn.SubmanifoldConvolution(3, 32, 32, 3, False))
+    for v in m.values():
+        v.to(DEV)
+    return m
+
+
+def _run_two_stage(scn, m, locs, feats, g=None):
+    layer = scn.InputLayer(3, list(S.FULL_SCALE), mode=4)
+    f = _t(feats).requires_grad_(True)
+    x0 = layer([_t(locs), f])
+    x1 = m["conv1"](x0)
+    x3 = m["conv3"](m["bn2"](m["conv2"](m["bn1"](x1))))
+    out = scn.add_feature_planes([x1, x3])
+    if g is not None:
+        out.features.backward(_t(g))
+    return out, f
+
+
+@pytest.mark.parametrize("npts,batch", [(3000, 2), (80000, 1)])
+def test_two_stage_slice_matches_oracle(npts, batch):
+    """BASELINE.json configs[1] (and a small batched variant): scene -> voxel scatter -> 2-stage
+    submanifold backbone, forward and backward, against the oracle composition."""
+    scn = _scn()
+    locs, feats = S.make_batch(batch, npts, 0, 20)
+    m = _two_stage_modules(scn, 9)
+    P = lambda t: t.detach().cpu().numpy()
+    W1, W2, W3 = (P(m[k].weight).reshape(27, -1, 32) for k in ("conv1", "conv2", "conv3"))
+    bn = [dict(weight=P(m[k].weight), bias=P(m[k].bias), running_mean=np.zeros(32), running_var=np.ones(32))
+          for k in ("bn1", "bn2")]
+    c = ref_net.two_stage_forward(locs, feats, W1, W2, W3, bn[0], bn[1])
+    rng = np.random.default_rng(3)
+    g = rng.standard_normal(c["out"].shape).astype(np.float32)
+    out, f = _run_two_stage(scn, m, locs, feats, g)
+    if npts == 80000:
+        assert c["il"]["V"] == 66094 and c["rb"].total == 243374
+    assert out.features.shape[0] == c["il"]["V"]
+    np.testing.assert_array_equal(out.get_spatial_locations().numpy(), c["il"]["coords"])
+    np.testing.assert_allclose(P(out.features), c["out"], rtol=2e-3, atol=2e-4 * np.abs(c["out"]).max())
+    r = ref_net.two_stage_backward(c, g, W1, W2, W3, bn[0], bn[1])
+    for name, ref in (("conv1", r["dW1"]), ("conv2", r["dW2"]), ("conv3", r["dW3"])):
+        got = P(m[name].weight.grad).reshape(ref.shape)
+        np.testing.assert_allclose(got, ref, rtol=5e-3, atol=5e-4 * np.abs(ref).max())
+    np.testing.assert_allclose(P(m["bn1"].weight.grad), r["dbn1w"], rtol=5e-3, atol=5e-3 * np.abs(r["dbn1w"]).max())
+    np.testing.assert_allclose(P(m["bn2"].bias.grad), r["dbn2b"], rtol=5e-3, atol=5e-3 * np.abs(r["dbn2b"]).max())
+    np.testing.assert_allclose(P(f.grad), r["d_feats"], rtol=5e-3, atol=5e-4 * np.abs(r["d_feats"]).max())
+
+
+def test_full_size_properties():
+    """size-independent properties at the BASELINE configs[4]-style scale (1.5 M points @ 2 cm):
+    bit-reproducibility, linearity of the convolution, restoration of the fine grid."""
+    scn = _scn()
+    locs, feats = S.make_scene(1500000, 0, 50)
+    layer = scn.InputLayer(3, list(S.FULL_SCALE), mode=4)
+    conv = scn.SubmanifoldConvolution(3, 9, 32, 3, False).to(DEV)
+    down = scn.Convolution(3, 32, 32, 2, 2, False).to(DEV)
+    up = scn.Deconvolution(3, 32, 32, 2, 2, False).to(DEV)
+    with torch.no_grad():
+        l, f = _t(locs), _t(feats)
+        x = layer([l, f])
+        V = x.features.shape[0]
+        il = O.input_layer(locs, None, 4)
+        assert V == il["V"]
+        np.testing.assert_array_equal(x.get_spatial_locations().numpy()[:, :3], il["coords"][:, :3])
+        y1 = conv(x).features
+        x2 = layer([l, f])
+        y2 = conv(x2).features
+        assert torch.equal(y1, y2)  # deterministic: no atomics in the accumulation
+        # linearity: conv(a*x) == a*conv(x) up to rounding
+        xs = scn.SparseConvNetTensor(x.features * 2.0, x.metadata, x.spatial_size)
+        torch.testing.assert_close(conv(xs).features, y1 * 2.0, rtol=1e-6, atol=1e-6)
+        tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+        rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+        np.testing.assert_array_equal(tb.counts.cpu().numpy(), rb.counts)
+        # checksum of the rule table: sum over rules of (in + 3*out) per offset
+        t = tb.out.to(torch.int64)
+        rows = torch.arange(V, device=DEV, dtype=torch.int64)[None, :]
+        chk = torch.where(t >= 0, t + 3 * rows, torch.zeros_like(t)).sum(1).cpu().numpy()
+        want = np.array([(rb.pairs(k)[:, 0].astype(np.int64) + 3 * rb.pairs(k)[:, 1].astype(np.int64)).sum()
+                         for k in range(27)])
+        np.testing.assert_array_equal(chk, want)
+        xc = scn.SparseConvNetTensor(y1, x.metadata, x.spatial_size)
+        z = up(down(xc))
+        assert z.features.shape[0] == V and z.spatial_size.tolist() == list(S.FULL_SCALE)
+
+
+def test_fpn_net_forward_backward_runs_and_is_consistent():
+    """default 9-scale backbone on a small scene: map sizes, site consistency with the oracle's
+    strided geometry, finite gradients for every parameter."""
+    from test_cabi_and_host import default_fpn
+    scn = _scn()
+    torch.manual_seed(1)
+    net = default_fpn().to(DEV)
+    locs, feats = S.make_batch(2, 20000, 5, 20)
+    rpn_maps, roi_maps = net([_t(locs), _t(feats)])
+    assert len(rpn_maps) == 6 and len(roi_maps) == 4
+    il = O.input_layer(locs, None, 4)
+    sites = il["coords"]
+    size = np.array(S.FULL_SCALE)
+    expect = {}
+    for _ in range(8):
+        osz = (size - 2) // 2 + 1
+        rb, sites = O.convolution_rules(sites, [2, 2, 2], [2, 2, 2], osz)
+        size = osz
+        expect[tuple(size)] = sites
+    for mp in rpn_maps[:3] + roi_maps:
+        key = tuple(mp.spatial_size.tolist())
+        assert mp.features.shape == (expect[key].shape[0], 128)
+        np.testing.assert_array_equal(mp.get_spatial_locations().numpy(), expect[key])
+    loss = sum(m.features.square().mean() for m in rpn_maps)
+    loss.backward()
+    for n, p in net.named_parameters():
+        if n.startswith("linear") or n.startswith("layers_out"):
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    assert torch.isfinite(loss)
+
+
+# ------------------------------------------------------------------------------------ IoU / NMS
+def test_rotate_iou_matrix_vs_oracle_and_golden(golden_dir):
+    from second.core.non_max_suppression.nms_gpu import rotate_iou_gpu_eval
+    g = np.load(os.path.join(golden_dir, "iou_golden.npz"))
+    # device cosf/sinf/sqrtf may differ from the host's by an ulp: 1e-5 absolute (SURVEY §8c quotes 1e-6
+    # for the reference's own host-vs-device discrepancy on well-conditioned pairs)
+    np.testing.assert_allclose(rotate_iou_gpu_eval(g["t_boxes"], g["t_boxes"]), g["t_iou"], atol=1e-5)
+    np.testing.assert_allclose(rotate_iou_gpu_eval(g["hw_boxes"], g["hw_boxes"], -1), g["hw_iou_c-1"], atol=1e-5)
+    np.testing.assert_allclose(rotate_iou_gpu_eval(g["lab_gt"], g["lab_anchor"], 6), g["lab_iou_c6"], atol=1e-5)
+    b7, _ = S.make_nms_boxes(700, 11)
+    b5 = np.ascontiguousarray(b7[:, [0, 1, 3, 4, 6]])
+    for crit in (-1, 0, 1, 2, 6):
+        got = rotate_iou_gpu_eval(b5[:300], b5[300:], crit)
+        np.testing.assert_allclose(got, O.rotate_iou_eval(b5[:300], b5[300:], crit), atol=2e-5)
+    assert rotate_iou_gpu_eval(np.zeros((0, 5), np.float32), b5).shape == (0, 700)
+
+
+def test_boxes_iou_3d_with_clamps():
+    from utils3d.rotate_nms_3d_torch import boxes_iou_3d
+    import _nms
+    b7, _ = S.make_nms_boxes(400, 12)
+    aug = {"target_Y": 0.3, "target_Z": 0.0, "anchor_Y": 0.0, "anchor_Z": 0.0}
+    got = boxes_iou_3d(_t(b7[:40]), _t(b7[40:]), aug, 6, flag="rpn_label_generation").cpu().numpy()
+    np.testing.assert_allclose(got, O.boxes_iou_3d(b7[:40], b7[40:], (0.3, 0, 0, 0), 6, True), atol=2e-5)
+    full = _nms.boxes_iou_3d(_t(b7[:40]), _t(b7[40:]), (0.1, 2.5, 0.2, 2.6), -1, only_xy=False).cpu().numpy()
+    np.testing.assert_allclose(full, O.boxes_iou_3d(b7[:40], b7[40:], (0.1, 2.5, 0.2, 2.6), -1, False), atol=2e-5)
+
+
+@pytest.mark.parametrize("n,post,thr", [(2000, 1000, 0.5), (2000, 100, 0.3), (777, 1000, 0.7), (64, 10, 0.1),
+                                        (1, 5, 0.5)])
+def test_rotate_nms_3d_survivors_exact(n, post, thr):
+    from second.pytorch.core.box_torch_ops import rotate_nms_3d
+    b7, sc = S.make_nms_boxes(n, 13 + n)
+    want = O.rotate_nms_3d(b7, sc, 2000, post, thr)
+    # survivors are bit-exact unless an IoU sits within rounding distance of the threshold
+    iou = O.boxes_iou_3d(b7, b7)
+    assert (np.abs(iou - thr) > 1e-4).all()
+    got = rotate_nms_3d(_t(b7), _t(sc), pre_max_size=2000, post_max_size=post, iou_threshold=thr, flag="rpn_post")
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_nms_degenerate_inputs():
+    from second.pytorch.core.box_torch_ops import rotate_nms_3d
+    from maskrcnn_benchmark.structures.boxlist_ops_3d import boxlist_nms_3d
+    assert rotate_nms_3d(torch.zeros(0, 7, device=DEV), torch.zeros(0, device=DEV), 2000, 100, 0.5).numel() == 0
+    # identical boxes: IoU forced to 1 -> only the best-scored survives
+    b = np.tile(np.array([[1, 1, 0, 0.2, 3, 2.5, 0.3]], np.float32), (130, 1))
+    sc = np.linspace(0, 1, 130).astype(np.float32)
+    k = rotate_nms_3d(_t(b), _t(sc), 2000, 1000, 0.5).cpu().numpy()
+    assert k.tolist() == [129]
+    # disjoint boxes: everything survives, in descending score order
+    b2 = b.copy()
+    b2[:, 0] = np.arange(130) * 10
+    k = rotate_nms_3d(_t(b2), _t(sc), 2000, 1000, 0.5).cpu().numpy()
+    assert k.tolist() == list(range(129, -1, -1))
+
+    class BL(object):  # duck-typed BoxList3D
+        mode = "yx_zb"
+
+        def __init__(self, b, s):
+            self.bbox3d, self.s = b, s
+
+        def get_field(self, _):
+            return self.s
+
+        def __len__(self):
+            return self.bbox3d.shape[0]
+
+        def __getitem__(self, idx):
+            return BL(self.bbox3d[idx], self.s[idx])
+
+    b7, s = S.make_nms_boxes(500, 99)
+    out = boxlist_nms_3d(BL(_t(b7), _t(s)), 0.5, [0.3, 0.3], 400, flag="rpn_post")
+    bc = b7.copy()
+    bc[:, 3:5] = np.maximum(bc[:, 3:5], 0.3)
+    bc[:, 5] = np.maximum(bc[:, 5], 0.3)
+    want = O.rotate_nms_3d(bc, s, 2000, 400, 0.5)
+    np.testing.assert_array_equal(out.s.cpu().numpy(), s[want])
+
+
+def test_axis_aligned_nms_matches_reference_cpu_rule():
+    from maskrcnn_benchmark.layers import nms
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(0, 100, (600, 2))
+    wh = rng.uniform(5, 40, (600, 2))
+    dets = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    sc = rng.random(600).astype(np.float32)
+    got = nms(_t(dets), _t(sc), 0.4).cpu().numpy()
+    np.testing.assert_array_equal(got, O.nms_axis_aligned(dets, sc, 0.4))
