@@ -308,8 +308,9 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, float *out_fea
   const int transpose = flags & 1, flip = (flags >> 1) & 1;
   const int nkc = nkc_of(n_in), nnb = nnb_of(n_out);
   int64_t total = (int64_t)vol * nkc * nnb * 512;
-  hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, W, vol, n_in,
-                     n_out, transpose, flip, wpack);
+  if (!(flags & 4)) // bit2: wpack already holds the packed weights of this (W, flags) pair
+    hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, W, vol, n_in,
+                       n_out, transpose, flip, wpack);
   const bool aligned = (n_in % kKC) == 0;
   // waves per workgroup chosen so the wave-private LDS tiles stay under 64 KiB per workgroup
 #define AABR_LAUNCH_CONV(NBW, WPB)                                                                      \

@@ -104,10 +104,15 @@ class Metadata_3(object):
         site_off = torch.empty(n + 1, dtype=torch.int32, device=device)
         site_pts = torch.empty(max(n, 1), dtype=torch.int32, device=device)
         meta = torch.empty(_hip.META_WORDS, dtype=torch.int32, device=device)
-        check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, ptr(keys), ptr(vals), cap, ptr(scratch),
-                                         ptr(point_site), ptr(site_coords), ptr(site_off), ptr(site_pts),
-                                         ptr(meta), stream()))
-        m = meta.tolist()  # the one host sync of the input layer: V sizes every later tensor
+        if n > 0:
+            check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, ptr(keys), ptr(vals), cap, ptr(scratch),
+                                             ptr(point_site), ptr(site_coords), ptr(site_off), ptr(site_pts),
+                                             ptr(meta), stream()))
+            m = meta.tolist()  # the one host sync of the input layer: V sizes every later tensor
+        else:  # empty scene: an empty grid (all keys EMPTY), nothing to launch
+            keys.fill_(-1)
+            site_off.zero_()
+            m = [0] * _hip.META_WORDS
         if m[2]:
             raise _hip.AabrError("InputLayer: coordinates must lie in [0, 65534] (batch index too)")
         V = m[0]

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- scenes/s (fwd+bwd) of the sparse-3D hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): one synthetic SUNCG-shaped scene per step (~80k points,
+5 cm voxels, C_in = 9, bs = 1) -> HIP voxel scatter (InputLayer mode 4, hash grid + rule table
+built on the device every step) -> 2-stage submanifold backbone (SubmConv3 9->32, residual
+block BNReLU-SubmConv3-BNReLU-SubmConv3 32->32, add), fp32, forward + backward (all weight
+gradients and the input-feature gradient) + gradient all-reduce (N > 1) + SGD update.
+Inputs are resident in HBM before the timed region.  One process per GPU; ranks take
+different scenes (weak scaling), the only collective is the gradient all-reduce.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the output-stationary
+MFMA gather-GEMM, k_conv_gather_mfma, 32->32 forward instance) timed with HIP events on the
+stream it is launched on; `cpu_baseline` is the oracle (CPU port of the reference path) timed
+on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+importlib.import_module("automatic-as-built-reconstruction_amd")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import synth_scenes as S  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+
+
+def build_model(scn, dev, c_in=9):
+    torch.manual_seed(0)
+    m = dict(inp=scn.InputLayer(3, list(S.FULL_SCALE), mode=4),
+             conv1=scn.SubmanifoldConvolution(3, c_in, 32, 3, False).to(dev),
+             bn1=scn.BatchNormLeakyReLU(32, momentum=0.95, leakiness=0).to(dev),
+             conv2=scn.SubmanifoldConvolution(3, 32, 32, 3, False).to(dev),
+             bn2=scn.BatchNormLeakyReLU(32, momentum=0.95, leakiness=0).to(dev),
+             conv3=scn.SubmanifoldConvolution(3, 32, 32, 3, False).to(dev))
+    return m
+
+
+def forward(scn, m, locs, feats):
+    x0 = m["inp"]([locs, feats])
+    x1 = m["conv1"](x0)
+    x3 = m["conv3"](m["bn2"](m["conv2"](m["bn1"](x1))))
+    return scn.add_feature_planes([x1, x3])
+
+
+def cpu_baseline(n_scenes_budget_s=15.0):
+    """oracle (CPU port of the reference path) on the same workload, bounded sample"""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_lib as O
+    import ref_net
+    rng = np.random.default_rng(0)
+    W1 = (rng.standard_normal((27, 9, 32)) * 0.09).astype(np.float32)
+    W2 = (rng.standard_normal((27, 32, 32)) * 0.05).astype(np.float32)
+    W3 = (rng.standard_normal((27, 32, 32)) * 0.05).astype(np.float32)
+    bn = dict(weight=np.ones(32, np.float32), bias=np.zeros(32, np.float32), running_mean=np.zeros(32),
+              running_var=np.ones(32))
+    locs, feats = S.make_batch(1, 80000, 0, 20)
+    done, t0 = 0, time.time()
+    while True:
+        c = ref_net.two_stage_forward(locs, feats, W1, W2, W3, bn, bn)
+        ref_net.two_stage_backward(c, np.ones_like(c["out"]), W1, W2, W3, bn, bn)
+        done += 1
+        el = time.time() - t0
+        if el > n_scenes_budget_s or done >= 64:
+            break
+    return dict(value=round(done / el, 3), unit="scenes/s", cores=O.num_threads(), kind="port",
+                sample="%d x S80k@5cm scene, voxel scatter + rule book + 2-stage fwd+bwd, %.1f s of CPU work, "
+                       "OpenMP over %d threads" % (done, el, O.num_threads()))
+
+
+def time_dominant_kernel(scn, m, scene, reps=30):
+    """average launch duration of k_conv_gather_mfma (32->32 forward, S80k rule table) with HIP
+    events recorded on the stream the kernel is launched on (torch's current stream)."""
+    import _hip
+    from _hip import ptr, stream, check
+    lib = _hip.load()
+    with torch.no_grad():
+        x0 = m["inp"]([scene[0], scene[1]])
+        y1 = m["bn1"](m["conv1"](x0))
+        tb = x0.metadata.getSubmanifoldRuleBook(x0.spatial_size, torch.LongTensor([3, 3, 3]))
+        inp = y1.features.contiguous()
+        V = inp.size(0)
+        out = torch.empty((V, 32), device=inp.device)
+        w = m["conv2"].weight.detach().contiguous()
+        wpack = torch.empty(lib.aabr_conv_wpack_floats(27, 32, 32), device=inp.device)
+        check(lib.aabr_conv_forward(ptr(inp), 32, ptr(out), 32, V, ptr(tb.out), 27, ptr(w), None, 0, ptr(wpack),
+                                    stream()))
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            check(lib.aabr_conv_forward(ptr(inp), 32, ptr(out), 32, V, ptr(tb.out), 27, ptr(w), None, 4,
+                                        ptr(wpack), stream()))
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        ms = ms[: max(1, len(ms) * 3 // 4)]  # drop the slow tail (first-touch / clock ramp)
+        R = tb.total_rules()
+        return sum(ms) / len(ms) * 1e-3, R, V
+
+
+def time_stage(fn, reps=10):
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank, cycled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import sparseconvnet as scn
+    import dp
+    m = build_model(scn, dev)
+    flat = dp.FlatParams([v for k, v in m.items() if k != "inp"])
+    flat.broadcast(0)
+
+    # resident inputs: `scenes` distinct scenes per rank (different seeds on every rank)
+    scenes = []
+    for i in range(args.scenes):
+        locs, feats = S.make_batch(1, 80000, 1000 * rank + i, 20)
+        scenes.append((torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)))
+    grads = []
+    with torch.no_grad():
+        for sc in scenes:
+            o = forward(scn, m, sc[0], sc[1])
+            g = torch.Generator(device=dev).manual_seed(7)
+            grads.append(torch.randn(o.features.shape, device=dev, generator=g))
+    feats_req = [(sc[0], sc[1].clone().requires_grad_(True)) for sc in scenes]
+
+    def step(i):
+        j = i % len(scenes)
+        flat.zero_grad()
+        out = forward(scn, m, feats_req[j][0], feats_req[j][1])
+        out.features.backward(grads[j])
+        feats_req[j][1].grad = None
+        flat.allreduce_mean(world)
+        flat.sgd_step(1e-4)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        ksec, R, V = time_dominant_kernel(scn, m, scenes[0])
+        flops = 2.0 * R * 32 * 32
+        roof = dict(kernel="k_conv_gather_mfma<2,4,true> (SubmConv3 32->32 forward)", bound="mfma",
+                    achieved=round(flops / ksec / 1e12, 4), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(flops / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5), traffic=None,
+                    launch_us=round(ksec * 1e6, 2), rules=int(R), sites=int(V),
+                    algorithmic_flops_per_launch=flops)
+        # voxel scatter (A1+A2): N*(32 + 4*C_in) + V*(4*C_in + 16) algorithmic bytes
+        N = scenes[0][0].shape[0]
+        with torch.no_grad():
+            t_sc = time_stage(lambda: m["inp"]([scenes[0][0], scenes[0][1]]))
+        sc_bytes = N * (32 + 4 * 9) + V * (4 * 9 + 16)
+        scatter = dict(bytes=sc_bytes, seconds=round(t_sc, 7), achieved_gbs=round(sc_bytes / t_sc / 1e9, 2),
+                       frac_of_hbm_peak=round(sc_bytes / t_sc / 1e9 / PEAK_HBM_GBS, 5),
+                       note="whole InputLayer call incl. hash build, site numbering, host read of V")
+        line = {
+            "metric": "scenes/sec (fwd+bwd)", "value": round(world * args.steps / el, 2), "unit": "scenes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S80k@5cm scene (79,998 pts -> ~66k voxels), voxel scatter + 2-stage "
+                                   "SubmanifoldConvolution backbone (9->32, residual 32->32 x2), fwd+bwd+SGD, "
+                                   "bs=1 per GPU (BASELINE.json configs[1])",
+                       "global_batch": world, "points_per_scene": int(N), "parallelism": "dp%d" % world},
+            "roofline": roof, "voxel_scatter": scatter,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

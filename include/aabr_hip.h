@@ -122,7 +122,8 @@ int aabr_spatial_locations(const int32_t *site_coords, int64_t V, int64_t *locat
  *   W        float32 [vol, nIn, nOut]  (the reference's [vol, groups=1, nIn, nOut])
  *   flags    bit0: use W[k]^T (input-gradient pass: `in` has nOut planes, `out` nIn planes,
  *            CPU/Convolution.cpp:108-112); bit1: weight index vol-1-k (submanifold
- *            input-gradient through the forward table).
+ *            input-gradient through the forward table); bit2: `wpack` already holds the packed
+ *            weights for this (W, flags) pair (skips the repack launch).
  *   wpack    float32 scratch, aabr_conv_wpack_floats(vol,nIn,nOut) elements
  * Returns the reference's multiply-add count through *macs_host when counts_host given.      */
 int64_t aabr_conv_wpack_floats(int vol, int n_in, int n_out);

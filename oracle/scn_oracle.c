@@ -59,7 +59,7 @@ static inline int64_t pack_key(int64_t b, int64_t x, int64_t y, int64_t z) {
   return ((b & 0xffff) << 48) | (((x + 1) & 0xffff) << 32) |
          (((y + 1) & 0xffff) << 16) | ((z + 1) & 0xffff);
 }
-static inline int coord_ok(int64_t v) { return v >= -1 && v < 65534; }
+static inline int coord_ok(int64_t v) { return v >= -1 && v <= 65534; }
 
 static inline uint64_t mix64(uint64_t k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33;

@@ -258,11 +258,19 @@ def _run_two_stage(scn, m, locs, feats, g=None):
     f = _t(feats).requires_grad_(True)
     x0 = layer([_t(locs), f])
     x1 = m["conv1"](x0)
-    x3 = m["conv3"](m["bn2"](m["conv2"](m["bn1"](x1))))
+    y1 = m["bn1"](x1)
+    x2 = m["conv2"](y1)
+    y2 = m["bn2"](x2)
+    x3 = m["conv3"](y2)
     out = scn.add_feature_planes([x1, x3])
     if g is not None:
         out.features.backward(_t(g))
-    return out, f
+    acts = dict(x0=x0, x1=x1, y1=y1, x2=x2, y2=y2, x3=x3)
+    return out, f, {k: v.features.detach().cpu().numpy() for k, v in acts.items()}
+
+
+def _relerr(got, ref):
+    return float(np.linalg.norm(got.astype(np.float64) - ref) / (np.linalg.norm(ref.astype(np.float64)) + 1e-30))
 
 
 @pytest.mark.parametrize("npts,batch", [(3000, 2), (80000, 1)])
@@ -279,18 +287,35 @@ def test_two_stage_slice_matches_oracle(npts, batch):
     c = ref_net.two_stage_forward(locs, feats, W1, W2, W3, bn[0], bn[1])
     rng = np.random.default_rng(3)
     g = rng.standard_normal(c["out"].shape).astype(np.float32)
-    out, f = _run_two_stage(scn, m, locs, feats, g)
+    out, f, acts = _run_two_stage(scn, m, locs, feats, g)
     if npts == 80000:
         assert c["il"]["V"] == 66094 and c["rb"].total == 243374
     assert out.features.shape[0] == c["il"]["V"]
     np.testing.assert_array_equal(out.get_spatial_locations().numpy(), c["il"]["coords"])
+    np.testing.assert_array_equal(acts["x0"], c["x0"])          # voxel means: bit-exact
+    # forward chain: fp32 MFMA + fp64-partial BN statistics vs the oracle's double-accumulated
+    # GEMM + sequential-fp32 BN statistics (the reference's own arithmetic)
+    for k in ("x1", "y1", "x2", "y2", "x3"):
+        assert _relerr(acts[k], c[k]) < 2e-4, k
     np.testing.assert_allclose(P(out.features), c["out"], rtol=2e-3, atol=2e-4 * np.abs(c["out"]).max())
-    r = ref_net.two_stage_backward(c, g, W1, W2, W3, bn[0], bn[1])
+    # backward: ReLU masks are taken from the forward activations, and an activation within
+    # rounding distance of 0 may fall on the other side; so the oracle backward is evaluated on
+    # the device's own forward activations (identical masks), which isolates the backward kernels
+    flips = int(((acts["y1"] > 0) != (c["y1"] > 0)).sum() + ((acts["y2"] > 0) != (c["y2"] > 0)).sum())
+    assert flips <= 1e-5 * acts["y1"].size + 2
+    cg = dict(c)
+    cg.update(acts)
+    r = ref_net.two_stage_backward(cg, g, W1, W2, W3, bn[0], bn[1])
     for name, ref in (("conv1", r["dW1"]), ("conv2", r["dW2"]), ("conv3", r["dW3"])):
         got = P(m[name].weight.grad).reshape(ref.shape)
-        np.testing.assert_allclose(got, ref, rtol=5e-3, atol=5e-4 * np.abs(ref).max())
-    np.testing.assert_allclose(P(m["bn1"].weight.grad), r["dbn1w"], rtol=5e-3, atol=5e-3 * np.abs(r["dbn1w"]).max())
-    np.testing.assert_allclose(P(m["bn2"].bias.grad), r["dbn2b"], rtol=5e-3, atol=5e-3 * np.abs(r["dbn2b"]).max())
+        assert _relerr(got, ref) < 2e-4, name
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
+    for name, ref in (("bn1.weight", r["dbn1w"]), ("bn1.bias", r["dbn1b"]), ("bn2.weight", r["dbn2w"]),
+                      ("bn2.bias", r["dbn2b"])):
+        mod, attr = name.split(".")
+        got = P(getattr(m[mod], attr).grad)
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    assert _relerr(P(f.grad), r["d_feats"]) < 5e-4
     np.testing.assert_allclose(P(f.grad), r["d_feats"], rtol=5e-3, atol=5e-4 * np.abs(r["d_feats"]).max())
 
 
@@ -358,8 +383,8 @@ def test_fpn_net_forward_backward_runs_and_is_consistent():
     loss = sum(m.features.square().mean() for m in rpn_maps)
     loss.backward()
     for n, p in net.named_parameters():
-        if n.startswith("linear") or n.startswith("layers_out"):
-            continue
+        if n.startswith("linear") or n.startswith("layers_out") or n.startswith("convs_pro2d.3"):
+            continue  # never reached by forward (rpn_3d_2d_selector drops the last 2-D map)
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
     assert torch.isfinite(loss)
 
@@ -398,11 +423,25 @@ def test_rotate_nms_3d_survivors_exact(n, post, thr):
     from second.pytorch.core.box_torch_ops import rotate_nms_3d
     b7, sc = S.make_nms_boxes(n, 13 + n)
     want = O.rotate_nms_3d(b7, sc, 2000, post, thr)
-    # survivors are bit-exact unless an IoU sits within rounding distance of the threshold
-    iou = O.boxes_iou_3d(b7, b7)
-    assert (np.abs(iou - thr) > 1e-4).all()
     got = rotate_nms_3d(_t(b7), _t(sc), pre_max_size=2000, post_max_size=post, iou_threshold=thr, flag="rpn_post")
-    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got = got.cpu().numpy()
+    # Survivors are bit-exact unless some pair's IoU lies within rounding distance of the threshold
+    # (device cosf/sinf vs libm).  Find such pairs from the device's own IoU matrix; if there are
+    # none the keep lists must be identical, otherwise the device list must equal the oracle's
+    # greedy rule applied to the device matrix and the disagreeing pairs must be razor-edge.
+    import _nms
+    idx = np.argsort(-sc, kind="stable")[: min(n, 2000)]
+    b = b7[idx]
+    iou_o = O.boxes_iou_3d(b, b)
+    iou_d = _nms.boxes_iou_3d(_t(b), _t(b), (0, 0, 0, 0), -1, True).cpu().numpy()
+    np.testing.assert_allclose(iou_d, iou_o, atol=2e-5)
+    amb = (iou_d >= thr) != (iou_o >= thr)
+    if not amb.any():
+        np.testing.assert_array_equal(got, want)
+    else:
+        assert (np.abs(iou_o[amb] - thr) < 2e-5).all()
+        keep = O.nms_from_matrix(iou_d, np.arange(len(idx), dtype=np.int32), thr)[:post]
+        np.testing.assert_array_equal(got, idx[keep])
 
 
 def test_nms_degenerate_inputs():
