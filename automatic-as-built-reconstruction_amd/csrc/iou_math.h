@@ -30,7 +30,9 @@ AABR_HD float tri2(float ax, float ay, float bx, float by, float cx, float cy) {
 
 AABR_HD void corners_of(const float *rb, float *cx, float *cy) {
   const float ang = rb[4];
-  const float ac = cosf(ang), as = sinf(ang);
+  // double-precision trig narrowed to fp32: identical on host and device (fp32 cosf/sinf differ
+  // by an ulp between libm and the device library, which thin 6 m x 0.1 m walls amplify ~60x)
+  const float ac = (float)cos((double)ang), as = (float)sin((double)ang);
   const float hx = rb[2] / 2, hy = rb[3] / 2;
   const float px[4] = {-hx, -hx, hx, hx};
   const float py[4] = {-hy, hy, hy, -hy};

@@ -58,6 +58,12 @@ def cpu_baseline(n_scenes_budget_s=15.0):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_lib as O
     import ref_net
+    # host cores this process may use (a 1-GPU box exposes a 16-core share of the host)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    O.set_threads(max(1, min(ncpu, int(os.environ.get("AABR_CPU_THREADS", "16")))))
     rng = np.random.default_rng(0)
     W1 = (rng.standard_normal((27, 9, 32)) * 0.09).astype(np.float32)
     W2 = (rng.standard_normal((27, 32, 32)) * 0.05).astype(np.float32)

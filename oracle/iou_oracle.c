@@ -134,7 +134,9 @@ static int quad_intersection(const float *p1, const float *p2, float *ip) {
 }
 
 static void box_corners(float *c, const float *rb) {
-  float ang = rb[4], ac = cosf(ang), as = sinf(ang);
+  /* math.cos / math.sin evaluate in double; the product with a float32 operand narrows the
+   * factor to float32 first (rbbox_to_corners, nms_gpu.py:358-359,375-378) */
+  float ang = rb[4], ac = (float)cos((double)ang), as = (float)sin((double)ang);
   float cx = rb[0], cy = rb[1], xd = rb[2], yd = rb[3];
   float px[4] = {-xd / 2, -xd / 2, xd / 2, xd / 2};
   float py[4] = {-yd / 2, yd / 2, yd / 2, -yd / 2};

@@ -524,6 +524,13 @@ void oracle_bn_bwd(const float *in, float *d_in, const float *out,
   free(gradMean); free(dotp); free(kk);
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

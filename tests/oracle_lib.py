@@ -46,6 +46,7 @@ def lib():
         L.oracle_nms_axis_aligned.restype = C.c_int64
         L.oracle_nms_axis_aligned.argtypes = [f32p, f32p, C.c_int64, C.c_float, i64p]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_region_points.restype = C.c_int64
         L.oracle_region_points.argtypes = [i64p, i64p, i64p]
         L.oracle_region_offset.restype = C.c_int32
@@ -63,6 +64,11 @@ def _opt(a):
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+    return num_threads()
 
 
 # ---------------------------------------------------------------- input layer

@@ -383,8 +383,13 @@ def test_fpn_net_forward_backward_runs_and_is_consistent():
     loss = sum(m.features.square().mean() for m in rpn_maps)
     loss.backward()
     for n, p in net.named_parameters():
-        if n.startswith("linear") or n.startswith("layers_out") or n.startswith("convs_pro2d.3"):
-            continue  # never reached by forward (rpn_3d_2d_selector drops the last 2-D map)
+        # not reached from the selected maps: fpn_scales_from_top = [4,3,2,1] uses ups[1..4] only, so the
+        # four finest up-path stages (and their lateral shortcuts) and the dropped 2-D head get no gradient
+        dead = ("linear", "layers_out", "convs_pro2d.3") + tuple(
+            "%s.%d." % (a, i) for a, r in (("m_shortcuts", range(0, 4)), ("m_ups", range(4, 8)),
+                                           ("m_mergeds", range(4, 8))) for i in r)
+        if n.startswith(dead) or (n + ".").startswith(dead):
+            continue
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
     assert torch.isfinite(loss)
 
