@@ -12,66 +12,112 @@
 
 namespace aabr {
 
-constexpr int kMaxParts = 256;
+constexpr int kMaxParts = 512;
+constexpr int kFinSlices = 32; // finalize: 8 planes x 32 slices of the partial list per block
+constexpr int kFinPlanes = 8;
 
 // two-quantity column reduction: for every plane p,
 //   A[p] = sum_rows fa(row,p),  B[p] = sum_rows fb(row,p)
 // MODE 0: fa = x, fb = x*x            (forward statistics)
 // MODE 1: fa = d*r, fb = (x-mean)*d*r (backward statistics, r = out>0 ? 1 : leakiness)
-template <int MODE>
+// VEC = 4: planes % 4 == 0, one float4 per thread per row (16-B coalesced streams); VEC = 1: any.
+template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void k_bn_partials(const float *__restrict__ x, const float *__restrict__ out,
                                                      const float *__restrict__ d_out,
                                                      const float *__restrict__ mean, float leak, int64_t rows,
                                                      int planes, double *__restrict__ part) {
-  __shared__ double ra[256], rb[256];
-  const int tpr = planes < 256 ? planes : 256; // threads per row
+  __shared__ double ra[256][VEC], rb[256][VEC];
+  const int pv = planes / VEC;                 // vector columns
+  const int tpr = pv < 256 ? pv : 256;         // threads per row
   const int rpi = 256 / tpr;                   // rows per iteration
   const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
-  for (int p0 = 0; p0 < planes; p0 += tpr) {
-    const int p = p0 + tx;
-    double a = 0.0, b = 0.0;
-    if (p < planes && ty < rpi) {
-      const float mu = (MODE == 1) ? mean[p] : 0.0f;
+  for (int c0 = 0; c0 < pv; c0 += tpr) {
+    const int cv = c0 + tx;
+    double a[VEC], b[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { a[j] = 0.0; b[j] = 0.0; }
+    if (cv < pv && ty < rpi) {
+      float mu[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) mu[j] = (MODE == 1) ? mean[cv * VEC + j] : 0.0f;
       for (int64_t r = (int64_t)blockIdx.x * rpi + ty; r < rows; r += (int64_t)gridDim.x * rpi) {
-        const int64_t i = r * planes + p;
-        if (MODE == 0) {
-          float v = x[i];
-          a += (double)v;
-          b += (double)v * (double)v;
+        const int64_t i = r * planes + (int64_t)cv * VEC;
+        float xv[VEC], ov[VEC], dv[VEC];
+        if (VEC == 4) {
+          float4 t = *reinterpret_cast<const float4 *>(x + i);
+          xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+          if (MODE == 1) {
+            float4 o = *reinterpret_cast<const float4 *>(out + i);
+            float4 d = *reinterpret_cast<const float4 *>(d_out + i);
+            ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
+            dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+          }
         } else {
-          float d = d_out[i];
-          d = (out[i] > 0.0f) ? d : d * leak;
-          a += (double)d;
-          b += (double)(x[i] - mu) * (double)d;
+          xv[0] = x[i];
+          if (MODE == 1) { ov[0] = out[i]; dv[0] = d_out[i]; }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (MODE == 0) {
+            a[j] += (double)xv[j];
+            b[j] += (double)xv[j] * (double)xv[j];
+          } else {
+            float d = (ov[j] > 0.0f) ? dv[j] : dv[j] * leak;
+            a[j] += (double)d;
+            b[j] += (double)(xv[j] - mu[j]) * (double)d;
+          }
         }
       }
     }
-    ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { ra[threadIdx.x][j] = a[j]; rb[threadIdx.x][j] = b[j]; }
     __syncthreads();
-    if (ty == 0 && p < planes) {
-      for (int j = 1; j < rpi; ++j) { a += ra[j * tpr + tx]; b += rb[j * tpr + tx]; }
-      part[((int64_t)blockIdx.x * 2 + 0) * planes + p] = a;
-      part[((int64_t)blockIdx.x * 2 + 1) * planes + p] = b;
+    if (ty == 0 && cv < pv) {
+      for (int q = 1; q < rpi; ++q)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { a[j] += ra[q * tpr + tx][j]; b[j] += rb[q * tpr + tx][j]; }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        part[((int64_t)blockIdx.x * 2 + 0) * planes + cv * VEC + j] = a[j];
+        part[((int64_t)blockIdx.x * 2 + 1) * planes + cv * VEC + j] = b[j];
+      }
     }
     __syncthreads();
   }
 }
 
-// forward finalize, one thread per plane (CPU/BatchNormalization.cpp:33-48): coef[p] = {w, b}
-// with y = x*w + b.
-__global__ void k_bn_fwd_finalize(const double *__restrict__ part, int nparts, int64_t rows, int planes,
-                                  float *save_mean, float *save_invstd, float *running_mean,
-                                  float *running_var, const float *weight, const float *bias, float eps,
-                                  float momentum, int train, float *coef) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= planes) return;
+// sum the per-block partials of one plane: 32 threads take interleaved slices of the list (loads
+// in flight instead of one dependent chain), then a fixed-order combine => deterministic.
+__device__ inline void reduce_partials(const double *__restrict__ part, int nparts, int planes, int p,
+                                       double &s0, double &s1) {
+  __shared__ double ra[kFinSlices][kFinPlanes], rb[kFinSlices][kFinPlanes];
+  const int pl = threadIdx.x % kFinPlanes, sl = threadIdx.x / kFinPlanes;
+  double a = 0.0, b = 0.0;
+  if (p < planes)
+    for (int j = sl; j < nparts; j += kFinSlices) {
+      a += part[((int64_t)j * 2 + 0) * planes + p];
+      b += part[((int64_t)j * 2 + 1) * planes + p];
+    }
+  ra[sl][pl] = a; rb[sl][pl] = b;
+  __syncthreads();
+  s0 = 0.0; s1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < kFinSlices; ++j) { s0 += ra[j][pl]; s1 += rb[j][pl]; }
+}
+
+// forward finalize (CPU/BatchNormalization.cpp:33-48): coef[p] = {w, b} with y = x*w + b.
+__global__ __launch_bounds__(256) void k_bn_fwd_finalize(const double *__restrict__ part, int nparts,
+                                                         int64_t rows, int planes, float *save_mean,
+                                                         float *save_invstd, float *running_mean,
+                                                         float *running_var, const float *weight,
+                                                         const float *bias, float eps, float momentum, int train,
+                                                         float *coef) {
+  const int p = blockIdx.x * kFinPlanes + (threadIdx.x % kFinPlanes);
+  double s = 0.0, ss = 0.0;
+  if (train) reduce_partials(part, nparts, planes, p, s, ss);
+  if (p >= planes || threadIdx.x >= kFinPlanes) return;
   float mean, invstd;
   if (train) {
-    double s = 0.0, ss = 0.0;
-    for (int j = 0; j < nparts; ++j) {
-      s += part[((int64_t)j * 2 + 0) * planes + p];
-      ss += part[((int64_t)j * 2 + 1) * planes + p];
-    }
     double m = s / (double)rows;
     double var_n = ss - m * m * (double)rows; // == sum (x-mean)^2
     mean = (float)m;
@@ -117,16 +163,14 @@ __global__ __launch_bounds__(256) void k_bn_fwd_apply1(const float *__restrict__
 }
 
 // backward finalize (CPU/BatchNormalization.cpp:85-90,103-106): coef = {gradMean, k, invstd*w}
-__global__ void k_bn_bwd_finalize(const double *__restrict__ part, int nparts, int64_t rows, int planes,
-                                  const float *save_invstd, const float *weight, float *d_weight,
-                                  float *d_bias, float *coef) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= planes) return;
-  double s = 0.0, dp = 0.0;
-  for (int j = 0; j < nparts; ++j) {
-    s += part[((int64_t)j * 2 + 0) * planes + p];
-    dp += part[((int64_t)j * 2 + 1) * planes + p];
-  }
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double *__restrict__ part, int nparts,
+                                                         int64_t rows, int planes, const float *save_invstd,
+                                                         const float *weight, float *d_weight, float *d_bias,
+                                                         float *coef) {
+  const int p = blockIdx.x * kFinPlanes + (threadIdx.x % kFinPlanes);
+  double s, dp;
+  reduce_partials(part, nparts, planes, p, s, dp);
+  if (p >= planes || threadIdx.x >= kFinPlanes) return;
   float is = save_invstd[p];
   if (d_bias) d_bias[p] = (float)s;
   if (d_weight) d_weight[p] = (float)dp * is;
@@ -148,9 +192,29 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
   d_in[i] = (d - coef[p] - (x[i] - mean[p]) * coef[planes + p]) * coef[2 * planes + p];
 }
 
-static int bn_parts(int64_t rows, int planes) {
-  int tpr = planes < 256 ? planes : 256, rpi = 256 / tpr;
-  int64_t want = ceil_div(rows, (int64_t)rpi * 8); // >= 8 rows per thread
+__global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float *__restrict__ x, float *__restrict__ d_in,
+                                                       const float *__restrict__ out,
+                                                       const float *__restrict__ d_out, int64_t total,
+                                                       int planes, const float *__restrict__ mean,
+                                                       const float *__restrict__ coef, float leak) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= total) return;
+  int p = (int)(i % planes);
+  float4 xv = *reinterpret_cast<const float4 *>(x + i), ov = *reinterpret_cast<const float4 *>(out + i);
+  float4 dv = *reinterpret_cast<const float4 *>(d_out + i), mu = *reinterpret_cast<const float4 *>(mean + p);
+  float4 gm = *reinterpret_cast<const float4 *>(coef + p), kk = *reinterpret_cast<const float4 *>(coef + planes + p);
+  float4 sw = *reinterpret_cast<const float4 *>(coef + 2 * planes + p), r;
+  float d;
+  d = ov.x > 0.0f ? dv.x : dv.x * leak; r.x = (d - gm.x - (xv.x - mu.x) * kk.x) * sw.x;
+  d = ov.y > 0.0f ? dv.y : dv.y * leak; r.y = (d - gm.y - (xv.y - mu.y) * kk.y) * sw.y;
+  d = ov.z > 0.0f ? dv.z : dv.z * leak; r.z = (d - gm.z - (xv.z - mu.z) * kk.z) * sw.z;
+  d = ov.w > 0.0f ? dv.w : dv.w * leak; r.w = (d - gm.w - (xv.w - mu.w) * kk.w) * sw.w;
+  *reinterpret_cast<float4 *>(d_in + i) = r;
+}
+
+static int bn_parts(int64_t rows, int planes, int vec) {
+  int pv = planes / vec, tpr = pv < 256 ? pv : 256, rpi = 256 / tpr;
+  int64_t want = ceil_div(rows, (int64_t)rpi * 4); // >= 4 rows per thread
   if (want < 1) want = 1;
   if (want > kMaxParts) want = kMaxParts;
   return (int)want;
@@ -177,11 +241,16 @@ extern "C" int aabr_bn_forward(const float *in, float *out, int64_t rows, int pl
   float *coef = scratch + (int64_t)kMaxParts * 2 * planes * 2;
   int nparts = 0;
   if (train) {
-    nparts = bn_parts(rows, planes);
-    hipLaunchKernelGGL(k_bn_partials<0>, dim3(nparts), dim3(256), 0, st, in, (const float *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
+    const bool v4 = (planes & 3) == 0 && ((uintptr_t)in & 15) == 0;
+    nparts = bn_parts(rows, planes, v4 ? 4 : 1);
+    if (v4)
+      hipLaunchKernelGGL((k_bn_partials<0, 4>), dim3(nparts), dim3(256), 0, st, in, (const float *)nullptr,
+                         (const float *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
+    else
+      hipLaunchKernelGGL((k_bn_partials<0, 1>), dim3(nparts), dim3(256), 0, st, in, (const float *)nullptr,
+                         (const float *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
   }
-  hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((unsigned)ceil_div(planes, 256)), dim3(256), 0, st, part, nparts,
+  hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
                      rows, planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps,
                      momentum, train, coef);
   int64_t total = rows * planes;
@@ -210,14 +279,23 @@ extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, 
   AABR_CHECK_ARG(in && d_in && out && d_out, "null pointer");
   double *part = reinterpret_cast<double *>(scratch);
   float *coef = scratch + (int64_t)kMaxParts * 2 * planes * 2;
-  int nparts = bn_parts(rows, planes);
-  hipLaunchKernelGGL(k_bn_partials<1>, dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean, leakiness,
-                     rows, planes, part);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, 256)), dim3(256), 0, st, part, nparts,
+  const bool v4 = (planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)d_out) & 15) == 0;
+  int nparts = bn_parts(rows, planes, v4 ? 4 : 1);
+  if (v4)
+    hipLaunchKernelGGL((k_bn_partials<1, 4>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
+                       leakiness, rows, planes, part);
+  else
+    hipLaunchKernelGGL((k_bn_partials<1, 1>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
+                       leakiness, rows, planes, part);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
                      rows, planes, save_invstd, weight, d_weight, d_bias, coef);
   int64_t total = rows * planes;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, d_in, out,
-                     d_out, total, planes, save_mean, coef, leakiness);
+  if (v4 && (((uintptr_t)d_in | (uintptr_t)save_mean) & 15) == 0)
+    hipLaunchKernelGGL(k_bn_bwd_apply4, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, d_in, out,
+                       d_out, total, planes, save_mean, coef, leakiness);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, d_in, out,
+                       d_out, total, planes, save_mean, coef, leakiness);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

@@ -53,40 +53,38 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
   Wp[idx] = v;
 }
 
-// NBW: number of 16-column blocks in the wave's column slab.  ALIGNED: ci % 32 == 0 (float4
-// gathers, no bounds checks).
+// One workgroup owns a tile of 64 output rows x (NBW*16) output columns.  Its WPB waves split
+// the filter offsets between them (wave w takes k = w, w+WPB, ...) so that WPB latency chains
+// (table -> ballot -> gather -> MFMA) are in flight per tile; each wave accumulates into a
+// private LDS tile and the tiles are summed in a fixed order at the end (deterministic).
+// ALIGNED: ci % 32 == 0 (float4 gathers, no bounds checks).
 template <int NBW, int WPB, bool ALIGNED>
 __global__ __launch_bounds__(WPB * 64) void k_conv_gather_mfma(const float *__restrict__ in, int ci,
-                                                          float *__restrict__ out, int co, int64_t V_out,
-                                                          const int32_t *__restrict__ table, int vol,
-                                                          const float *__restrict__ Wp,
-                                                          const float *__restrict__ bias) {
+                                                              float *__restrict__ out, int co,
+                                                              int64_t V_out, const int32_t *__restrict__ table,
+                                                              int vol, const float *__restrict__ Wp,
+                                                              const float *__restrict__ bias) {
   constexpr int WS = NBW * 16 + 4;          // C-tile row stride (floats), keeps 16-B alignment
+  constexpr int TILE = 65 * WS + 128;       // floats per wave: 64 rows + 1 dummy row + pair lists
   extern __shared__ __align__(16) float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
-  float *Ct = smem + (size_t)wave * (65 * WS + 128);
+  float *Ct = smem + (size_t)wave * TILE;
   int32_t *listIn = reinterpret_cast<int32_t *>(Ct + 65 * WS);
   int32_t *listRow = listIn + 64;
 
   const int nkc = nkc_of(ci), nnb = nnb_of(co);
   const int nb0 = blockIdx.y * NBW;                       // first global n-block of the slab
-  const int64_t row0 = ((int64_t)blockIdx.x * WPB + wave) * 64;
-  if (row0 >= V_out) return;                              // whole wave out of range
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
   const int64_t myrow = row0 + lane;
   const bool valid = myrow < V_out;
 
-  // init the tile with the bias (CPU/Convolution.cpp:59-62) or zero
-  for (int i = lane; i < 65 * (NBW * 16); i += 64) {
-    int r = i / (NBW * 16), cc = i % (NBW * 16);
-    int n = nb0 * 16 + cc;
-    Ct[r * WS + cc] = (bias && n < co && r < 64) ? bias[n] : 0.0f;
-  }
+  for (int i = lane; i < 65 * WS; i += 64) Ct[i] = 0.0f;
 
-  int t_next = valid ? table[myrow] : -1;
-  for (int k = 0; k < vol; ++k) {
+  int t_next = (valid && wave < vol) ? table[(int64_t)wave * V_out + myrow] : -1;
+  for (int k = wave; k < vol; k += WPB) {
     const int t = t_next;
-    if (k + 1 < vol) t_next = valid ? table[(int64_t)(k + 1) * V_out + myrow] : -1;
+    if (k + WPB < vol) t_next = valid ? table[(int64_t)(k + WPB) * V_out + myrow] : -1;
     const unsigned long long m = __ballot(t >= 0);
     if (m == 0) continue;
     const int cnt = __popcll(m);
@@ -148,21 +146,33 @@ __global__ __launch_bounds__(WPB * 64) void k_conv_gather_mfma(const float *__re
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // write the tile once
-  const int64_t nrows = (V_out - row0) < 64 ? (V_out - row0) : 64;
+  __syncthreads();
+  // combine the per-wave tiles in wave order (+ bias, CPU/Convolution.cpp:59-62) and write once
+  const int nt = vol < WPB ? vol : WPB;
+  const int nrows = (int)((V_out - row0) < 64 ? (V_out - row0) : 64);
   const int wcols = (co - nb0 * 16) < NBW * 16 ? (co - nb0 * 16) : NBW * 16;
   if ((co & 3) == 0) {
     const int q = wcols >> 2; // float4 per row
-    for (int i = lane; i < (int)nrows * q; i += 64) {
+    for (int i = threadIdx.x; i < nrows * q; i += WPB * 64) {
       int r = i / q, cq = i % q;
-      float4 v = *reinterpret_cast<const float4 *>(Ct + r * WS + cq * 4);
+      float4 v = *reinterpret_cast<const float4 *>(smem + r * WS + cq * 4);
+      for (int w = 1; w < nt; ++w) {
+        float4 u = *reinterpret_cast<const float4 *>(smem + (size_t)w * TILE + r * WS + cq * 4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      if (bias) {
+        const float *bb = bias + nb0 * 16 + cq * 4;
+        v.x += bb[0]; v.y += bb[1]; v.z += bb[2]; v.w += bb[3];
+      }
       *reinterpret_cast<float4 *>(out + (row0 + r) * co + nb0 * 16 + cq * 4) = v;
     }
   } else {
-    for (int i = lane; i < (int)nrows * wcols; i += 64) {
+    for (int i = threadIdx.x; i < nrows * wcols; i += WPB * 64) {
       int r = i / wcols, cc = i % wcols;
-      out[(row0 + r) * co + nb0 * 16 + cc] = Ct[r * WS + cc];
+      float v = smem[r * WS + cc];
+      for (int w = 1; w < nt; ++w) v += smem[(size_t)w * TILE + r * WS + cc];
+      if (bias) v += bias[nb0 * 16 + cc];
+      out[(row0 + r) * co + nb0 * 16 + cc] = v;
     }
   }
 }
@@ -206,27 +216,33 @@ __global__ __launch_bounds__(256) void k_conv_dw_partial(const float *__restrict
     const int pos = __popcll(m & ((1ull << lane) - 1ull));
     if (t >= 0) { lt[pos] = t; lo[pos] = (int32_t)(row - base); }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int q0 = 0; q0 < cnt; q0 += 4) {
-      const int q = q0 + g;
-      const bool on = q < cnt;
-      const int64_t tq = on ? lt[q] : 0;
-      const int64_t oq = on ? base + lo[q] : 0;
-      float av[CB], bv[NB];
+    for (int q0 = 0; q0 < cnt; q0 += 16) {
+      // 16 pairs per step: issue every gather first (4 independent K-steps in flight), then the MFMAs
+      float av[4][CB], bv[4][NB];
 #pragma unroll
-      for (int a = 0; a < CB; ++a) {
-        int c = (cb0 + a) * 16 + c16;
-        av[a] = (on && c < ci) ? in[tq * ci + c] : 0.0f;
+      for (int st = 0; st < 4; ++st) {
+        const int q = q0 + st * 4 + g;
+        const bool on = q < cnt;
+        const int64_t tq = on ? lt[q] : 0;
+        const int64_t oq = on ? base + lo[q] : 0;
+#pragma unroll
+        for (int a = 0; a < CB; ++a) {
+          int c = (cb0 + a) * 16 + c16;
+          av[st][a] = (on && c < ci) ? in[tq * ci + c] : 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          int n = (nb0 + b) * 16 + c16;
+          bv[st][b] = (on && n < co) ? d_out[oq * co + n] : 0.0f;
+        }
       }
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        int n = (nb0 + b) * 16 + c16;
-        bv[b] = (on && n < co) ? d_out[oq * co + n] : 0.0f;
-      }
+      for (int st = 0; st < 4; ++st)
 #pragma unroll
-      for (int a = 0; a < CB; ++a)
+        for (int a = 0; a < CB; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][a], bv[st][b], acc[a][b], 0, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
@@ -248,7 +264,8 @@ __global__ __launch_bounds__(256) void k_conv_dw_reduce(const float *__restrict_
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= elems) return;
   float s = 0.0f;
-  for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * elems + i];
+#pragma unroll 8
+  for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * elems + i]; // fixed order: deterministic
   dW[i] = s;
 }
 
@@ -268,12 +285,12 @@ __global__ __launch_bounds__(256) void k_col_sum(const float *__restrict__ x, in
 }
 
 static int dw_chunks(int64_t V_out, int vol, int tiles) {
-  int64_t want = 2048 / ((int64_t)vol * tiles);
+  int64_t want = 4096 / ((int64_t)vol * tiles); // ~4 waves per SIMD over the chip
   if (want < 1) want = 1;
   int64_t maxc = ceil_div(V_out, 256);
   if (maxc < 1) maxc = 1;
   if (want > maxc) want = maxc;
-  if (want > 64) want = 64;
+  if (want > 128) want = 128;
   return (int)want;
 }
 static void dw_tiling(int ci, int co, int &cb, int &nb, int &tiles) {
@@ -312,11 +329,13 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, float *out_fea
     hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, W, vol, n_in,
                        n_out, transpose, flip, wpack);
   const bool aligned = (n_in % kKC) == 0;
-  // waves per workgroup chosen so the wave-private LDS tiles stay under 64 KiB per workgroup
+  // WPB waves split the filter offsets of one 64-row tile.  Pick the split that minimises
+  // (rounds of resident workgroups) x (offsets per wave): a grid one workgroup larger than what
+  // fits on the chip at once would otherwise pay a whole second round.
 #define AABR_LAUNCH_CONV(NBW, WPB)                                                                      \
   do {                                                                                                  \
     size_t lds = (size_t)(WPB) * (65 * ((NBW)*16 + 4) + 128) * sizeof(float);                           \
-    dim3 grid((unsigned)ceil_div(V_out, 64 * (WPB)), (unsigned)ceil_div(nnb, (NBW)));                   \
+    dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                           \
     if (aligned)                                                                                        \
       hipLaunchKernelGGL((k_conv_gather_mfma<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,         \
                          in_feats, n_in, out_feats, n_out, V_out, table, vol, wpack, bias);             \
@@ -324,9 +343,25 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, float *out_fea
       hipLaunchKernelGGL((k_conv_gather_mfma<NBW, WPB, false>), grid, dim3(64 * (WPB)), lds, st,        \
                          in_feats, n_in, out_feats, n_out, V_out, table, vol, wpack, bias);             \
   } while (0)
-  if (nnb <= 1) AABR_LAUNCH_CONV(1, 4);
-  else if (nnb == 2) AABR_LAUNCH_CONV(2, 4);
-  else AABR_LAUNCH_CONV(4, 2);
+  const int nbw = nnb <= 1 ? 1 : (nnb == 2 ? 2 : 4);
+  const int64_t wgs = ceil_div(V_out, 64) * ceil_div(nnb, nbw);
+  int best_wpb = 2;
+  int64_t best_cost = -1;
+  for (int wpb = 2; wpb <= (nbw == 4 ? 3 : 4); ++wpb) {
+    int64_t lds = (int64_t)wpb * (65 * (nbw * 16 + 4) + 128) * 4;
+    int64_t per_cu = (160 * 1024) / lds;
+    if (per_cu > 32 / wpb) per_cu = 32 / wpb;
+    int64_t rounds = ceil_div(wgs, 256 * per_cu);
+    int64_t cost = rounds * ceil_div(vol, wpb);
+    if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_wpb = wpb; }
+  }
+  if (nbw == 1) {
+    if (best_wpb == 2) AABR_LAUNCH_CONV(1, 2); else if (best_wpb == 3) AABR_LAUNCH_CONV(1, 3); else AABR_LAUNCH_CONV(1, 4);
+  } else if (nbw == 2) {
+    if (best_wpb == 2) AABR_LAUNCH_CONV(2, 2); else if (best_wpb == 3) AABR_LAUNCH_CONV(2, 3); else AABR_LAUNCH_CONV(2, 4);
+  } else {
+    if (best_wpb == 2) AABR_LAUNCH_CONV(4, 2); else AABR_LAUNCH_CONV(4, 3);
+  }
 #undef AABR_LAUNCH_CONV
   AABR_CHECK_LAUNCH();
   return AABR_OK;

@@ -162,7 +162,14 @@ __global__ __launch_bounds__(kScanThreads) void k_assign_sites(
       ra += 1; rb += c[j];
     }
   }
-  if (MODE == 0 && maxc > 0) atomicMax(&meta[1], maxc);
+  if (MODE == 0) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      int o = __shfl_xor(maxc, d);
+      maxc = o > maxc ? o : maxc;
+    }
+    if ((threadIdx.x & 63) == 0 && maxc > 0) atomicMax(&meta[1], maxc);
+  }
 }
 
 // ------------------------------------------------------------------ input layer
@@ -286,6 +293,16 @@ __global__ __launch_bounds__(256) void k_input_rule_table(const int32_t *__restr
 // ------------------------------------------------------------------ rule tables
 struct Filter3 { int size[3]; };
 
+// counts[k * gridDim.x + blockIdx.x] = number of hits in this block (plain store: 27 hot
+// addresses hammered by one atomic per wave cost more than the whole table build)
+__device__ inline void block_count_store(int hit, int32_t *__restrict__ counts, int k) {
+  __shared__ int wc[4];
+  unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (int)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[(int64_t)k * gridDim.x + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
 __global__ __launch_bounds__(256) void k_submanifold_table(const int32_t *__restrict__ site_coords,
                                                            int64_t V, const uint64_t *__restrict__ keys,
                                                            const int32_t *__restrict__ vals, uint64_t mask,
@@ -306,10 +323,7 @@ __global__ __launch_bounds__(256) void k_submanifold_table(const int32_t *__rest
     table[(int64_t)k * V + v] = r;
     hit = r >= 0;
   }
-  if (counts) {
-    unsigned long long m = __ballot(hit);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], (int)__popcll(m));
-  }
+  if (counts) block_count_store(hit, counts, k);
 }
 
 __global__ __launch_bounds__(256) void k_conv_insert_sites(const int32_t *__restrict__ in_coords,
@@ -353,10 +367,7 @@ __global__ __launch_bounds__(256) void k_conv_table_out(const int32_t *__restric
     table[(int64_t)k * V_out + o] = r;
     hit = r >= 0;
   }
-  if (counts) {
-    unsigned long long m = __ballot(hit);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[k], (int)__popcll(m));
-  }
+  if (counts) block_count_store(hit, counts, k);
 }
 
 // table_in[k][u]: the output row whose window holds input u at offset k, if that output cell
@@ -508,7 +519,6 @@ extern "C" int aabr_submanifold_table(const int32_t *site_coords, int64_t V, con
     vol *= fs_host[i];
   }
   AABR_CHECK_ARG(vol <= 65535, "filter volume too large");
-  if (counts) hipMemsetAsync(counts, 0, vol * sizeof(int32_t), st);
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(site_coords && keys && vals && table, "null pointer");
   hipLaunchKernelGGL(k_submanifold_table, dim3((unsigned)ceil_div(V, 256), (unsigned)vol), dim3(256), 0, st,
@@ -575,7 +585,6 @@ extern "C" int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, c
   ConvGeom g;
   AABR_CHECK_ARG(make_geom(size_host, stride_host, out_spatial_host, g) == 0, "bad filter geometry");
   int vol = g.size[0] * g.size[1] * g.size[2];
-  if (counts) hipMemsetAsync(counts, 0, vol * sizeof(int32_t), st);
   if (V_out > 0 && table_out) {
     AABR_CHECK_ARG(out_coords && in_keys && in_vals, "null pointer");
     hipLaunchKernelGGL(k_conv_table_out, dim3((unsigned)ceil_div(V_out, 256), (unsigned)vol), dim3(256), 0, st,

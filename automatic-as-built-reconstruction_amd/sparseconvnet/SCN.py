@@ -44,10 +44,15 @@ class _Table(object):
         self.V_out, self.V_in, self.flip_ok = V_out, V_in, flip_ok
         self._host_counts = None
 
-    def total_rules(self):
+    def rule_counts(self):
+        """per-offset rule counts (host list); one small D2H read, cached"""
         if self._host_counts is None:
-            self._host_counts = self.counts.tolist()
-        return float(sum(self._host_counts))
+            self._host_counts = self.counts.view(self.vol, -1).sum(1).tolist() if self.counts.numel() else \
+                [0] * self.vol
+        return self._host_counts
+
+    def total_rules(self):
+        return float(sum(self.rule_counts()))
 
 
 class Metadata_3(object):
@@ -133,7 +138,7 @@ class Metadata_3(object):
             vol = fs[0] * fs[1] * fs[2]
             dev = g.keys.device
             table = torch.empty((vol, g.V), dtype=torch.int32, device=dev)
-            counts = torch.empty(vol, dtype=torch.int32, device=dev)
+            counts = torch.empty(vol * ((g.V + 255) // 256), dtype=torch.int32, device=dev)
             check(_hip.load().aabr_submanifold_table(ptr(g.coords), g.V, ptr(g.keys), ptr(g.vals), g.cap,
                                                      _hip.i32x3(fs), ptr(table), ptr(counts), stream()))
             # odd filters: the input-gradient gather is the same table read with the mirrored
@@ -173,7 +178,7 @@ class Metadata_3(object):
             self.grids[osz] = go
             t_out = torch.empty((vol, V_out), dtype=torch.int32, device=dev)
             t_in = torch.empty((vol, gi.V), dtype=torch.int32, device=dev)
-            counts = torch.empty(vol, dtype=torch.int32, device=dev)
+            counts = torch.empty(vol * ((V_out + 255) // 256), dtype=torch.int32, device=dev)
             check(lib.aabr_convolution_tables(ptr(gi.coords), gi.V, ptr(gi.keys), ptr(gi.vals), gi.cap,
                                               ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
                                               _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),

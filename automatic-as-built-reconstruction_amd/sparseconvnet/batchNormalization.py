@@ -80,7 +80,7 @@ class BatchNormalizationFunction(Function):
         ctx.leakiness = leakiness
         output_features = input_features.new()
         saveMean = input_features.new().resize_(ctx.nPlanes)
-        saveInvStd = running_mean.clone().resize_(ctx.nPlanes)
+        saveInvStd = input_features.new().resize_(ctx.nPlanes)
         SCN.BatchNormalization_updateOutput(input_features, output_features, saveMean, saveInvStd, running_mean,
                                             running_var, weight, bias, eps, momentum, ctx.train, ctx.leakiness)
         ctx.save_for_backward(input_features, output_features, weight, bias, running_mean, running_var, saveMean,
@@ -93,8 +93,8 @@ class BatchNormalizationFunction(Function):
             ctx.saved_tensors
         assert ctx.train
         grad_input = grad_output.new()
-        grad_weight = torch.zeros_like(weight)
-        grad_bias = torch.zeros_like(bias)
+        grad_weight = torch.empty_like(weight)  # fully written by the backward finalize kernel
+        grad_bias = torch.empty_like(bias)
         SCN.BatchNormalization_backward(input_features, grad_input, output_features, grad_output.contiguous(),
                                         saveMean, saveInvStd, running_mean, running_var, weight, bias, grad_weight,
                                         grad_bias, ctx.leakiness)

@@ -72,7 +72,9 @@ class ConvolutionFunction(Function):
         input_features, weight, bias = ctx.saved_tensors
         input_spatial_size, output_spatial_size, filter_size, filter_stride = ctx.geom
         grad_input = grad_output.new()
-        grad_weight = torch.zeros_like(weight)
+        # the weight-gradient kernel writes every element (the reference pre-zeroes because its
+        # CUDA path accumulates with atomicAdd, Convolution.cu:318); no fill launch needed
+        grad_weight = torch.empty_like(weight)
         grad_bias = torch.zeros_like(bias)
         SCN.Convolution_backward(input_spatial_size, output_spatial_size, filter_size, filter_stride,
                                  ctx.input_metadata, input_features, grad_input, grad_output.contiguous(), weight,

@@ -68,7 +68,9 @@ class SubmanifoldConvolutionFunction(Function):
     def backward(ctx, grad_output):
         input_features, weight, bias = ctx.saved_tensors
         grad_input = grad_output.new()
-        grad_weight = torch.zeros_like(weight)
+        # the weight-gradient kernel writes every element (the reference pre-zeroes because its
+        # CUDA path accumulates with atomicAdd, Convolution.cu:318); no fill launch needed
+        grad_weight = torch.empty_like(weight)
         grad_bias = torch.zeros_like(bias)
         SCN.SubmanifoldConvolution_backward(ctx.spatial_size, ctx.filter_size, ctx.input_metadata, input_features,
                                             grad_input, grad_output.contiguous(), weight, grad_weight, grad_bias)

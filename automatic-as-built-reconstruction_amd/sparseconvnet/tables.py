@@ -2,6 +2,7 @@
 import torch
 
 from .sparseConvNetTensor import SparseConvNetTensor
+from .utils import _sum_features
 
 
 class JoinTable(torch.nn.Sequential):
@@ -22,7 +23,7 @@ class AddTable(torch.nn.Sequential):
         output = SparseConvNetTensor()
         output.metadata = input[0].metadata
         output.spatial_size = input[0].spatial_size
-        output.features = sum([i.features for i in input])
+        output.features = _sum_features(input)
         return output
 
     def input_spatial_size(self, out_size):

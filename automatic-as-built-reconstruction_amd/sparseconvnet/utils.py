@@ -35,5 +35,14 @@ def add_feature_planes(input):
     output = SparseConvNetTensor()
     output.metadata = input[0].metadata
     output.spatial_size = input[0].spatial_size
-    output.features = sum([i.features for i in input])
+    output.features = _sum_features(input)
     return output
+
+
+def _sum_features(tensors):
+    """left-to-right sum like the reference's `sum([...])`, minus its leading `0 +` (one
+    elementwise launch saved; x + 0 is exact, so the result is bit-identical)"""
+    f = tensors[0].features
+    for t in tensors[1:]:
+        f = f + t.features
+    return f

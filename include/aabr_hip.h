@@ -77,7 +77,8 @@ int aabr_input_layer_rule_table(const int32_t *site_off, const int32_t *site_pts
  * SubmanifoldConvolution_SgToRules (Metadata.cpp:429-443, SubmanifoldConvolutionRules.h:11-45).
  * table[k*V + v] = row of the site at coords[v] + offset_k (offset enumeration of
  * RectangularRegion::offset, RectangularRegions.h:30-38: z fastest), or -1.
- * counts (int32 [vol], optional) receives the per-offset rule counts.                        */
+ * counts (int32 [vol * ceil(V/256)], optional) receives per-offset, per-256-row-block rule
+ * counts (sum over the second index = rules at that offset).                                 */
 int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t *keys,
                            const int32_t *vals, int64_t cap, const int32_t *filter_size_host,
                            int32_t *table, int32_t *counts, void *stream);
@@ -93,7 +94,8 @@ int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, const int32_t
                            uint64_t *out_keys, int32_t *out_vals, int64_t out_cap,
                            int32_t *scratch, int32_t *out_site_coords, int32_t *meta,
                            void *stream);
-/* table_out[k*V_out + o] = input row at offset k of output o's window (or -1);
+/* counts (optional): int32 [vol * ceil(V_out/256)] per-block rule counts, as above.
+ * table_out[k*V_out + o] = input row at offset k of output o's window (or -1);
  * table_in [k*V_in  + u] = output row whose window holds input u at offset k (or -1).       */
 int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
                             const int32_t *in_vals, int64_t in_cap,
