@@ -33,8 +33,12 @@ _SIGS = {
     "aabr_spatial_locations": (C.c_int, [_vp, _i64, _vp, _vp]),
     "aabr_conv_wpack_floats": (C.c_int64, [_i32, _i32, _i32]),
     "aabr_conv_forward": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
-    "aabr_conv_dw_scratch_floats": (C.c_int64, [_i64, _i32, _i32, _i32]),
-    "aabr_conv_backward_weight": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "aabr_conv_dw_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),
+    "aabr_conv_backward_weight": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "aabr_tile_blocks_words": (C.c_int64, [_i64, _i32]),
+    "aabr_build_tile_blocks": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "aabr_offset_pairs_words": (C.c_int64, [_i64, _i32]),
+    "aabr_build_offset_pairs": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "aabr_bn_scratch_floats": (C.c_int64, [_i32]),
     "aabr_bn_forward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32,
                                   _vp, _vp]),
@@ -68,8 +72,19 @@ def load():
     return _lib
 
 
+_gpu_ok = None
+
+
 def require_gpu(t=None):
-    if not torch.cuda.is_available():
+    global _gpu_ok
+    if t is not None:
+        if t.is_cuda:
+            return
+        if _gpu_ok:
+            raise AabrError("expected a tensor in device memory, got %s" % t.device)
+    if _gpu_ok is None:
+        _gpu_ok = bool(torch.cuda.is_available())
+    if not _gpu_ok:
         raise AabrError("the MI355X hot path needs a GPU (torch.cuda.is_available() is False); "
                         "there is no CPU fallback")
     if t is not None and not t.is_cuda:
@@ -82,14 +97,41 @@ def check(rc):
 
 
 def ptr(t):
-    """device pointer of a tensor, None -> NULL"""
-    if t is None or t.numel() == 0:
+    """device pointer of a tensor (plain int, which ctypes converts for c_void_p), None -> NULL"""
+    if t is None:
         return None
-    return C.c_void_p(t.data_ptr())
+    p = t.data_ptr()
+    return p if p else None
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """raw hipStream_t of torch's CURRENT stream on the current device (honours
+    `torch.cuda.stream(...)` contexts); the private fast path avoids the ~13 us
+    `torch.cuda.current_stream()` spends re-checking the device count on every call"""
+    return _raw_stream(torch._C._cuda_getDevice()) or None
+
+
+_ws = {}
+
+
+def workspace(name, numel, dtype, device):
+    """Grow-only scratch buffer per (purpose, dtype, device).  Kernels on one stream run in
+    order, so a scratch buffer whose contents never outlive the call that fills it can be shared
+    by consecutive calls; buffers are keyed by the current stream so concurrent streams never
+    share one."""
+    key = (name, dtype, device, _raw_stream(torch._C._cuda_getDevice()))
+    t = _ws.get(key)
+    if t is None or t.numel() < numel:
+        t = torch.empty(max(int(numel), 1), dtype=dtype, device=device)
+        _ws[key] = t
+    return t
+
+
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    def _raw_stream(idx):
+        return torch.cuda.current_stream(idx).cuda_stream
 
 
 def i32x3(v):

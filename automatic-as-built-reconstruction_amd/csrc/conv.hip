@@ -6,12 +6,12 @@
 //
 //     out[o] = bias + sum_k  in[ table[k][o] ] @ Wl[k]          (table entry -1 -> no term)
 //
-// It is OUTPUT-STATIONARY: a wave owns 64 consecutive output rows and a slab of output
+// It is OUTPUT-STATIONARY: a workgroup owns 64 consecutive output rows and a slab of output
 // columns, keeps that tile in LDS for the whole sweep over the filter offsets and writes it to
 // HBM exactly once -- no read-modify-write of `out` per offset and no atomics (the reference's
 // GPU path re-reads and re-writes `out` 27 times and its rule book crosses PCIe per offset).
-// Per offset the wave ballots which of its 64 rows have a partner, compacts those (row,
-// partner) pairs, and multiplies them 16 at a time on v_mfma_f32_16x16x4_f32:
+// The gather table is compiled once per rule book into per-tile blocks of 16 (partner row,
+// local row) pairs sharing one offset; each block is one v_mfma_f32_16x16x4_f32 chain:
 //     D^T[out col][pair] += Wl^T[out col][c] * in[partner(pair)][c]
 // so each lane ends up with 4 consecutive output columns of one pair (one 16-byte LDS
 // read-add-write).  Accumulation order is fixed (offset order, then channel order inside the
@@ -53,102 +53,204 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
   Wp[idx] = v;
 }
 
-// One workgroup owns a tile of 64 output rows x (NBW*16) output columns.  Its WPB waves split
-// the filter offsets between them (wave w takes k = w, w+WPB, ...) so that WPB latency chains
-// (table -> ballot -> gather -> MFMA) are in flight per tile; each wave accumulates into a
-// private LDS tile and the tiles are summed in a fixed order at the end (deterministic).
-// ALIGNED: ci % 32 == 0 (float4 gathers, no bounds checks).
-template <int NBW, int WPB, bool ALIGNED>
-__global__ __launch_bounds__(WPB * 64) void k_conv_gather_mfma(const float *__restrict__ in, int ci,
-                                                              float *__restrict__ out, int co,
-                                                              int64_t V_out, const int32_t *__restrict__ table,
-                                                              int vol, const float *__restrict__ Wp,
-                                                              const float *__restrict__ bias) {
-  constexpr int WS = NBW * 16 + 4;          // C-tile row stride (floats), keeps 16-B alignment
-  constexpr int TILE = 65 * WS + 128;       // floats per wave: 64 rows + 1 dummy row + pair lists
-  extern __shared__ __align__(16) float smem[];
+// ------------------------------------------------------------------ compiled rule book, part 1
+// Tile-major MFMA block lists.  For every tile of 64 consecutive output rows the gather table
+// is compiled ONCE per rule book into blocks of 16 (partner row, local row) pairs that share a
+// filter offset; every convolution that uses the rule book (forward of each layer at that scale,
+// and the input-gradient passes) then streams these blocks with no ballots and no table reads.
+//   words:  [ntiles] nblk | [ntiles][MAXB] offset k of each block | [ntiles][MAXB][16] entries
+//   entry = (partner_row << 6) | local_row, or -1 for padding;  MAXB = 4 * vol.
+__host__ __device__ inline int64_t tb_ntiles(int64_t V) { return (V + 63) / 64; }
+__host__ __device__ inline int tb_maxb(int vol) { return 4 * vol; }
+
+__global__ __launch_bounds__(256) void k_build_tile_blocks(const int32_t *__restrict__ table, int64_t V,
+                                                           int vol, int32_t *__restrict__ words) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int g = lane >> 4, c16 = lane & 15;
-  float *Ct = smem + (size_t)wave * TILE;
-  int32_t *listIn = reinterpret_cast<int32_t *>(Ct + 65 * WS);
-  int32_t *listRow = listIn + 64;
-
-  const int nkc = nkc_of(ci), nnb = nnb_of(co);
-  const int nb0 = blockIdx.y * NBW;                       // first global n-block of the slab
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
-  const int64_t myrow = row0 + lane;
-  const bool valid = myrow < V_out;
-
-  for (int i = lane; i < 65 * WS; i += 64) Ct[i] = 0.0f;
-
-  int t_next = (valid && wave < vol) ? table[(int64_t)wave * V_out + myrow] : -1;
-  for (int k = wave; k < vol; k += WPB) {
-    const int t = t_next;
-    if (k + WPB < vol) t_next = valid ? table[(int64_t)(k + WPB) * V_out + myrow] : -1;
+  const int64_t ntiles = tb_ntiles(V), tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int maxb = tb_maxb(vol);
+  int32_t *nblk = words;
+  int32_t *blk_k = words + ntiles + tile * maxb;
+  int32_t *ent = words + ntiles + ntiles * maxb + tile * maxb * 16;
+  const int64_t row = tile * 64 + lane;
+  const bool valid = row < V;
+  int b0 = 0;
+  for (int k = 0; k < vol; ++k) {
+    const int t = valid ? table[(int64_t)k * V + row] : -1;
     const unsigned long long m = __ballot(t >= 0);
     if (m == 0) continue;
     const int cnt = __popcll(m);
     const int pos = __popcll(m & ((1ull << lane) - 1ull));
-    if (t >= 0) { listIn[pos] = t; listRow[pos] = lane; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const float *Wk = Wp + (int64_t)k * nkc * nnb * 512;
-    for (int mb = 0; mb * 16 < cnt; ++mb) {
-      const int p = mb * 16 + c16;
-      const int inrow = (p < cnt) ? listIn[p] : -1;
-      const int orow = (p < cnt) ? listRow[p] : 64;
-      f32x4 acc[NBW];
+    const int nmb = (cnt + 15) >> 4;
+    if (t >= 0) ent[b0 * 16 + pos] = (t << 6) | lane;
+    if (lane < nmb * 16 - cnt) ent[b0 * 16 + cnt + lane] = -1;
+    if (lane < nmb) blk_k[b0 + lane] = k;
+    b0 += nmb;
+  }
+  if (lane == 0) nblk[tile] = b0;
+}
+
+// gather 8 consecutive channels of the block entry's partner row (zeros for padding entries)
+template <bool ALIGNED>
+__device__ inline void conv_block_load(const float *__restrict__ in, int ci, int e, int g, int kc,
+                                       float (&b8)[8]) {
+  const int inrow = e >> 6;
+  if (ALIGNED) {
+    if (e >= 0) {
+      const float4 *src = reinterpret_cast<const float4 *>(in + (int64_t)inrow * ci + kc * kKC + g * 8);
+      float4 v0 = src[0], v1 = src[1];
+      b8[0] = v0.x; b8[1] = v0.y; b8[2] = v0.z; b8[3] = v0.w;
+      b8[4] = v1.x; b8[5] = v1.y; b8[6] = v1.z; b8[7] = v1.w;
+    } else {
 #pragma unroll
-      for (int j = 0; j < NBW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int kc = 0; kc < nkc; ++kc) {
-        float b8[8];
-        if (ALIGNED) {
-          if (inrow >= 0) {
-            const float4 *src = reinterpret_cast<const float4 *>(in + (int64_t)inrow * ci + kc * kKC + g * 8);
-            float4 v0 = src[0], v1 = src[1];
-            b8[0] = v0.x; b8[1] = v0.y; b8[2] = v0.z; b8[3] = v0.w;
-            b8[4] = v1.x; b8[5] = v1.y; b8[6] = v1.z; b8[7] = v1.w;
-          } else {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) b8[s] = 0.0f;
-          }
-        } else {
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            int c = kc * kKC + g * 8 + s;
-            b8[s] = (inrow >= 0 && c < ci) ? in[(int64_t)inrow * ci + c] : 0.0f;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-          if (nb0 + j < nnb) {
-            const float4 *wsrc =
-                reinterpret_cast<const float4 *>(Wk + (((int64_t)kc * nnb + nb0 + j) * 64 + lane) * 8);
-            float4 w0 = wsrc[0], w1 = wsrc[1];
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, b8[0], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, b8[1], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, b8[2], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, b8[3], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, b8[4], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, b8[5], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, b8[6], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, b8[7], acc[j], 0, 0, 0);
-          }
-        }
-      }
-      // lane holds D^T[out col = j*16 + g*4 + r][pair c16]: 4 consecutive columns of row orow
-#pragma unroll
-      for (int j = 0; j < NBW; ++j) {
-        float4 *dst = reinterpret_cast<float4 *>(Ct + orow * WS + j * 16 + g * 4);
-        float4 cur = *dst;
-        cur.x += acc[j][0]; cur.y += acc[j][1]; cur.z += acc[j][2]; cur.w += acc[j][3];
-        *dst = cur;
-      }
+      for (int s = 0; s < 8; ++s) b8[s] = 0.0f;
     }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      int c = kc * kKC + g * 8 + s;
+      b8[s] = (e >= 0 && c < ci) ? in[(int64_t)inrow * ci + c] : 0.0f;
+    }
+  }
+}
+
+// gathered operands of one pipeline step: the same 32-channel chunk of two blocks (A, B)
+struct ConvStep {
+  float a8[8], b8[8];
+  int eA, eB;
+};
+
+// weights stream from L2 (packed, lane-linear, 2 KiB per block and chunk) right before their MFMAs;
+// the two blocks' chains are interleaved: two independent accumulators keep the 40-cycle
+// dependent latency of v_mfma_f32_16x16x4_f32 off the critical path
+template <int NBW>
+__device__ inline void conv_step_mfma(const ConvStep &st, const float *__restrict__ WkA,
+                                      const float *__restrict__ WkB, int kc, int nnb, int nb0, int lane,
+                                      f32x4 (&accA)[NBW], f32x4 (&accB)[NBW]) {
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    if (nb0 + j < nnb) {
+      const int64_t off = (((int64_t)kc * nnb + nb0 + j) * 64 + lane) * 8;
+      const float4 *wa = reinterpret_cast<const float4 *>(WkA + off);
+      const float4 *wb = reinterpret_cast<const float4 *>(WkB + off);
+      const float4 w0 = wa[0], w1 = wa[1], u0 = wb[0], u1 = wb[1];
+      accA[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, st.a8[0], accA[j], 0, 0, 0);
+      accB[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0.x, st.b8[0], accB[j], 0, 0, 0);
+      accA[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, st.a8[1], accA[j], 0, 0, 0);
+      accB[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0.y, st.b8[1], accB[j], 0, 0, 0);
+      accA[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, st.a8[2], accA[j], 0, 0, 0);
+      accB[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0.z, st.b8[2], accB[j], 0, 0, 0);
+      accA[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, st.a8[3], accA[j], 0, 0, 0);
+      accB[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0.w, st.b8[3], accB[j], 0, 0, 0);
+      accA[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, st.a8[4], accA[j], 0, 0, 0);
+      accB[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1.x, st.b8[4], accB[j], 0, 0, 0);
+      accA[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, st.a8[5], accA[j], 0, 0, 0);
+      accB[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1.y, st.b8[5], accB[j], 0, 0, 0);
+      accA[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, st.a8[6], accA[j], 0, 0, 0);
+      accB[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1.z, st.b8[6], accB[j], 0, 0, 0);
+      accA[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, st.a8[7], accA[j], 0, 0, 0);
+      accB[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1.w, st.b8[7], accB[j], 0, 0, 0);
+    }
+  }
+}
+
+// lane holds D^T[out col = j*16 + g*4 + r][pair c16]: 4 consecutive columns of the pair's row
+template <int NBW, int WS>
+__device__ inline void conv_block_accumulate(float *Ct, int e, int g, const f32x4 (&acc)[NBW]) {
+  if (e >= 0) {
+    const int orow = e & 63;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      float4 *dst = reinterpret_cast<float4 *>(Ct + orow * WS + j * 16 + g * 4);
+      float4 cur = *dst;
+      cur.x += acc[j][0]; cur.y += acc[j][1]; cur.z += acc[j][2]; cur.w += acc[j][3];
+      *dst = cur;
+    }
+  }
+}
+
+// One workgroup owns a tile of 64 output rows x (NBW*16) output columns.  Its WPB waves take
+// the tile's blocks round-robin, two blocks per step, and software-pipeline three stages in
+// registers: block entries two pairs ahead, weights + gathered rows one step ahead, MFMAs now.
+// Each wave accumulates into a private LDS tile; the tiles are summed in wave order at the end,
+// so the result is bit-reproducible.  ALIGNED: ci % 32 == 0 (float4 gathers, no bounds checks).
+struct PairEnt { int eA, eB, kA, kB; };
+
+template <int NBW, int WPB, bool ALIGNED>
+__global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mfma(const float *__restrict__ in, int ci,
+                                                              float *__restrict__ out, int co,
+                                                              int64_t V_out, const int32_t *__restrict__ words,
+                                                              int vol, int wflip, const float *__restrict__ Wp,
+                                                              const float *__restrict__ bias) {
+  constexpr int WS = NBW * 16;              // C-tile row stride (floats)
+  constexpr int TILE = 64 * WS;             // floats per wave
+  extern __shared__ __align__(16) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  float *Ct = smem + (size_t)wave * TILE;
+  const int maxb = tb_maxb(vol);
+
+  const int nkc = nkc_of(ci), nnb = nnb_of(co);
+  const int nb0 = blockIdx.y * NBW;                       // first global n-block of the slab
+  const int64_t tile = blockIdx.x, row0 = tile * 64;
+  const int64_t ntiles = tb_ntiles(V_out);
+  const int nblk = words[tile];
+  const int32_t *blk_k = words + ntiles + tile * maxb;
+  const int32_t *ent = words + ntiles + ntiles * maxb + tile * maxb * 16;
+  const int64_t wk_stride = (int64_t)nkc * nnb * 512;
+
+  for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
+
+  // this wave's blocks: wave, wave + WPB, ...; consumed two per pair
+  const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
+  const int npairs = (nmine + 1) >> 1;
+  auto load_pair = [&](int pr) {
+    PairEnt p;
+    const int bA = wave + (2 * pr) * WPB, bB = bA + WPB;
+    if (pr < npairs) {
+      const bool hasB = bB < nblk;
+      p.eA = ent[bA * 16 + c16];
+      p.eB = hasB ? ent[bB * 16 + c16] : -1;
+      p.kA = blk_k[bA];
+      p.kB = hasB ? blk_k[bB] : p.kA;
+    } else {
+      p.eA = p.eB = -1; p.kA = p.kB = 0;
+    }
+    return p;
+  };
+  auto fetch = [&](ConvStep &st, const PairEnt &p, int kc) {
+    st.eA = p.eA; st.eB = p.eB;
+    conv_block_load<ALIGNED>(in, ci, st.eA, g, kc, st.a8);
+    conv_block_load<ALIGNED>(in, ci, st.eB, g, kc, st.b8);
+  };
+  PairEnt p0 = load_pair(0), p1 = load_pair(1), p2 = load_pair(2);
+  ConvStep cur, nxt;
+  if (npairs > 0) fetch(cur, p0, 0);
+  f32x4 accA[NBW], accB[NBW];
+  for (int pr = 0; pr < npairs; ++pr) {
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accB[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int kA = __builtin_amdgcn_readfirstlane(p0.kA), kB = __builtin_amdgcn_readfirstlane(p0.kB);
+    if (wflip) { kA = vol - 1 - kA; kB = vol - 1 - kB; }
+    const float *WkA = Wp + kA * wk_stride, *WkB = Wp + kB * wk_stride;
+    for (int kc = 0; kc < nkc; ++kc) {
+      // the gathers of the following step go in flight before this step's MFMAs issue
+      if (kc + 1 < nkc) fetch(nxt, p0, kc + 1);
+      else if (pr + 1 < npairs) fetch(nxt, p1, 0);
+      conv_step_mfma<NBW>(cur, WkA, WkB, kc, nnb, nb0, lane, accA, accB);
+      cur = nxt;
+    }
+    conv_block_accumulate<NBW, WS>(Ct, p0.eA, g, accA);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // A and B may hit the same row
+    conv_block_accumulate<NBW, WS>(Ct, p0.eB, g, accB);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    p0 = p1; p1 = p2; p2 = load_pair(pr + 3);
   }
   __syncthreads();
   // combine the per-wave tiles in wave order (+ bias, CPU/Convolution.cpp:59-62) and write once
-  const int nt = vol < WPB ? vol : WPB;
   const int nrows = (int)((V_out - row0) < 64 ? (V_out - row0) : 64);
   const int wcols = (co - nb0 * 16) < NBW * 16 ? (co - nb0 * 16) : NBW * 16;
   if ((co & 3) == 0) {
@@ -156,7 +258,8 @@ __global__ __launch_bounds__(WPB * 64) void k_conv_gather_mfma(const float *__re
     for (int i = threadIdx.x; i < nrows * q; i += WPB * 64) {
       int r = i / q, cq = i % q;
       float4 v = *reinterpret_cast<const float4 *>(smem + r * WS + cq * 4);
-      for (int w = 1; w < nt; ++w) {
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) {
         float4 u = *reinterpret_cast<const float4 *>(smem + (size_t)w * TILE + r * WS + cq * 4);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
       }
@@ -170,70 +273,143 @@ __global__ __launch_bounds__(WPB * 64) void k_conv_gather_mfma(const float *__re
     for (int i = threadIdx.x; i < nrows * wcols; i += WPB * 64) {
       int r = i / wcols, cc = i % wcols;
       float v = smem[r * WS + cc];
-      for (int w = 1; w < nt; ++w) v += smem[(size_t)w * TILE + r * WS + cc];
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) v += smem[(size_t)w * TILE + r * WS + cc];
       if (bias) v += bias[nb0 * 16 + cc];
       out[(row0 + r) * co + nb0 * 16 + cc] = v;
     }
   }
 }
 
+// ------------------------------------------------------------------ compiled rule book, part 2
+// Offset-major compacted pairs (the reference's RuleBook layout: for offset k the (in, out)
+// pairs in ascending out order, Metadata.h:34) for the weight-gradient pass, whose reduction
+// runs over the pairs of ONE offset.
+//   words: [vol] R_k | [vol+1] first chunk of offset k | [vol][nb256] block bases | [vol][V][2] pairs
+constexpr int kDwChunk = 1024; // pairs per weight-gradient chunk (one workgroup = 4 waves x 256)
+__host__ __device__ inline int64_t op_nb256(int64_t V) { return (V + 255) / 256; }
+
+// one block per offset: exclusive scan of the per-256-row hit counts
+__global__ __launch_bounds__(256) void k_offset_bases(const int32_t *__restrict__ counts, int64_t nb,
+                                                      int vol, int32_t *__restrict__ words) {
+  __shared__ int ws[4];
+  __shared__ int carry_s;
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int32_t *bases = words + vol + (vol + 1) + (int64_t)k * nb;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nb; base += 256) {
+    int64_t i = base + threadIdx.x;
+    int v = (i < nb) ? counts[(int64_t)k * nb + i] : 0, inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int u = __shfl_up(inc, d);
+      if (lane >= d) inc += u;
+    }
+    if (lane == 63) ws[wave] = inc;
+    __syncthreads();
+    int pre = carry_s;
+    for (int j = 0; j < wave; ++j) pre += ws[j];
+    if (i < nb) bases[i] = pre + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = pre + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) words[k] = carry_s; // R_k
+}
+
+// chunk layout: offset k owns chunks [cstart[k], cstart[k+1]) of kDwChunk pairs each
+__global__ void k_offset_chunks(int vol, int32_t *__restrict__ words) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int c = 0;
+    for (int k = 0; k < vol; ++k) {
+      words[vol + k] = c;
+      c += (words[k] + kDwChunk - 1) / kDwChunk;
+    }
+    words[vol + vol] = c;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fill_offset_pairs(const int32_t *__restrict__ table, int64_t V,
+                                                           int vol, int32_t *__restrict__ words) {
+  __shared__ int ws[4];
+  const int k = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nb = op_nb256(V);
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int t = (row < V) ? table[(int64_t)k * V + row] : -1;
+  const unsigned long long m = __ballot(t >= 0);
+  if (lane == 0) ws[wave] = (int)__popcll(m);
+  __syncthreads();
+  int pre = words[vol + (vol + 1) + (int64_t)k * nb + blockIdx.x];
+  for (int j = 0; j < wave; ++j) pre += ws[j];
+  if (t >= 0) {
+    int pos = pre + (int)__popcll(m & ((1ull << lane) - 1ull));
+    int2 *pairs = reinterpret_cast<int2 *>(words + vol + (vol + 1) + (int64_t)vol * nb) + (int64_t)k * V;
+    pairs[pos] = make_int2(t, (int)row);
+  }
+}
+
 // ----------------------------------------------------------------------------- dW
-// partial[chunk][k][c][n] = sum over the chunk's output rows o with t = table[k][o] >= 0 of
-// in[t][c] * d_out[o][n];  MFMA with the reduction (pair) index as K.  CB x NB blocks of 16.
+// partial[chunk][c][n] = sum over the chunk's pairs (t, o) of in[t][c] * d_out[o][n]; one workgroup
+// per chunk of kDwChunk pairs of one offset (each wave a quarter), MFMA with the pair index as the
+// reduction dimension.  Pair indices are loaded 64 at a time (coalesced) and handed to the lane
+// groups by shuffles; 16 pairs are gathered per step before their MFMAs issue.  The four waves'
+// accumulators are summed through LDS in wave order (deterministic).  CB x NB blocks of 16.
 template <int CB, int NB>
-__global__ __launch_bounds__(256) void k_conv_dw_partial(const float *__restrict__ in, int ci,
-                                                         const float *__restrict__ d_out, int co,
-                                                         int64_t V_out, const int32_t *__restrict__ table,
-                                                         int vol, int nchunks, int64_t rows_per_chunk,
-                                                         float *__restrict__ partial) {
-  __shared__ int32_t lists[4][2][64];
+__global__ __launch_bounds__(256) void k_conv_dw_pairs(const float *__restrict__ in, int ci,
+                                                       const float *__restrict__ d_out, int co, int64_t V,
+                                                       const int32_t *__restrict__ words, int vol,
+                                                       float *__restrict__ partial) {
+  __shared__ f32x4 red[CB * NB][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
-  const int ncb = nnb_of(ci), nnb = nnb_of(co);
+  const int nnb = nnb_of(co);
   const int tiles_n = (nnb + NB - 1) / NB;
-  const int tile = blockIdx.z;
+  const int tile = blockIdx.y;
   const int cb0 = (tile / tiles_n) * CB, nb0 = (tile % tiles_n) * NB;
-  const int k = blockIdx.y;
-  const int chunk = blockIdx.x * 4 + wave;
-  if (chunk >= nchunks) return;
-  int32_t *lt = lists[wave][0], *lo = lists[wave][1];
-
+  const int chunk = blockIdx.x;
+  const int32_t *cstart = words + vol;
+  if (chunk >= cstart[vol]) return;                        // workgroup-uniform
+  // which offset owns this chunk (cstart is non-decreasing)
+  int k = 0;
+  for (int k0 = 0; k0 < vol; k0 += 64) {
+    int kk = k0 + lane;
+    bool mine = kk < vol && cstart[kk] <= chunk && chunk < cstart[kk + 1];
+    unsigned long long m = __ballot(mine);
+    if (m) { k = k0 + (__ffsll((long long)m) - 1); break; }
+  }
+  const int rk = words[k];
+  const int p0 = (chunk - cstart[k]) * kDwChunk + wave * (kDwChunk / 4);
+  int p1 = p0 + kDwChunk / 4;
+  if (p1 > rk) p1 = rk;
+  const int2 *pairs = reinterpret_cast<const int2 *>(words + vol + (vol + 1) + (int64_t)vol * op_nb256(V)) +
+                      (int64_t)k * V;
   f32x4 acc[CB][NB];
 #pragma unroll
   for (int a = 0; a < CB; ++a)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int64_t r_begin = (int64_t)chunk * rows_per_chunk;
-  int64_t r_end = r_begin + rows_per_chunk;
-  if (r_end > V_out) r_end = V_out;
-  for (int64_t base = r_begin; base < r_end; base += 64) {
-    const int64_t row = base + lane;
-    const int t = (row < r_end) ? table[(int64_t)k * V_out + row] : -1;
-    const unsigned long long m = __ballot(t >= 0);
-    if (m == 0) continue;
-    const int cnt = __popcll(m);
-    const int pos = __popcll(m & ((1ull << lane) - 1ull));
-    if (t >= 0) { lt[pos] = t; lo[pos] = (int32_t)(row - base); }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int q0 = 0; q0 < cnt; q0 += 16) {
-      // 16 pairs per step: issue every gather first (4 independent K-steps in flight), then the MFMAs
+  for (int q64 = p0; q64 < p1; q64 += 64) {
+    const int q = q64 + lane;
+    int2 pr = (q < p1) ? pairs[q] : make_int2(-1, -1);
+    const int nhere = (p1 - q64) < 64 ? (p1 - q64) : 64;
+    for (int q0 = 0; q0 < nhere; q0 += 16) {
       float av[4][CB], bv[4][NB];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        const int q = q0 + st * 4 + g;
-        const bool on = q < cnt;
-        const int64_t tq = on ? lt[q] : 0;
-        const int64_t oq = on ? base + lo[q] : 0;
+        const int src = q0 + st * 4 + g;
+        const int tq = __shfl(pr.x, src), oq = __shfl(pr.y, src);
+        const bool on = tq >= 0;
 #pragma unroll
         for (int a = 0; a < CB; ++a) {
           int c = (cb0 + a) * 16 + c16;
-          av[st][a] = (on && c < ci) ? in[tq * ci + c] : 0.0f;
+          av[st][a] = (on && c < ci) ? in[(int64_t)tq * ci + c] : 0.0f;
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           int n = (nb0 + b) * 16 + c16;
-          bv[st][b] = (on && n < co) ? d_out[oq * co + n] : 0.0f;
+          bv[st][b] = (on && n < co) ? d_out[(int64_t)oq * co + n] : 0.0f;
         }
       }
 #pragma unroll
@@ -244,29 +420,52 @@ __global__ __launch_bounds__(256) void k_conv_dw_partial(const float *__restrict
           for (int b = 0; b < NB; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][a], bv[st][b], acc[a][b], 0, 0, 0);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
+  // sum the four waves' accumulators in wave order: w0 + w1 + w2 + w3
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (w == 0) red[a * NB + b][lane] = acc[a][b];
+          else {
+            f32x4 t = red[a * NB + b][lane];
+            t[0] += acc[a][b][0]; t[1] += acc[a][b][1]; t[2] += acc[a][b][2]; t[3] += acc[a][b][3];
+            red[a * NB + b][lane] = t;
+          }
+        }
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
   // D[i = c (row of dW) = g*4 + r][j = n = c16]
-  float *P = partial + ((int64_t)chunk * vol + k) * ci * co;
+  float *P = partial + (int64_t)chunk * ci * co;
 #pragma unroll
   for (int a = 0; a < CB; ++a)
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b) {
+      f32x4 t = red[a * NB + b][lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int c = (cb0 + a) * 16 + g * 4 + r, n = (nb0 + b) * 16 + c16;
-        if (c < ci && n < co) P[(int64_t)c * co + n] = acc[a][b][r];
+        if (c < ci && n < co) P[(int64_t)c * co + n] = t[r];
       }
+    }
 }
 
-__global__ __launch_bounds__(256) void k_conv_dw_reduce(const float *__restrict__ partial, int nchunks,
-                                                        int64_t elems, float *__restrict__ dW) {
+// dW[k][i] = sum of the partials of offset k's chunks, in chunk order (deterministic)
+__global__ __launch_bounds__(256) void k_conv_dw_reduce(const float *__restrict__ partial,
+                                                        const int32_t *__restrict__ words, int vol,
+                                                        int64_t cico, float *__restrict__ dW) {
+  const int k = blockIdx.y;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= elems) return;
+  if (i >= cico) return;
+  const int c0 = words[vol + k], c1 = words[vol + k + 1];
   float s = 0.0f;
-#pragma unroll 8
-  for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * elems + i]; // fixed order: deterministic
-  dW[i] = s;
+#pragma unroll 4
+  for (int c = c0; c < c1; ++c) s += partial[(int64_t)c * cico + i];
+  dW[(int64_t)k * cico + i] = s;
 }
 
 // d_bias[n] = sum_rows d_out[row][n] (at::sum_out, CPU/Convolution.cpp:100-101); one block per
@@ -284,21 +483,14 @@ __global__ __launch_bounds__(256) void k_col_sum(const float *__restrict__ x, in
     out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-static int dw_chunks(int64_t V_out, int vol, int tiles) {
-  int64_t want = 4096 / ((int64_t)vol * tiles); // ~4 waves per SIMD over the chip
-  if (want < 1) want = 1;
-  int64_t maxc = ceil_div(V_out, 256);
-  if (maxc < 1) maxc = 1;
-  if (want > maxc) want = maxc;
-  if (want > 128) want = 128;
-  return (int)want;
-}
+
 static void dw_tiling(int ci, int co, int &cb, int &nb, int &tiles) {
   int ncb = nnb_of(ci), nnb = nnb_of(co);
   cb = ncb >= 4 ? 4 : (ncb >= 2 ? 2 : 1);
   nb = nnb >= 4 ? 4 : (nnb >= 2 ? 2 : 1);
   tiles = (int)(ceil_div(ncb, cb) * ceil_div(nnb, nb));
 }
+
 
 } // namespace aabr
 
@@ -311,91 +503,131 @@ extern "C" int64_t aabr_conv_wpack_floats(int vol, int n_in, int n_out) {
   return a > b ? a : b;
 }
 
+extern "C" int64_t aabr_tile_blocks_words(int64_t V, int vol) {
+  int64_t nt = tb_ntiles(V);
+  return nt + nt * tb_maxb(vol) + nt * tb_maxb(vol) * 16;
+}
+
+extern "C" int aabr_build_tile_blocks(const int32_t *table, int64_t V, int vol, int32_t *blocks, void *stream_) {
+  AABR_CHECK_ARG(V >= 0 && vol > 0 && vol <= 4096, "bad sizes");
+  AABR_CHECK_ARG(V < (1ll << 25), "more than 2^25 sites per grid are not supported");
+  if (V == 0) return AABR_OK;
+  AABR_CHECK_ARG(table && blocks, "null pointer");
+  hipLaunchKernelGGL(k_build_tile_blocks, dim3((unsigned)ceil_div(tb_ntiles(V), 4)), dim3(256), 0,
+                     (hipStream_t)stream_, table, V, vol, blocks);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int64_t aabr_offset_pairs_words(int64_t V, int vol) {
+  return (int64_t)vol + (vol + 1) + (int64_t)vol * op_nb256(V) + 2 * (int64_t)vol * V;
+}
+
+extern "C" int aabr_build_offset_pairs(const int32_t *table, const int32_t *block_counts, int64_t V, int vol,
+                                       int32_t *pairs, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(V >= 0 && vol > 0 && vol <= 65535 && pairs, "bad arguments");
+  if (V == 0) {
+    hipMemsetAsync(pairs, 0, (size_t)(2 * vol + 1) * sizeof(int32_t), st);
+    return AABR_OK;
+  }
+  AABR_CHECK_ARG(table && block_counts, "null pointer");
+  hipLaunchKernelGGL(k_offset_bases, dim3((unsigned)vol), dim3(256), 0, st, block_counts, op_nb256(V), vol, pairs);
+  hipLaunchKernelGGL(k_offset_chunks, dim3(1), dim3(64), 0, st, vol, pairs);
+  hipLaunchKernelGGL(k_fill_offset_pairs, dim3((unsigned)op_nb256(V), (unsigned)vol), dim3(256), 0, st, table, V,
+                     vol, pairs);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
 extern "C" int aabr_conv_forward(const float *in_feats, int n_in, float *out_feats, int n_out, int64_t V_out,
-                                 const int32_t *table, int vol, const float *W, const float *bias, int flags,
+                                 const int32_t *blocks, int vol, const float *W, const float *bias, int flags,
                                  float *wpack, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && vol > 0 && V_out >= 0, "bad sizes");
   AABR_CHECK_ARG(n_in <= 4096 && n_out <= 4096, "plane count too large");
   if (V_out == 0) return AABR_OK;
-  AABR_CHECK_ARG(in_feats && out_feats && table && W && wpack, "null pointer");
+  AABR_CHECK_ARG(in_feats && out_feats && blocks && W && wpack, "null pointer");
   AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 15) == 0 &&
                      ((uintptr_t)wpack & 15) == 0,
                  "feature / scratch pointers must be 16-byte aligned");
   const int transpose = flags & 1, flip = (flags >> 1) & 1;
   const int nkc = nkc_of(n_in), nnb = nnb_of(n_out);
   int64_t total = (int64_t)vol * nkc * nnb * 512;
-  if (!(flags & 4)) // bit2: wpack already holds the packed weights of this (W, flags) pair
+  if (!(flags & 4)) // bit2: wpack already holds the packed weights of this (W, flags & 1) pair
     hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, W, vol, n_in,
-                       n_out, transpose, flip, wpack);
+                       n_out, transpose, 0, wpack);
   const bool aligned = (n_in % kKC) == 0;
-  // WPB waves split the filter offsets of one 64-row tile.  Pick the split that minimises
-  // (rounds of resident workgroups) x (offsets per wave): a grid one workgroup larger than what
+  // WPB waves share the blocks of one 64-row tile.  Pick the split that minimises
+  // (rounds of resident workgroups) x (blocks per wave): a grid one workgroup larger than what
   // fits on the chip at once would otherwise pay a whole second round.
 #define AABR_LAUNCH_CONV(NBW, WPB)                                                                      \
   do {                                                                                                  \
-    size_t lds = (size_t)(WPB) * (65 * ((NBW)*16 + 4) + 128) * sizeof(float);                           \
+    size_t lds = (size_t)(WPB) * 64 * ((NBW)*16) * sizeof(float);                                       \
     dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                           \
     if (aligned)                                                                                        \
-      hipLaunchKernelGGL((k_conv_gather_mfma<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,         \
-                         in_feats, n_in, out_feats, n_out, V_out, table, vol, wpack, bias);             \
+      hipLaunchKernelGGL((k_conv_blocks_mfma<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,         \
+                         in_feats, n_in, out_feats, n_out, V_out, blocks, vol, flip, wpack, bias);      \
     else                                                                                                \
-      hipLaunchKernelGGL((k_conv_gather_mfma<NBW, WPB, false>), grid, dim3(64 * (WPB)), lds, st,        \
-                         in_feats, n_in, out_feats, n_out, V_out, table, vol, wpack, bias);             \
+      hipLaunchKernelGGL((k_conv_blocks_mfma<NBW, WPB, false>), grid, dim3(64 * (WPB)), lds, st,        \
+                         in_feats, n_in, out_feats, n_out, V_out, blocks, vol, flip, wpack, bias);      \
   } while (0)
   const int nbw = nnb <= 1 ? 1 : (nnb == 2 ? 2 : 4);
   const int64_t wgs = ceil_div(V_out, 64) * ceil_div(nnb, nbw);
   int best_wpb = 2;
   int64_t best_cost = -1;
   for (int wpb = 2; wpb <= (nbw == 4 ? 3 : 4); ++wpb) {
-    int64_t lds = (int64_t)wpb * (65 * (nbw * 16 + 4) + 128) * 4;
+    int64_t lds = (int64_t)wpb * 64 * (nbw * 16) * 4;
     int64_t per_cu = (160 * 1024) / lds;
-    if (per_cu > 32 / wpb) per_cu = 32 / wpb;
+    int64_t wave_cap = (nbw == 4 ? 16 : 20) / wpb; // register budget: 4 resp. 5 waves per SIMD
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu < 1) per_cu = 1;
     int64_t rounds = ceil_div(wgs, 256 * per_cu);
+    if (lds > 64 * 1024) continue; // default dynamic-LDS limit per workgroup
     int64_t cost = rounds * ceil_div(vol, wpb);
     if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_wpb = wpb; }
   }
   if (nbw == 1) {
-    if (best_wpb == 2) AABR_LAUNCH_CONV(1, 2); else if (best_wpb == 3) AABR_LAUNCH_CONV(1, 3); else AABR_LAUNCH_CONV(1, 4);
+    if (best_wpb == 2) AABR_LAUNCH_CONV(1, 2);
+    else if (best_wpb == 3) AABR_LAUNCH_CONV(1, 3);
+    else AABR_LAUNCH_CONV(1, 4);
   } else if (nbw == 2) {
-    if (best_wpb == 2) AABR_LAUNCH_CONV(2, 2); else if (best_wpb == 3) AABR_LAUNCH_CONV(2, 3); else AABR_LAUNCH_CONV(2, 4);
+    if (best_wpb == 2) AABR_LAUNCH_CONV(2, 2);
+    else if (best_wpb == 3) AABR_LAUNCH_CONV(2, 3);
+    else AABR_LAUNCH_CONV(2, 4);
   } else {
-    if (best_wpb == 2) AABR_LAUNCH_CONV(4, 2); else AABR_LAUNCH_CONV(4, 3);
+    if (best_wpb == 2) AABR_LAUNCH_CONV(4, 2);
+    else AABR_LAUNCH_CONV(4, 3);
   }
 #undef AABR_LAUNCH_CONV
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
 
-extern "C" int64_t aabr_conv_dw_scratch_floats(int64_t V_out, int vol, int n_in, int n_out) {
-  int cb, nb, tiles;
-  dw_tiling(n_in, n_out, cb, nb, tiles);
-  return (int64_t)dw_chunks(V_out, vol, tiles) * vol * n_in * n_out;
+extern "C" int64_t aabr_conv_dw_scratch_floats(int64_t max_chunks, int n_in, int n_out) {
+  return max_chunks * n_in * n_out;
 }
 
 extern "C" int aabr_conv_backward_weight(const float *in_feats, int n_in, const float *d_out, int n_out,
-                                         int64_t V_out, const int32_t *table, int vol, float *dW,
-                                         float *d_bias, float *scratch, void *stream_) {
+                                         int64_t V_out, const int32_t *pairs, int vol, int64_t max_chunks,
+                                         float *dW, float *d_bias, float *scratch, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && vol > 0 && V_out >= 0 && vol <= 65535, "bad sizes");
   AABR_CHECK_ARG(dW, "null dW");
-  int64_t elems = (int64_t)vol * n_in * n_out;
-  if (V_out == 0) {
-    hipMemsetAsync(dW, 0, elems * sizeof(float), st);
+  int64_t cico = (int64_t)n_in * n_out;
+  if (V_out == 0 || max_chunks == 0) {
+    hipMemsetAsync(dW, 0, vol * cico * sizeof(float), st);
     if (d_bias) hipMemsetAsync(d_bias, 0, n_out * sizeof(float), st);
     return AABR_OK;
   }
-  AABR_CHECK_ARG(in_feats && d_out && table && scratch, "null pointer");
+  AABR_CHECK_ARG(in_feats && d_out && pairs && scratch && max_chunks > 0, "null pointer");
   int cb, nb, tiles;
   dw_tiling(n_in, n_out, cb, nb, tiles);
   AABR_CHECK_ARG(tiles <= 65535, "too many tiles");
-  const int nchunks = dw_chunks(V_out, vol, tiles);
-  int64_t rpc = ceil_div(V_out, nchunks);
-  rpc = ceil_div(rpc, 64) * 64;
-  dim3 grid((unsigned)ceil_div(nchunks, 4), (unsigned)vol, (unsigned)tiles);
+  dim3 grid((unsigned)max_chunks, (unsigned)tiles);
 #define AABR_LAUNCH_DW(CB, NB)                                                                           \
-  hipLaunchKernelGGL((k_conv_dw_partial<CB, NB>), grid, dim3(256), 0, st, in_feats, n_in, d_out, n_out,  \
-                     V_out, table, vol, nchunks, rpc, scratch)
+  hipLaunchKernelGGL((k_conv_dw_pairs<CB, NB>), grid, dim3(256), 0, st, in_feats, n_in, d_out, n_out,    \
+                     V_out, pairs, vol, scratch)
   if (cb == 1 && nb == 1) AABR_LAUNCH_DW(1, 1);
   else if (cb == 1 && nb == 2) AABR_LAUNCH_DW(1, 2);
   else if (cb == 1 && nb == 4) AABR_LAUNCH_DW(1, 4);
@@ -406,8 +638,8 @@ extern "C" int aabr_conv_backward_weight(const float *in_feats, int n_in, const 
   else if (cb == 4 && nb == 2) AABR_LAUNCH_DW(4, 2);
   else AABR_LAUNCH_DW(4, 4);
 #undef AABR_LAUNCH_DW
-  hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, st, scratch, nchunks,
-                     elems, dW);
+  hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 256), (unsigned)vol), dim3(256), 0, st,
+                     scratch, pairs, vol, cico, dW);
   if (d_bias)
     hipLaunchKernelGGL(k_col_sum, dim3((unsigned)ceil_div(n_out, 64)), dim3(256), 0, st, d_out, V_out, n_out,
                        d_bias);

@@ -13,6 +13,11 @@ import torch.distributed as dist
 
 
 class FlatParams(object):
+    """All parameters of the given modules in ONE flat buffer (views), so a step issues one
+    fused SGD update and -- for N > 1 -- one gradient all-reduce.  Gradients are left where
+    autograd puts them (no zero-fill and no accumulate launches per step); they are packed into
+    the flat gradient buffer by a single multi-tensor copy right before the collective."""
+
     def __init__(self, modules):
         params = []
         for m in modules:
@@ -22,21 +27,28 @@ class FlatParams(object):
         dev, dt = params[0].device, params[0].dtype
         self.flat = torch.empty(n, device=dev, dtype=dt)
         self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
+        self.grad_views = []
         o = 0
         for p in params:
             k = p.numel()
             self.flat[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + k].view_as(p.data)
-            p.grad = self.flat_grad[o:o + k].view_as(p.data)
+            self.grad_views.append(self.flat_grad[o:o + k].view_as(p.data))
             o += k
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def pack_grads(self):
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        torch._foreach_copy_(self.grad_views, grads)
 
     def allreduce_mean(self, world_size=None, group=None):
         """gradient all-reduce (mean) -- the one collective of a training step"""
         if world_size is None:
             world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.pack_grads()
         if world_size > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
             self.flat_grad.mul_(1.0 / world_size)

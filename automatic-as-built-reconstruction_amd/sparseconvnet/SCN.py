@@ -14,8 +14,84 @@ import torch
 import _hip
 from _hip import ptr, stream, check
 
-count_macs = True  # the reference returns the multiply-add count of every conv (costs one
-                   # small D2H read per rule book, cached afterwards)
+count_macs = True  # the reference returns the multiply-add count of every conv; here the count is
+                   # a LAZY number: the rule counts stay on the device until somebody reads it
+
+
+class LazyMacs(object):
+    """Sum of (device rule-count tensor, multiplier) terms that behaves like the float the
+    reference returns (`sparseconvnet.forward_pass_multiplyAdd_count += ...`,
+    submanifoldConvolution.py:85-94) but performs the device->host read only when the value
+    is actually looked at -- so counting costs no host synchronisation in the training loop.
+    Only the small per-offset count tensors are referenced (never the rule tables), and the
+    pending list is folded into the base value once it holds more than 256 terms."""
+    __slots__ = ("terms", "base")
+
+    def __init__(self, terms=(), base=0.0):
+        self.terms, self.base = list(terms), float(base)
+
+    def _value(self):
+        if self.terms:
+            tot = None
+            for counts, mult in self.terms:
+                v = counts.sum(dtype=torch.float64) * mult
+                tot = v if tot is None else tot + v.to(tot.device)
+            self.base += float(tot.item())
+            self.terms = []
+        return self.base
+
+    def __add__(self, other):
+        if isinstance(other, LazyMacs):
+            r = LazyMacs(self.terms + other.terms, self.base + other.base)
+        else:
+            r = LazyMacs(self.terms, self.base + float(other))
+        if len(r.terms) > 256:
+            r._value()
+        return r
+
+    __radd__ = __add__
+
+    def __iadd__(self, other):  # `counter += macs` in the layer code: amortised O(1), in place
+        if isinstance(other, LazyMacs):
+            self.terms.extend(other.terms)
+            self.base += other.base
+        else:
+            self.base += float(other)
+        if len(self.terms) > 256:
+            self._value()
+        return self
+
+    def __float__(self):
+        return self._value()
+
+    def __int__(self):
+        return int(self._value())
+
+    def __eq__(self, other):
+        return self._value() == float(other)
+
+    def __lt__(self, other):
+        return self._value() < float(other)
+
+    def __le__(self, other):
+        return self._value() <= float(other)
+
+    def __gt__(self, other):
+        return self._value() > float(other)
+
+    def __ge__(self, other):
+        return self._value() >= float(other)
+
+    def __hash__(self):
+        return hash(self._value())
+
+    def __repr__(self):
+        return repr(self._value())
+
+    __str__ = __repr__
+
+    def __format__(self, spec):
+        return format(self._value(), spec)
 
 
 def n_rulebook_bits():
@@ -23,8 +99,21 @@ def n_rulebook_bits():
     return 32
 
 
+_key_cache = {}
+
+
 def _key(t):
-    return tuple(int(x) for x in (t.tolist() if hasattr(t, "tolist") else t))
+    """tuple form of a (small, long-lived, CPU) size tensor; memoised per tensor object/version"""
+    if not hasattr(t, "tolist"):
+        return tuple(int(x) for x in t)
+    k = (id(t), t._version)
+    v = _key_cache.get(k)
+    if v is None or v[0] is not t:
+        if len(_key_cache) > 4096:
+            _key_cache.clear()
+        v = (t, tuple(int(x) for x in t.tolist()))
+        _key_cache[k] = v
+    return v[1]
 
 
 class _Grid(object):
@@ -35,21 +124,70 @@ class _Grid(object):
         self.coords, self.keys, self.vals, self.cap, self.V = coords, keys, vals, cap, V
 
 
-class _Table(object):
-    """gather table(s) of one rule book"""
-    __slots__ = ("out", "inn", "counts", "vol", "V_out", "V_in", "_host_counts", "flip_ok")
+class _Gather(object):
+    """one gather table [vol, rows] + its compiled streaming forms (built lazily, cached)"""
+    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_pairs", "_host_counts")
 
-    def __init__(self, out, inn, counts, vol, V_out, V_in, flip_ok=False):
-        self.out, self.inn, self.counts, self.vol = out, inn, counts, vol
-        self.V_out, self.V_in, self.flip_ok = V_out, V_in, flip_ok
-        self._host_counts = None
+    def __init__(self, table, counts, vol, rows):
+        self.table, self.counts, self.vol, self.rows = table, counts, vol, rows
+        self._blocks = self._pairs = self._host_counts = None
+
+    def _ensure_counts(self):
+        if self.counts is None:  # table built without counts (input side of a strided book)
+            nb = (self.rows + 255) // 256
+            c = (self.table >= 0).to(torch.int32)
+            pad = nb * 256 - self.rows
+            if pad:
+                c = torch.nn.functional.pad(c, (0, pad))
+            self.counts = c.view(self.vol, nb, 256).sum(2, dtype=torch.int32).contiguous().view(-1)
+        return self.counts
+
+    def blocks(self):
+        """tile blocks for aabr_conv_forward"""
+        if self._blocks is None:
+            lib = _hip.load()
+            w = torch.empty(max(lib.aabr_tile_blocks_words(self.rows, self.vol), 1), dtype=torch.int32,
+                            device=self.table.device)
+            check(lib.aabr_build_tile_blocks(ptr(self.table), self.rows, self.vol, ptr(w), stream()))
+            self._blocks = w
+        return self._blocks
+
+    def pairs(self):
+        """offset-major compacted pairs for aabr_conv_backward_weight"""
+        if self._pairs is None:
+            lib = _hip.load()
+            w = torch.empty(max(lib.aabr_offset_pairs_words(self.rows, self.vol), 1), dtype=torch.int32,
+                            device=self.table.device)
+            check(lib.aabr_build_offset_pairs(ptr(self.table), ptr(self._ensure_counts()), self.rows, self.vol,
+                                              ptr(w), stream()))
+            self._pairs = w
+        return self._pairs
 
     def rule_counts(self):
         """per-offset rule counts (host list); one small D2H read, cached"""
         if self._host_counts is None:
-            self._host_counts = self.counts.view(self.vol, -1).sum(1).tolist() if self.counts.numel() else \
-                [0] * self.vol
+            c = self._ensure_counts()
+            self._host_counts = c.view(self.vol, -1).sum(1).tolist() if c.numel() else [0] * self.vol
         return self._host_counts
+
+    def max_chunks(self):
+        """upper bound on the 1024-pair chunks of the weight-gradient pass"""
+        if self._host_counts is not None:
+            return sum((c + 1023) // 1024 for c in self._host_counts)
+        return (self.vol * self.rows + 1023) // 1024 + self.vol
+
+
+class _Table(object):
+    """rule book: `out` gathers input rows per output row, `inn` gathers output rows per input row
+    (for submanifold books `inn` is `out` read with mirrored offsets)"""
+    __slots__ = ("out", "inn", "vol", "V_out", "V_in", "flip_ok")
+
+    def __init__(self, out, inn, vol, V_out, V_in, flip_ok=False):
+        self.out, self.inn, self.vol = out, inn, vol
+        self.V_out, self.V_in, self.flip_ok = V_out, V_in, flip_ok
+
+    def rule_counts(self):
+        return self.out.rule_counts()
 
     def total_rules(self):
         return float(sum(self.rule_counts()))
@@ -84,6 +222,18 @@ class Metadata_3(object):
         check(_hip.load().aabr_spatial_locations(ptr(g.coords), g.V, ptr(loc), stream()))
         return loc
 
+    def device_tensors(self):
+        """tensors owned by the input-layer state (for cross-stream hand-over)"""
+        ts = []
+        pend = getattr(self, "_pending", None)
+        if pend is not None:
+            ts += [pend["site_coords"], pend["keys"], pend["vals"]]
+        for g in self.grids.values():
+            ts += [g.coords, g.keys, g.vals]
+        if self.input is not None:
+            ts += [self.input["point_site"], self.input["site_off"], self.input["site_pts"]]
+        return ts
+
     def getNActive(self, spatial_size):
         return self.grids[_key(spatial_size)].V
 
@@ -93,8 +243,17 @@ class Metadata_3(object):
     # ---- builders ---------------------------------------------------------------------------
     def inputLayer(self, spatial_size, coords, batch_size, mode, device):
         """Metadata::inputLayer (Metadata.cpp:405-417)"""
+        if self.input is not None and self.input.get("coords_id") == (coords.data_ptr(), coords.shape[0]) \
+                and self.input["mode"] == int(mode):
+            return self.inputLayerFinish()  # prepared ahead of time (InputLayer.prepare)
+        self.inputLayerEnqueue(spatial_size, coords, mode, device)
+        return self.inputLayerFinish()
+
+    def inputLayerEnqueue(self, spatial_size, coords, mode, device):
+        """enqueue the site-numbering kernels and an asynchronous read-back of (V, maxActive, err)"""
         assert coords.dim() == 2 and coords.size(1) in (3, 4)
         assert self.input is None and len(self.grids) == 0, "Metadata already holds an input layer"
+        coords_id = (coords.data_ptr(), coords.shape[0])
         lib = _hip.load()
         self.device = device
         coords = coords.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
@@ -109,24 +268,38 @@ class Metadata_3(object):
         site_off = torch.empty(n + 1, dtype=torch.int32, device=device)
         site_pts = torch.empty(max(n, 1), dtype=torch.int32, device=device)
         meta = torch.empty(_hip.META_WORDS, dtype=torch.int32, device=device)
+        host = torch.empty(_hip.META_WORDS, dtype=torch.int32, pin_memory=True)
         if n > 0:
             check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, ptr(keys), ptr(vals), cap, ptr(scratch),
                                              ptr(point_site), ptr(site_coords), ptr(site_off), ptr(site_pts),
                                              ptr(meta), stream()))
-            m = meta.tolist()  # the one host sync of the input layer: V sizes every later tensor
+            host.copy_(meta, non_blocking=True)
         else:  # empty scene: an empty grid (all keys EMPTY), nothing to launch
             keys.fill_(-1)
             site_off.zero_()
-            m = [0] * _hip.META_WORDS
-        if m[2]:
-            raise _hip.AabrError("InputLayer: coordinates must lie in [0, 65534] (batch index too)")
-        V = m[0]
-        key = _key(spatial_size)
-        self.grids[key] = _Grid(site_coords[:V], keys, vals, cap, V)
-        self.input = dict(point_site=point_site, site_off=site_off, site_pts=site_pts, n=n, V=V,
-                          mode=int(mode), max_active=m[1], spatial=key)
-        self.input_spatial = key
-        return V
+            host.zero_()
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = dict(host=host, event=ev, site_coords=site_coords, keys=keys, vals=vals, cap=cap,
+                             coords=coords)
+        self.input = dict(point_site=point_site, site_off=site_off, site_pts=site_pts, n=n, V=None,
+                          mode=int(mode), max_active=None, spatial=_key(spatial_size), coords_id=coords_id)
+
+    def inputLayerFinish(self):
+        """wait for the read-back (the one host sync of the input layer: V sizes every later tensor)"""
+        pend = getattr(self, "_pending", None)
+        if pend is not None:
+            pend["event"].synchronize()
+            m = pend["host"].tolist()
+            self._pending = None
+            if m[2]:
+                raise _hip.AabrError("InputLayer: coordinates must lie in [0, 65534] (batch index too)")
+            V = m[0]
+            key = self.input["spatial"]
+            self.grids[key] = _Grid(pend["site_coords"][:V], pend["keys"], pend["vals"], pend["cap"], V)
+            self.input["V"], self.input["max_active"] = V, m[1]
+            self.input_spatial = key
+        return self.input["V"]
 
     def getSubmanifoldRuleBook(self, spatial_size, filter_size):
         """Metadata::getSubmanifoldRuleBook (Metadata.cpp:429-443) -> cached gather table"""
@@ -143,7 +316,8 @@ class Metadata_3(object):
                                                      _hip.i32x3(fs), ptr(table), ptr(counts), stream()))
             # odd filters: the input-gradient gather is the same table read with the mirrored
             # offset (u = v + off_k  <=>  v = u + off_{vol-1-k})
-            tb = _Table(table, None, counts, vol, g.V, g.V, flip_ok=all(f % 2 == 1 for f in fs))
+            tb = _Table(_Gather(table, counts, vol, g.V), None, vol, g.V, g.V,
+                        flip_ok=all(f % 2 == 1 for f in fs))
             if not tb.flip_ok:
                 raise NotImplementedError("even-sized submanifold filters")
             self.submanifold[k] = tb
@@ -183,7 +357,7 @@ class Metadata_3(object):
                                               ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
                                               _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),
                                               ptr(t_in), ptr(counts), stream()))
-            tb = _Table(t_out, t_in, counts, vol, V_out, gi.V)
+            tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, None, vol, gi.V), vol, V_out, gi.V)
             self.rulebooks[k] = tb
         return tb
 
@@ -257,7 +431,7 @@ def InputLayer_updateGradInput(metadata, d_input_features, d_output_features):
 # ------------------------------------------------------------------------------------------------
 # the shared gather-GEMM
 # ------------------------------------------------------------------------------------------------
-def _conv_fwd(inp, out, n_rows_out, table, vol, weight, bias, flags):
+def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags):
     lib = _hip.load()
     n_in = inp.size(1)
     w = weight.contiguous()
@@ -268,28 +442,31 @@ def _conv_fwd(inp, out, n_rows_out, table, vol, weight, bias, flags):
     else:
         n_out = w.size(3)
         assert w.size(2) == n_in, (w.shape, n_in)
+    assert gather.rows == n_rows_out
     out.resize_(n_rows_out, n_out)
-    wpack = torch.empty(lib.aabr_conv_wpack_floats(vol, w.size(2), w.size(3)), dtype=torch.float32,
-                        device=inp.device)
-    check(lib.aabr_conv_forward(ptr(inp), n_in, ptr(out), n_out, n_rows_out, ptr(table), vol, ptr(w),
-                                ptr(_opt(bias)), flags, ptr(wpack), stream()))
+    wpack = _hip.workspace("wpack", lib.aabr_conv_wpack_floats(gather.vol, w.size(2), w.size(3)), torch.float32,
+                           inp.device)
+    check(lib.aabr_conv_forward(ptr(inp), n_in, ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
+                                ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
     return n_out
 
 
-def _conv_dw(inp, d_out, table, vol, d_weight, d_bias):
+def _conv_dw(inp, d_out, gather, d_weight, d_bias):
     lib = _hip.load()
     n_in, n_out, V_out = inp.size(1), d_out.size(1), d_out.size(0)
-    assert d_weight.is_contiguous() and d_weight.numel() == vol * n_in * n_out
-    scratch = torch.empty(max(lib.aabr_conv_dw_scratch_floats(V_out, vol, n_in, n_out), 1), dtype=torch.float32,
-                          device=inp.device)
-    check(lib.aabr_conv_backward_weight(ptr(inp), n_in, ptr(d_out), n_out, V_out, ptr(table), vol,
+    assert gather.rows == V_out
+    assert d_weight.is_contiguous() and d_weight.numel() == gather.vol * n_in * n_out
+    pairs = gather.pairs()
+    mc = gather.max_chunks()
+    scratch = _hip.workspace("dw", lib.aabr_conv_dw_scratch_floats(mc, n_in, n_out), torch.float32, inp.device)
+    check(lib.aabr_conv_backward_weight(ptr(inp), n_in, ptr(d_out), n_out, V_out, ptr(pairs), gather.vol, mc,
                                         ptr(d_weight), ptr(_opt(d_bias)), ptr(scratch), stream()))
 
 
 def _macs(tb, weight):
     if not count_macs:
         return 0.0
-    return tb.total_rules() * weight.size(2) * weight.size(3) * weight.size(1)
+    return LazyMacs([(tb.out._ensure_counts(), float(weight.size(2) * weight.size(3) * weight.size(1)))])
 
 
 # SubmanifoldConvolution (pybind.cpp:134-143)
@@ -297,7 +474,7 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, metadata, inp
                                         weight, bias):
     inp = _f32c(input_features, "input_features")
     tb = metadata.getSubmanifoldRuleBook(spatial_size, filter_size)
-    _conv_fwd(inp, output_features, tb.V_out, tb.out, tb.vol, weight, bias, 0)
+    _conv_fwd(inp, output_features, tb.V_out, tb.out, weight, bias, 0)
     return _macs(tb, weight)
 
 
@@ -307,8 +484,8 @@ def SubmanifoldConvolution_backward(spatial_size, filter_size, metadata, input_f
     d_out = _f32c(d_output_features, "d_output_features")
     tb = metadata.getSubmanifoldRuleBook(spatial_size, filter_size)
     # d_in[u] = sum_k d_out[table[k'][u]] @ W[vol-1-k']^T  (flags: transpose | mirrored offset)
-    _conv_fwd(d_out, d_input_features, tb.V_in, tb.out, tb.vol, weight, None, 1 | 2)
-    _conv_dw(inp, d_out, tb.out, tb.vol, d_weight, d_bias)
+    _conv_fwd(d_out, d_input_features, tb.V_in, tb.out, weight, None, 1 | 2)
+    _conv_dw(inp, d_out, tb.out, d_weight, d_bias)
 
 
 # Convolution (pybind.cpp:54-65)
@@ -316,7 +493,7 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
                              output_features, weight, bias):
     inp = _f32c(input_features, "input_features")
     tb = metadata.getRuleBook(input_size, output_size, filter_size, filter_stride)
-    _conv_fwd(inp, output_features, tb.V_out, tb.out, tb.vol, weight, bias, 0)
+    _conv_fwd(inp, output_features, tb.V_out, tb.out, weight, bias, 0)
     return _macs(tb, weight)
 
 
@@ -325,8 +502,8 @@ def Convolution_backward(input_size, output_size, filter_size, filter_stride, me
     inp = _f32c(input_features, "input_features")
     d_out = _f32c(d_output_features, "d_output_features")
     tb = metadata.getRuleBook(input_size, output_size, filter_size, filter_stride)
-    _conv_fwd(d_out, d_input_features, tb.V_in, tb.inn, tb.vol, weight, None, 1)
-    _conv_dw(inp, d_out, tb.out, tb.vol, d_weight, d_bias)
+    _conv_fwd(d_out, d_input_features, tb.V_in, tb.inn, weight, None, 1)
+    _conv_dw(inp, d_out, tb.out, d_weight, d_bias)
 
 
 # Deconvolution (pybind.cpp:78-89): the rule book is looked up as (outputSize, inputSize) with
@@ -335,7 +512,7 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
                                output_features, weight, bias):
     inp = _f32c(input_features, "input_features")
     tb = metadata.getRuleBook(output_size, input_size, filter_size, filter_stride)
-    _conv_fwd(inp, output_features, tb.V_in, tb.inn, tb.vol, weight, bias, 0)
+    _conv_fwd(inp, output_features, tb.V_in, tb.inn, weight, bias, 0)
     return _macs(tb, weight)
 
 
@@ -344,8 +521,8 @@ def Deconvolution_backward(input_size, output_size, filter_size, filter_stride, 
     inp = _f32c(input_features, "input_features")
     d_out = _f32c(d_output_features, "d_output_features")
     tb = metadata.getRuleBook(output_size, input_size, filter_size, filter_stride)
-    _conv_fwd(d_out, d_input_features, tb.V_out, tb.out, tb.vol, weight, None, 1)
-    _conv_dw(inp, d_out, tb.inn, tb.vol, d_weight, d_bias)
+    _conv_fwd(d_out, d_input_features, tb.V_out, tb.out, weight, None, 1)
+    _conv_dw(inp, d_out, tb.inn, d_weight, d_bias)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -359,7 +536,7 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
     if inp.dim() != 2:
         return
     rows, planes = inp.shape
-    scratch = torch.empty(lib.aabr_bn_scratch_floats(planes), dtype=torch.float32, device=inp.device)
+    scratch = _hip.workspace("bn", lib.aabr_bn_scratch_floats(planes), torch.float32, inp.device)
     check(lib.aabr_bn_forward(ptr(inp), ptr(output_features), rows, planes, ptr(saveMean), ptr(saveInvStd),
                               ptr(runningMean), ptr(runningVar), ptr(_opt(weight)), ptr(_opt(bias)), float(eps),
                               float(momentum), int(bool(train)), float(leakiness), ptr(scratch), stream()))
@@ -377,7 +554,7 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     if inp.dim() != 2:
         return
     rows, planes = inp.shape
-    scratch = torch.empty(lib.aabr_bn_scratch_floats(planes), dtype=torch.float32, device=inp.device)
+    scratch = _hip.workspace("bn", lib.aabr_bn_scratch_floats(planes), torch.float32, inp.device)
     check(lib.aabr_bn_backward(ptr(inp), ptr(d_input_features), ptr(output_features.contiguous()), ptr(d_out),
                                rows, planes, ptr(saveMean), ptr(saveInvStd), ptr(_opt(weight)),
                                ptr(_opt(d_weight)), ptr(_opt(d_bias)), float(leakiness), ptr(scratch), stream()))

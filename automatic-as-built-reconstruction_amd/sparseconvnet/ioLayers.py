@@ -26,8 +26,35 @@ class InputLayer(Module):
         self.device = device
         return self
 
+    def prepare(self, coords, device=None, stream=None):
+        """Optional extension (not in the reference): build the hash grid / site numbering of a
+        coordinate list AHEAD of the forward call, e.g. for the next scene on a side stream while
+        the current scene trains.  The geometry depends on the coordinates only, so this is the
+        device-side analogue of a data-loader prefetch; `forward` picks the prepared Metadata up
+        when it is called with the same coordinate tensor."""
+        if device is None:
+            device = self.device if self.device is not None else coords.device
+        md = Metadata(self.dimension)
+        side = stream if stream is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            # kernels + an asynchronous read-back of the site count; nothing blocks here
+            md.inputLayerEnqueue(self.spatial_size, coords.long(), self.mode if self.mode else 3, device)
+            md.prepared_on = side
+        if not hasattr(self, "_prepared"):
+            self._prepared = {}
+        self._prepared[(coords.data_ptr(), coords.shape[0])] = md
+
     def forward(self, input):
-        output = SparseConvNetTensor(metadata=Metadata(self.dimension), spatial_size=self.spatial_size)
+        prepared = getattr(self, "_prepared", None)
+        md = prepared.pop((input[0].data_ptr(), input[0].shape[0]), None) if prepared else None
+        if md is not None:
+            cur = torch.cuda.current_stream()
+            if md.prepared_on != cur:
+                cur.wait_stream(md.prepared_on)  # tensors were produced on the side stream
+                for t in md.device_tensors():
+                    t.record_stream(cur)
+        output = SparseConvNetTensor(metadata=md if md is not None else Metadata(self.dimension),
+                                     spatial_size=self.spatial_size)
         output.features = InputLayerFunction.apply(
             self.dimension, output.metadata, self.spatial_size, input[0].long(),
             input[1].to(self.device) if self.device else input[1], 0 if len(input) == 2 else input[2],

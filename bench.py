@@ -10,7 +10,7 @@ Inputs are resident in HBM before the timed region.  One process per GPU; ranks 
 different scenes (weak scaling), the only collective is the gradient all-reduce.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the output-stationary
-MFMA gather-GEMM, k_conv_gather_mfma, 32->32 forward instance) timed with HIP events on the
+MFMA gather-GEMM, k_conv_blocks_mfma, 32->32 forward instance) timed with HIP events on the
 stream it is launched on; `cpu_baseline` is the oracle (CPU port of the reference path) timed
 on this box's host cores on a bounded sample of the same workload.
 """
@@ -85,7 +85,7 @@ def cpu_baseline(n_scenes_budget_s=15.0):
 
 
 def time_dominant_kernel(scn, m, scene, reps=30):
-    """average launch duration of k_conv_gather_mfma (32->32 forward, S80k rule table) with HIP
+    """average launch duration of k_conv_blocks_mfma (32->32 forward, S80k rule book) with HIP
     events recorded on the stream the kernel is launched on (torch's current stream)."""
     import _hip
     from _hip import ptr, stream, check
@@ -99,13 +99,13 @@ def time_dominant_kernel(scn, m, scene, reps=30):
         out = torch.empty((V, 32), device=inp.device)
         w = m["conv2"].weight.detach().contiguous()
         wpack = torch.empty(lib.aabr_conv_wpack_floats(27, 32, 32), device=inp.device)
-        check(lib.aabr_conv_forward(ptr(inp), 32, ptr(out), 32, V, ptr(tb.out), 27, ptr(w), None, 0, ptr(wpack),
+        check(lib.aabr_conv_forward(ptr(inp), 32, ptr(out), 32, V, ptr(tb.out.blocks()), 27, ptr(w), None, 0, ptr(wpack),
                                     stream()))
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in evs:
             a.record()
-            check(lib.aabr_conv_forward(ptr(inp), 32, ptr(out), 32, V, ptr(tb.out), 27, ptr(w), None, 4,
+            check(lib.aabr_conv_forward(ptr(inp), 32, ptr(out), 32, V, ptr(tb.out.blocks()), 27, ptr(w), None, 4,
                                         ptr(wpack), stream()))
             b.record()
         torch.cuda.synchronize()
@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-profile", default="", help="write a cProfile of the timed loop to this file")
+    ap.add_argument("--prefetch", type=int, default=0,
+                    help="1: build the next scene's hash grid on a side stream while the current scene trains")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,11 +168,20 @@ def main():
             grads.append(torch.randn(o.features.shape, device=dev, generator=g))
     feats_req = [(sc[0], sc[1].clone().requires_grad_(True)) for sc in scenes]
 
+    side = torch.cuda.Stream()
+
     def step(i):
         j = i % len(scenes)
         flat.zero_grad()
+        # geometry of the NEXT scene (hash grid + site numbering; needs only its coordinates) is
+        # built on a side stream now, so its one host read-back overlaps this scene's compute
+        nj = (i + 1) % len(scenes)
+        if args.prefetch and i == 0:
+            m["inp"].prepare(feats_req[j][0], dev, side)
         out = forward(scn, m, feats_req[j][0], feats_req[j][1])
         out.features.backward(grads[j])
+        if args.prefetch:
+            m["inp"].prepare(feats_req[nj][0], dev, side)
         feats_req[j][1].grad = None
         flat.allreduce_mean(world)
         flat.sgd_step(1e-4)
@@ -180,10 +192,23 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    prof = None
+    if args.host_profile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(45)
+        open(args.host_profile, "w").write("enqueue s/step: %g\n" % (t_enq / args.steps) + buf.getvalue())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -196,7 +221,7 @@ def main():
     if rank == 0:
         ksec, R, V = time_dominant_kernel(scn, m, scenes[0])
         flops = 2.0 * R * 32 * 32
-        roof = dict(kernel="k_conv_gather_mfma<2,4,true> (SubmConv3 32->32 forward)", bound="mfma",
+        roof = dict(kernel="k_conv_blocks_mfma (SubmConv3 32->32 forward)", bound="mfma",
                     achieved=round(flops / ksec / 1e12, 4), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(flops / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5), traffic=None,
                     launch_us=round(ksec * 1e6, 2), rules=int(R), sites=int(V),

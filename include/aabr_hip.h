@@ -116,30 +116,46 @@ int aabr_table_to_rulebook(const int32_t *table, int64_t V, int vol, int32_t *ru
 int aabr_spatial_locations(const int32_t *site_coords, int64_t V, int64_t *locations,
                            void *stream);
 
+/* ---- compiled rule books -------------------------------------------------------------------
+ * A gather table is compiled once per rule book (and reused by every layer at that scale, forward
+ * and backward) into the two streaming layouts the MFMA kernels read:
+ *  (1) tile blocks: for each tile of 64 output rows, blocks of 16 (partner row, local row) pairs
+ *      that share one filter offset -- input of aabr_conv_forward;
+ *  (2) offset pairs: for each offset the (partner row, row) pairs in ascending row order -- the
+ *      reference's RuleBook layout (Metadata.h:34) -- input of aabr_conv_backward_weight.
+ * block_counts is the `counts` output of the table builder.  Limits: V < 2^25.                   */
+int64_t aabr_tile_blocks_words(int64_t V, int vol);   /* int32 words of `blocks` */
+int aabr_build_tile_blocks(const int32_t *table, int64_t V, int vol, int32_t *blocks, void *stream);
+int64_t aabr_offset_pairs_words(int64_t V, int vol);  /* int32 words of `pairs` */
+int aabr_build_offset_pairs(const int32_t *table, const int32_t *block_counts, int64_t V, int vol,
+                            int32_t *pairs, void *stream);
+
 /* ---- sparse convolution (fp32 features, fp32 MFMA) ----------------------------------------
  * out[o] = bias + sum_k in[table[k][o]] @ W[wk(k)]      (rows with table == -1 contribute 0)
  * Replaces {Submanifold,}Convolution_updateOutput / Deconvolution_updateOutput
  * (SCN/sparseconvnet_cuda.cpp:281-310; CPU/Convolution.cpp:45-79,117-149;
  *  CPU/Deconvolution.cpp:7-41; CUDA/Convolution.cu:57-233,444-521,618-642).
+ *   blocks   tile blocks compiled from the gather table whose entries index `in_feats`
  *   W        float32 [vol, nIn, nOut]  (the reference's [vol, groups=1, nIn, nOut])
  *   flags    bit0: use W[k]^T (input-gradient pass: `in` has nOut planes, `out` nIn planes,
  *            CPU/Convolution.cpp:108-112); bit1: weight index vol-1-k (submanifold
  *            input-gradient through the forward table); bit2: `wpack` already holds the packed
- *            weights for this (W, flags) pair (skips the repack launch).
- *   wpack    float32 scratch, aabr_conv_wpack_floats(vol,nIn,nOut) elements
- * Returns the reference's multiply-add count through *macs_host when counts_host given.      */
+ *            weights for this (W, bit0) pair (skips the repack launch).
+ *   wpack    float32 scratch, aabr_conv_wpack_floats(vol,nIn,nOut) elements                   */
 int64_t aabr_conv_wpack_floats(int vol, int n_in, int n_out);
 int aabr_conv_forward(const float *in_feats, int n_in, float *out_feats, int n_out,
-                      int64_t V_out, const int32_t *table, int vol, const float *W,
+                      int64_t V_out, const int32_t *blocks, int vol, const float *W,
                       const float *bias, int flags, float *wpack, void *stream);
-/* dW[k] = sum_o in[table[k][o]]^T (x) d_out[o]; partials scratch float32
- * [aabr_conv_dw_scratch_floats(...)]; d_bias (optional) = column sums of d_out.
+/* dW[k] = sum over offset k's pairs (t, o) of in[t]^T (x) d_out[o]; d_bias (optional) = column
+ * sums of d_out.  max_chunks bounds the number of 1024-pair chunks: sum_k ceil(R_k/1024) when the
+ * rule counts are known on the host, else ceil(vol*V/1024) + vol; scratch float32
+ * [aabr_conv_dw_scratch_floats(max_chunks, nIn, nOut)].  Deterministic (no atomics).
  * Replaces the dW half of *_backward (CPU/Convolution.cpp:81-115,151-185;
  * CUDA/Convolution.cu:249-441,526-667).                                                     */
-int64_t aabr_conv_dw_scratch_floats(int64_t V_out, int vol, int n_in, int n_out);
+int64_t aabr_conv_dw_scratch_floats(int64_t max_chunks, int n_in, int n_out);
 int aabr_conv_backward_weight(const float *in_feats, int n_in, const float *d_out, int n_out,
-                              int64_t V_out, const int32_t *table, int vol, float *dW,
-                              float *d_bias, float *scratch, void *stream);
+                              int64_t V_out, const int32_t *pairs, int vol, int64_t max_chunks,
+                              float *dW, float *d_bias, float *scratch, void *stream);
 
 /* ---- batch normalisation + leaky ReLU ------------------------------------------------------
  * Replaces BatchNormalization_updateOutput / _backward (SCN/CPU/BatchNormalization.cpp:12-157,

@@ -25,6 +25,7 @@ def _worker(rank, world, port, q):
     for s in mine:
         x = torch.full((2, 4), float(s + 1))
         lin(x).sum().backward()
+    fp.pack_grads()
     local = fp.flat_grad.clone()
     fp.allreduce_mean(world)
     fp.sgd_step(0.1)

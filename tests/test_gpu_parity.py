@@ -97,7 +97,7 @@ def test_submanifold_rulebook_exact():
         tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor(fs))
         rb = O.submanifold_rules(ref_il["coords"], fs)
         np.testing.assert_array_equal(np.array(tb.rule_counts()), rb.counts)
-        got = scn.SCN.Metadata_3.tableToRuleBook(tb.out)
+        got = scn.SCN.Metadata_3.tableToRuleBook(tb.out.table)
         for k in range(rb.vol):  # same order too: ascending output row within an offset
             np.testing.assert_array_equal(got[k].cpu().numpy(), rb.pairs(k))
 
@@ -121,8 +121,8 @@ def test_strided_rulebook_and_output_sites_exact(fs, st):
     # output sites: same set, same (insertion) order, batch-contiguous
     np.testing.assert_array_equal(x.metadata.getSpatialLocations(torch.LongTensor(osz)).numpy(), oc)
     np.testing.assert_array_equal(np.array(tb.rule_counts()), rb.counts)
-    t_out = scn.SCN.Metadata_3.tableToRuleBook(tb.out)   # (in, out) pairs
-    t_in = scn.SCN.Metadata_3.tableToRuleBook(tb.inn)    # (out, in) pairs
+    t_out = scn.SCN.Metadata_3.tableToRuleBook(tb.out.table)   # (in, out) pairs
+    t_in = scn.SCN.Metadata_3.tableToRuleBook(tb.inn.table)    # (out, in) pairs
     for k in range(rb.vol):
         want = _pairs_set(rb.pairs(k))
         assert _pairs_set(t_out[k].cpu().numpy()) == want
@@ -350,7 +350,7 @@ def test_full_size_properties():
         rb = O.submanifold_rules(il["coords"], [3, 3, 3])
         np.testing.assert_array_equal(np.array(tb.rule_counts()), rb.counts)
         # checksum of the rule table: sum over rules of (in + 3*out) per offset
-        t = tb.out.to(torch.int64)
+        t = tb.out.table.to(torch.int64)
         rows = torch.arange(V, device=DEV, dtype=torch.int64)[None, :]
         chk = torch.where(t >= 0, t + 3 * rows, torch.zeros_like(t)).sum(1).cpu().numpy()
         want = np.array([(rb.pairs(k)[:, 0].astype(np.int64) + 3 * rb.pairs(k)[:, 1].astype(np.int64)).sum()
