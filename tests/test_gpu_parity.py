@@ -398,6 +398,23 @@ def test_fpn_net_forward_backward_runs_and_is_consistent():
     assert torch.isfinite(loss)
 
 
+def test_fpn_net_multiply_add_count_matches_reference_counter():
+    """BASELINE.md §2 "Derived": the reference's own counter (forward_pass_multiplyAdd_count) reports
+    ~21.3 G MACs for one default-backbone forward on S80k @ 5 cm.  Same counter definition here
+    (sum over conv layers of rules x nIn x nOut), evaluated lazily from the device rule counts."""
+    from test_cabi_and_host import default_fpn
+    scn = _scn()
+    torch.manual_seed(0)
+    net = default_fpn().to(DEV)
+    locs, feats = S.make_batch(1, 80000, 0, 20)
+    scn.forward_pass_multiplyAdd_count = 0
+    with torch.no_grad():
+        rpn_maps, _ = net([_t(locs), _t(feats)])
+    macs = float(scn.forward_pass_multiplyAdd_count)
+    assert abs(macs - 21.3e9) / 21.3e9 < 0.01, macs
+    assert rpn_maps[0].metadata.input["V"] == 66094
+
+
 # ------------------------------------------------------------------------------------ IoU / NMS
 def test_rotate_iou_matrix_vs_oracle_and_golden(golden_dir):
     from second.core.non_max_suppression.nms_gpu import rotate_iou_gpu_eval

@@ -1,0 +1,42 @@
+"""Dev tool: time the default 9-scale FPN_Net (fwd, fwd+bwd) on a synthetic scene."""
+import importlib, os, sys, time
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+importlib.import_module("automatic-as-built-reconstruction_amd")
+import torch, numpy as np
+import sparseconvnet as scn
+import synth_scenes as S
+from test_cabi_and_host import default_fpn
+
+npts = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
+vs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bs = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+dev = "cuda:0"
+torch.manual_seed(0)
+net = default_fpn().to(dev)
+locs, feats = S.make_batch(bs, npts, 0, vs)
+l, f = torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)
+
+
+def run(bwd):
+    scn.forward_pass_multiplyAdd_count = 0
+    rpn, roi = net([l, f])
+    if bwd:
+        loss = sum(m.features.square().mean() for m in rpn)
+        loss.backward()
+    return rpn
+
+
+for _ in range(3):
+    run(True)
+torch.cuda.synchronize()
+for bwd in (False, True):
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        r = run(bwd)
+    torch.cuda.synchronize()
+    print("FPN_Net %d pts x bs%d @scale %d  %s: %.2f ms/iter  (V0=%d, MACs=%.3g)" % (
+        npts, bs, vs, "fwd+bwd" if bwd else "fwd", (time.perf_counter() - t0) / n * 1e3,
+        r[0].metadata.input["V"], float(scn.forward_pass_multiplyAdd_count)))
+print("max mem GB", torch.cuda.max_memory_allocated() / 1e9)

@@ -81,3 +81,46 @@ if len(sys.argv) > 1:
     pr.disable()
     s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(sys.argv[1]).print_stats(40)
     print(s.getvalue()[:9000])
+
+def timeit(fn, n=300):
+    for _ in range(20): fn()
+    t0 = time.perf_counter()
+    for _ in range(n): fn()
+    return (time.perf_counter() - t0) / n * 1e6
+
+with torch.no_grad():
+    print("fwd no_grad us: %.1f" % timeit(lambda: bench.forward(scn, m, locs, feats)))
+print("fwd grad us: %.1f" % timeit(lambda: bench.forward(scn, m, locs, feats)))
+x0 = m["inp"]([locs, feats])
+with torch.no_grad():
+    print("  inputlayer us: %.1f" % timeit(lambda: m["inp"]([locs, feats])))
+    print("  conv1 us: %.1f" % timeit(lambda: m["conv1"](x0)))
+    x1 = m["conv1"](x0)
+    print("  bn1 us: %.1f" % timeit(lambda: m["bn1"](x1)))
+    print("  add us: %.1f" % timeit(lambda: scn.add_feature_planes([x1, x1])))
+    import sparseconvnet.SCN as SCN
+    w = m["conv2"].weight
+    out = torch.empty(0)
+    fs = torch.LongTensor([3,3,3])
+    print("  SCN.SubmConv_updateOutput us: %.1f" % timeit(lambda: SCN.SubmanifoldConvolution_updateOutput(x1.spatial_size, fs, x1.metadata, x1.features, out, w, torch.Tensor())))
+    tb = x1.metadata.getSubmanifoldRuleBook(x1.spatial_size, fs)
+    print("  getSubmanifoldRuleBook us: %.1f" % timeit(lambda: x1.metadata.getSubmanifoldRuleBook(x1.spatial_size, fs)))
+    print("  _conv_fwd us: %.1f" % timeit(lambda: SCN._conv_fwd(x1.features, out, tb.V_out, tb.out, w, None, 0)))
+
+def fb():
+    out = bench.forward(scn, m, locs, feats)
+    out.features.backward(g)
+print("fwd+bwd us: %.1f" % timeit(fb))
+def fb2():
+    flat.zero_grad()
+    out = bench.forward(scn, m, locs, feats)
+    out.features.backward(g)
+print("zero+fwd+bwd us: %.1f" % timeit(fb2))
+print("pack_grads us: %.1f" % timeit(lambda: flat.pack_grads()))
+print("sgd us: %.1f" % timeit(lambda: flat.sgd_step(1e-4)))
+x1 = m["conv1"](x0)
+d = torch.zeros_like(x1.features)
+gw = torch.empty_like(m["conv1"].weight)
+fs = torch.LongTensor([3,3,3])
+import sparseconvnet.SCN as SCN
+print("  SCN.SubmConv_backward us: %.1f" % timeit(lambda: SCN.SubmanifoldConvolution_backward(x0.spatial_size, fs, x0.metadata, x0.features.detach(), torch.empty(0), d, m["conv1"].weight.detach(), gw, torch.Tensor())))

@@ -1,0 +1,35 @@
+"""Dev tool: time the voxel scatter (InputLayer) and rule-book builds at several scene sizes."""
+import importlib, os, sys, time
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+importlib.import_module("automatic-as-built-reconstruction_amd")
+import torch
+import sparseconvnet as scn
+import synth_scenes as S
+dev = "cuda:0"
+for npts, vs, ext in ((80000, 20, (16.0, 12.0, 2.7)), (1500000, 50, (16.0, 12.0, 2.7)), (1500000, 50, (40.0, 30.0, 2.7))):
+    locs, feats = S.make_batch(1, npts, 0, vs, ext)
+    l, f = torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)
+    layer = scn.InputLayer(3, list(S.FULL_SCALE), mode=4)
+    with torch.no_grad():
+        for _ in range(3):
+            x = layer([l, f])
+        torch.cuda.synchronize()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            x = layer([l, f])
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / n
+        V = x.features.shape[0]
+        N = l.shape[0]
+        by = N * (32 + 36) + V * (36 + 16)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            x = layer([l, f])
+            tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+            tb.out.blocks(); tb.out.pairs()
+        torch.cuda.synchronize()
+        t2 = (time.perf_counter() - t0) / n - t
+        print("N=%d V=%d ext=%s: scatter %.1f us = %.1f GB/s (%.2f%% of 8 TB/s) | table+blocks+pairs %.1f us" % (
+            N, V, ext, t * 1e6, by / t / 1e9, by / t / 8e12 * 100, t2 * 1e6))
