@@ -1,0 +1,150 @@
+"""Boundary shapes of the HIP path against the oracle: tile / block / chunk edges, ragged batches,
+empty samples, mode 0, score ties and oversize NMS inputs."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import synth_scenes as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scn():
+    import sparseconvnet as scn
+    return scn
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def _unique_sites(rng, V, size=(9, 9, 9), batch=1):
+    """exactly V distinct sites (dense enough that most have neighbours), batch-sorted"""
+    cells = np.stack(np.meshgrid(*[np.arange(s) for s in size], indexing="ij"), -1).reshape(-1, 3)
+    out = []
+    per = [V // batch + (1 if b < V % batch else 0) for b in range(batch)]
+    for b in range(batch):
+        idx = rng.choice(len(cells), per[b], replace=False)
+        out.append(np.concatenate([cells[idx], np.full((per[b], 1), b)], 1))
+    return np.concatenate(out, 0).astype(np.int64)
+
+
+@pytest.mark.parametrize("V", [1, 2, 15, 16, 17, 63, 64, 65, 127, 129, 255, 256, 257, 700])
+def test_conv_forward_backward_at_tile_and_chunk_edges(V):
+    scn = _scn()
+    rng = np.random.default_rng(V)
+    coords = _unique_sites(rng, V)
+    nIn, nOut = 32, 48
+    feats = rng.standard_normal((V, nIn)).astype(np.float32)
+    layer = scn.InputLayer(3, [16, 16, 16], mode=4)
+    f = _t(feats).requires_grad_(True)
+    x = layer([_t(coords), f])
+    conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, True).to(DEV)
+    conv.bias.data.normal_()
+    y = conv(x)
+    il = O.input_layer(coords, feats, 4)
+    assert il["V"] == V
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    W = conv.weight.detach().cpu().numpy().reshape(27, nIn, nOut)
+    ref, _ = O.conv_fwd(il["out"], W, rb, V, conv.bias.detach().cpu().numpy())
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(_t(g))
+    d_in, dW, db = O.conv_bwd(il["out"], g, W, rb, want_bias=True)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.input_layer_bwd(il, d_in), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(dW.shape), dW, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), db, rtol=1e-4, atol=1e-4)
+
+
+def test_ragged_batch_with_empty_sample_and_strided_chain():
+    """samples 0, 2, 3 present, sample 1 empty; two stride-2 convolutions and the transposes back"""
+    scn = _scn()
+    rng = np.random.default_rng(7)
+    parts = []
+    for b, n in ((0, 300), (2, 5), (3, 900)):
+        c = np.stack([rng.integers(0, 16, n), rng.integers(0, 16, n), rng.integers(0, 8, n), np.full(n, b)], 1)
+        parts.append(c)
+    coords = np.concatenate(parts, 0).astype(np.int64)
+    feats = rng.standard_normal((coords.shape[0], 16)).astype(np.float32)
+    x = scn.InputLayer(3, [16, 16, 8], mode=3)([_t(coords), _t(feats), 4])
+    c1 = scn.Convolution(3, 16, 16, 2, 2, False).to(DEV)
+    c2 = scn.Convolution(3, 16, 16, 2, 2, False).to(DEV)
+    d2 = scn.Deconvolution(3, 16, 16, 2, 2, False).to(DEV)
+    d1 = scn.Deconvolution(3, 16, 16, 2, 2, False).to(DEV)
+    with torch.no_grad():
+        y1 = c1(x)
+        y2 = c2(y1)
+        z = d1(d2(y2))
+    il = O.input_layer(coords, feats, 3)
+    rb1, oc1 = O.convolution_rules(il["coords"], [2, 2, 2], [2, 2, 2], [8, 8, 4])
+    rb2, oc2 = O.convolution_rules(oc1, [2, 2, 2], [2, 2, 2], [4, 4, 2])
+    np.testing.assert_array_equal(y1.get_spatial_locations().numpy(), oc1)
+    np.testing.assert_array_equal(y2.get_spatial_locations().numpy(), oc2)
+    assert set(np.unique(oc2[:, 3])) == {0, 2, 3} and (np.diff(oc2[:, 3]) >= 0).all()
+    P = lambda m: m.weight.detach().cpu().numpy().reshape(8, 16, 16)
+    r1, _ = O.conv_fwd(il["out"], P(c1), rb1, oc1.shape[0])
+    r2, _ = O.conv_fwd(r1, P(c2), rb2, oc2.shape[0])
+    u2, _ = O.conv_fwd(r2, P(d2), rb2, oc1.shape[0], in_col=1)
+    u1, _ = O.conv_fwd(u2, P(d1), rb1, il["V"], in_col=1)
+    np.testing.assert_allclose(z.features.cpu().numpy(), u1, rtol=1e-4, atol=1e-4 * np.abs(u1).max())
+    np.testing.assert_array_equal(z.get_spatial_locations().numpy(), il["coords"])
+
+
+def test_input_layer_mode0_and_duplicate_rejection():
+    scn = _scn()
+    import _hip
+    rng = np.random.default_rng(8)
+    coords = _unique_sites(rng, 300, (8, 8, 8), 2)
+    feats = rng.standard_normal((300, 4)).astype(np.float32)
+    x = scn.InputLayer(3, [8, 8, 8], mode=0)([_t(coords), _t(feats)])
+    np.testing.assert_array_equal(x.features.cpu().numpy(), feats)  # unique input: identity
+    np.testing.assert_array_equal(x.get_spatial_locations().numpy(), coords)
+    dup = np.concatenate([coords, coords[:1]], 0)
+    with pytest.raises(_hip.AabrError):
+        scn.InputLayer(3, [8, 8, 8], mode=0)([_t(dup), _t(np.zeros((301, 4), np.float32))])
+
+
+def test_zcollapse_conv_vol32_matches_oracle():
+    """convs_pro2d geometry: filter [1,1,32] stride 1 (32 offsets, the largest volume FPN_Net uses)"""
+    scn = _scn()
+    rng = np.random.default_rng(9)
+    n = 4000
+    coords = np.stack([rng.integers(0, 24, n), rng.integers(0, 24, n), rng.integers(0, 32, n),
+                       np.sort(rng.integers(0, 2, n))], 1).astype(np.int64)
+    feats = rng.standard_normal((n, 128)).astype(np.float32)
+    f = _t(feats).requires_grad_(True)
+    x = scn.InputLayer(3, [24, 24, 32], mode=4)([_t(coords), f])
+    conv = scn.Convolution(3, 128, 128, [1, 1, 32], [1, 1, 1], False).to(DEV)
+    y = conv(x)
+    assert y.spatial_size.tolist() == [24, 24, 1]
+    il = O.input_layer(coords, feats, 4)
+    rb, oc = O.convolution_rules(il["coords"], [1, 1, 32], [1, 1, 1], [24, 24, 1])
+    W = conv.weight.detach().cpu().numpy().reshape(32, 128, 128)
+    ref, _ = O.conv_fwd(il["out"], W, rb, oc.shape[0])
+    np.testing.assert_array_equal(y.get_spatial_locations().numpy(), oc)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(_t(g))
+    d_in, dW, _ = O.conv_bwd(il["out"], g, W, rb)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(dW.shape), dW, rtol=1e-4,
+                               atol=2e-5 * np.abs(dW).max())
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.input_layer_bwd(il, d_in), rtol=1e-4,
+                               atol=2e-5 * np.abs(d_in).max())
+
+
+def test_nms_more_boxes_than_pre_max_and_score_ties():
+    from second.pytorch.core.box_torch_ops import rotate_nms_3d
+    b7, sc = S.make_nms_boxes(3000, 21)
+    got = rotate_nms_3d(_t(b7), _t(sc), pre_max_size=2000, post_max_size=1000, iou_threshold=0.5, flag="rpn_post")
+    want = O.rotate_nms_3d(b7, sc, 2000, 1000, 0.5)
+    assert set(got.cpu().numpy().tolist()) == set(want.tolist())
+    # tied scores: survivors are mutually non-overlapping and every dropped box overlaps a kept one
+    sc_t = np.round(sc * 4) / 4
+    keep = rotate_nms_3d(_t(b7[:500]), _t(sc_t[:500]), None, None, 0.5).cpu().numpy()
+    iou = O.boxes_iou_3d(b7[:500], b7[:500])
+    sub = iou[np.ix_(keep, keep)] - np.eye(len(keep))
+    assert (sub < 0.5).all()
+    dropped = np.setdiff1d(np.arange(500), keep)
+    assert (iou[np.ix_(dropped, keep)].max(1) >= 0.5).all()
