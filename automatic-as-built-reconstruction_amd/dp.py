@@ -48,13 +48,21 @@ class FlatParams(object):
         """gradient all-reduce (mean) -- the one collective of a training step"""
         if world_size is None:
             world_size = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.pack_grads()
         if world_size > 1:
+            self.pack_grads()
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
             self.flat_grad.mul_(1.0 / world_size)
 
-    def sgd_step(self, lr):
-        self.flat.add_(self.flat_grad, alpha=-lr)
+    def sgd_step(self, lr, world_size=1):
+        """fused SGD update.  With one rank the gradients are consumed where autograd left them (one
+        multi-tensor launch, no packing); with several ranks the all-reduced flat buffer is used."""
+        if world_size > 1:
+            self.flat.add_(self.flat_grad, alpha=-lr)
+        else:
+            ps = [p.data for p in self.params if p.grad is not None]
+            gs = [p.grad for p in self.params if p.grad is not None]
+            if ps:
+                torch._foreach_add_(ps, gs, alpha=-lr)
 
     def broadcast(self, src=0, group=None):
         if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -227,11 +227,11 @@ class Metadata_3(object):
         ts = []
         pend = getattr(self, "_pending", None)
         if pend is not None:
-            ts += [pend["site_coords"], pend["keys"], pend["vals"]]
+            ts += [pend["buf"]]
         for g in self.grids.values():
             ts += [g.coords, g.keys, g.vals]
         if self.input is not None:
-            ts += [self.input["point_site"], self.input["site_off"], self.input["site_pts"]]
+            ts += [self.input["point_site"]]
         return ts
 
     def getNActive(self, spatial_size):
@@ -246,11 +246,12 @@ class Metadata_3(object):
         if self.input is not None and self.input.get("coords_id") == (coords.data_ptr(), coords.shape[0]) \
                 and self.input["mode"] == int(mode):
             return self.inputLayerFinish()  # prepared ahead of time (InputLayer.prepare)
-        self.inputLayerEnqueue(spatial_size, coords, mode, device)
+        self.inputLayerEnqueue(spatial_size, coords, mode, device, asynchronous=False)
         return self.inputLayerFinish()
 
-    def inputLayerEnqueue(self, spatial_size, coords, mode, device):
-        """enqueue the site-numbering kernels and an asynchronous read-back of (V, maxActive, err)"""
+    def inputLayerEnqueue(self, spatial_size, coords, mode, device, asynchronous=True):
+        """enqueue the site-numbering kernels (+ an asynchronous read-back of (V, maxActive, err)
+        when `asynchronous`); all integer state of the input layer lives in ONE device allocation"""
         assert coords.dim() == 2 and coords.size(1) in (3, 4)
         assert self.input is None and len(self.grids) == 0, "Metadata already holds an input layer"
         coords_id = (coords.data_ptr(), coords.shape[0])
@@ -260,28 +261,39 @@ class Metadata_3(object):
         n, ncols = coords.shape
         cap = _hip.next_pow2(2 * n)
         nblk = (max(n, 1) + 1023) // 1024
-        keys = torch.empty(cap, dtype=torch.int64, device=device)
-        vals = torch.empty(cap, dtype=torch.int32, device=device)
-        scratch = torch.empty(3 * cap + 2 * n + 4 * nblk + 16, dtype=torch.int32, device=device)
-        point_site = torch.empty(n, dtype=torch.int32, device=device)
-        site_coords = torch.empty((max(n, 1), 4), dtype=torch.int32, device=device)
-        site_off = torch.empty(n + 1, dtype=torch.int32, device=device)
-        site_pts = torch.empty(max(n, 1), dtype=torch.int32, device=device)
-        meta = torch.empty(_hip.META_WORDS, dtype=torch.int32, device=device)
-        host = torch.empty(_hip.META_WORDS, dtype=torch.int32, pin_memory=True)
+        n1 = max(n, 1)
+        # int32 words: keys(2*cap) | vals(cap) | point_site(n) | site_coords(4*n1) | site_off(n+1) |
+        #              site_pts(n1) | meta(8) | scratch(3*cap + 2n + 4*nblk + 16); 16-byte aligned pieces
+        sizes = [2 * cap, cap, n, 4 * n1, n + 1, n1, _hip.META_WORDS, 3 * cap + 2 * n + 4 * nblk + 16]
+        offs, tot = [], 0
+        for sz in sizes:
+            offs.append(tot)
+            tot += (sz + 3) & ~3
+        buf = torch.empty(tot, dtype=torch.int32, device=device)
+        keys = buf[offs[0]:offs[0] + 2 * cap].view(torch.int64)
+        vals = buf[offs[1]:offs[1] + cap]
+        point_site = buf[offs[2]:offs[2] + n]
+        site_coords = buf[offs[3]:offs[3] + 4 * n1].view(n1, 4)
+        site_off = buf[offs[4]:offs[4] + n + 1]
+        site_pts = buf[offs[5]:offs[5] + n1]
+        meta = buf[offs[6]:offs[6] + _hip.META_WORDS]
+        base = buf.data_ptr()
+        host = ev = None
         if n > 0:
-            check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, ptr(keys), ptr(vals), cap, ptr(scratch),
-                                             ptr(point_site), ptr(site_coords), ptr(site_off), ptr(site_pts),
-                                             ptr(meta), stream()))
-            host.copy_(meta, non_blocking=True)
+            check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, base + 4 * offs[0], base + 4 * offs[1], cap,
+                                             base + 4 * offs[7], base + 4 * offs[2], base + 4 * offs[3],
+                                             base + 4 * offs[4], base + 4 * offs[5], base + 4 * offs[6], stream()))
+            if asynchronous:
+                host = torch.empty(_hip.META_WORDS, dtype=torch.int32, pin_memory=True)
+                host.copy_(meta, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
         else:  # empty scene: an empty grid (all keys EMPTY), nothing to launch
             keys.fill_(-1)
             site_off.zero_()
-            host.zero_()
-        ev = torch.cuda.Event()
-        ev.record()
-        self._pending = dict(host=host, event=ev, site_coords=site_coords, keys=keys, vals=vals, cap=cap,
-                             coords=coords)
+            meta.zero_()
+        self._pending = dict(host=host, event=ev, meta=meta, site_coords=site_coords, keys=keys, vals=vals,
+                             cap=cap, coords=coords, buf=buf)
         self.input = dict(point_site=point_site, site_off=site_off, site_pts=site_pts, n=n, V=None,
                           mode=int(mode), max_active=None, spatial=_key(spatial_size), coords_id=coords_id)
 
@@ -289,8 +301,11 @@ class Metadata_3(object):
         """wait for the read-back (the one host sync of the input layer: V sizes every later tensor)"""
         pend = getattr(self, "_pending", None)
         if pend is not None:
-            pend["event"].synchronize()
-            m = pend["host"].tolist()
+            if pend["event"] is not None:
+                pend["event"].synchronize()
+                m = pend["host"].tolist()
+            else:
+                m = pend["meta"].tolist()  # synchronous read-back
             self._pending = None
             if m[2]:
                 raise _hip.AabrError("InputLayer: coordinates must lie in [0, 65534] (batch index too)")

@@ -184,7 +184,7 @@ def main():
             m["inp"].prepare(feats_req[nj][0], dev, side)
         feats_req[j][1].grad = None
         flat.allreduce_mean(world)
-        flat.sgd_step(1e-4)
+        flat.sgd_step(1e-4, world)
 
     for i in range(args.warmup):
         step(i)

@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
     fp.pack_grads()
     local = fp.flat_grad.clone()
     fp.allreduce_mean(world)
-    fp.sgd_step(0.1)
+    fp.sgd_step(0.1, world)
     q.put((rank, mine, local, fp.flat_grad.clone(), fp.flat.clone()))
     dist.barrier()
     dist.destroy_process_group()
