@@ -200,6 +200,8 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
   const int64_t wk_stride = (int64_t)nkc * nnb * 512;
 
   for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
+  const int dbg = wflip >> 8; // timing experiments only (tools_conv_bench.py): 1 = no MFMAs, 2 = no gathers
+  wflip &= 1;
 
   // this wave's blocks: wave, wave + WPB, ...; consumed two per pair
   const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
@@ -238,9 +240,11 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
     const float *WkA = Wp + kA * wk_stride, *WkB = Wp + kB * wk_stride;
     for (int kc = 0; kc < nkc; ++kc) {
       // the gathers of the following step go in flight before this step's MFMAs issue
-      if (kc + 1 < nkc) fetch(nxt, p0, kc + 1);
-      else if (pr + 1 < npairs) fetch(nxt, p1, 0);
-      conv_step_mfma<NBW>(cur, WkA, WkB, kc, nnb, nb0, lane, accA, accB);
+      if (!(dbg & 2)) {
+        if (kc + 1 < nkc) fetch(nxt, p0, kc + 1);
+        else if (pr + 1 < npairs) fetch(nxt, p1, 0);
+      }
+      if (!(dbg & 1)) conv_step_mfma<NBW>(cur, WkA, WkB, kc, nnb, nb0, lane, accA, accB);
       cur = nxt;
     }
     conv_block_accumulate<NBW, WS>(Ct, p0.eA, g, accA);
@@ -551,7 +555,7 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, float *out_fea
   AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 15) == 0 &&
                      ((uintptr_t)wpack & 15) == 0,
                  "feature / scratch pointers must be 16-byte aligned");
-  const int transpose = flags & 1, flip = (flags >> 1) & 1;
+  const int transpose = flags & 1, flip = ((flags >> 1) & 1) | ((flags >> 8) << 8);
   const int nkc = nkc_of(n_in), nnb = nnb_of(n_out);
   int64_t total = (int64_t)vol * nkc * nnb * 512;
   if (!(flags & 4)) // bit2: wpack already holds the packed weights of this (W, flags & 1) pair

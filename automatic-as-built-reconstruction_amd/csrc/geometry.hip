@@ -181,6 +181,10 @@ __global__ __launch_bounds__(256) void k_insert_points(const int64_t *__restrict
   if (i >= n) return;
   const int64_t *c = coords + i * ncols;
   int64_t x = c[0], y = c[1], z = c[2], b = ncols == 4 ? c[3] : 0;
+  if (x == -1 && y == -1 && z == -1) { // dropped by aabr_quantize_points (outside FULL_SCALE): skip silently
+    slot[i] = -1;
+    return;
+  }
   if (x < 0 || y < 0 || z < 0 || b < 0 || x > kMaxCoord || y > kMaxCoord || z > kMaxCoord ||
       b > kMaxCoord) {
     slot[i] = -1;
@@ -420,6 +424,33 @@ __global__ __launch_bounds__(1024) void k_table_to_rulebook(const int32_t *__res
   if (threadIdx.x == 0) counts[k] = run;
 }
 
+// A1: the dataset's host quantisation on the device (data3d/suncg_utils/suncg_dataset.py:126-188
+// without the train-time augmentations): a = xyz*scale - min; keep 0 <= a < full_scale;
+// locs = trunc(a); feature xyz = a / scale.  Dropped points get the (-1,-1,-1) sentinel that the
+// input layer skips, so no compaction (and no host read-back) is needed.  Arithmetic in double
+// like numpy's.
+template <typename T>
+__global__ __launch_bounds__(256) void k_quantize_points(const T *__restrict__ xyz, int64_t n, double scale,
+                                                         const T *__restrict__ amin, const int32_t *fs,
+                                                         int64_t batch, int64_t *__restrict__ locs,
+                                                         float *__restrict__ feats, int fstride) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a[3];
+  bool keep = true;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    a[d] = (double)xyz[3 * i + d] * scale - (double)amin[d] * scale;
+    keep = keep && a[d] >= 0.0 && a[d] < (double)fs[d];
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) locs[4 * i + d] = keep ? (int64_t)a[d] : -1;
+  locs[4 * i + 3] = batch;
+  if (feats)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) feats[i * fstride + d] = (float)(a[d] / scale);
+}
+
 __global__ __launch_bounds__(256) void k_spatial_locations(const int32_t *__restrict__ sc, int64_t n4,
                                                            int64_t *__restrict__ loc) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -609,6 +640,25 @@ extern "C" int aabr_table_to_rulebook(const int32_t *table, int64_t V, int vol, 
   AABR_CHECK_ARG(table && rules, "null pointer");
   hipLaunchKernelGGL(k_table_to_rulebook, dim3((unsigned)vol), dim3(1024), 0, (hipStream_t)stream_, table, V,
                      rules, counts);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale, const void *xyz_min,
+                                    const int32_t *full_scale_dev, int64_t batch_index, int64_t *locs,
+                                    float *feats_xyz, int feat_stride, void *stream_) {
+  AABR_CHECK_ARG(n >= 0 && scale > 0 && batch_index >= 0 && batch_index <= kMaxCoord, "bad arguments");
+  if (n == 0) return AABR_OK;
+  AABR_CHECK_ARG(xyz && xyz_min && full_scale_dev && locs, "null pointer");
+  AABR_CHECK_ARG(!feats_xyz || feat_stride >= 3, "feature stride must cover the 3 xyz planes");
+  if (is_double)
+    hipLaunchKernelGGL(k_quantize_points<double>, grid1(n, 256), dim3(256), 0, (hipStream_t)stream_,
+                       (const double *)xyz, n, scale, (const double *)xyz_min, full_scale_dev, batch_index, locs,
+                       feats_xyz, feat_stride);
+  else
+    hipLaunchKernelGGL(k_quantize_points<float>, grid1(n, 256), dim3(256), 0, (hipStream_t)stream_,
+                       (const float *)xyz, n, scale, (const float *)xyz_min, full_scale_dev, batch_index, locs,
+                       feats_xyz, feat_stride);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

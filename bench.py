@@ -143,11 +143,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # rehearsal knobs (1-GPU boxes): AABR_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # AABR_BENCH_BACKEND=gloo runs the collective through the host, so the N>1 code path can be
+    # exercised where only one GPU exists.  Never set by the driver.
+    if os.environ.get("AABR_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("AABR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import sparseconvnet as scn
     import dp

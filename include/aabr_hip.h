@@ -38,6 +38,18 @@ int aabr_version(void);
 /* meta[0] = number of active sites, meta[1] = max points per site (input layer only),
  * meta[2] = error flag (non-zero: coordinate out of range), meta[3] = total of 2nd scan lane */
 
+/* ---- input pipeline ---------------------------------------------------------------------------
+ * Device-side form of the dataset's host quantisation (data3d/suncg_utils/suncg_dataset.py:126-188,
+ * test-time path: no augmentation): a = xyz*scale - min(xyz)*scale; keep 0 <= a < full_scale;
+ * locs = trunc(a) (int64 [n,4], 4th column = batch_index); feats_xyz (optional, float32 rows of
+ * stride feat_stride) receives a/scale.  xyz / xyz_min are float32 or float64 device arrays
+ * ([n,3] / [3]); full_scale_dev int32[3] on the device.  Points outside the range are not
+ * compacted away: they get the coordinate sentinel (-1,-1,-1), which aabr_input_layer_sites skips
+ * (the reference drops them on the host before the input layer, suncg_dataset.py:183-185).      */
+int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale, const void *xyz_min,
+                         const int32_t *full_scale_dev, int64_t batch_index, int64_t *locs,
+                         float *feats_xyz, int feat_stride, void *stream);
+
 /* ---- hash grid ---------------------------------------------------------------------------
  * A grid is an open-addressing table: keys uint64[cap] (packed b,x,y,z), vals int32[cap]
  * (row of the site).  cap must be a power of two >= 2 * (number of inserted keys).

@@ -110,6 +110,10 @@ int64_t oracle_input_layer_sites(const int64_t *coords, int64_t n, int ncols,
   for (int64_t i = 0; i < n; ++i) {
     const int64_t *c = coords + i * ncols;
     int64_t b = (ncols == 4) ? c[3] : 0;
+    if (c[0] == -1 && c[1] == -1 && c[2] == -1) { /* dropped upstream (suncg_dataset.py:183-185) */
+      point_voxel[i] = -1;
+      continue;
+    }
     if (!coord_ok(c[0]) || !coord_ok(c[1]) || !coord_ok(c[2]) || c[0] < 0 ||
         c[1] < 0 || c[2] < 0 || b < 0 || b > 65534) {
       omap_free(&m);
@@ -144,6 +148,7 @@ void oracle_input_layer_rules(const Int *point_voxel, int64_t n, int64_t V,
   Int w = ((mode == 3 || mode == 4) ? max_active : 1) + 1;
   memset(rules, 0, (size_t)V * w * sizeof(Int));
   for (int64_t i = 0; i < n; ++i) {
+    if (point_voxel[i] < 0) continue;
     Int *r = rules + (int64_t)point_voxel[i] * w;
     if (mode == 3 || mode == 4) {
       r[0]++; r[r[0]] = (Int)i;

@@ -148,3 +148,39 @@ def test_nms_more_boxes_than_pre_max_and_score_ties():
     assert (sub < 0.5).all()
     dropped = np.setdiff1d(np.arange(500), keep)
     assert (iou[np.ix_(dropped, keep)].max(1) >= 0.5).all()
+
+
+def test_device_quantisation_pipeline_matches_host_rule():
+    """A1: xyz (metres) -> locs/feats on the device vs the dataset's host rule
+    (suncg_dataset.py:126-188: scale, shift to the minimum, drop outside FULL_SCALE, truncate),
+    then through the InputLayer: dropped points are skipped via the coordinate sentinel."""
+    scn = _scn()
+    import input_pipeline
+    full = (300, 200, 60)  # small FULL_SCALE so that some points fall outside and are dropped
+    xyz_l, ex_l, ref_locs, ref_feats = [], [], [], []
+    for b in range(2):
+        xyz, rng = S.synth_points(6000, 30 + b)
+        extra = rng.random((xyz.shape[0], 6)).astype(np.float32)
+        a = xyz * 20.0
+        a = a - a.min(0)
+        keep = (a.min(1) >= 0) & (a < np.array(full)).all(1)
+        assert 0 < keep.sum() < len(keep)
+        ref_locs.append(np.concatenate([np.trunc(a[keep]).astype(np.int64), np.full((keep.sum(), 1), b)], 1))
+        ref_feats.append(np.concatenate([(a[keep] / 20.0).astype(np.float32), extra[keep]], 1))
+        xyz_l.append(_t(xyz))
+        ex_l.append(_t(extra))
+    locs, feats = input_pipeline.quantize_scenes(xyz_l, ex_l, 20.0, full)
+    kept = (locs[:, 0] >= 0).cpu().numpy()
+    np.testing.assert_array_equal(locs.cpu().numpy()[kept], np.concatenate(ref_locs, 0))
+    np.testing.assert_array_equal(feats.cpu().numpy()[kept], np.concatenate(ref_feats, 0))
+    assert (locs.cpu().numpy()[~kept, :3] == -1).all()
+    f = feats.clone().requires_grad_(True)
+    x = scn.InputLayer(3, list(full), mode=4)([locs, f])
+    il = O.input_layer(np.concatenate(ref_locs, 0), np.concatenate(ref_feats, 0), 4)
+    np.testing.assert_array_equal(x.get_spatial_locations().numpy(), il["coords"])
+    np.testing.assert_array_equal(x.features.detach().cpu().numpy(), il["out"])
+    g = np.random.default_rng(0).standard_normal(il["out"].shape).astype(np.float32)
+    x.features.backward(_t(g))
+    gin = f.grad.cpu().numpy()
+    np.testing.assert_array_equal(gin[kept], O.input_layer_bwd(il, g))
+    assert (gin[~kept] == 0).all()  # dropped points receive no gradient

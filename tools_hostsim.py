@@ -74,7 +74,7 @@ t0 = time.perf_counter()
 for _ in range(N):
     step()
 print("host us/step: %.1f" % ((time.perf_counter() - t0) / N * 1e6))
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] != "glue":
     pr = cProfile.Profile(); pr.enable()
     for _ in range(N):
         step()
@@ -124,3 +124,11 @@ gw = torch.empty_like(m["conv1"].weight)
 fs = torch.LongTensor([3,3,3])
 import sparseconvnet.SCN as SCN
 print("  SCN.SubmConv_backward us: %.1f" % timeit(lambda: SCN.SubmanifoldConvolution_backward(x0.spatial_size, fs, x0.metadata, x0.features.detach(), torch.empty(0), d, m["conv1"].weight.detach(), gw, torch.Tensor())))
+
+if "glue" in sys.argv:
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(2000):
+        SCN.SubmanifoldConvolution_backward(x0.spatial_size, fs, x0.metadata, x0.features.detach(), torch.empty(0), d, m["conv1"].weight.detach(), gw, torch.Tensor())
+    pr.disable()
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18)
+    print(s.getvalue()[:5000])
