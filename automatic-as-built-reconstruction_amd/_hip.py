@@ -46,6 +46,7 @@ _SIGS = {
     "aabr_bn_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "aabr_rotate_iou_eval": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "aabr_boxes_iou_3d": (C.c_int, [_vp, _i64, _vp, _i64, _f32p, _i32, _i32, _vp, _vp]),
+    "aabr_rpn_decode": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f32, _f32p, _f32p, _f32, _vp, _vp]),
     "aabr_rotate_nms_sorted": (C.c_int, [_vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "aabr_nms_sorted": (C.c_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
 }
@@ -141,6 +142,11 @@ def i32x3(v):
 
 def f32x4(v):
     return (C.c_float * 4)(*[float(x) for x in v])
+
+
+def f32xn(v):
+    v = [float(x) for x in v]
+    return (C.c_float * len(v))(*v)
 
 
 def next_pow2(n):

@@ -65,6 +65,57 @@ __global__ __launch_bounds__(256) void k_scale_by_z(float *__restrict__ iou, int
   iou[idx] = iou[idx] * (overlap / common);
 }
 
+// RPN glue: anchors from sparse locations + BoxCoder3D.decode_centroid_box for the selected
+// (top-k) anchors, fused (reference: modeling/rpn/anchor_generator_sparse3d.py:88-104,
+// modeling/box_coder_3d.py:53-80, second/pytorch/core/box_torch_ops.py:118-154 with
+// smooth_dim=True, utils3d/geometric_torch.py:4-10).  Flat anchor index t = site * A + yaw.
+struct RpnDecodeParams {
+  float inv_scale_num;      // voxel_scale
+  float stride[3];
+  float weights[7];
+  float clip;               // bbox_xform_clip
+};
+
+__global__ __launch_bounds__(256) void k_rpn_decode(const int32_t *__restrict__ site_coords, int64_t site0,
+                                                    const int64_t *__restrict__ sel, int64_t k,
+                                                    const float *__restrict__ regression, int64_t reg0,
+                                                    const float *__restrict__ base_anchors, int A,
+                                                    RpnDecodeParams p, float *__restrict__ boxes) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const int64_t t = sel[i];
+  const int64_t site = site0 + t / A;
+  const int a = (int)(t % A);
+  const float *ba = base_anchors + 7 * a;
+  float an[7];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)  // (location.float() + 0) / voxel_scale * stride  + base
+    an[d] = (float)site_coords[4 * site + d] / p.inv_scale_num * p.stride[d] + ba[d];
+#pragma unroll
+  for (int d = 3; d < 7; ++d) an[d] = 0.0f + ba[d];
+  const float *r = regression + 7 * (reg0 + t);
+  float e[7];
+#pragma unroll
+  for (int d = 0; d < 7; ++d) e[d] = r[d] / p.weights[d];
+#pragma unroll
+  for (int d = 3; d < 6; ++d) e[d] = e[d] > p.clip ? p.clip : e[d];
+  // second_box_decode: anchors split as (xa, ya, za, wa, la, ha, ra)
+  const float diagonal = sqrtf(an[4] * an[4] + an[3] * an[3]);
+  float o[7];
+  o[0] = e[0] * diagonal + an[0];
+  o[1] = e[1] * diagonal + an[1];
+  o[2] = e[2] * an[5] + an[2];
+  o[3] = (e[3] + 1) * an[3];   // wg = (wt + 1) * wa
+  o[4] = (e[4] + 1) * an[4];   // lg = (lt + 1) * la
+  o[5] = (e[5] + 1) * an[5];
+  float rg = e[6] + an[6];
+  const float period = 3.14159265358979323846f;
+  rg = rg - floorf(rg / period + 0.5f) * period; // limit_period(., 0.5, pi)
+  o[6] = rg;
+#pragma unroll
+  for (int d = 0; d < 7; ++d) boxes[7 * i + d] = o[d];
+}
+
 // KIND 0: rotated 3-D boxes [n,7] (2-D IoU, optionally times z-IoU); KIND 1: axis-aligned [n,4]
 template <int KIND>
 __global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes, int64_t n, float thresh,
@@ -206,6 +257,26 @@ extern "C" int aabr_boxes_iou_3d(const float *targets, int64_t M, const float *a
   if (!only_xy)
     hipLaunchKernelGGL(k_scale_by_z, dim3((unsigned)ceil_div(M * K, 256)), dim3(256), 0, st, iou, M, K, tz, az);
   hipFreeAsync(tmp, st);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_rpn_decode(const int32_t *site_coords, int64_t site_begin, const int64_t *selected,
+                               int64_t k, const float *regression, int64_t reg_begin,
+                               const float *base_anchors, int num_anchors, float voxel_scale,
+                               const float *stride_host, const float *weights_host, float clip, float *boxes,
+                               void *stream_) {
+  AABR_CHECK_ARG(k >= 0 && num_anchors > 0 && voxel_scale > 0 && stride_host && weights_host, "bad arguments");
+  if (k == 0) return AABR_OK;
+  AABR_CHECK_ARG(site_coords && selected && regression && base_anchors && boxes, "null pointer");
+  RpnDecodeParams p;
+  p.inv_scale_num = voxel_scale;
+  for (int d = 0; d < 3; ++d) p.stride[d] = stride_host[d];
+  for (int d = 0; d < 7; ++d) p.weights[d] = weights_host[d];
+  p.clip = clip;
+  hipLaunchKernelGGL(k_rpn_decode, dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, (hipStream_t)stream_,
+                     site_coords, site_begin, selected, k, regression, reg_begin, base_anchors, num_anchors, p,
+                     boxes);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

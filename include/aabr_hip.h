@@ -195,6 +195,18 @@ int aabr_rotate_iou_eval(const float *boxes, int64_t N, const float *query, int6
 int aabr_boxes_iou_3d(const float *targets, int64_t M, const float *anchors, int64_t K,
                       const float *aug_host, int criterion, int only_xy, float *iou,
                       void *stream);
+/* RPN glue: anchors of the selected flat indices t = site*A + yaw, generated from
+ * the sparse site coordinates (modeling/rpn/anchor_generator_sparse3d.py:88-104:
+ * centroid = loc / voxel_scale * stride, + base anchor), fused with BoxCoder3D.decode_centroid_box
+ * (modeling/box_coder_3d.py:53-80; second_box_decode with smooth_dim, box_torch_ops.py:118-154;
+ * limit_period to [-pi/2, pi/2]).  site_coords int32 [V,4]; selected int64 [k] indices relative
+ * to (site_begin, reg_begin) of one example; regression float32 [*,7]; base_anchors [A,7];
+ * boxes float32 [k,7] out (yx_zb).                                                             */
+int aabr_rpn_decode(const int32_t *site_coords, int64_t site_begin, const int64_t *selected, int64_t k,
+                    const float *regression, int64_t reg_begin, const float *base_anchors,
+                    int num_anchors, float voxel_scale, const float *stride_host,
+                    const float *weights_host, float clip, float *boxes, void *stream);
+
 /* Greedy rotated NMS over boxes already sorted by descending score: rotate_nms_3d_cc
  * (second/core/non_max_suppression/nms_cpu.py:32-44) with the suppression rule of
  * spconv-1.x rotate_non_max_suppression_cpu (IoU(i,j) > 0 and >= thresh).

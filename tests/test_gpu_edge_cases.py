@@ -184,3 +184,60 @@ def test_device_quantisation_pipeline_matches_host_rule():
     gin = f.grad.cpu().numpy()
     np.testing.assert_array_equal(gin[kept], O.input_layer_bwd(il, g))
     assert (gin[~kept] == 0).all()  # dropped points receive no gradient
+
+
+def _np_decode(reg, anchors, weights, clip):
+    """numpy float32 restatement of BoxCoder3D.decode_centroid_box (box_coder_3d.py:53-80) +
+    second_box_decode(smooth_dim=True) (box_torch_ops.py:118-154) + limit_period (geometric_torch.py:4-10)"""
+    e = (reg / np.asarray(weights, np.float32)).astype(np.float32)
+    e[:, 3:6] = np.minimum(e[:, 3:6], np.float32(clip))
+    xa, ya, za, wa, la, ha, ra = [anchors[:, i] for i in range(7)]
+    diag = np.sqrt(la * la + wa * wa).astype(np.float32)
+    out = np.stack([e[:, 0] * diag + xa, e[:, 1] * diag + ya, e[:, 2] * ha + za, (e[:, 3] + 1) * wa,
+                    (e[:, 4] + 1) * la, (e[:, 5] + 1) * ha, e[:, 6] + ra], 1).astype(np.float32)
+    pi = np.float32(np.pi)
+    out[:, 6] = out[:, 6] - np.floor(out[:, 6] / pi + np.float32(0.5)) * pi
+    return out
+
+
+def test_rpn_glue_anchors_decode_nms_on_device():
+    scn = _scn()
+    import rpn_glue
+    rng = np.random.default_rng(17)
+    n = 3000
+    coords = np.stack([rng.integers(0, 64, n), rng.integers(0, 64, n), rng.integers(0, 8, n),
+                       np.sort(rng.integers(0, 2, n))], 1).astype(np.int64)
+    x = scn.InputLayer(3, [64, 64, 8], mode=3)([_t(coords), _t(np.zeros((n, 1), np.float32))])
+    sites = x.get_spatial_locations().numpy()
+    V, A = sites.shape[0], 4
+    base = np.zeros((A, 7), np.float32)
+    base[:, 3:6] = [0.2, 2.0, 2.6]
+    base[:, 6] = [0.0, np.pi / 4, np.pi / 2, -np.pi / 4]
+    stride = [4.0, 4.0, 2.0]
+    weights = (1.0, 1.0, 1.0, 2.0, 2.0, 2.0, 1.5)
+    obj = rng.standard_normal(V * A).astype(np.float32)
+    reg = (rng.standard_normal((V * A, 7)) * 0.3).astype(np.float32)
+    res = rpn_glue.rpn_proposals_single_map(x, _t(obj), _t(reg), torch.as_tensor(base), 20.0, stride, 500, 100,
+                                            0.5, (0.3, 0.3), weights, 10000.0)
+    # anchors: grid_anchors vs the reference formula in numpy float32
+    anc_d = rpn_glue.grid_anchors(x.metadata.grids[(64, 64, 8)].coords, torch.as_tensor(base), 20.0, stride)
+    cen = (sites[:, :3].astype(np.float32) / np.float32(20.0) * np.asarray(stride, np.float32)).astype(np.float32)
+    anc = (np.concatenate([cen, np.zeros((V, 4), np.float32)], 1)[:, None, :] + base[None]).reshape(-1, 7)
+    # (torch's device-side float division may differ from IEEE by an ulp; the fused decode kernel divides exactly)
+    np.testing.assert_allclose(anc_d.cpu().numpy(), anc, rtol=3e-7, atol=1e-6)
+    assert len(res) == 2
+    s = 0
+    for bi in range(2):
+        e = s + int((sites[:, 3] == bi).sum())
+        o = 1.0 / (1.0 + np.exp(-obj[s * A:e * A].astype(np.float64)))
+        idx = np.argsort(-o, kind="stable")[:500]
+        dec = _np_decode(reg[s * A:e * A][idx], anc[s * A:e * A][idx], weights, 10000.0)
+        nb = dec.copy()
+        nb[:, 3:5] = np.maximum(nb[:, 3:5], 0.3)
+        nb[:, 5] = np.maximum(nb[:, 5], 0.3)
+        iou = O.boxes_iou_3d(nb, nb)
+        keep = O.nms_from_matrix(iou, np.arange(len(idx), dtype=np.int32), 0.5)[:100]
+        boxes_d, score_d = res[bi]
+        np.testing.assert_allclose(boxes_d.cpu().numpy(), dec[keep], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(score_d.cpu().numpy(), o[idx][keep], rtol=1e-5, atol=1e-6)
+        s = e
