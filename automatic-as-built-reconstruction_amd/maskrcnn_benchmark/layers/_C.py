@@ -17,9 +17,36 @@ def nms(dets, scores, threshold):
     return torch.sort(order[keep_sorted])[0]
 
 
-def roi_align_rotated_3d_forward(*args):
-    raise NotImplementedError("ROIAlignRotated3D is SURVEY.md §8(f) rank 3 (next), not part of the hot path yet")
+def roi_align_rotated_3d_forward(input, rois, spatial_scale, pooled_height, pooled_width, pooled_zsize,
+                                 sampling_ratio):
+    """csrc/vision.cpp:19, csrc/cuda/ROIAlignRotated3D_cuda.cu:349-398: input [B,C,H,W,Z], rois [n,8] ->
+    [n, C, ph, pw, pz]"""
+    import _hip
+    from _hip import ptr, stream, check
+    _hip.require_gpu(input)
+    inp = input.contiguous().float()
+    r = rois.contiguous().float()
+    B, Cc, H, W, Z = inp.shape
+    out = torch.empty((r.size(0), Cc, int(pooled_height), int(pooled_width), int(pooled_zsize)), dtype=torch.float32,
+                      device=inp.device)
+    check(_hip.load().aabr_roi_align_rotated_3d_forward(ptr(inp), ptr(r), r.size(0), float(spatial_scale), Cc, H, W,
+                                                        Z, int(pooled_height), int(pooled_width), int(pooled_zsize),
+                                                        int(sampling_ratio), ptr(out), stream()))
+    return out
 
 
-def roi_align_rotated_3d_backward(*args):
-    raise NotImplementedError("ROIAlignRotated3D is SURVEY.md §8(f) rank 3 (next), not part of the hot path yet")
+def roi_align_rotated_3d_backward(grad, rois, spatial_scale, pooled_height, pooled_width, pooled_zsize, batch_size,
+                                  channels, height, width, zsize, sampling_ratio):
+    """csrc/vision.cpp:20, ROIAlignRotated3D_cuda.cu:401-454"""
+    import _hip
+    from _hip import ptr, stream, check
+    _hip.require_gpu(grad)
+    g = grad.contiguous().float()
+    r = rois.contiguous().float()
+    gin = torch.empty((int(batch_size), int(channels), int(height), int(width), int(zsize)), dtype=torch.float32,
+                      device=g.device)
+    check(_hip.load().aabr_roi_align_rotated_3d_backward(ptr(g), ptr(r), r.size(0), float(spatial_scale),
+                                                         int(pooled_height), int(pooled_width), int(pooled_zsize),
+                                                         int(batch_size), int(channels), int(height), int(width),
+                                                         int(zsize), int(sampling_ratio), ptr(gin), stream()))
+    return gin

@@ -573,3 +573,39 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     check(lib.aabr_bn_backward(ptr(inp), ptr(d_input_features), ptr(output_features.contiguous()), ptr(d_out),
                                rows, planes, ptr(saveMean), ptr(saveInvStd), ptr(_opt(weight)),
                                ptr(_opt(d_weight)), ptr(_opt(d_bias)), float(leakiness), ptr(scratch), stream()))
+
+
+# ------------------------------------------------------------------------------------------------
+# SparseToDense (pybind.cpp:124-133; SCN/CPU/SparseToDense.cpp:36-87)
+# ------------------------------------------------------------------------------------------------
+def _batch_size(metadata):
+    """number of samples = size of the per-sample grid vector in the reference
+    (`m.grids.begin()->second.size()`, SparseToDense.cpp:43); one small read-back, cached"""
+    bs = getattr(metadata, "_batch_size_cache", None)
+    if bs is None:
+        g = metadata.grids[metadata.input_spatial]
+        bs = int(g.coords[:, 3].max().item()) + 1 if g.V else 0
+        metadata._batch_size_cache = bs
+    return bs
+
+
+def SparseToDense_updateOutput(spatial_size, metadata, input_features, output_features, nPlanes):
+    inp = _f32c(input_features, "input_features")
+    g = metadata.grids[_key(spatial_size)]
+    sp = _key(spatial_size)
+    bs = _batch_size(metadata)
+    output_features.resize_(bs, int(nPlanes), *sp)
+    check(_hip.load().aabr_sparse_to_dense_forward(ptr(g.coords), g.V, ptr(inp), inp.size(1) if inp.dim() == 2 else
+                                                   int(nPlanes), _hip.i32x3(sp), bs, ptr(output_features),
+                                                   stream()))
+
+
+def SparseToDense_updateGradInput(spatial_size, metadata, input_features, d_input_features, d_output_features):
+    d_out = _f32c(d_output_features, "d_output_features")
+    g = metadata.grids[_key(spatial_size)]
+    d_input_features.resize_as_(input_features)
+    if input_features.dim() != 2:
+        return
+    check(_hip.load().aabr_sparse_to_dense_backward(ptr(g.coords), g.V, ptr(d_input_features),
+                                                    input_features.size(1), _hip.i32x3(_key(spatial_size)),
+                                                    ptr(d_out), stream()))

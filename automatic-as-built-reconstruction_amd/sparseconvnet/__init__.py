@@ -14,6 +14,8 @@ from .metadata import Metadata  # noqa: E402
 from .networkInNetwork import NetworkInNetwork  # noqa: E402
 from .sequential import Sequential  # noqa: E402
 from .sparseConvNetTensor import SparseConvNetTensor  # noqa: E402
+from . import sparseToDense  # noqa: E402
+from .sparseToDense import SparseToDense  # noqa: E402
 from .submanifoldConvolution import SubmanifoldConvolution, ValidConvolution  # noqa: E402
 from .tables import JoinTable, AddTable, ConcatTable  # noqa: E402
 from .utils import add_feature_planes, concatenate_feature_planes, toLongTensor, optionalTensor, \

@@ -221,6 +221,27 @@ int aabr_rotate_nms_sorted(const float *boxes7, int64_t n, float thresh, int onl
 int aabr_nms_sorted(const float *dets4, int64_t n, float thresh, uint64_t *mask, int64_t *keep,
                     int32_t *meta, void *stream);
 
+/* ---- SparseToDense + rotated 3-D ROI align ----------------------------------
+ * SparseToDense_updateOutput / _updateGradInput (SCN/CPU/SparseToDense.cpp:7-87, pybind.cpp:124-133):
+ * out float32 [batch, planes, X, Y, Z] (zero-filled here), out[b][p][(x*Y+y)*Z+z] = in[row][p].   */
+int aabr_sparse_to_dense_forward(const int32_t *site_coords, int64_t V, const float *in_feats, int planes,
+                                 const int32_t *spatial_host, int64_t batch_size, float *out,
+                                 void *stream);
+int aabr_sparse_to_dense_backward(const int32_t *site_coords, int64_t V, float *d_in_feats, int planes,
+                                  const int32_t *spatial_host, const float *d_out, void *stream);
+/* `_C.roi_align_rotated_3d_forward / _backward` (maskrcnn_benchmark/csrc/vision.cpp:19-20,
+ * csrc/cuda/ROIAlignRotated3D_cuda.cu:89-346): input [B,C,H,W,Z], rois [n,8] = (batch, center_w,
+ * center_h, center_z, width, height, zsize, theta in degrees), output [n,C,ph,pw,pz].  The backward
+ * zero-fills grad_input and accumulates with fp32 atomics, as the reference does.                   */
+int aabr_roi_align_rotated_3d_forward(const float *input, const float *rois, int64_t num_rois,
+                                      float spatial_scale, int channels, int height, int width, int zsize,
+                                      int pooled_h, int pooled_w, int pooled_z, int sampling_ratio,
+                                      float *output, void *stream);
+int aabr_roi_align_rotated_3d_backward(const float *grad_output, const float *rois, int64_t num_rois,
+                                       float spatial_scale, int pooled_h, int pooled_w, int pooled_z,
+                                       int batch_size, int channels, int height, int width, int zsize,
+                                       int sampling_ratio, float *grad_input, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

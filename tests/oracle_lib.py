@@ -45,6 +45,11 @@ def lib():
         L.oracle_nms_from_matrix.argtypes = [f32p, C.c_int64, i32p, C.c_float, i64p]
         L.oracle_nms_axis_aligned.restype = C.c_int64
         L.oracle_nms_axis_aligned.argtypes = [f32p, f32p, C.c_int64, C.c_float, i64p]
+        L.oracle_sparse_to_dense_fwd.argtypes = [i64p, C.c_int64, f32p, C.c_int, i64p, C.c_int64, f32p]
+        L.oracle_sparse_to_dense_bwd.argtypes = [i64p, C.c_int64, f32p, C.c_int, i64p, f32p]
+        L.oracle_roi_align_rot3d.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_region_points.restype = C.c_int64
@@ -253,3 +258,41 @@ def nms_axis_aligned(dets, scores, thresh):
     keep = np.zeros(max(len(scores), 1), np.int64)
     nk = lib().oracle_nms_axis_aligned(dets, scores, len(scores), thresh, keep)
     return keep[:nk].copy()
+
+
+# ---------------------------------------------------------------- SparseToDense / ROI align
+def sparse_to_dense(site_coords, feats, spatial, batch):
+    sc = np.ascontiguousarray(site_coords, np.int64)
+    f = np.ascontiguousarray(feats, np.float32)
+    sp = np.asarray(spatial, np.int64)
+    out = np.zeros((batch, f.shape[1]) + tuple(int(v) for v in sp), np.float32)
+    lib().oracle_sparse_to_dense_fwd(sc, sc.shape[0], f, f.shape[1], sp, batch, out)
+    return out
+
+
+def sparse_to_dense_bwd(site_coords, d_out, planes, spatial):
+    sc = np.ascontiguousarray(site_coords, np.int64)
+    d_in = np.zeros((sc.shape[0], planes), np.float32)
+    lib().oracle_sparse_to_dense_bwd(sc, sc.shape[0], d_in, planes, np.asarray(spatial, np.int64),
+                                     np.ascontiguousarray(d_out, np.float32))
+    return d_in
+
+
+def roi_align_rot3d_fwd(inp, rois, scale, out_size, sampling):
+    inp = np.ascontiguousarray(inp, np.float32)
+    rois = np.ascontiguousarray(rois, np.float32)
+    B, Cc, H, W, Z = inp.shape
+    out = np.zeros((rois.shape[0], Cc) + tuple(out_size), np.float32)
+    lib().oracle_roi_align_rot3d(_opt(inp), rois, rois.shape[0], scale, Cc, H, W, Z, out_size[0], out_size[1],
+                                 out_size[2], sampling, _opt(out), None, None, 0)
+    return out
+
+
+def roi_align_rot3d_bwd(grad, rois, scale, out_size, shape, sampling):
+    grad = np.ascontiguousarray(grad, np.float32)
+    rois = np.ascontiguousarray(rois, np.float32)
+    B, Cc, H, W, Z = shape
+    gin = np.zeros(shape, np.float32)
+    lib().oracle_roi_align_rot3d(None, rois, rois.shape[0], scale, Cc, H, W, Z, out_size[0], out_size[1],
+                                 out_size[2], sampling, None, _opt(grad), _opt(gin), 1)
+    return gin

@@ -241,3 +241,41 @@ def test_rpn_glue_anchors_decode_nms_on_device():
         np.testing.assert_allclose(boxes_d.cpu().numpy(), dec[keep], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(score_d.cpu().numpy(), o[idx][keep], rtol=1e-5, atol=1e-6)
         s = e
+
+
+def test_sparse_to_dense_and_rotated_roi_align_3d():
+    """§8f rank 3: SparseToDense (SCN/CPU/SparseToDense.cpp) + `_C.roi_align_rotated_3d_*`
+    (csrc/cuda/ROIAlignRotated3D_cuda.cu) through the reference's ROIAlignRotated3D module"""
+    scn = _scn()
+    from maskrcnn_benchmark.layers import ROIAlignRotated3D
+    rng = np.random.default_rng(31)
+    n = 2500
+    coords = np.stack([rng.integers(0, 20, n), rng.integers(0, 14, n), rng.integers(0, 5, n),
+                       np.sort(rng.integers(0, 2, n))], 1).astype(np.int64)
+    feats = rng.standard_normal((n, 6)).astype(np.float32)
+    f = _t(feats).requires_grad_(True)
+    x = scn.InputLayer(3, [24, 16, 6], mode=4)([_t(coords), f])
+    il = O.input_layer(coords, feats, 4)
+    dense = scn.SparseToDense(3, 6)(x)
+    ref_dense = O.sparse_to_dense(il["coords"], il["out"], [24, 16, 6], 2)
+    np.testing.assert_array_equal(dense.detach().cpu().numpy(), ref_dense)
+    # rois: (batch, center_w, center_h, center_z, width, height, zsize, theta[deg]) incl. one partly outside
+    rois = np.array([[0, 6.0, 9.0, 2.0, 5.0, 8.0, 3.0, 30.0], [1, 3.0, 4.0, 1.0, 4.0, 4.0, 2.0, -75.0],
+                     [1, 13.0, 19.0, 4.5, 9.0, 6.0, 4.0, 10.0], [0, 1.0, 1.0, 0.5, 0.2, 0.3, 0.1, 0.0]], np.float32)
+    layer = ROIAlignRotated3D((3, 4, 2), 1.0, 2)
+    out = layer(x, _t(rois))
+    mx = il["coords"].max(0) + 1
+    crop = ref_dense[:, :, :mx[0], :mx[1], :mx[2]]
+    want = O.roi_align_rot3d_fwd(crop, rois, 1.0, (3, 4, 2), 2)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    out.backward(_t(g))
+    gd = O.roi_align_rot3d_bwd(g, rois, 1.0, (3, 4, 2), crop.shape, 2)
+    full = np.zeros_like(ref_dense)
+    full[:, :, :mx[0], :mx[1], :mx[2]] = gd
+    d_sparse = O.sparse_to_dense_bwd(il["coords"], full, 6, [24, 16, 6])
+    np.testing.assert_allclose(f.grad.cpu().numpy(), O.input_layer_bwd(il, d_sparse), rtol=1e-4, atol=1e-5)
+    # adaptive sampling grid (sampling_ratio <= 0) and a spatial scale
+    out2 = ROIAlignRotated3D((2, 2, 2), 0.5, 0)(x, _t(rois * np.array([1, 2, 2, 2, 2, 2, 2, 1], np.float32)))
+    want2 = O.roi_align_rot3d_fwd(crop, rois * np.array([1, 2, 2, 2, 2, 2, 2, 1], np.float32), 0.5, (2, 2, 2), 0)
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), want2, rtol=1e-4, atol=1e-5)
