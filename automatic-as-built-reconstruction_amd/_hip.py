@@ -33,7 +33,7 @@ _SIGS = {
     "aabr_table_to_rulebook": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "aabr_spatial_locations": (C.c_int, [_vp, _i64, _vp, _vp]),
     "aabr_conv_wpack_floats": (C.c_int64, [_i32, _i32, _i32]),
-    "aabr_conv_forward": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "aabr_conv_forward": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "aabr_conv_dw_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),
     "aabr_conv_backward_weight": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
     "aabr_tile_blocks_words": (C.c_int64, [_i64, _i32]),

@@ -19,6 +19,7 @@
 //
 // fp32 MFMA == k-ordered fmaf chain (exact fp32); peak 157 TFLOP/s.
 #include "common.h"
+#include <stdlib.h>
 
 namespace aabr {
 
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
 // filter offset; every convolution that uses the rule book (forward of each layer at that scale,
 // and the input-gradient passes) then streams these blocks with no ballots and no table reads.
 //   words:  [ntiles] nblk | [ntiles][MAXB] offset k of each block | [ntiles][MAXB][16] entries
-//   entry = (partner_row << 6) | local_row, or -1 for padding;  MAXB = 4 * vol.
+//   entry = (partner_row << 6) | local_row; padding entries repeat the block's first pair with
+//   bit 31 set (gather is valid, result is discarded);  MAXB = 4 * vol.
 __host__ __device__ inline int64_t tb_ntiles(int64_t V) { return (V + 63) / 64; }
 __host__ __device__ inline int tb_maxb(int vol) { return 4 * vol; }
 
@@ -82,8 +84,12 @@ __global__ __launch_bounds__(256) void k_build_tile_blocks(const int32_t *__rest
     const int cnt = __popcll(m);
     const int pos = __popcll(m & ((1ull << lane) - 1ull));
     const int nmb = (cnt + 15) >> 4;
-    if (t >= 0) ent[b0 * 16 + pos] = (t << 6) | lane;
-    if (lane < nmb * 16 - cnt) ent[b0 * 16 + cnt + lane] = -1;
+    const int e = (t << 6) | lane;
+    if (t >= 0) ent[b0 * 16 + pos] = e;
+    // padding: a copy of the first pair with the discard bit (31) set, so the MFMA kernel can gather
+    // unconditionally (no zero-fill selects) and simply drops the result
+    const int e_first = __shfl(e, __ffsll((long long)m) - 1);
+    if (lane < nmb * 16 - cnt) ent[b0 * 16 + cnt + lane] = e_first | (int)0x80000000;
     if (lane < nmb) blk_k[b0 + lane] = k;
     b0 += nmb;
   }
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
   wflip &= 1;
 
   // this wave's blocks: wave, wave + WPB, ...; consumed two per pair
-  const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
+  const int nmine = (wave < nblk && !(dbg & 4)) ? (nblk - wave + WPB - 1) / WPB : 0; // dbg 4: skip the main loop
   const int npairs = (nmine + 1) >> 1;
   auto load_pair = [&](int pr) {
     PairEnt p;
@@ -259,6 +265,170 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
   const int wcols = (co - nb0 * 16) < NBW * 16 ? (co - nb0 * 16) : NBW * 16;
   if ((co & 3) == 0) {
     const int q = wcols >> 2; // float4 per row
+    for (int i = threadIdx.x; i < nrows * q; i += WPB * 64) {
+      int r = i / q, cq = i % q;
+      float4 v = *reinterpret_cast<const float4 *>(smem + r * WS + cq * 4);
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) {
+        float4 u = *reinterpret_cast<const float4 *>(smem + (size_t)w * TILE + r * WS + cq * 4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      if (bias) {
+        const float *bb = bias + nb0 * 16 + cq * 4;
+        v.x += bb[0]; v.y += bb[1]; v.z += bb[2]; v.w += bb[3];
+      }
+      *reinterpret_cast<float4 *>(out + (row0 + r) * co + nb0 * 16 + cq * 4) = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nrows * wcols; i += WPB * 64) {
+      int r = i / wcols, cc = i % wcols;
+      float v = smem[r * WS + cc];
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) v += smem[(size_t)w * TILE + r * WS + cc];
+      if (bias) v += bias[nb0 * 16 + cc];
+      out[(row0 + r) * co + nb0 * 16 + cc] = v;
+    }
+  }
+}
+
+// Lean variant for ci % 32 == 0 and tensors < 2 GiB: every load goes through a buffer descriptor
+// (32-bit per-lane offsets, wave-uniform parts in SGPRs, hardware range check), padding entries are
+// gathered like real ones, the step registers ping-pong (no copies) and the first MFMA of a chain
+// takes a literal zero accumulator.  fp32 MFMA shares the vector datapath with the VALU on gfx950
+// (ablation: kernel time = MFMA time + everything-else time), so every VALU instruction removed
+// from the loop is time given back to the matrix pipe.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct GStep { u32x4 a0, a1, b0, b1; };
+
+__device__ inline float bcf(unsigned int v) { return __builtin_bit_cast(float, v); }
+
+template <int NBW>
+__device__ inline void conv_step_mfma_buf(const GStep &q, __amdgpu_buffer_rsrc_t rw, unsigned lane32,
+                                          unsigned soA, unsigned soB, int nvalid, f32x4 (&accA)[NBW],
+                                          f32x4 (&accB)[NBW]) {
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    if (j >= nvalid) break; // last column slab may hold fewer than NBW blocks (wave-uniform)
+    const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soA + j * 2048, 0);
+    const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soA + j * 2048, 0);
+    const u32x4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soB + j * 2048, 0);
+    const u32x4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soB + j * 2048, 0);
+    f32x4 ca = accA[j], cb = accB[j];
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[0]), bcf(q.a0[0]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[0]), bcf(q.b0[0]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[1]), bcf(q.a0[1]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[1]), bcf(q.b0[1]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[2]), bcf(q.a0[2]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[2]), bcf(q.b0[2]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[3]), bcf(q.a0[3]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[3]), bcf(q.b0[3]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[0]), bcf(q.a1[0]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[0]), bcf(q.b1[0]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[1]), bcf(q.a1[1]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[1]), bcf(q.b1[1]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[2]), bcf(q.a1[2]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[2]), bcf(q.b1[2]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[3]), bcf(q.a1[3]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[3]), bcf(q.b1[3]), cb, 0, 0, 0);
+    accA[j] = ca; accB[j] = cb;
+  }
+}
+
+template <int NBW, int WPB>
+__global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mfma_buf(
+    const float *__restrict__ in, int ci, int64_t in_bytes, float *__restrict__ out, int co, int64_t V_out,
+    const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const float *__restrict__ Wp,
+    int64_t wp_bytes, const float *__restrict__ bias) {
+  constexpr int WS = NBW * 16;              // C-tile row stride (floats)
+  constexpr int TILE = 64 * WS;             // floats per wave
+  extern __shared__ __align__(16) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  float *Ct = smem + (size_t)wave * TILE;
+  const int maxb = tb_maxb(vol);
+  const int nkc = ci >> 5, nnb = nnb_of(co);
+  const int nb0 = blockIdx.y * NBW;
+  const int64_t tile = blockIdx.x, row0 = tile * 64;
+  const int64_t ntiles = tb_ntiles(V_out);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, (int)wp_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwords =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(words), 0, (int)words_bytes, 0x00020000);
+  const int nblk = words[tile];
+  const unsigned kbase = (unsigned)((ntiles + tile * maxb) * 4);                       // byte offset of blk_k
+  const unsigned ebase = (unsigned)((ntiles + ntiles * maxb + tile * maxb * 16) * 4);  // byte offset of ent
+  const unsigned rowbytes = (unsigned)ci * 4u, g32 = (unsigned)g * 32u, lane32 = (unsigned)lane * 32u;
+  const unsigned wk_bytes = (unsigned)nkc * (unsigned)nnb * 2048u;                     // packed bytes per offset
+  const unsigned c16x4 = (unsigned)c16 * 4u;
+  const int nvalid = (nnb - nb0) < NBW ? (nnb - nb0) : NBW;
+
+  for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
+
+  const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
+  const int npairs = (nmine + 1) >> 1;
+  auto load_pair = [&](int pr) {
+    PairEnt p;
+    int bA = wave + (2 * pr) * WPB;
+    if (bA >= nblk) bA = nblk > 0 ? nblk - 1 : 0;      // past the end: harmless re-read, never consumed
+    int bB = bA + WPB;
+    const bool hasB = bB < nblk;
+    if (!hasB) bB = bA;
+    p.eA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bA * 64u, 0);
+    p.eB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bB * 64u, 0);
+    if (!hasB) p.eB |= (int)0x80000000;
+    p.kA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bA * 4u, 0);
+    p.kB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bB * 4u, 0);
+    return p;
+  };
+  auto gather = [&](GStep &q, const PairEnt &p, int kc) {
+    const unsigned va = (((unsigned)p.eA & 0x7fffffffu) >> 6) * rowbytes + g32;
+    const unsigned vb = (((unsigned)p.eB & 0x7fffffffu) >> 6) * rowbytes + g32;
+    const unsigned so = (unsigned)kc * 128u;
+    q.a0 = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
+    q.a1 = __builtin_amdgcn_raw_buffer_load_b128(rin, va + 16u, so, 0);
+    q.b0 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb, so, 0);
+    q.b1 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb + 16u, so, 0);
+  };
+  PairEnt p0 = load_pair(0), p1 = load_pair(1), p2 = load_pair(2);
+  GStep s0, s1;
+  if (npairs > 0) gather(s0, p0, 0);
+  f32x4 accA[NBW], accB[NBW];
+  int step = 0; // parity selects the ping-pong register set
+  for (int pr = 0; pr < npairs; ++pr) {
+    int kA = __builtin_amdgcn_readfirstlane(p0.kA), kB = __builtin_amdgcn_readfirstlane(p0.kB);
+    if (wflip) { kA = vol - 1 - kA; kB = vol - 1 - kB; }
+    const unsigned soA0 = (unsigned)kA * wk_bytes + (unsigned)nb0 * 2048u;
+    const unsigned soB0 = (unsigned)kB * wk_bytes + (unsigned)nb0 * 2048u;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accB[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int kc = 0; kc < nkc; ++kc, ++step) {
+      const bool more = (kc + 1 < nkc) || (pr + 1 < npairs);
+      const PairEnt &pn = (kc + 1 < nkc) ? p0 : p1;
+      const int kcn = (kc + 1 < nkc) ? kc + 1 : 0;
+      const unsigned so = (unsigned)kc * (unsigned)nnb * 2048u;
+      if (step & 1) {
+        if (more) gather(s0, pn, kcn);
+        conv_step_mfma_buf<NBW>(s1, rw, lane32, soA0 + so, soB0 + so, nvalid, accA, accB);
+      } else {
+        if (more) gather(s1, pn, kcn);
+        conv_step_mfma_buf<NBW>(s0, rw, lane32, soA0 + so, soB0 + so, nvalid, accA, accB);
+      }
+    }
+    conv_block_accumulate<NBW, WS>(Ct, p0.eA, g, accA);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // A and B may hit the same row
+    conv_block_accumulate<NBW, WS>(Ct, p0.eB, g, accB);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    p0 = p1; p1 = p2; p2 = load_pair(pr + 3);
+  }
+  __syncthreads();
+  const int nrows = (int)((V_out - row0) < 64 ? (V_out - row0) : 64);
+  const int wcols = (co - nb0 * 16) < NBW * 16 ? (co - nb0 * 16) : NBW * 16;
+  if ((co & 3) == 0) {
+    const int q = wcols >> 2;
     for (int i = threadIdx.x; i < nrows * q; i += WPB * 64) {
       int r = i / q, cq = i % q;
       float4 v = *reinterpret_cast<const float4 *>(smem + r * WS + cq * 4);
@@ -544,14 +714,14 @@ extern "C" int aabr_build_offset_pairs(const int32_t *table, const int32_t *bloc
   return AABR_OK;
 }
 
-extern "C" int aabr_conv_forward(const float *in_feats, int n_in, float *out_feats, int n_out, int64_t V_out,
-                                 const int32_t *blocks, int vol, const float *W, const float *bias, int flags,
-                                 float *wpack, void *stream_) {
+extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
+                                 int64_t V_out, const int32_t *blocks, int vol, const float *W, const float *bias,
+                                 int flags, float *wpack, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && vol > 0 && V_out >= 0, "bad sizes");
+  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && vol > 0 && V_out >= 0 && rows_in >= 0, "bad sizes");
   AABR_CHECK_ARG(n_in <= 4096 && n_out <= 4096, "plane count too large");
   if (V_out == 0) return AABR_OK;
-  AABR_CHECK_ARG(in_feats && out_feats && blocks && W && wpack, "null pointer");
+  AABR_CHECK_ARG(in_feats && out_feats && blocks && W && wpack && rows_in > 0, "null pointer / empty input");
   AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 15) == 0 &&
                      ((uintptr_t)wpack & 15) == 0,
                  "feature / scratch pointers must be 16-byte aligned");
@@ -565,11 +735,20 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, float *out_fea
   // WPB waves share the blocks of one 64-row tile.  Pick the split that minimises
   // (rounds of resident workgroups) x (blocks per wave): a grid one workgroup larger than what
   // fits on the chip at once would otherwise pay a whole second round.
+  // lean buffer-descriptor kernel: aligned channels and every buffer below 2 GiB (32-bit offsets)
+  const int64_t in_bytes = rows_in * n_in * 4, wp_bytes = total * 4,
+                words_bytes = aabr_tile_blocks_words(V_out, vol) * 4;
+  const bool lean = aligned && in_bytes < (1ll << 31) && wp_bytes < (1ll << 31) && words_bytes < (1ll << 31) &&
+                    !(flags >> 8);
 #define AABR_LAUNCH_CONV(NBW, WPB)                                                                      \
   do {                                                                                                  \
     size_t lds = (size_t)(WPB) * 64 * ((NBW)*16) * sizeof(float);                                       \
     dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                           \
-    if (aligned)                                                                                        \
+    if (lean)                                                                                           \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB>), grid, dim3(64 * (WPB)), lds, st, in_feats,  \
+                         n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip & 1,   \
+                         wpack, wp_bytes, bias);                                                        \
+    else if (aligned)                                                                                   \
       hipLaunchKernelGGL((k_conv_blocks_mfma<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,         \
                          in_feats, n_in, out_feats, n_out, V_out, blocks, vol, flip, wpack, bias);      \
     else                                                                                                \
@@ -590,6 +769,10 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, float *out_fea
     if (lds > 64 * 1024) continue; // default dynamic-LDS limit per workgroup
     int64_t cost = rounds * ceil_div(vol, wpb);
     if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_wpb = wpb; }
+  }
+  if (const char *ov = getenv("AABR_CONV_WPB")) { // tuning experiments only
+    int v = atoi(ov);
+    if (v >= 2 && v <= (nbw == 4 ? 3 : 4)) best_wpb = v;
   }
   if (nbw == 1) {
     if (best_wpb == 2) AABR_LAUNCH_CONV(1, 2);

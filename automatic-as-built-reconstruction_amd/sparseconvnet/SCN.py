@@ -461,7 +461,7 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags):
     out.resize_(n_rows_out, n_out)
     wpack = _hip.workspace("wpack", lib.aabr_conv_wpack_floats(gather.vol, w.size(2), w.size(3)), torch.float32,
                            inp.device)
-    check(lib.aabr_conv_forward(ptr(inp), n_in, ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
+    check(lib.aabr_conv_forward(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
                                 ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
     return n_out
 

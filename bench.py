@@ -99,13 +99,13 @@ def time_dominant_kernel(scn, m, scene, reps=30):
         out = torch.empty((V, 32), device=inp.device)
         w = m["conv2"].weight.detach().contiguous()
         wpack = torch.empty(lib.aabr_conv_wpack_floats(27, 32, 32), device=inp.device)
-        check(lib.aabr_conv_forward(ptr(inp), 32, ptr(out), 32, V, ptr(tb.out.blocks()), 27, ptr(w), None, 0, ptr(wpack),
+        check(lib.aabr_conv_forward(ptr(inp), 32, V, ptr(out), 32, V, ptr(tb.out.blocks()), 27, ptr(w), None, 0, ptr(wpack),
                                     stream()))
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in evs:
             a.record()
-            check(lib.aabr_conv_forward(ptr(inp), 32, ptr(out), 32, V, ptr(tb.out.blocks()), 27, ptr(w), None, 4,
+            check(lib.aabr_conv_forward(ptr(inp), 32, V, ptr(out), 32, V, ptr(tb.out.blocks()), 27, ptr(w), None, 4,
                                         ptr(wpack), stream()))
             b.record()
         torch.cuda.synchronize()

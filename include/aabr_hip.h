@@ -147,15 +147,17 @@ int aabr_build_offset_pairs(const int32_t *table, const int32_t *block_counts, i
  * Replaces {Submanifold,}Convolution_updateOutput / Deconvolution_updateOutput
  * (SCN/sparseconvnet_cuda.cpp:281-310; CPU/Convolution.cpp:45-79,117-149;
  *  CPU/Deconvolution.cpp:7-41; CUDA/Convolution.cu:57-233,444-521,618-642).
+ *   rows_in  number of rows of `in_feats` (bounds the gather; V_out for submanifold layers)
  *   blocks   tile blocks compiled from the gather table whose entries index `in_feats`
  *   W        float32 [vol, nIn, nOut]  (the reference's [vol, groups=1, nIn, nOut])
  *   flags    bit0: use W[k]^T (input-gradient pass: `in` has nOut planes, `out` nIn planes,
  *            CPU/Convolution.cpp:108-112); bit1: weight index vol-1-k (submanifold
  *            input-gradient through the forward table); bit2: `wpack` already holds the packed
- *            weights for this (W, bit0) pair (skips the repack launch).
+ *            weights for this (W, bit0) pair (skips the repack launch); bits 8-9: timing
+ *            experiments only (skip MFMAs / gathers).
  *   wpack    float32 scratch, aabr_conv_wpack_floats(vol,nIn,nOut) elements                   */
 int64_t aabr_conv_wpack_floats(int vol, int n_in, int n_out);
-int aabr_conv_forward(const float *in_feats, int n_in, float *out_feats, int n_out,
+int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
                       int64_t V_out, const int32_t *blocks, int vol, const float *W,
                       const float *bias, int flags, float *wpack, void *stream);
 /* dW[k] = sum over offset k's pairs (t, o) of in[t]^T (x) d_out[o]; d_bias (optional) = column

@@ -27,23 +27,23 @@ for ci, co in ((32, 32), (64, 64), (128, 128), (256, 256), (32, 128), (128, 32))
     out = torch.empty(V, co, device=dev)
     w = torch.randn(27, ci, co, device=dev)
     wpack = torch.empty(lib.aabr_conv_wpack_floats(27, ci, co), device=dev)
-    check(lib.aabr_conv_forward(ptr(inp), ci, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 0, ptr(wpack), stream()))
+    check(lib.aabr_conv_forward(ptr(inp), ci, V, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 0, ptr(wpack), stream()))
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 20
     a.record()
     for _ in range(n):
-        check(lib.aabr_conv_forward(ptr(inp), ci, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 4, ptr(wpack), stream()))
+        check(lib.aabr_conv_forward(ptr(inp), ci, V, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 4, ptr(wpack), stream()))
     b.record(); torch.cuda.synchronize()
     t = a.elapsed_time(b) / n * 1e-3
     extra = []
-    for dbg in (1, 2, 3):
+    for dbg in (1, 2, 3, 4):
         a.record()
         for _ in range(n):
-            check(lib.aabr_conv_forward(ptr(inp), ci, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 4 | (dbg << 8), ptr(wpack), stream()))
+            check(lib.aabr_conv_forward(ptr(inp), ci, V, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 4 | (dbg << 8), ptr(wpack), stream()))
         b.record(); torch.cuda.synchronize()
         extra.append(a.elapsed_time(b) / n * 1e3)
-    print("   fwd variants: no-MFMA %.1f us, no-gather %.1f us, neither %.1f us" % tuple(extra))
+    print("   fwd variants (flat kernel): no-MFMA %.1f us, no-gather %.1f us, neither %.1f us, no main loop %.1f us" % tuple(extra))
     dW = torch.empty_like(w)
     scratch = torch.empty(lib.aabr_conv_dw_scratch_floats(mc, ci, co), device=dev)
     dout = torch.randn(V, co, device=dev)
