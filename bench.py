@@ -230,9 +230,19 @@ def main():
     if rank == 0:
         ksec, R, V = time_dominant_kernel(scn, m, scenes[0])
         flops = 2.0 * R * 32 * 32
-        roof = dict(kernel="k_conv_blocks_mfma (SubmConv3 32->32 forward)", bound="mfma",
+        # HBM traffic of that kernel from the committed PMC passes (profiles/, separate --pmc runs of
+        # this same command): FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_fetch_write_per_kernel.json")))["kernels"]
+            for kname, v in pm.items():
+                if "k_conv_blocks_mfma_buf<2, 4>" in kname:
+                    traffic = int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
+        except Exception:
+            traffic = None
+        roof = dict(kernel="k_conv_blocks_mfma_buf<2,4> (SubmConv3 32->32 forward)", bound="mfma",
                     achieved=round(flops / ksec / 1e12, 4), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(flops / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5), traffic=None,
+                    frac=round(flops / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5), traffic=traffic,
                     launch_us=round(ksec * 1e6, 2), rules=int(R), sites=int(V),
                     algorithmic_flops_per_launch=flops)
         # voxel scatter (A1+A2): N*(32 + 4*C_in) + V*(4*C_in + 16) algorithmic bytes

@@ -1,0 +1,17 @@
+"""Summarise the two PMC passes of tools_pmc.sh into profiles/r01_pmc_fetch_write_per_kernel.json"""
+import collections, csv, glob, json
+def agg(pat):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(sorted(glob.glob(pat))[-1])):
+        d[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return d
+f = agg('gpurun_out/pmc_FETCH_SIZE/*/*counter_collection.csv')
+w = agg('gpurun_out/pmc_WRITE_SIZE/*/*counter_collection.csv')
+out = {}
+for k, v in f.items():
+    wv = w.get(k, [0.0])
+    out[k] = {"launches": len(v), "FETCH_SIZE_KB_avg": round(sum(v) / len(v), 1), "WRITE_SIZE_KB_avg": round(sum(wv) / len(wv), 1)}
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 10 --warmup 3`; values are KB per launch, averaged over launches. gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section); other access widths are uncalibrated.", "kernels": out},
+          open('profiles/r01_pmc_fetch_write_per_kernel.json', 'w'), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["FETCH_SIZE_KB_avg"])[:8]:
+    print(k[:70], v)
