@@ -36,6 +36,10 @@ _SIGS = {
     "aabr_conv_forward": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "aabr_conv_dw_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),
     "aabr_conv_backward_weight": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "aabr_conv_wpack_bf16_elems": (C.c_int64, [_i32, _i32, _i32]),
+    "aabr_conv_forward_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "aabr_conv_backward_weight_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp,
+                                                 _vp]),
     "aabr_tile_blocks_words": (C.c_int64, [_i64, _i32]),
     "aabr_build_tile_blocks": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "aabr_offset_pairs_words": (C.c_int64, [_i64, _i32]),
@@ -44,6 +48,10 @@ _SIGS = {
     "aabr_bn_forward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32,
                                   _vp, _vp]),
     "aabr_bn_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
+    "aabr_bn_forward_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32,
+                                       _vp, _vp]),
+    "aabr_bn_backward_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp,
+                                        _vp]),
     "aabr_rotate_iou_eval": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "aabr_boxes_iou_3d": (C.c_int, [_vp, _i64, _vp, _i64, _f32p, _i32, _i32, _vp, _vp]),
     "aabr_sparse_to_dense_forward": (C.c_int, [_vp, _i64, _vp, _i32, _i32p, _i64, _vp, _vp]),

@@ -16,14 +16,31 @@ constexpr int kMaxParts = 512;
 constexpr int kFinSlices = 32; // finalize: 8 planes x 32 slices of the partial list per block
 constexpr int kFinPlanes = 8;
 
+// feature element access: fp32 (reference precision) or bf16 storage (extension, fp32/fp64 maths)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ inline float4 ld4(const float *p, int64_t i) { return *reinterpret_cast<const float4 *>(p + i); }
+__device__ inline float4 ld4(const __bf16 *p, int64_t i) {
+  bf16x4 v = *reinterpret_cast<const bf16x4 *>(p + i);
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ inline void st4(float *p, int64_t i, float4 v) { *reinterpret_cast<float4 *>(p + i) = v; }
+__device__ inline void st4(__bf16 *p, int64_t i, float4 v) {
+  bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  *reinterpret_cast<bf16x4 *>(p + i) = o;
+}
+__device__ inline float ld1(const float *p, int64_t i) { return p[i]; }
+__device__ inline float ld1(const __bf16 *p, int64_t i) { return (float)p[i]; }
+__device__ inline void st1(float *p, int64_t i, float v) { p[i] = v; }
+__device__ inline void st1(__bf16 *p, int64_t i, float v) { p[i] = (__bf16)v; }
+
 // two-quantity column reduction: for every plane p,
 //   A[p] = sum_rows fa(row,p),  B[p] = sum_rows fb(row,p)
 // MODE 0: fa = x, fb = x*x            (forward statistics)
 // MODE 1: fa = d*r, fb = (x-mean)*d*r (backward statistics, r = out>0 ? 1 : leakiness)
 // VEC = 4: planes % 4 == 0, one float4 per thread per row (16-B coalesced streams); VEC = 1: any.
-template <int MODE, int VEC>
-__global__ __launch_bounds__(256) void k_bn_partials(const float *__restrict__ x, const float *__restrict__ out,
-                                                     const float *__restrict__ d_out,
+template <int MODE, int VEC, typename T>
+__global__ __launch_bounds__(256) void k_bn_partials(const T *__restrict__ x, const T *__restrict__ out,
+                                                     const T *__restrict__ d_out,
                                                      const float *__restrict__ mean, float leak, int64_t rows,
                                                      int planes, double *__restrict__ part) {
   __shared__ double ra[256][VEC], rb[256][VEC];
@@ -44,17 +61,17 @@ __global__ __launch_bounds__(256) void k_bn_partials(const float *__restrict__ x
         const int64_t i = r * planes + (int64_t)cv * VEC;
         float xv[VEC], ov[VEC], dv[VEC];
         if (VEC == 4) {
-          float4 t = *reinterpret_cast<const float4 *>(x + i);
+          float4 t = ld4(x, i);
           xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
           if (MODE == 1) {
-            float4 o = *reinterpret_cast<const float4 *>(out + i);
-            float4 d = *reinterpret_cast<const float4 *>(d_out + i);
+            float4 o = ld4(out, i);
+            float4 d = ld4(d_out, i);
             ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
             dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
           }
         } else {
-          xv[0] = x[i];
-          if (MODE == 1) { ov[0] = out[i]; dv[0] = d_out[i]; }
+          xv[0] = ld1(x, i);
+          if (MODE == 1) { ov[0] = ld1(out, i); dv[0] = ld1(d_out, i); }
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -135,7 +152,8 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const double *__restric
   coef[planes + p] = -mean * w + (bias ? bias[p] : 0.0f);
 }
 
-__global__ __launch_bounds__(256) void k_bn_fwd_apply(const float *__restrict__ x, float *__restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_fwd_apply(const T *__restrict__ x, T *__restrict__ y,
                                                       int64_t total, int planes,
                                                       const float *__restrict__ coef, float leak) {
   // planes % 4 == 0 path: float4 per thread
@@ -143,23 +161,24 @@ __global__ __launch_bounds__(256) void k_bn_fwd_apply(const float *__restrict__ 
   int64_t i = i4 * 4;
   if (i >= total) return;
   int p = (int)(i % planes);
-  float4 v = *reinterpret_cast<const float4 *>(x + i);
+  float4 v = ld4(x, i);
   float4 w = *reinterpret_cast<const float4 *>(coef + p);
   float4 b = *reinterpret_cast<const float4 *>(coef + planes + p);
   float4 o;
   o.x = v.x * w.x + b.x; o.y = v.y * w.y + b.y; o.z = v.z * w.z + b.z; o.w = v.w * w.w + b.w;
   o.x = o.x > 0.0f ? o.x : o.x * leak; o.y = o.y > 0.0f ? o.y : o.y * leak;
   o.z = o.z > 0.0f ? o.z : o.z * leak; o.w = o.w > 0.0f ? o.w : o.w * leak;
-  *reinterpret_cast<float4 *>(y + i) = o;
+  st4(y, i, o);
 }
-__global__ __launch_bounds__(256) void k_bn_fwd_apply1(const float *__restrict__ x, float *__restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_fwd_apply1(const T *__restrict__ x, T *__restrict__ y,
                                                        int64_t total, int planes,
                                                        const float *__restrict__ coef, float leak) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int p = (int)(i % planes);
-  float o = x[i] * coef[p] + coef[planes + p];
-  y[i] = o > 0.0f ? o : o * leak;
+  float o = ld1(x, i) * coef[p] + coef[planes + p];
+  st1(y, i, o > 0.0f ? o : o * leak);
 }
 
 // backward finalize (CPU/BatchNormalization.cpp:85-90,103-106): coef = {gradMean, k, invstd*w}
@@ -179,29 +198,31 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double *__restric
   coef[2 * planes + p] = is * (weight ? weight[p] : 1.0f);
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, float *__restrict__ d_in,
-                                                      const float *__restrict__ out,
-                                                      const float *__restrict__ d_out, int64_t total,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, T *__restrict__ d_in,
+                                                      const T *__restrict__ out,
+                                                      const T *__restrict__ d_out, int64_t total,
                                                       int planes, const float *__restrict__ mean,
                                                       const float *__restrict__ coef, float leak) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int p = (int)(i % planes);
-  float d = d_out[i];
-  d = (out[i] > 0.0f) ? d : d * leak;
-  d_in[i] = (d - coef[p] - (x[i] - mean[p]) * coef[planes + p]) * coef[2 * planes + p];
+  float d = ld1(d_out, i);
+  d = (ld1(out, i) > 0.0f) ? d : d * leak;
+  st1(d_in, i, (d - coef[p] - (ld1(x, i) - mean[p]) * coef[planes + p]) * coef[2 * planes + p]);
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float *__restrict__ x, float *__restrict__ d_in,
-                                                       const float *__restrict__ out,
-                                                       const float *__restrict__ d_out, int64_t total,
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply4(const T *__restrict__ x, T *__restrict__ d_in,
+                                                       const T *__restrict__ out,
+                                                       const T *__restrict__ d_out, int64_t total,
                                                        int planes, const float *__restrict__ mean,
                                                        const float *__restrict__ coef, float leak) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   int p = (int)(i % planes);
-  float4 xv = *reinterpret_cast<const float4 *>(x + i), ov = *reinterpret_cast<const float4 *>(out + i);
-  float4 dv = *reinterpret_cast<const float4 *>(d_out + i), mu = *reinterpret_cast<const float4 *>(mean + p);
+  float4 xv = ld4(x, i), ov = ld4(out, i);
+  float4 dv = ld4(d_out, i), mu = *reinterpret_cast<const float4 *>(mean + p);
   float4 gm = *reinterpret_cast<const float4 *>(coef + p), kk = *reinterpret_cast<const float4 *>(coef + planes + p);
   float4 sw = *reinterpret_cast<const float4 *>(coef + 2 * planes + p), r;
   float d;
@@ -209,7 +230,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float *__restrict__
   d = ov.y > 0.0f ? dv.y : dv.y * leak; r.y = (d - gm.y - (xv.y - mu.y) * kk.y) * sw.y;
   d = ov.z > 0.0f ? dv.z : dv.z * leak; r.z = (d - gm.z - (xv.z - mu.z) * kk.z) * sw.z;
   d = ov.w > 0.0f ? dv.w : dv.w * leak; r.w = (d - gm.w - (xv.w - mu.w) * kk.w) * sw.w;
-  *reinterpret_cast<float4 *>(d_in + i) = r;
+  st4(d_in, i, r);
 }
 
 static int bn_parts(int64_t rows, int planes, int vec) {
@@ -227,10 +248,10 @@ extern "C" int64_t aabr_bn_scratch_floats(int planes) {
   return (int64_t)kMaxParts * 2 * planes * 2 /* doubles */ + 4 * (int64_t)planes + 8;
 }
 
-extern "C" int aabr_bn_forward(const float *in, float *out, int64_t rows, int planes, float *save_mean,
-                               float *save_invstd, float *running_mean, float *running_var,
-                               const float *weight, const float *bias, float eps, float momentum, int train,
-                               float leakiness, float *scratch, void *stream_) {
+template <typename T>
+static int bn_forward_t(const T *in, T *out, int64_t rows, int planes, float *save_mean, float *save_invstd,
+                        float *running_mean, float *running_var, const float *weight, const float *bias,
+                        float eps, float momentum, int train, float leakiness, float *scratch, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(rows >= 0 && planes > 0, "bad sizes");
   AABR_CHECK_ARG(save_mean && save_invstd && running_mean && running_var && scratch, "null pointer");
@@ -244,30 +265,30 @@ extern "C" int aabr_bn_forward(const float *in, float *out, int64_t rows, int pl
     const bool v4 = (planes & 3) == 0 && ((uintptr_t)in & 15) == 0;
     nparts = bn_parts(rows, planes, v4 ? 4 : 1);
     if (v4)
-      hipLaunchKernelGGL((k_bn_partials<0, 4>), dim3(nparts), dim3(256), 0, st, in, (const float *)nullptr,
-                         (const float *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
+      hipLaunchKernelGGL((k_bn_partials<0, 4, T>), dim3(nparts), dim3(256), 0, st, in, (const T *)nullptr,
+                         (const T *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
     else
-      hipLaunchKernelGGL((k_bn_partials<0, 1>), dim3(nparts), dim3(256), 0, st, in, (const float *)nullptr,
-                         (const float *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
+      hipLaunchKernelGGL((k_bn_partials<0, 1, T>), dim3(nparts), dim3(256), 0, st, in, (const T *)nullptr,
+                         (const T *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
   }
   hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
                      rows, planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps,
                      momentum, train, coef);
   int64_t total = rows * planes;
   if ((planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
-    hipLaunchKernelGGL(k_bn_fwd_apply, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, out,
+    hipLaunchKernelGGL((k_bn_fwd_apply<T>), dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, out,
                        total, planes, coef, leakiness);
   else
-    hipLaunchKernelGGL(k_bn_fwd_apply1, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, out, total,
+    hipLaunchKernelGGL((k_bn_fwd_apply1<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, out, total,
                        planes, coef, leakiness);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
 
-extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, const float *d_out,
-                                int64_t rows, int planes, const float *save_mean, const float *save_invstd,
-                                const float *weight, float *d_weight, float *d_bias, float leakiness,
-                                float *scratch, void *stream_) {
+template <typename T>
+static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int64_t rows, int planes,
+                         const float *save_mean, const float *save_invstd, const float *weight,
+                         float *d_weight, float *d_bias, float leakiness, float *scratch, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(rows >= 0 && planes > 0, "bad sizes");
   AABR_CHECK_ARG(save_mean && save_invstd && scratch, "null pointer");
@@ -282,20 +303,56 @@ extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, 
   const bool v4 = (planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)d_out) & 15) == 0;
   int nparts = bn_parts(rows, planes, v4 ? 4 : 1);
   if (v4)
-    hipLaunchKernelGGL((k_bn_partials<1, 4>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
+    hipLaunchKernelGGL((k_bn_partials<1, 4, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
                        leakiness, rows, planes, part);
   else
-    hipLaunchKernelGGL((k_bn_partials<1, 1>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
+    hipLaunchKernelGGL((k_bn_partials<1, 1, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
                        leakiness, rows, planes, part);
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
                      rows, planes, save_invstd, weight, d_weight, d_bias, coef);
   int64_t total = rows * planes;
   if (v4 && (((uintptr_t)d_in | (uintptr_t)save_mean) & 15) == 0)
-    hipLaunchKernelGGL(k_bn_bwd_apply4, dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, d_in, out,
+    hipLaunchKernelGGL((k_bn_bwd_apply4<T>), dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, d_in, out,
                        d_out, total, planes, save_mean, coef, leakiness);
   else
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, d_in, out,
+    hipLaunchKernelGGL((k_bn_bwd_apply<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, d_in, out,
                        d_out, total, planes, save_mean, coef, leakiness);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
+}
+
+extern "C" int aabr_bn_forward(const float *in, float *out, int64_t rows, int planes, float *save_mean,
+                               float *save_invstd, float *running_mean, float *running_var,
+                               const float *weight, const float *bias, float eps, float momentum, int train,
+                               float leakiness, float *scratch, void *stream_) {
+  return bn_forward_t<float>(in, out, rows, planes, save_mean, save_invstd, running_mean, running_var, weight,
+                             bias, eps, momentum, train, leakiness, scratch, stream_);
+}
+
+extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, const float *d_out,
+                                int64_t rows, int planes, const float *save_mean, const float *save_invstd,
+                                const float *weight, float *d_weight, float *d_bias, float leakiness,
+                                float *scratch, void *stream_) {
+  return bn_backward_t<float>(in, d_in, out, d_out, rows, planes, save_mean, save_invstd, weight, d_weight,
+                              d_bias, leakiness, scratch, stream_);
+}
+
+// bf16 feature storage (extension; statistics in fp64, affine maths in fp32, parameters fp32)
+extern "C" int aabr_bn_forward_bf16(const uint16_t *in, uint16_t *out, int64_t rows, int planes,
+                                    float *save_mean, float *save_invstd, float *running_mean,
+                                    float *running_var, const float *weight, const float *bias, float eps,
+                                    float momentum, int train, float leakiness, float *scratch, void *stream_) {
+  return bn_forward_t<__bf16>(reinterpret_cast<const __bf16 *>(in), reinterpret_cast<__bf16 *>(out), rows, planes,
+                              save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum,
+                              train, leakiness, scratch, stream_);
+}
+
+extern "C" int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out,
+                                     const uint16_t *d_out, int64_t rows, int planes, const float *save_mean,
+                                     const float *save_invstd, const float *weight, float *d_weight,
+                                     float *d_bias, float leakiness, float *scratch, void *stream_) {
+  return bn_backward_t<__bf16>(reinterpret_cast<const __bf16 *>(in), reinterpret_cast<__bf16 *>(d_in),
+                               reinterpret_cast<const __bf16 *>(out), reinterpret_cast<const __bf16 *>(d_out),
+                               rows, planes, save_mean, save_invstd, weight, d_weight, d_bias, leakiness,
+                               scratch, stream_);
 }

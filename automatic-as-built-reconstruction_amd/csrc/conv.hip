@@ -455,6 +455,182 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
   }
 }
 
+// ------------------------------------------------------------------ bf16 features (extension)
+// The reference is fp32-only (sparseconvnet_cuda.cpp instantiates <float>); BASELINE configs 3-5 ask
+// for bf16.  Features are stored bf16, weights stay fp32 master parameters and are packed to bf16
+// per call, accumulation is fp32 (v_mfma_f32_16x16x32_bf16: one instruction covers the 32-channel
+// chunk that takes eight fp32 MFMAs), the LDS output tile is fp32 and is rounded to bf16 once at
+// the final store.  Same tile-block streams, same determinism.  Requires ci % 32 == 0.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline float bf2f(__bf16 v) { return (float)v; }
+
+// Wp16[k][kc][nb][lane][j] = bf16(Wl[k][kc*32 + (lane>>4)*8 + j][nb*16 + (lane&15)])
+__global__ __launch_bounds__(256) void k_pack_weights_bf16(const float *__restrict__ W, int vol, int ci, int co,
+                                                           int transpose, __bf16 *__restrict__ Wp) {
+  const int nkc = nkc_of(ci), nnb = nnb_of(co);
+  int64_t total = (int64_t)vol * nkc * nnb * 512;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int s = idx & 7;
+  int lane = (idx >> 3) & 63;
+  int64_t r = idx >> 9;
+  int nb = (int)(r % nnb); r /= nnb;
+  int kc = (int)(r % nkc); r /= nkc;
+  int k = (int)r;
+  int c = kc * kKC + (lane >> 4) * 8 + s;
+  int n = nb * 16 + (lane & 15);
+  float v = 0.0f;
+  if (c < ci && n < co) v = transpose ? W[((int64_t)k * co + n) * ci + c] : W[((int64_t)k * ci + c) * co + n];
+  Wp[idx] = (__bf16)v;
+}
+
+// KG = channel chunks (of 32) gathered per work item; an item is (pair of blocks, chunk group).
+template <int NBW, int WPB, int KG>
+__global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_bf16(
+    const __bf16 *__restrict__ in, int ci, int64_t in_bytes, __bf16 *__restrict__ out, int co, int64_t V_out,
+    const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const __bf16 *__restrict__ Wp,
+    int64_t wp_bytes, const float *__restrict__ bias) {
+  constexpr int WS = NBW * 16;
+  constexpr int TILE = 64 * WS;
+  extern __shared__ __align__(16) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  float *Ct = smem + (size_t)wave * TILE;
+  const int maxb = tb_maxb(vol);
+  const int nnb = nnb_of(co), nkc = ci / kKC;
+  const int ngrp = (nkc + KG - 1) / KG;
+  const int nb0 = blockIdx.y * NBW;
+  const int64_t tile = blockIdx.x, row0 = tile * 64;
+  const int64_t ntiles = tb_ntiles(V_out);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(Wp), 0, (int)wp_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwords =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(words), 0, (int)words_bytes, 0x00020000);
+  const int nblk = words[tile];
+  const unsigned kbase = (unsigned)((ntiles + tile * maxb) * 4);
+  const unsigned ebase = (unsigned)((ntiles + ntiles * maxb + tile * maxb * 16) * 4);
+  const unsigned rowbytes = (unsigned)ci * 2u, g16 = (unsigned)g * 16u, lane16 = (unsigned)lane * 16u;
+  const unsigned wk_bytes = (unsigned)nkc * (unsigned)nnb * 1024u; // packed bytes per offset
+  const unsigned c16x4 = (unsigned)c16 * 4u;
+  const int nvalid = (nnb - nb0) < NBW ? (nnb - nb0) : NBW;
+
+  for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
+
+  const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
+  const int npairs = (nmine + 1) >> 1;
+  const int nitems = npairs * ngrp;
+  struct Item { int eA, eB, kA, kB, kc0; };
+  auto load_item = [&](int it) {
+    Item p;
+    const int pr = it / ngrp;
+    p.kc0 = (it - pr * ngrp) * KG;
+    int bA = wave + (2 * pr) * WPB;
+    if (bA >= nblk) bA = nblk > 0 ? nblk - 1 : 0;
+    int bB = bA + WPB;
+    const bool hasB = bB < nblk;
+    if (!hasB) bB = bA;
+    p.eA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bA * 64u, 0);
+    p.eB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bB * 64u, 0);
+    if (!hasB) p.eB |= (int)0x80000000;
+    p.kA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bA * 4u, 0);
+    p.kB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bB * 4u, 0);
+    return p;
+  };
+  // the KG channel chunks of an item are gathered together (KG x 2 x 16 B per lane in flight)
+  struct G16 { u32x4 a[KG], b[KG]; };
+  auto gather = [&](G16 &q, const Item &p) {
+    const unsigned va = (((unsigned)p.eA & 0x7fffffffu) >> 6) * rowbytes + g16;
+    const unsigned vb = (((unsigned)p.eB & 0x7fffffffu) >> 6) * rowbytes + g16;
+#pragma unroll
+    for (int t = 0; t < KG; ++t) {
+      if (p.kc0 + t < nkc) {
+        q.a[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, va, (unsigned)(p.kc0 + t) * 64u, 0);
+        q.b[t] = __builtin_amdgcn_raw_buffer_load_b128(rin, vb, (unsigned)(p.kc0 + t) * 64u, 0);
+      }
+    }
+  };
+  auto compute = [&](const G16 &q, const Item &p) {
+    int kA = __builtin_amdgcn_readfirstlane(p.kA), kB = __builtin_amdgcn_readfirstlane(p.kB);
+    if (wflip) { kA = vol - 1 - kA; kB = vol - 1 - kB; }
+    const unsigned soA0 = (unsigned)kA * wk_bytes + (unsigned)nb0 * 1024u;
+    const unsigned soB0 = (unsigned)kB * wk_bytes + (unsigned)nb0 * 1024u;
+    f32x4 accA[NBW], accB[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      accB[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < KG; ++t) {
+      if (p.kc0 + t < nkc) {
+        const unsigned so = (unsigned)(p.kc0 + t) * (unsigned)nnb * 1024u;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+          if (j < nvalid) {
+            const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, soA0 + so + j * 1024, 0);
+            const u32x4 wb = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, soB0 + so + j * 1024, 0);
+            accA[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa),
+                                                              __builtin_bit_cast(bf16x8, q.a[t]), accA[j], 0, 0, 0);
+            accB[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb),
+                                                              __builtin_bit_cast(bf16x8, q.b[t]), accB[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    conv_block_accumulate<NBW, WS>(Ct, p.eA, g, accA);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    conv_block_accumulate<NBW, WS>(Ct, p.eB, g, accB);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+  Item p0 = load_item(0), p1 = load_item(1), p2 = load_item(2);
+  G16 s0, s1;
+  if (nitems > 0) gather(s0, p0);
+  for (int it = 0; it < nitems; it += 2) {
+    if (it + 1 < nitems) gather(s1, p1);
+    compute(s0, p0);
+    Item p3 = load_item(it + 3);
+    if (it + 1 < nitems) {
+      if (it + 2 < nitems) gather(s0, p2);
+      compute(s1, p1);
+    }
+    Item p4 = load_item(it + 4);
+    p0 = p2; p1 = p3; p2 = p4;
+  }
+  __syncthreads();
+  // combine in wave order, add bias, round to bf16 once, write the tile
+  const int nrows = (int)((V_out - row0) < 64 ? (V_out - row0) : 64);
+  const int wcols = (co - nb0 * 16) < NBW * 16 ? (co - nb0 * 16) : NBW * 16;
+  if ((co & 3) == 0) {
+    const int q = wcols >> 2;
+    for (int i = threadIdx.x; i < nrows * q; i += WPB * 64) {
+      int r = i / q, cq = i % q;
+      float4 v = *reinterpret_cast<const float4 *>(smem + r * WS + cq * 4);
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) {
+        float4 u = *reinterpret_cast<const float4 *>(smem + (size_t)w * TILE + r * WS + cq * 4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      if (bias) {
+        const float *bb = bias + nb0 * 16 + cq * 4;
+        v.x += bb[0]; v.y += bb[1]; v.z += bb[2]; v.w += bb[3];
+      }
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      *reinterpret_cast<bf16x4 *>(out + (row0 + r) * co + nb0 * 16 + cq * 4) = o;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nrows * wcols; i += WPB * 64) {
+      int r = i / wcols, cc = i % wcols;
+      float v = smem[r * WS + cc];
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) v += smem[(size_t)w * TILE + r * WS + cc];
+      if (bias) v += bias[nb0 * 16 + cc];
+      out[(row0 + r) * co + nb0 * 16 + cc] = (__bf16)v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ compiled rule book, part 2
 // Offset-major compacted pairs (the reference's RuleBook layout: for offset k the (in, out)
 // pairs in ascending out order, Metadata.h:34) for the weight-gradient pass, whose reduction
@@ -529,9 +705,12 @@ __global__ __launch_bounds__(256) void k_fill_offset_pairs(const int32_t *__rest
 // reduction dimension.  Pair indices are loaded 64 at a time (coalesced) and handed to the lane
 // groups by shuffles; 16 pairs are gathered per step before their MFMAs issue.  The four waves'
 // accumulators are summed through LDS in wave order (deterministic).  CB x NB blocks of 16.
-template <int CB, int NB>
-__global__ __launch_bounds__(256) void k_conv_dw_pairs(const float *__restrict__ in, int ci,
-                                                       const float *__restrict__ d_out, int co, int64_t V,
+__device__ inline float ldf(const float *p, int64_t i) { return p[i]; }
+__device__ inline float ldf(const __bf16 *p, int64_t i) { return (float)p[i]; }
+
+template <int CB, int NB, typename T>
+__global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in, int ci,
+                                                       const T *__restrict__ d_out, int co, int64_t V,
                                                        const int32_t *__restrict__ words, int vol,
                                                        float *__restrict__ partial) {
   __shared__ f32x4 red[CB * NB][64];
@@ -578,12 +757,12 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs(const float *__restrict__
 #pragma unroll
         for (int a = 0; a < CB; ++a) {
           int c = (cb0 + a) * 16 + c16;
-          av[st][a] = (on && c < ci) ? in[(int64_t)tq * ci + c] : 0.0f;
+          av[st][a] = (on && c < ci) ? ldf(in, (int64_t)tq * ci + c) : 0.0f;
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           int n = (nb0 + b) * 16 + c16;
-          bv[st][b] = (on && n < co) ? d_out[(int64_t)oq * co + n] : 0.0f;
+          bv[st][b] = (on && n < co) ? ldf(d_out, (int64_t)oq * co + n) : 0.0f;
         }
       }
 #pragma unroll
@@ -644,13 +823,14 @@ __global__ __launch_bounds__(256) void k_conv_dw_reduce(const float *__restrict_
 
 // d_bias[n] = sum_rows d_out[row][n] (at::sum_out, CPU/Convolution.cpp:100-101); one block per
 // 64 columns, fixed-order tree => deterministic.
-__global__ __launch_bounds__(256) void k_col_sum(const float *__restrict__ x, int64_t rows, int co,
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_sum(const T *__restrict__ x, int64_t rows, int co,
                                                  float *__restrict__ out) {
   __shared__ float red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   float s = 0.0f;
   if (col < co)
-    for (int64_t r = part; r < rows; r += 4) s += x[r * co + col];
+    for (int64_t r = part; r < rows; r += 4) s += ldf(x, r * co + col);
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
   if (part == 0 && col < co)
@@ -795,9 +975,10 @@ extern "C" int64_t aabr_conv_dw_scratch_floats(int64_t max_chunks, int n_in, int
   return max_chunks * n_in * n_out;
 }
 
-extern "C" int aabr_conv_backward_weight(const float *in_feats, int n_in, const float *d_out, int n_out,
-                                         int64_t V_out, const int32_t *pairs, int vol, int64_t max_chunks,
-                                         float *dW, float *d_bias, float *scratch, void *stream_) {
+template <typename T>
+static int conv_backward_weight_t(const T *in_feats, int n_in, const T *d_out, int n_out, int64_t V_out,
+                                  const int32_t *pairs, int vol, int64_t max_chunks, float *dW, float *d_bias,
+                                  float *scratch, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && vol > 0 && V_out >= 0 && vol <= 65535, "bad sizes");
   AABR_CHECK_ARG(dW, "null dW");
@@ -813,7 +994,7 @@ extern "C" int aabr_conv_backward_weight(const float *in_feats, int n_in, const 
   AABR_CHECK_ARG(tiles <= 65535, "too many tiles");
   dim3 grid((unsigned)max_chunks, (unsigned)tiles);
 #define AABR_LAUNCH_DW(CB, NB)                                                                           \
-  hipLaunchKernelGGL((k_conv_dw_pairs<CB, NB>), grid, dim3(256), 0, st, in_feats, n_in, d_out, n_out,    \
+  hipLaunchKernelGGL((k_conv_dw_pairs<CB, NB, T>), grid, dim3(256), 0, st, in_feats, n_in, d_out, n_out, \
                      V_out, pairs, vol, scratch)
   if (cb == 1 && nb == 1) AABR_LAUNCH_DW(1, 1);
   else if (cb == 1 && nb == 2) AABR_LAUNCH_DW(1, 2);
@@ -828,8 +1009,99 @@ extern "C" int aabr_conv_backward_weight(const float *in_feats, int n_in, const 
   hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 256), (unsigned)vol), dim3(256), 0, st,
                      scratch, pairs, vol, cico, dW);
   if (d_bias)
-    hipLaunchKernelGGL(k_col_sum, dim3((unsigned)ceil_div(n_out, 64)), dim3(256), 0, st, d_out, V_out, n_out,
-                       d_bias);
+    hipLaunchKernelGGL((k_col_sum<T>), dim3((unsigned)ceil_div(n_out, 64)), dim3(256), 0, st, d_out, V_out,
+                       n_out, d_bias);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_conv_backward_weight(const float *in_feats, int n_in, const float *d_out, int n_out,
+                                         int64_t V_out, const int32_t *pairs, int vol, int64_t max_chunks,
+                                         float *dW, float *d_bias, float *scratch, void *stream_) {
+  return conv_backward_weight_t<float>(in_feats, n_in, d_out, n_out, V_out, pairs, vol, max_chunks, dW, d_bias,
+                                       scratch, stream_);
+}
+
+extern "C" int aabr_conv_backward_weight_bf16(const uint16_t *in_feats, int n_in, const uint16_t *d_out,
+                                              int n_out, int64_t V_out, const int32_t *pairs, int vol,
+                                              int64_t max_chunks, float *dW, float *d_bias, float *scratch,
+                                              void *stream_) {
+  return conv_backward_weight_t<__bf16>(reinterpret_cast<const __bf16 *>(in_feats), n_in,
+                                        reinterpret_cast<const __bf16 *>(d_out), n_out, V_out, pairs, vol,
+                                        max_chunks, dW, d_bias, scratch, stream_);
+}
+
+extern "C" int64_t aabr_conv_wpack_bf16_elems(int vol, int n_in, int n_out) {
+  return aabr_conv_wpack_floats(vol, n_in, n_out);
+}
+
+extern "C" int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
+                                      int n_out, int64_t V_out, const int32_t *blocks, int vol, const float *W,
+                                      const float *bias, int flags, uint16_t *wpack, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && vol > 0 && V_out >= 0 && rows_in >= 0, "bad sizes");
+  AABR_CHECK_ARG(n_in <= 4096 && n_out <= 4096, "plane count too large");
+  AABR_CHECK_ARG(n_in % kKC == 0 && n_out % kKC == 0, "bf16 features need plane counts divisible by 32");
+  if (V_out == 0) return AABR_OK;
+  AABR_CHECK_ARG(in_feats && out_feats && blocks && W && wpack && rows_in > 0, "null pointer / empty input");
+  AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 15) == 0 &&
+                     ((uintptr_t)wpack & 15) == 0,
+                 "feature / scratch pointers must be 16-byte aligned");
+  const int transpose = flags & 1, flip = (flags >> 1) & 1;
+  const int nkc = nkc_of(n_in), nnb = nnb_of(n_out);
+  const int64_t total = (int64_t)vol * nkc * nnb * 512;
+  const int64_t in_bytes = rows_in * n_in * 2, wp_bytes = total * 2,
+                words_bytes = aabr_tile_blocks_words(V_out, vol) * 4;
+  AABR_CHECK_ARG(in_bytes < (1ll << 31) && wp_bytes < (1ll << 31) && words_bytes < (1ll << 31),
+                 "bf16 convolution addresses its buffers with 32-bit offsets (each must be < 2 GiB)");
+  __bf16 *wp = reinterpret_cast<__bf16 *>(wpack);
+  if (!(flags & 4))
+    hipLaunchKernelGGL(k_pack_weights_bf16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, W, vol, n_in,
+                       n_out, transpose, wp);
+  const int nbw = nnb == 2 ? 2 : 4;
+  const int kg = nkc >= 3 ? 4 : nkc;
+  const int64_t wgs = ceil_div(V_out, 64) * ceil_div(nnb, nbw);
+  int best_wpb = 2;
+  int64_t best_cost = -1;
+  for (int wpb = 2; wpb <= (nbw == 4 ? 3 : 4); ++wpb) {
+    int64_t lds = (int64_t)wpb * 64 * (nbw * 16) * 4;
+    int64_t per_cu = (160 * 1024) / lds;
+    int64_t wave_cap = 16 / wpb;
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu < 1) per_cu = 1;
+    int64_t rounds = ceil_div(wgs, 256 * per_cu);
+    int64_t cost = rounds * ceil_div(vol, wpb);
+    if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_wpb = wpb; }
+  }
+  if (const char *ov = getenv("AABR_CONV_WPB")) { // tuning experiments only
+    int v = atoi(ov);
+    if (v >= 2 && v <= (nbw == 4 ? 3 : 4)) best_wpb = v;
+  }
+#define AABR_LAUNCH_CONV16(NBW, WPB, KG)                                                                 \
+  do {                                                                                                   \
+    size_t lds = (size_t)(WPB) * 64 * ((NBW)*16) * sizeof(float);                                        \
+    dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                            \
+    hipLaunchKernelGGL((k_conv_blocks_mfma_bf16<NBW, WPB, KG>), grid, dim3(64 * (WPB)), lds, st,         \
+                       reinterpret_cast<const __bf16 *>(in_feats), n_in, in_bytes,                       \
+                       reinterpret_cast<__bf16 *>(out_feats), n_out, V_out, blocks, words_bytes, vol,    \
+                       flip, wp, wp_bytes, bias);                                                        \
+  } while (0)
+#define AABR_LAUNCH_CONV16_KG(NBW, WPB)                                                                  \
+  do {                                                                                                   \
+    if (kg == 1) AABR_LAUNCH_CONV16(NBW, WPB, 1);                                                        \
+    else if (kg == 2) AABR_LAUNCH_CONV16(NBW, WPB, 2);                                                   \
+    else AABR_LAUNCH_CONV16(NBW, WPB, 4);                                                                \
+  } while (0)
+  if (nbw == 2) {
+    if (best_wpb == 2) AABR_LAUNCH_CONV16_KG(2, 2);
+    else if (best_wpb == 3) AABR_LAUNCH_CONV16_KG(2, 3);
+    else AABR_LAUNCH_CONV16_KG(2, 4);
+  } else {
+    if (best_wpb == 2) AABR_LAUNCH_CONV16_KG(4, 2);
+    else AABR_LAUNCH_CONV16_KG(4, 3);
+  }
+#undef AABR_LAUNCH_CONV16_KG
+#undef AABR_LAUNCH_CONV16
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

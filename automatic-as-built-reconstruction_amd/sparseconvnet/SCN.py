@@ -401,6 +401,20 @@ def _opt(t):
     return t if (t is not None and t.numel() > 0) else None
 
 
+def _featc(t, what):
+    """feature matrices of the convolution / batch-norm path: fp32 (the reference's precision) or
+    bf16 storage (extension, BASELINE configs 3-5; fp32 accumulation, fp32 parameters)"""
+    _hip.require_gpu(t)
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("%s must be float32 or bfloat16, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+def _same_dtype(a, b, what):
+    if a.dtype != b.dtype:
+        raise TypeError("%s: feature dtypes differ (%s vs %s)" % (what, a.dtype, b.dtype))
+
+
 def _f32c(t, what):
     _hip.require_gpu(t)
     if t.dtype != torch.float32:
@@ -458,7 +472,17 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags):
         n_out = w.size(3)
         assert w.size(2) == n_in, (w.shape, n_in)
     assert gather.rows == n_rows_out
+    _same_dtype(inp, out, "convolution")
     out.resize_(n_rows_out, n_out)
+    if w.dtype != torch.float32:
+        raise TypeError("convolution weights are fp32 master parameters, got %s" % w.dtype)
+    if inp.dtype == torch.bfloat16:
+        wpack = _hip.workspace("wpack16", lib.aabr_conv_wpack_bf16_elems(gather.vol, w.size(2), w.size(3)),
+                               torch.bfloat16, inp.device)
+        check(lib.aabr_conv_forward_bf16(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
+                                         ptr(gather.blocks()), gather.vol, ptr(w), ptr(_opt(bias)), flags,
+                                         ptr(wpack), stream()))
+        return n_out
     wpack = _hip.workspace("wpack", lib.aabr_conv_wpack_floats(gather.vol, w.size(2), w.size(3)), torch.float32,
                            inp.device)
     check(lib.aabr_conv_forward(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
@@ -474,8 +498,10 @@ def _conv_dw(inp, d_out, gather, d_weight, d_bias):
     pairs = gather.pairs()
     mc = gather.max_chunks()
     scratch = _hip.workspace("dw", lib.aabr_conv_dw_scratch_floats(mc, n_in, n_out), torch.float32, inp.device)
-    check(lib.aabr_conv_backward_weight(ptr(inp), n_in, ptr(d_out), n_out, V_out, ptr(pairs), gather.vol, mc,
-                                        ptr(d_weight), ptr(_opt(d_bias)), ptr(scratch), stream()))
+    _same_dtype(inp, d_out, "convolution backward")
+    fn = lib.aabr_conv_backward_weight_bf16 if inp.dtype == torch.bfloat16 else lib.aabr_conv_backward_weight
+    check(fn(ptr(inp), n_in, ptr(d_out), n_out, V_out, ptr(pairs), gather.vol, mc,
+             ptr(d_weight), ptr(_opt(d_bias)), ptr(scratch), stream()))
 
 
 def _macs(tb, weight):
@@ -487,7 +513,7 @@ def _macs(tb, weight):
 # SubmanifoldConvolution (pybind.cpp:134-143)
 def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, metadata, input_features, output_features,
                                         weight, bias):
-    inp = _f32c(input_features, "input_features")
+    inp = _featc(input_features, "input_features")
     tb = metadata.getSubmanifoldRuleBook(spatial_size, filter_size)
     _conv_fwd(inp, output_features, tb.V_out, tb.out, weight, bias, 0)
     return _macs(tb, weight)
@@ -495,8 +521,8 @@ def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, metadata, inp
 
 def SubmanifoldConvolution_backward(spatial_size, filter_size, metadata, input_features, d_input_features,
                                     d_output_features, weight, d_weight, d_bias):
-    inp = _f32c(input_features, "input_features")
-    d_out = _f32c(d_output_features, "d_output_features")
+    inp = _featc(input_features, "input_features")
+    d_out = _featc(d_output_features, "d_output_features")
     tb = metadata.getSubmanifoldRuleBook(spatial_size, filter_size)
     # d_in[u] = sum_k d_out[table[k'][u]] @ W[vol-1-k']^T  (flags: transpose | mirrored offset)
     _conv_fwd(d_out, d_input_features, tb.V_in, tb.out, weight, None, 1 | 2)
@@ -506,7 +532,7 @@ def SubmanifoldConvolution_backward(spatial_size, filter_size, metadata, input_f
 # Convolution (pybind.cpp:54-65)
 def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride, metadata, input_features,
                              output_features, weight, bias):
-    inp = _f32c(input_features, "input_features")
+    inp = _featc(input_features, "input_features")
     tb = metadata.getRuleBook(input_size, output_size, filter_size, filter_stride)
     _conv_fwd(inp, output_features, tb.V_out, tb.out, weight, bias, 0)
     return _macs(tb, weight)
@@ -514,8 +540,8 @@ def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride
 
 def Convolution_backward(input_size, output_size, filter_size, filter_stride, metadata, input_features,
                          d_input_features, d_output_features, weight, d_weight, d_bias):
-    inp = _f32c(input_features, "input_features")
-    d_out = _f32c(d_output_features, "d_output_features")
+    inp = _featc(input_features, "input_features")
+    d_out = _featc(d_output_features, "d_output_features")
     tb = metadata.getRuleBook(input_size, output_size, filter_size, filter_stride)
     _conv_fwd(d_out, d_input_features, tb.V_in, tb.inn, weight, None, 1)
     _conv_dw(inp, d_out, tb.out, d_weight, d_bias)
@@ -525,7 +551,7 @@ def Convolution_backward(input_size, output_size, filter_size, filter_stride, me
 # the columns swapped (CPU/Deconvolution.cpp:15-16,34-37)
 def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stride, metadata, input_features,
                                output_features, weight, bias):
-    inp = _f32c(input_features, "input_features")
+    inp = _featc(input_features, "input_features")
     tb = metadata.getRuleBook(output_size, input_size, filter_size, filter_stride)
     _conv_fwd(inp, output_features, tb.V_in, tb.inn, weight, bias, 0)
     return _macs(tb, weight)
@@ -533,8 +559,8 @@ def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stri
 
 def Deconvolution_backward(input_size, output_size, filter_size, filter_stride, metadata, input_features,
                            d_input_features, d_output_features, weight, d_weight, d_bias):
-    inp = _f32c(input_features, "input_features")
-    d_out = _f32c(d_output_features, "d_output_features")
+    inp = _featc(input_features, "input_features")
+    d_out = _featc(d_output_features, "d_output_features")
     tb = metadata.getRuleBook(output_size, input_size, filter_size, filter_stride)
     _conv_fwd(d_out, d_input_features, tb.V_out, tb.out, weight, None, 1)
     _conv_dw(inp, d_out, tb.inn, d_weight, d_bias)
@@ -545,14 +571,16 @@ def Deconvolution_backward(input_size, output_size, filter_size, filter_stride, 
 # ------------------------------------------------------------------------------------------------
 def BatchNormalization_updateOutput(input_features, output_features, saveMean, saveInvStd, runningMean,
                                     runningVar, weight, bias, eps, momentum, train, leakiness):
-    inp = _f32c(input_features, "input_features")
+    inp = _featc(input_features, "input_features")
     lib = _hip.load()
     output_features.resize_as_(inp)
     if inp.dim() != 2:
         return
     rows, planes = inp.shape
     scratch = _hip.workspace("bn", lib.aabr_bn_scratch_floats(planes), torch.float32, inp.device)
-    check(lib.aabr_bn_forward(ptr(inp), ptr(output_features), rows, planes, ptr(saveMean), ptr(saveInvStd),
+    _same_dtype(inp, output_features, "BatchNormalization")
+    fn = lib.aabr_bn_forward_bf16 if inp.dtype == torch.bfloat16 else lib.aabr_bn_forward
+    check(fn(ptr(inp), ptr(output_features), rows, planes, ptr(saveMean), ptr(saveInvStd),
                               ptr(runningMean), ptr(runningVar), ptr(_opt(weight)), ptr(_opt(bias)), float(eps),
                               float(momentum), int(bool(train)), float(leakiness), ptr(scratch), stream()))
 
@@ -562,15 +590,18 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     """NB: the reference overwrites d_output_features in place with the activation-masked
     gradient (CPU/BatchNormalization.cpp:79-82); nothing downstream reads it, so this
     implementation leaves it untouched (one HBM write pass saved)."""
-    inp = _f32c(input_features, "input_features")
-    d_out = _f32c(d_output_features, "d_output_features")
+    inp = _featc(input_features, "input_features")
+    d_out = _featc(d_output_features, "d_output_features")
     lib = _hip.load()
     d_input_features.resize_as_(inp)
     if inp.dim() != 2:
         return
     rows, planes = inp.shape
     scratch = _hip.workspace("bn", lib.aabr_bn_scratch_floats(planes), torch.float32, inp.device)
-    check(lib.aabr_bn_backward(ptr(inp), ptr(d_input_features), ptr(output_features.contiguous()), ptr(d_out),
+    _same_dtype(inp, d_out, "BatchNormalization backward")
+    _same_dtype(inp, output_features, "BatchNormalization backward")
+    fn = lib.aabr_bn_backward_bf16 if inp.dtype == torch.bfloat16 else lib.aabr_bn_backward
+    check(fn(ptr(inp), ptr(d_input_features), ptr(output_features.contiguous()), ptr(d_out),
                                rows, planes, ptr(saveMean), ptr(saveInvStd), ptr(_opt(weight)),
                                ptr(_opt(d_weight)), ptr(_opt(d_bias)), float(leakiness), ptr(scratch), stream()))
 

@@ -79,8 +79,9 @@ class BatchNormalizationFunction(Function):
         ctx.train = train
         ctx.leakiness = leakiness
         output_features = input_features.new()
-        saveMean = input_features.new().resize_(ctx.nPlanes)
-        saveInvStd = input_features.new().resize_(ctx.nPlanes)
+        # statistics are fp32 whatever the feature storage type is
+        saveMean = torch.empty(ctx.nPlanes, dtype=torch.float32, device=input_features.device)
+        saveInvStd = torch.empty(ctx.nPlanes, dtype=torch.float32, device=input_features.device)
         SCN.BatchNormalization_updateOutput(input_features, output_features, saveMean, saveInvStd, running_mean,
                                             running_var, weight, bias, eps, momentum, ctx.train, ctx.leakiness)
         ctx.save_for_backward(input_features, output_features, weight, bias, running_mean, running_var, saveMean,

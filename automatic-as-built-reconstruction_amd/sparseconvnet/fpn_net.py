@@ -16,8 +16,14 @@ import sparseconvnet as scn
 class FPN_Net(torch.nn.Module):
     def __init__(self, full_scale, dimension, raw_elements, reps, nPlanesF, nPlaneM, residual_blocks,
                  fpn_scales_from_top, roi_scales_from_top, downsample, rpn_map_sizes, rpn_3d_2d_selector,
-                 leakiness=0, voxel_scale=None, bn_momentum=0.9, track_running_stats=True):
+                 leakiness=0, voxel_scale=None, bn_momentum=0.9, track_running_stats=True,
+                 feature_dtype=torch.float32):
+        """`feature_dtype` (extension, not in the reference): torch.bfloat16 stores every feature
+        matrix after the first (raw_elements -> nPlanesF[0]) convolution in bf16; parameters, batch-norm
+        statistics and all accumulation stay fp32, the returned maps are cast back to fp32."""
         nn.Module.__init__(self)
+        assert feature_dtype in (torch.float32, torch.bfloat16)
+        self.feature_dtype = feature_dtype
         self.bn_momentum = bn_momentum
         self.track_running_stats = track_running_stats
         self.dimension = dimension
@@ -112,9 +118,22 @@ class FPN_Net(torch.nn.Module):
         self.operations_down = operations_down
         self.operations_up = operations_up
 
+    @staticmethod
+    def _cast(net, dtype):
+        if net.features.dtype == dtype:
+            return net
+        out = scn.SparseConvNetTensor()
+        out.metadata = net.metadata
+        out.spatial_size = net.spatial_size
+        out.features = net.features.to(dtype)
+        return out
+
     def forward(self, net0):
         net1 = self.layers_in(net0)
-        return self.forward_fpn(net1)
+        if self.feature_dtype == torch.float32:
+            return self.forward_fpn(net1)
+        rpn_maps, roi_maps = self.forward_fpn(self._cast(net1, self.feature_dtype))
+        return ([self._cast(m, torch.float32) for m in rpn_maps], [self._cast(m, torch.float32) for m in roi_maps])
 
     def forward_fpn(self, net):
         scales_num = len(self.m_downs)

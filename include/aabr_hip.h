@@ -185,6 +185,31 @@ int aabr_bn_backward(const float *in, float *d_in, const float *out, const float
                      const float *weight, float *d_weight, float *d_bias, float leakiness,
                      float *scratch, void *stream);
 
+/* ---- bf16 feature storage (extension; BASELINE.json configs 3-5) ------------------------------
+ * The reference instantiates its operators for float only (SCN/sparseconvnet_cuda.cpp:281-310).
+ * These variants keep the SAME rule-book formats, fp32 parameters (W, bias, batch-norm affine and
+ * statistics) and fp32/fp64 accumulation; only the [rows, planes] feature matrices (and their
+ * gradients) are bfloat16, passed as uint16_t bit patterns.  Convolution: nIn % 32 == 0 and
+ * nOut % 32 == 0 (v_mfma_f32_16x16x32_bf16 consumes one 32-plane chunk per instruction), every
+ * buffer < 2 GiB; flags bits 0-2 as aabr_conv_forward; wpack = uint16
+ * [aabr_conv_wpack_bf16_elems(vol,nIn,nOut)].  dW / d_bias stay fp32.                           */
+int64_t aabr_conv_wpack_bf16_elems(int vol, int n_in, int n_out);
+int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
+                           int n_out, int64_t V_out, const int32_t *blocks, int vol, const float *W,
+                           const float *bias, int flags, uint16_t *wpack, void *stream);
+int aabr_conv_backward_weight_bf16(const uint16_t *in_feats, int n_in, const uint16_t *d_out,
+                                   int n_out, int64_t V_out, const int32_t *pairs, int vol,
+                                   int64_t max_chunks, float *dW, float *d_bias, float *scratch,
+                                   void *stream);
+int aabr_bn_forward_bf16(const uint16_t *in, uint16_t *out, int64_t rows, int planes,
+                         float *save_mean, float *save_invstd, float *running_mean,
+                         float *running_var, const float *weight, const float *bias, float eps,
+                         float momentum, int train, float leakiness, float *scratch, void *stream);
+int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out,
+                          const uint16_t *d_out, int64_t rows, int planes, const float *save_mean,
+                          const float *save_invstd, const float *weight, float *d_weight,
+                          float *d_bias, float leakiness, float *scratch, void *stream);
+
 /* ---- rotated IoU / NMS ---------------------------------------------------------------------
  * iou[n,k] = devRotateIoUEval(query k, box n, criterion), then forced to 1 where the five
  * parameters differ by < 1e-6 -- rotate_iou_gpu_eval + check_same_boxes

@@ -74,13 +74,13 @@ def test_operator_surface_matches_reference_names():
     from utils3d.rotate_nms_3d_torch import boxes_iou_3d, iou_one_dim  # noqa: F401
 
 
-def default_fpn():
+def default_fpn(**extra):
     import sparseconvnet as scn
     return scn.FPN_Net([4096, 4096, 512], 3, ["xyz", "color", "normal"], 1,
                        [32, 64, 64, 128, 128, 128, 256, 256, 256], 128, True, [4, 3, 2, 1], [4, 3, 2, 1],
                        [[[2, 2, 2]] * 8, [[2, 2, 2]] * 8],
                        [[256, 256, 32], [128, 128, 16], [64, 64, 8], [32, 32, 4]], [1, 2, 3, 4, 5, 6], leakiness=0,
-                       voxel_scale=20, bn_momentum=0.95)
+                       voxel_scale=20, bn_momentum=0.95, **extra)
 
 
 def test_fpn_net_inventory_matches_reference_probe():

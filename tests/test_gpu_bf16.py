@@ -1,0 +1,206 @@
+"""bf16 feature storage (extension; BASELINE.json configs 3-5) against the fp32 oracle.
+
+The reference has no bf16 path (SCN/sparseconvnet_cuda.cpp:281-310 instantiates <float>), so
+the yardstick is the oracle evaluated on the SAME bf16-rounded operands: products of two bf16
+values are exact in fp32, accumulation is fp32 on the device / double in the oracle, so the only
+expected difference is the single final rounding of each stored feature to bf16 (2^-8 relative).
+Tolerances below are written from that model."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import synth_scenes as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+BF16_EPS = 2.0 ** -8  # half an ulp of an 8-bit significand, relative
+
+
+def _scn():
+    import sparseconvnet as scn
+    return scn
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def _bf(a):
+    """round an fp32 numpy array to bf16 (RNE) and return it as fp32"""
+    return torch.as_tensor(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _rand_scene(rng, n, size, batch, C):
+    coords = np.stack([rng.integers(0, s, n) for s in size] + [np.sort(rng.integers(0, batch, n))], 1)
+    return coords.astype(np.int64), rng.standard_normal((n, C)).astype(np.float32)
+
+
+def _bf16_input(scn, coords, feats, spatial):
+    """fp32 InputLayer (mode 4), then a bf16 leaf holding the rounded site features"""
+    x = scn.InputLayer(3, list(spatial), mode=4)([_t(coords), _t(feats)])
+    leaf = x.features.detach().to(torch.bfloat16).requires_grad_(True)
+    xb = scn.SparseConvNetTensor()
+    xb.metadata, xb.spatial_size, xb.features = x.metadata, x.spatial_size, leaf
+    return xb, leaf
+
+
+def _assert_bf16_close(got, ref, what):
+    got = got.detach().to(torch.float32).cpu().numpy()
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref)
+    bound = 1.02 * BF16_EPS * np.abs(ref) + 2e-5 * scale  # final rounding + fp32-vs-double accumulation
+    bad = err > bound
+    assert not bad.any(), "%s: %d of %d outside the bf16 rounding bound (max err %.3e, scale %.3e)" % (
+        what, bad.sum(), bad.size, err.max(), scale)
+
+
+@pytest.mark.parametrize("nIn,nOut", [(32, 32), (32, 64), (64, 64), (96, 64), (64, 128), (128, 128), (160, 96),
+                                      (256, 128), (128, 256)])
+def test_submanifold_conv_bf16_forward_backward(nIn, nOut):
+    scn = _scn()
+    rng = np.random.default_rng(nIn * 7 + nOut)
+    coords, feats = _rand_scene(rng, 2500, (14, 12, 6), 2, nIn)
+    x, leaf = _bf16_input(scn, coords, feats, (16, 16, 8))
+    conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, nIn == 64).to(DEV)
+    if nIn == 64:
+        conv.bias.data.normal_()
+    y = conv(x)
+    assert y.features.dtype == torch.bfloat16
+    il = O.input_layer(coords, feats, 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    xin = _bf(il["out"])
+    np.testing.assert_array_equal(leaf.detach().float().cpu().numpy(), xin)
+    W = conv.weight.detach().cpu().numpy().reshape(27, nIn, nOut)
+    Wb = _bf(W)
+    bias = conv.bias.detach().cpu().numpy() if nIn == 64 else None
+    ref, _ = O.conv_fwd(xin, Wb, rb, il["V"], bias)
+    _assert_bf16_close(y.features, ref, "forward")
+    g = _bf(rng.standard_normal(ref.shape).astype(np.float32))
+    y.features.backward(_t(g).to(torch.bfloat16))
+    d_in, dW, db = O.conv_bwd(xin, g, Wb, rb, want_bias=bias is not None)
+    assert leaf.grad.dtype == torch.bfloat16 and conv.weight.grad.dtype == torch.float32
+    _assert_bf16_close(leaf.grad, d_in, "d_input")
+    # dW: bf16 operands, exact products, fp32 accumulation, fp32 result
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(27, nIn, nOut), dW, rtol=1e-4,
+                               atol=1e-5 * np.abs(dW).max())
+    if bias is not None:
+        np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), db, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("fs,st,nIn,nOut", [([2, 2, 2], [2, 2, 2], 32, 64), ([2, 2, 2], [2, 2, 2], 64, 64),
+                                            ([1, 1, 8], [1, 1, 1], 128, 128)])
+def test_strided_conv_and_deconv_bf16(fs, st, nIn, nOut):
+    scn = _scn()
+    rng = np.random.default_rng(140 + nIn)
+    size = np.array([16, 16, 8])
+    coords, feats = _rand_scene(rng, 2500, tuple(size), 2, nIn)
+    x, leaf = _bf16_input(scn, coords, feats, tuple(size))
+    conv = scn.Convolution(3, nIn, nOut, fs, st, False).to(DEV)
+    dec = scn.Deconvolution(3, nOut, nIn, fs, st, False).to(DEV)
+    y = conv(x)
+    z = dec(y)
+    il = O.input_layer(coords, feats, 4)
+    osz = (size - np.array(fs)) // np.array(st) + 1
+    rb, oc = O.convolution_rules(il["coords"], fs, st, osz)
+    xin = _bf(il["out"])
+    Wc = _bf(conv.weight.detach().cpu().numpy().reshape(rb.vol, nIn, nOut))
+    Wd = _bf(dec.weight.detach().cpu().numpy().reshape(rb.vol, nOut, nIn))
+    yr, _ = O.conv_fwd(xin, Wc, rb, oc.shape[0])
+    _assert_bf16_close(y.features, yr, "strided forward")
+    # continue the oracle from the device's stored (rounded) intermediate
+    yd = y.features.detach().float().cpu().numpy()
+    zr, _ = O.conv_fwd(yd, Wd, rb, il["V"], in_col=1)
+    _assert_bf16_close(z.features, zr, "transposed forward")
+    g = _bf(rng.standard_normal(zr.shape).astype(np.float32))
+    d_y_holder = []
+    y.features.register_hook(lambda gr: d_y_holder.append(gr.detach().float().cpu().numpy()))
+    z.features.backward(_t(g).to(torch.bfloat16))
+    d_y, dWd, _ = O.conv_bwd(yd, g, Wd, rb, in_col=1)
+    _assert_bf16_close(torch.as_tensor(d_y_holder[0]), d_y, "d_y")
+    d_x, dWc, _ = O.conv_bwd(xin, d_y_holder[0], Wc, rb)
+    _assert_bf16_close(leaf.grad, d_x, "d_x")
+    np.testing.assert_allclose(dec.weight.grad.cpu().numpy().reshape(Wd.shape), dWd, rtol=1e-4,
+                               atol=1e-5 * np.abs(dWd).max())
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(Wc.shape), dWc, rtol=1e-4,
+                               atol=1e-5 * np.abs(dWc).max())
+
+
+@pytest.mark.parametrize("planes,leak", [(32, 0.0), (64, 0.333), (256, 0.0), (10, 0.1)])
+def test_batchnorm_bf16_forward_backward(planes, leak):
+    scn = _scn()
+    rng = np.random.default_rng(250 + planes)
+    coords, feats = _rand_scene(rng, 6000, (24, 24, 8), 2, planes)
+    feats = (feats * 1.7 + 0.4).astype(np.float32)
+    x, leaf = _bf16_input(scn, coords, feats, (32, 32, 8))
+    bn = scn.BatchNormLeakyReLU(planes, momentum=0.95, leakiness=leak).to(DEV)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_()
+    w, b = bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy()
+    y = bn(x)
+    assert y.features.dtype == torch.bfloat16
+    il = O.input_layer(coords, feats, 4)
+    xin = _bf(il["out"])
+    out, sm, si, rm, rv = O.bn_fwd(xin, w, b, np.zeros(planes), np.ones(planes), 1e-4, 0.95, True, leak)
+    yd = y.features.detach().float().cpu().numpy()
+    # statistics: fp64 partials on the device vs sequential fp32 in the oracle; then one bf16 rounding
+    np.testing.assert_allclose(yd, out, rtol=1.1 * BF16_EPS + 1e-3, atol=3e-4)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), rm, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), rv, rtol=1e-3)
+    g = _bf(rng.standard_normal(out.shape).astype(np.float32))
+    y.features.backward(_t(g).to(torch.bfloat16))
+    d_in, dw, db, _ = O.bn_bwd(xin, yd, g, sm, si, w, leak)  # masks from the device's stored output
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), dw, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), db, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(leaf.grad.float().cpu().numpy(), d_in, rtol=1.1 * BF16_EPS + 2e-3, atol=6e-4)
+
+
+def test_bf16_rejects_unaligned_planes_and_mixed_dtypes():
+    scn = _scn()
+    from _hip import AabrError
+    rng = np.random.default_rng(5)
+    coords, feats = _rand_scene(rng, 500, (8, 8, 8), 1, 16)
+    x, _ = _bf16_input(scn, coords, feats, (8, 8, 8))
+    conv = scn.SubmanifoldConvolution(3, 16, 32, 3, False).to(DEV)
+    with pytest.raises(AabrError, match="divisible by 32"):
+        conv(x)
+
+
+def test_fpn_net_bf16_tracks_fp32():
+    """whole backbone, S3DIS-like scene: bf16 feature storage vs the fp32 run of the same weights"""
+    from test_cabi_and_host import default_fpn
+    scn = _scn()
+    torch.manual_seed(0)
+    locs, feats = S.make_batch(1, 20000, 11, 20)
+    net32 = default_fpn().to(DEV)
+    net16 = default_fpn(feature_dtype=torch.bfloat16).to(DEV)
+    net16.load_state_dict(net32.state_dict())
+
+    def run(net):
+        net.zero_grad()
+        rpn, roi = net([_t(locs), _t(feats)])
+        loss = sum((m.features.float() ** 2).mean() for m in rpn)
+        loss.backward()
+        return [m.features.detach().float() for m in rpn], loss.item()
+
+    m32, l32 = run(net32)
+    m16, l16 = run(net16)
+    for a, b in zip(m32, m16):
+        assert a.shape == b.shape and b.dtype == torch.float32
+        rel = ((a - b).norm() / a.norm()).item()
+        assert rel < 5e-2, rel
+    assert abs(l16 - l32) < 5e-2 * abs(l32)
+    # gradients of every parameter the loss reaches point the same way
+    cos = []
+    for (n, p), q in zip(net32.named_parameters(), net16.parameters()):
+        if p.grad is None:
+            assert q.grad is None, n
+            continue
+        assert q.grad.dtype == torch.float32
+        c = torch.nn.functional.cosine_similarity(p.grad.flatten(), q.grad.flatten(), dim=0).item()
+        cos.append((c, n))
+    # the coarsest scales hold a handful of sites (batch-norm over < 20 rows amplifies any perturbation),
+    # so the bound is on the distribution, not on the single worst tensor
+    vals = np.sort(np.array([c for c, _ in cos]))
+    assert np.median(vals) > 0.99 and vals[len(vals) // 10] > 0.93 and vals[0] > 0.7, sorted(cos)[:8]

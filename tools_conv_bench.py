@@ -57,3 +57,33 @@ for ci, co in ((32, 32), (64, 64), (128, 128), (256, 256), (32, 128), (128, 32))
     fl = 2.0 * R * ci * co
     print("%3d->%3d  fwd %8.1f us %6.2f TFLOP/s (%.1f%% fp32 MFMA peak) | dW %8.1f us %6.2f TFLOP/s" % (
         ci, co, t * 1e6, fl / t / 1e12, fl / t / 1e12 / 157.3 * 100, t2 * 1e6, fl / t2 / 1e12))
+
+print("bf16 feature storage (v_mfma_f32_16x16x32_bf16, dense bf16 MFMA peak 2516 TFLOP/s):")
+for ci, co in ((32, 32), (64, 64), (128, 128), (256, 256), (32, 128), (128, 32)):
+    inp = torch.randn(V, ci, device=dev).to(torch.bfloat16)
+    out = torch.empty(V, co, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(27, ci, co, device=dev)
+    wpack = torch.empty(lib.aabr_conv_wpack_bf16_elems(27, ci, co), device=dev, dtype=torch.bfloat16)
+    check(lib.aabr_conv_forward_bf16(ptr(inp), ci, V, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 0, ptr(wpack), stream()))
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    a.record()
+    for _ in range(n):
+        check(lib.aabr_conv_forward_bf16(ptr(inp), ci, V, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 4, ptr(wpack), stream()))
+    b.record(); torch.cuda.synchronize()
+    t = a.elapsed_time(b) / n * 1e-3
+    dW = torch.empty_like(w)
+    scratch = torch.empty(lib.aabr_conv_dw_scratch_floats(mc, ci, co), device=dev)
+    dout = torch.randn(V, co, device=dev).to(torch.bfloat16)
+    check(lib.aabr_conv_backward_weight_bf16(ptr(inp), ci, ptr(dout), co, V, ptr(pairs), 27, mc, ptr(dW), None, ptr(scratch), stream()))
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(n):
+        check(lib.aabr_conv_backward_weight_bf16(ptr(inp), ci, ptr(dout), co, V, ptr(pairs), 27, mc, ptr(dW), None, ptr(scratch), stream()))
+    b.record(); torch.cuda.synchronize()
+    t2 = a.elapsed_time(b) / n * 1e-3
+    fl = 2.0 * R * ci * co
+    gb = (R * ci * 2 + V * co * 2) / 1e9  # algorithmic bytes: one gathered row per rule + the output
+    print("%3d->%3d  fwd %8.1f us %7.2f TFLOP/s (%.1f%% bf16 MFMA peak, %.0f GB/s gathered) | dW %8.1f us %6.2f TFLOP/s" % (
+        ci, co, t * 1e6, fl / t / 1e12, fl / t / 1e12 / 2516 * 100, gb / t, t2 * 1e6, fl / t2 / 1e12))
