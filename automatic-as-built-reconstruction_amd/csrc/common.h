@@ -23,6 +23,15 @@ void set_error(const char *fmt, ...);
     }                                                                         \
   } while (0)
 
+#define AABR_CHECK_HIP(call)                                                  \
+  do {                                                                        \
+    hipError_t e__ = (call);                                                  \
+    if (e__ != hipSuccess) {                                                  \
+      aabr::set_error("%s: HIP error %s", __func__, hipGetErrorString(e__));  \
+      return AABR_ELAUNCH;                                                    \
+    }                                                                         \
+  } while (0)
+
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kMaxCoord = 65534;
 

@@ -455,6 +455,444 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
   }
 }
 
+// packed weights of JG column blocks for the two blocks (A, B) of a step: JG x 4 x 16 B per lane
+template <int JG> struct WSet { u32x4 a0[JG], a1[JG], b0[JG], b1[JG]; };
+
+template <int JG>
+__device__ inline void conv_load_w(WSet<JG> &w, __amdgpu_buffer_rsrc_t rw, unsigned lane32, unsigned soA,
+                                   unsigned soB, int nvalid) {
+#pragma unroll
+  for (int j = 0; j < JG; ++j) {
+    if (j < nvalid) { // last column slab may hold fewer blocks (wave-uniform)
+      w.a0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soA + j * 2048, 0);
+      w.a1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soA + j * 2048, 0);
+      w.b0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soB + j * 2048, 0);
+      w.b1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soB + j * 2048, 0);
+    }
+  }
+}
+
+template <int JG>
+__device__ inline void conv_step_mfma_w(const GStep &q, const WSet<JG> &w, int nvalid, f32x4 *accA, f32x4 *accB) {
+#pragma unroll
+  for (int j = 0; j < JG; ++j) {
+    if (j < nvalid) {
+      f32x4 ca = accA[j], cb = accB[j];
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.a0[j][0]), bcf(q.a0[0]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.b0[j][0]), bcf(q.b0[0]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.a0[j][1]), bcf(q.a0[1]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.b0[j][1]), bcf(q.b0[1]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.a0[j][2]), bcf(q.a0[2]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.b0[j][2]), bcf(q.b0[2]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.a0[j][3]), bcf(q.a0[3]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.b0[j][3]), bcf(q.b0[3]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.a1[j][0]), bcf(q.a1[0]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.b1[j][0]), bcf(q.b1[0]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.a1[j][1]), bcf(q.a1[1]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.b1[j][1]), bcf(q.b1[1]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.a1[j][2]), bcf(q.a1[2]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.b1[j][2]), bcf(q.b1[2]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.a1[j][3]), bcf(q.a1[3]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w.b1[j][3]), bcf(q.b1[3]), cb, 0, 0, 0);
+      accA[j] = ca; accB[j] = cb;
+    }
+  }
+}
+
+// weights streamed right before their MFMAs, one column block at a time (16 VGPRs live)
+template <int NBW>
+__device__ inline void conv_step_mfma_stream(const GStep &q, __amdgpu_buffer_rsrc_t rw, unsigned lane32,
+                                             unsigned soA, unsigned soB, int nvalid, f32x4 *accA, f32x4 *accB) {
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    if (j >= nvalid) break; // last column slab may hold fewer than NBW blocks (wave-uniform)
+    WSet<1> w;
+    conv_load_w<1>(w, rw, lane32, soA + j * 2048, soB + j * 2048, 1);
+    conv_step_mfma_w<1>(q, w, 1, accA + j, accB + j);
+  }
+}
+
+// Three register-resident prefetch streams per wave: block entries two pairs ahead, gathered rows one
+// step ahead, packed weights one micro-step (JG column blocks) ahead -- no load is waited on in the
+// step that issues it.
+// WPIPE: prefetch the packed weights one micro-step ahead (pays for wide slabs, NBW = 4; with narrow
+// slabs the extra 32-64 VGPRs cost a wave of occupancy and the step is too short to need it).
+template <int NBW, int WPB, bool WPIPE>
+__global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_wpipe(
+    const float *__restrict__ in, int ci, int64_t in_bytes, float *__restrict__ out, int co, int64_t V_out,
+    const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const float *__restrict__ Wp,
+    int64_t wp_bytes, const float *__restrict__ bias) {
+  constexpr int WS = NBW * 16;              // C-tile row stride (floats)
+  constexpr int TILE = 64 * WS;             // floats per wave
+  constexpr int JG = NBW >= 2 ? 2 : 1;      // column blocks per weight set
+  constexpr int NJG = NBW / JG;             // weight sets (micro-steps) per step
+  extern __shared__ __align__(16) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  float *Ct = smem + (size_t)wave * TILE;
+  const int maxb = tb_maxb(vol);
+  const int nkc = ci >> 5, nnb = nnb_of(co);
+  const int nb0 = blockIdx.y * NBW;
+  const int64_t tile = blockIdx.x, row0 = tile * 64;
+  const int64_t ntiles = tb_ntiles(V_out);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, (int)wp_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwords =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(words), 0, (int)words_bytes, 0x00020000);
+  const int nblk = words[tile];
+  const unsigned kbase = (unsigned)((ntiles + tile * maxb) * 4);                       // byte offset of blk_k
+  const unsigned ebase = (unsigned)((ntiles + ntiles * maxb + tile * maxb * 16) * 4);  // byte offset of ent
+  const unsigned rowbytes = (unsigned)ci * 4u, g32 = (unsigned)g * 32u, lane32 = (unsigned)lane * 32u;
+  const unsigned wk_bytes = (unsigned)nkc * (unsigned)nnb * 2048u;                     // packed bytes per offset
+  const unsigned kc_bytes = (unsigned)nnb * 2048u;                                     // packed bytes per chunk
+  const unsigned c16x4 = (unsigned)c16 * 4u;
+  const int nvalid = (nnb - nb0) < NBW ? (nnb - nb0) : NBW;
+
+  for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
+
+  const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
+  const int npairs = (nmine + 1) >> 1;
+  auto load_pair = [&](int pr) {
+    PairEnt p;
+    int bA = wave + (2 * pr) * WPB;
+    if (bA >= nblk) bA = nblk > 0 ? nblk - 1 : 0;      // past the end: harmless re-read, never consumed
+    int bB = bA + WPB;
+    const bool hasB = bB < nblk;
+    if (!hasB) bB = bA;
+    p.eA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bA * 64u, 0);
+    p.eB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bB * 64u, 0);
+    if (!hasB) p.eB |= (int)0x80000000;
+    p.kA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bA * 4u, 0);
+    p.kB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bB * 4u, 0);
+    return p;
+  };
+  auto gather = [&](GStep &q, const PairEnt &p, int kc) {
+    const unsigned va = (((unsigned)p.eA & 0x7fffffffu) >> 6) * rowbytes + g32;
+    const unsigned vb = (((unsigned)p.eB & 0x7fffffffu) >> 6) * rowbytes + g32;
+    const unsigned so = (unsigned)kc * 128u;
+    q.a0 = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
+    q.a1 = __builtin_amdgcn_raw_buffer_load_b128(rin, va + 16u, so, 0);
+    q.b0 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb, so, 0);
+    q.b1 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb + 16u, so, 0);
+  };
+  // byte offsets (wave-uniform) of a pair's packed weights for this column slab
+  auto w_base = [&](int k) {
+    if (wflip) k = vol - 1 - k;
+    return (unsigned)k * wk_bytes + (unsigned)nb0 * 2048u;
+  };
+  // block entries run three pairs ahead: a pair's offsets (wave-uniform, needed one step early for the
+  // weight prefetch) have been in flight for two pairs when they are first read, so waiting for them
+  // does not drain the younger gathers behind them in the in-order VMEM queue
+  PairEnt p0 = load_pair(0), p1 = load_pair(1), p2 = load_pair(2), p3 = load_pair(3);
+  GStep s0, s1;
+  WSet<JG> w0, w1;
+  f32x4 accA[NBW], accB[NBW];
+  unsigned soA = w_base(__builtin_amdgcn_readfirstlane(p0.kA)), soB = w_base(__builtin_amdgcn_readfirstlane(p0.kB));
+  unsigned soA1 = 0, soB1 = 0;
+  if (WPIPE) {
+    soA1 = w_base(__builtin_amdgcn_readfirstlane(p1.kA));
+    soB1 = w_base(__builtin_amdgcn_readfirstlane(p1.kB));
+  }
+  if (npairs > 0) {
+    gather(s0, p0, 0);
+    if (WPIPE) conv_load_w<JG>(w0, rw, lane32, soA, soB, nvalid);
+  }
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accB[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  int pr = 0, kc = 0;
+  // one step = one 32-channel chunk of one pair of blocks; the register sets a step reads and the
+  // ones it prefetches into are fixed by the call site (the loop below is unrolled by two), so the
+  // ping-pong costs no register moves
+  auto do_step = [&](const GStep &xc, GStep &xn, WSet<JG> &wc, WSet<JG> &wo) {
+    // loop state is wave-uniform; say so (keeps the buffer soffsets in SGPRs, no waterfall loops)
+    kc = __builtin_amdgcn_readfirstlane(kc); pr = __builtin_amdgcn_readfirstlane(pr);
+    soA = __builtin_amdgcn_readfirstlane(soA); soB = __builtin_amdgcn_readfirstlane(soB);
+    const bool last_kc = kc + 1 == nkc;
+    const bool more = !last_kc || (pr + 1 < npairs);
+    const PairEnt &pn = last_kc ? p1 : p0;
+    const int kcn = last_kc ? 0 : kc + 1;
+    if (more) gather(xn, pn, kcn);
+    const unsigned cA = soA + (unsigned)kc * kc_bytes, cB = soB + (unsigned)kc * kc_bytes;
+    if (!WPIPE) {
+      // weights stream from L2 right before their MFMAs (other waves cover the latency)
+      conv_step_mfma_stream<NBW>(xc, rw, lane32, cA, cB, nvalid, accA, accB);
+    } else {
+      soA1 = __builtin_amdgcn_readfirstlane(soA1); soB1 = __builtin_amdgcn_readfirstlane(soB1);
+      const unsigned nA = last_kc ? soA1 : cA + kc_bytes; // first weight set of the next step
+      const unsigned nB = last_kc ? soB1 : cB + kc_bytes;
+      if (NJG == 1) {
+        if (more) conv_load_w<JG>(wo, rw, lane32, nA, nB, nvalid);
+        conv_step_mfma_w<JG>(xc, wc, nvalid, accA, accB);
+      } else {
+        conv_load_w<JG>(wo, rw, lane32, cA + JG * 2048u, cB + JG * 2048u, nvalid - JG);
+        conv_step_mfma_w<JG>(xc, wc, nvalid, accA, accB);
+        if (more) conv_load_w<JG>(wc, rw, lane32, nA, nB, nvalid);
+        conv_step_mfma_w<JG>(xc, wo, nvalid - JG, accA + JG, accB + JG);
+      }
+    }
+    if (last_kc) {
+      conv_block_accumulate<NBW, WS>(Ct, p0.eA, g, accA);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // A and B may hit the same row
+      conv_block_accumulate<NBW, WS>(Ct, p0.eB, g, accB);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        accB[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      p0 = p1; p1 = p2; p2 = p3; p3 = load_pair(pr + 4);
+      if (WPIPE) {
+        soA = soA1; soB = soB1;
+        soA1 = w_base(__builtin_amdgcn_readfirstlane(p1.kA));
+        soB1 = w_base(__builtin_amdgcn_readfirstlane(p1.kB));
+      } else {
+        soA = w_base(__builtin_amdgcn_readfirstlane(p0.kA));
+        soB = w_base(__builtin_amdgcn_readfirstlane(p0.kB));
+      }
+      kc = 0; ++pr;
+    } else {
+      ++kc;
+    }
+  };
+  while (pr < npairs) {
+    if (NJG == 1) {
+      do_step(s0, s1, w0, w1);
+      if (pr >= npairs) break;
+      do_step(s1, s0, w1, w0);
+    } else {
+      do_step(s0, s1, w0, w1);
+      if (pr >= npairs) break;
+      do_step(s1, s0, w0, w1);
+    }
+  }
+  __syncthreads();
+  const int nrows = (int)((V_out - row0) < 64 ? (V_out - row0) : 64);
+  const int wcols = (co - nb0 * 16) < NBW * 16 ? (co - nb0 * 16) : NBW * 16;
+  if ((co & 3) == 0) {
+    const int q = wcols >> 2;
+    for (int i = threadIdx.x; i < nrows * q; i += WPB * 64) {
+      int r = i / q, cq = i % q;
+      float4 v = *reinterpret_cast<const float4 *>(smem + r * WS + cq * 4);
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) {
+        float4 u = *reinterpret_cast<const float4 *>(smem + (size_t)w * TILE + r * WS + cq * 4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      if (bias) {
+        const float *bb = bias + nb0 * 16 + cq * 4;
+        v.x += bb[0]; v.y += bb[1]; v.z += bb[2]; v.w += bb[3];
+      }
+      *reinterpret_cast<float4 *>(out + (row0 + r) * co + nb0 * 16 + cq * 4) = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nrows * wcols; i += WPB * 64) {
+      int r = i / wcols, cc = i % wcols;
+      float v = smem[r * WS + cc];
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) v += smem[(size_t)w * TILE + r * WS + cc];
+      if (bias) v += bias[nb0 * 16 + cc];
+      out[(row0 + r) * co + nb0 * 16 + cc] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LDS-resident weights
+// For layers whose whole packed filter bank fits in LDS next to the output tiles
+// (vol * ceil(ci/32) * ceil(co/16) * 2 KiB <= ~110 KiB: 3x3x3 at <=32->32 planes, the 2x2x2 strided
+// layers at 32<->64) the weights are copied to LDS once per workgroup and every MFMA A-operand is a
+// conflict-free ds_read_b128.  The lean kernel above streams 2 KiB of weights through the vector
+// memory path per 16-pair block and chunk -- twice the bytes of the gathered rows -- and the L2->CU
+// path (~70 GB/s per CU measured, MI355X_MICROARCH.md "Indexed rows") is what bounds it; here that
+// path carries only the gathered rows.  One wave owns one 64-row tile end to end (all its blocks,
+// all output columns): no cross-wave summation, no barrier after the weight copy, and the grid is
+// persistent (waves loop over tiles).  Same block order per tile => same bits as the other kernels.
+//   LDS image:  Wl[k][kc][nb][half][lane][4]   (half h holds k-slots 4h..4h+3 of the 8 per lane)
+template <int NBW>
+__device__ inline void conv_step_mfma_lds(const GStep &q, const float *__restrict__ WA,
+                                          const float *__restrict__ WB, int lane, f32x4 (&accA)[NBW],
+                                          f32x4 (&accB)[NBW]) {
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(WA + j * 512 + lane * 4);
+    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(WA + j * 512 + 256 + lane * 4);
+    const f32x4 u0 = *reinterpret_cast<const f32x4 *>(WB + j * 512 + lane * 4);
+    const f32x4 u1 = *reinterpret_cast<const f32x4 *>(WB + j * 512 + 256 + lane * 4);
+    f32x4 ca = accA[j], cb = accB[j];
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[0], bcf(q.a0[0]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[0], bcf(q.b0[0]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[1], bcf(q.a0[1]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[1], bcf(q.b0[1]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[2], bcf(q.a0[2]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[2], bcf(q.b0[2]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[3], bcf(q.a0[3]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[3], bcf(q.b0[3]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[0], bcf(q.a1[0]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[0], bcf(q.b1[0]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[1], bcf(q.a1[1]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[1], bcf(q.b1[1]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[2], bcf(q.a1[2]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[2], bcf(q.b1[2]), cb, 0, 0, 0);
+    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[3], bcf(q.a1[3]), ca, 0, 0, 0);
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[3], bcf(q.b1[3]), cb, 0, 0, 0);
+    accA[j] = ca; accB[j] = cb;
+  }
+}
+
+// NBW = column blocks per workgroup slab (blockIdx.y selects the slab), NKC = ceil(ci/32); the
+// number of waves per workgroup is the launch's block size / 64.  Gathers run RING-1 pairs ahead of
+// the MFMAs and block entries 2*RING-1 pairs ahead (registers, static ring indices through an
+// unrolled loop): with one or two waves per SIMD the latency has to be hidden inside the wave.
+template <int NKC> struct WStage { u32x4 a0[NKC], a1[NKC], b0[NKC], b1[NKC]; };
+
+template <int NBW, int NKC, bool ALIGNED>
+__global__ __launch_bounds__(512, 1) void k_conv_blocks_mfma_wlds(
+    const float *__restrict__ in, int ci, int64_t in_bytes, float *__restrict__ out, int co, int64_t V_out,
+    const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const float *__restrict__ Wp,
+    const float *__restrict__ bias) {
+  constexpr int WS = NBW * 16;
+  constexpr int TILE = 64 * WS;
+  constexpr int RING = 4;
+  extern __shared__ __align__(16) float smem[];
+  const int NW = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int nnb = nnb_of(co);
+  const int nb0 = blockIdx.y * NBW;
+  const int nvalid = (nnb - nb0) < NBW ? (nnb - nb0) : NBW;
+  const int wfloats = vol * NKC * NBW * 512;
+  float *Wl = smem;
+  float *Ct = smem + wfloats + (size_t)wave * TILE;
+  // ---- weight copy: global [k][kc][nb][lane][8] -> LDS [k][kc][j = nb - nb0][half][lane][4]
+  for (int i = threadIdx.x; i < vol * NKC * NBW * 128; i += blockDim.x) {
+    const int f = i >> 7, r = i & 127, ln = r >> 1, h = r & 1;
+    const int kk = f / NBW, j = f - kk * NBW; // kk = k*NKC + kc
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < nvalid) v = *reinterpret_cast<const float4 *>(Wp + ((size_t)(kk * nnb + nb0 + j) * 128 + r) * 4);
+    *reinterpret_cast<float4 *>(Wl + ((kk * NBW + j) * 2 + h) * 256 + ln * 4) = v;
+  }
+  __syncthreads();
+  const int maxb = tb_maxb(vol);
+  const int64_t ntiles = tb_ntiles(V_out);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwords =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(words), 0, (int)words_bytes, 0x00020000);
+  const unsigned rowbytes = (unsigned)ci * 4u, g32 = (unsigned)g * 32u, c16x4 = (unsigned)c16 * 4u;
+  constexpr int kstride = NKC * NBW * 512; // floats per offset in the LDS image
+
+  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
+    const int64_t row0 = tile * 64;
+    for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
+    const int nblk = __builtin_amdgcn_readfirstlane(words[tile]);
+    const unsigned kbase = (unsigned)((ntiles + tile * maxb) * 4);
+    const unsigned ebase = (unsigned)((ntiles + ntiles * maxb + tile * maxb * 16) * 4);
+    const int npairs = (nblk + 1) >> 1;
+    auto load_pair = [&](int pr) {
+      PairEnt p;
+      int bA = 2 * pr;
+      if (bA >= nblk) bA = nblk > 0 ? nblk - 1 : 0; // past the end: harmless re-read, never consumed
+      int bB = bA + 1;
+      const bool hasB = bB < nblk;
+      if (!hasB) bB = bA;
+      p.eA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bA * 64u, 0);
+      p.eB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bB * 64u, 0);
+      if (!hasB) p.eB |= (int)0x80000000;
+      p.kA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bA * 4u, 0);
+      p.kB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bB * 4u, 0);
+      return p;
+    };
+    auto gather = [&](WStage<NKC> &q, const PairEnt &p) {
+      const unsigned va = (((unsigned)p.eA & 0x7fffffffu) >> 6) * rowbytes + g32;
+      const unsigned vb = (((unsigned)p.eB & 0x7fffffffu) >> 6) * rowbytes + g32;
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        const unsigned so = (unsigned)kc * 128u;
+        if (ALIGNED) {
+          q.a0[kc] = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
+          q.a1[kc] = __builtin_amdgcn_raw_buffer_load_b128(rin, va + 16u, so, 0);
+          q.b0[kc] = __builtin_amdgcn_raw_buffer_load_b128(rin, vb, so, 0);
+          q.b1[kc] = __builtin_amdgcn_raw_buffer_load_b128(rin, vb + 16u, so, 0);
+        } else {
+          // any plane count: element loads, channels past ci read as zero (their weights are zero too)
+          const int c0 = kc * kKC + g * 8;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const bool ok0 = c0 + t < ci, ok1 = c0 + 4 + t < ci;
+            q.a0[kc][t] = ok0 ? __builtin_amdgcn_raw_buffer_load_b32(rin, va + 4u * t, so, 0) : 0u;
+            q.a1[kc][t] = ok1 ? __builtin_amdgcn_raw_buffer_load_b32(rin, va + 16u + 4u * t, so, 0) : 0u;
+            q.b0[kc][t] = ok0 ? __builtin_amdgcn_raw_buffer_load_b32(rin, vb + 4u * t, so, 0) : 0u;
+            q.b1[kc][t] = ok1 ? __builtin_amdgcn_raw_buffer_load_b32(rin, vb + 16u + 4u * t, so, 0) : 0u;
+          }
+        }
+      }
+    };
+    auto compute = [&](const WStage<NKC> &q, const PairEnt &p) {
+      int kA = __builtin_amdgcn_readfirstlane(p.kA), kB = __builtin_amdgcn_readfirstlane(p.kB);
+      if (wflip) { kA = vol - 1 - kA; kB = vol - 1 - kB; }
+      const float *WA0 = Wl + kA * kstride, *WB0 = Wl + kB * kstride;
+      f32x4 accA[NBW], accB[NBW];
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        accB[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        GStep t;
+        t.a0 = q.a0[kc]; t.a1 = q.a1[kc]; t.b0 = q.b0[kc]; t.b1 = q.b1[kc];
+        conv_step_mfma_lds<NBW>(t, WA0 + kc * NBW * 512, WB0 + kc * NBW * 512, lane, accA, accB);
+      }
+      conv_block_accumulate<NBW, WS>(Ct, p.eA, g, accA);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // A and B may hit the same row
+      conv_block_accumulate<NBW, WS>(Ct, p.eB, g, accB);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    PairEnt p[2 * RING];
+    WStage<NKC> st[RING];
+#pragma unroll
+    for (int u = 0; u < 2 * RING - 1; ++u) p[u] = load_pair(u);
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u)
+      if (u < npairs) gather(st[u], p[u]);
+    for (int pr0 = 0; pr0 < npairs; pr0 += 2 * RING) {
+#pragma unroll
+      for (int u = 0; u < 2 * RING; ++u) {
+        const int pr = pr0 + u;
+        if (pr < npairs) {
+          p[(u + 2 * RING - 1) % (2 * RING)] = load_pair(pr + 2 * RING - 1);
+          if (pr + RING - 1 < npairs) gather(st[(u + RING - 1) % RING], p[(u + RING - 1) % (2 * RING)]);
+          compute(st[u % RING], p[u]);
+        }
+      }
+    }
+    // the wave's own tile goes out once (+ bias, CPU/Convolution.cpp:59-62)
+    const int nrows = (int)((V_out - row0) < 64 ? (V_out - row0) : 64);
+    const int wcols = (co - nb0 * 16) < NBW * 16 ? (co - nb0 * 16) : NBW * 16;
+    if ((co & 3) == 0) {
+      const int q = wcols >> 2;
+      for (int i = lane; i < nrows * q; i += 64) {
+        const int r = i / q, cq = i - r * q;
+        float4 v = *reinterpret_cast<const float4 *>(Ct + r * WS + cq * 4);
+        if (bias) {
+          const float *bb = bias + nb0 * 16 + cq * 4;
+          v.x += bb[0]; v.y += bb[1]; v.z += bb[2]; v.w += bb[3];
+        }
+        *reinterpret_cast<float4 *>(out + (row0 + r) * co + nb0 * 16 + cq * 4) = v;
+      }
+    } else {
+      for (int i = lane; i < nrows * wcols; i += 64) {
+        const int r = i / wcols, cc = i - r * wcols;
+        float v = Ct[r * WS + cc];
+        if (bias) v += bias[nb0 * 16 + cc];
+        out[(row0 + r) * co + nb0 * 16 + cc] = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // tile reads done before the next tile's zero fill
+  }
+}
+
 // ------------------------------------------------------------------ bf16 features (extension)
 // The reference is fp32-only (sparseconvnet_cuda.cpp instantiates <float>); BASELINE configs 3-5 ask
 // for bf16.  Features are stored bf16, weights stay fp32 master parameters and are packed to bf16
@@ -920,12 +1358,70 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
                 words_bytes = aabr_tile_blocks_words(V_out, vol) * 4;
   const bool lean = aligned && in_bytes < (1ll << 31) && wp_bytes < (1ll << 31) && words_bytes < (1ll << 31) &&
                     !(flags >> 8);
+  // LDS-resident weights: the slab's packed filter bank + enough per-wave output tiles fit in 160 KiB
+  if (nkc <= 2 && in_bytes < (1ll << 31) && words_bytes < (1ll << 31) && !(flags >> 8)) {
+    const char *ov = getenv("AABR_CONV_WLDS"); // tuning experiments only: 0 disables, 1/2/4 forces the slab width
+    const int forced = ov ? atoi(ov) : -1;
+    const int64_t ntiles = ceil_div(V_out, 64);
+    // Measured (tools_conv_bench.py, S80k and 1.5 M points): 16-column slabs with 8 waves per CU beat
+    // wider slabs (fewer waves fit beside the larger filter bank) and beat the streaming kernel when the
+    // layer is at least 64 planes wide; narrow layers (<= 32 output planes) stay on the streaming kernel.
+    int nbw = 0, nw = 0;
+    for (int cand = 1; cand <= 4; cand <<= 1) {
+      if (forced > 0 ? cand != forced : (cand != 1 || nnb < 4)) continue;
+      if (cand > 1 && cand / 2 >= nnb) continue; // no wider than the layer
+      const int64_t w_lds = (int64_t)vol * nkc * cand * 2048, tile_lds = (int64_t)64 * cand * 16 * 4;
+      int64_t fit = (160 * 1024 - w_lds) / tile_lds;
+      if (fit > 8) fit = 8; // 512 threads: two waves per SIMD, 256 VGPRs each
+      if (fit < 4) continue;
+      nbw = cand; nw = (int)fit;
+      break;
+    }
+    if (nbw > 0 && forced != 0) {
+      const int64_t slabs = ceil_div(nnb, nbw);
+      const int64_t w_lds = (int64_t)vol * nkc * nbw * 2048, tile_lds = (int64_t)64 * nbw * 16 * 4;
+      int64_t wgx = ceil_div(ntiles, nw);
+      const int64_t cap = 256 / slabs > 0 ? 256 / slabs : 1; // persistent: about one workgroup per CU
+      if (wgx > cap) wgx = cap;
+      // a small tile count spreads over more CUs with fewer waves each
+      while (nw > 4 && wgx < cap && ceil_div(ntiles, nw - 1) <= cap) { --nw; wgx = ceil_div(ntiles, nw); }
+      const size_t lds = (size_t)(w_lds + nw * tile_lds);
+#define AABR_LAUNCH_WLDS(NBW, NKC, AL)                                                                   \
+  do {                                                                                                   \
+    static bool attr_set = false;                                                                        \
+    if (!attr_set) {                                                                                     \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_blocks_mfma_wlds<NBW, NKC, AL>,            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
+      attr_set = true;                                                                                   \
+    }                                                                                                    \
+    hipLaunchKernelGGL((k_conv_blocks_mfma_wlds<NBW, NKC, AL>), dim3((unsigned)wgx, (unsigned)slabs),    \
+                       dim3(64 * nw), lds, st, in_feats, n_in, in_bytes, out_feats, n_out, V_out,        \
+                       blocks, words_bytes, vol, flip & 1, wpack, bias);                                 \
+  } while (0)
+#define AABR_LAUNCH_WLDS_K(NBW)                                                                          \
+  do {                                                                                                   \
+    if (nkc == 1) { if (aligned) AABR_LAUNCH_WLDS(NBW, 1, true); else AABR_LAUNCH_WLDS(NBW, 1, false); } \
+    else { if (aligned) AABR_LAUNCH_WLDS(NBW, 2, true); else AABR_LAUNCH_WLDS(NBW, 2, false); }          \
+  } while (0)
+      if (nbw == 1) AABR_LAUNCH_WLDS_K(1);
+      else if (nbw == 2) AABR_LAUNCH_WLDS_K(2);
+      else AABR_LAUNCH_WLDS_K(4);
+#undef AABR_LAUNCH_WLDS_K
+#undef AABR_LAUNCH_WLDS
+      AABR_CHECK_LAUNCH();
+      return AABR_OK;
+    }
+  }
 #define AABR_LAUNCH_CONV(NBW, WPB)                                                                      \
   do {                                                                                                  \
     size_t lds = (size_t)(WPB) * 64 * ((NBW)*16) * sizeof(float);                                       \
     dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                           \
-    if (lean)                                                                                           \
-      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB>), grid, dim3(64 * (WPB)), lds, st, in_feats,  \
+    if (lean && (NBW) == 4)                                                                             \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_wpipe<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,   \
+                         in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
+                         flip & 1, wpack, wp_bytes, bias);                                              \
+    else if (lean)                                                                                      \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB>), grid, dim3(64 * (WPB)), lds, st, in_feats, \
                          n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip & 1,   \
                          wpack, wp_bytes, bias);                                                        \
     else if (aligned)                                                                                   \
@@ -942,7 +1438,7 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
   for (int wpb = 2; wpb <= (nbw == 4 ? 3 : 4); ++wpb) {
     int64_t lds = (int64_t)wpb * 64 * (nbw * 16) * 4;
     int64_t per_cu = (160 * 1024) / lds;
-    int64_t wave_cap = (nbw == 4 ? 16 : 20) / wpb; // register budget: 4 resp. 5 waves per SIMD
+    int64_t wave_cap = (nbw == 4 ? 12 : 20) / wpb; // register budget: 3 (164 VGPRs, weight prefetch) resp. 5 waves per SIMD
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
     int64_t rounds = ceil_div(wgs, 256 * per_cu);

@@ -22,7 +22,7 @@ lib = _hip.load()
 blocks, pairs = tb.out.blocks(), tb.out.pairs()
 mc = tb.out.max_chunks()
 print("V=%d R=%d" % (V, R))
-for ci, co in ((32, 32), (64, 64), (128, 128), (256, 256), (32, 128), (128, 32)):
+for ci, co in ((9, 32), (32, 32), (32, 64), (64, 32), (64, 64), (128, 128), (256, 256), (32, 128), (128, 32)):
     inp = torch.randn(V, ci, device=dev)
     out = torch.empty(V, co, device=dev)
     w = torch.randn(27, ci, co, device=dev)
