@@ -129,8 +129,11 @@ def time_stage(fn, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults sized for steady state: the first few hundred steps of a fresh process run with the GPU
+    # and host clocks still ramping (measured on MI355X: 200 timed steps after 20 warm-up steps read
+    # ~0.8 ms/step, 2000 after 300 read ~0.55-0.6 ms/step); the whole default run is still ~3 s
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-profile", default="", help="write a cProfile of the timed loop to this file")
