@@ -54,6 +54,38 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
   Wp[idx] = v;
 }
 
+// both orientations in one launch: the forward layout (Wl = W[k]) into Wf and the input-gradient
+// layout (Wl = W[k]^T, plane counts swapped) into Wt -- a training step needs each exactly once per
+// weight version, so the backward pass can run with the "prepacked" flag and no pack launch of its own
+template <typename TO>
+__device__ inline TO pack_cvt(float v);
+template <> __device__ inline float pack_cvt<float>(float v) { return v; }
+template <> __device__ inline __bf16 pack_cvt<__bf16>(float v) { return (__bf16)v; }
+
+template <typename TO>
+__global__ __launch_bounds__(256) void k_pack_weights2(const float *__restrict__ W, int vol, int n_in, int n_out,
+                                                       TO *__restrict__ Wf, TO *__restrict__ Wt) {
+  const int64_t total_f = (int64_t)vol * nkc_of(n_in) * nnb_of(n_out) * 512;
+  const int64_t total_t = (int64_t)vol * nkc_of(n_out) * nnb_of(n_in) * 512;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool tr = idx >= total_f;
+  if (tr) idx -= total_f;
+  if (idx >= (tr ? total_t : total_f)) return;
+  const int ci = tr ? n_out : n_in, co = tr ? n_in : n_out;
+  const int nkc = nkc_of(ci), nnb = nnb_of(co);
+  int s = idx & 7;
+  int lane = (idx >> 3) & 63;
+  int64_t r = idx >> 9;
+  int nb = (int)(r % nnb); r /= nnb;
+  int kc = (int)(r % nkc); r /= nkc;
+  int k = (int)r;
+  int c = kc * kKC + (lane >> 4) * 8 + s;
+  int n = nb * 16 + (lane & 15);
+  float v = 0.0f;
+  if (c < ci && n < co) v = tr ? W[((int64_t)k * co + n) * ci + c] : W[((int64_t)k * ci + c) * co + n];
+  (tr ? Wt : Wf)[idx] = pack_cvt<TO>(v);
+}
+
 // ------------------------------------------------------------------ compiled rule book, part 1
 // Tile-major MFMA block lists.  For every tile of 64 consecutive output rows the gather table
 // is compiled ONCE per rule book into blocks of 16 (partner row, local row) pairs that share a
@@ -307,31 +339,40 @@ template <int NBW>
 __device__ inline void conv_step_mfma_buf(const GStep &q, __amdgpu_buffer_rsrc_t rw, unsigned lane32,
                                           unsigned soA, unsigned soB, int nvalid, f32x4 (&accA)[NBW],
                                           f32x4 (&accB)[NBW]) {
+  // all of the step's weight loads go out before its first MFMA: the L2 latency is paid once per
+  // step, not once per column block (the last column slab may hold fewer than NBW blocks)
+  u32x4 w0[NBW], w1[NBW], u0[NBW], u1[NBW];
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
-    if (j >= nvalid) break; // last column slab may hold fewer than NBW blocks (wave-uniform)
-    const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soA + j * 2048, 0);
-    const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soA + j * 2048, 0);
-    const u32x4 u0 = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soB + j * 2048, 0);
-    const u32x4 u1 = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soB + j * 2048, 0);
-    f32x4 ca = accA[j], cb = accB[j];
-    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[0]), bcf(q.a0[0]), ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[0]), bcf(q.b0[0]), cb, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[1]), bcf(q.a0[1]), ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[1]), bcf(q.b0[1]), cb, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[2]), bcf(q.a0[2]), ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[2]), bcf(q.b0[2]), cb, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[3]), bcf(q.a0[3]), ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[3]), bcf(q.b0[3]), cb, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[0]), bcf(q.a1[0]), ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[0]), bcf(q.b1[0]), cb, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[1]), bcf(q.a1[1]), ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[1]), bcf(q.b1[1]), cb, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[2]), bcf(q.a1[2]), ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[2]), bcf(q.b1[2]), cb, 0, 0, 0);
-    ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[3]), bcf(q.a1[3]), ca, 0, 0, 0);
-    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[3]), bcf(q.b1[3]), cb, 0, 0, 0);
-    accA[j] = ca; accB[j] = cb;
+    if (j < nvalid) {
+      w0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soA + j * 2048, 0);
+      w1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soA + j * 2048, 0);
+      u0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soB + j * 2048, 0);
+      u1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soB + j * 2048, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    if (j < nvalid) {
+      f32x4 ca = accA[j], cb = accB[j];
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[j][0]), bcf(q.a0[0]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[j][0]), bcf(q.b0[0]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[j][1]), bcf(q.a0[1]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[j][1]), bcf(q.b0[1]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[j][2]), bcf(q.a0[2]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[j][2]), bcf(q.b0[2]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w0[j][3]), bcf(q.a0[3]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u0[j][3]), bcf(q.b0[3]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[j][0]), bcf(q.a1[0]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[j][0]), bcf(q.b1[0]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[j][1]), bcf(q.a1[1]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[j][1]), bcf(q.b1[1]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[j][2]), bcf(q.a1[2]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[j][2]), bcf(q.b1[2]), cb, 0, 0, 0);
+      ca = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(w1[j][3]), bcf(q.a1[3]), ca, 0, 0, 0);
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(u1[j][3]), bcf(q.b1[3]), cb, 0, 0, 0);
+      accA[j] = ca; accB[j] = cb;
+    }
   }
 }
 
@@ -1106,17 +1147,6 @@ __global__ __launch_bounds__(256) void k_offset_bases(const int32_t *__restrict_
   if (threadIdx.x == 0) words[k] = carry_s; // R_k
 }
 
-// chunk layout: offset k owns chunks [cstart[k], cstart[k+1]) of kDwChunk pairs each
-__global__ void k_offset_chunks(int vol, int32_t *__restrict__ words) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int c = 0;
-    for (int k = 0; k < vol; ++k) {
-      words[vol + k] = c;
-      c += (words[k] + kDwChunk - 1) / kDwChunk;
-    }
-    words[vol + vol] = c;
-  }
-}
 
 __global__ __launch_bounds__(256) void k_fill_offset_pairs(const int32_t *__restrict__ table, int64_t V,
                                                            int vol, int32_t *__restrict__ words) {
@@ -1124,6 +1154,16 @@ __global__ __launch_bounds__(256) void k_fill_offset_pairs(const int32_t *__rest
   const int k = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nb = op_nb256(V);
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // chunk layout (one thread of the grid): offset k owns chunks [cstart[k], cstart[k+1]) of kDwChunk
+  // pairs each; the R_k were written by k_offset_bases, the previous launch on this stream
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    int c = 0;
+    for (int kk = 0; kk < vol; ++kk) {
+      words[vol + kk] = c;
+      c += (words[kk] + kDwChunk - 1) / kDwChunk;
+    }
+    words[vol + vol] = c;
+  }
   const int t = (row < V) ? table[(int64_t)k * V + row] : -1;
   const unsigned long long m = __ballot(t >= 0);
   if (lane == 0) ws[wave] = (int)__popcll(m);
@@ -1325,7 +1365,6 @@ extern "C" int aabr_build_offset_pairs(const int32_t *table, const int32_t *bloc
   }
   AABR_CHECK_ARG(table && block_counts, "null pointer");
   hipLaunchKernelGGL(k_offset_bases, dim3((unsigned)vol), dim3(256), 0, st, block_counts, op_nb256(V), vol, pairs);
-  hipLaunchKernelGGL(k_offset_chunks, dim3(1), dim3(64), 0, st, vol, pairs);
   hipLaunchKernelGGL(k_fill_offset_pairs, dim3((unsigned)op_nb256(V), (unsigned)vol), dim3(256), 0, st, table, V,
                      vol, pairs);
   AABR_CHECK_LAUNCH();
@@ -1600,4 +1639,30 @@ extern "C" int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_
 #undef AABR_LAUNCH_CONV16
   AABR_CHECK_LAUNCH();
   return AABR_OK;
+}
+
+// ---- weight packing as its own entry point (training: pack both orientations once per step) --------
+template <typename TO>
+static int conv_pack_weights2_t(const float *W, int vol, int n_in, int n_out, TO *wpack_fwd, TO *wpack_t,
+                                void *stream_) {
+  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && vol > 0 && n_in <= 4096 && n_out <= 4096, "bad sizes");
+  AABR_CHECK_ARG(W && wpack_fwd && wpack_t, "null pointer");
+  AABR_CHECK_ARG(((uintptr_t)wpack_fwd & 15) == 0 && ((uintptr_t)wpack_t & 15) == 0, "packs must be 16-byte aligned");
+  const int64_t total = (int64_t)vol * 512 *
+                        ((int64_t)nkc_of(n_in) * nnb_of(n_out) + (int64_t)nkc_of(n_out) * nnb_of(n_in));
+  hipLaunchKernelGGL((k_pack_weights2<TO>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_,
+                     W, vol, n_in, n_out, wpack_fwd, wpack_t);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_conv_pack_weights2(const float *W, int vol, int n_in, int n_out, float *wpack_fwd,
+                                       float *wpack_t, void *stream_) {
+  return conv_pack_weights2_t<float>(W, vol, n_in, n_out, wpack_fwd, wpack_t, stream_);
+}
+
+extern "C" int aabr_conv_pack_weights2_bf16(const float *W, int vol, int n_in, int n_out, uint16_t *wpack_fwd,
+                                            uint16_t *wpack_t, void *stream_) {
+  return conv_pack_weights2_t<__bf16>(W, vol, n_in, n_out, reinterpret_cast<__bf16 *>(wpack_fwd),
+                                      reinterpret_cast<__bf16 *>(wpack_t), stream_);
 }

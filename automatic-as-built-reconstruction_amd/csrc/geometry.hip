@@ -480,8 +480,12 @@ extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncol
   int32_t *seg = slot + n;
   int32_t *blocksums = seg + n;
   int32_t *prefix = blocksums + 2 * nblk;
-  hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st);
-  hipMemsetAsync(minidx, 0xFF, 2 * cap * sizeof(uint32_t), st);
+  if ((void *)(keys + cap) == (void *)minidx) { // caller laid scratch right behind keys: one fill
+    hipMemsetAsync(keys, 0xFF, cap * (sizeof(uint64_t) + 2 * sizeof(uint32_t)), st);
+  } else {
+    hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st);
+    hipMemsetAsync(minidx, 0xFF, 2 * cap * sizeof(uint32_t), st);
+  }
   hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st);
   ConvGeom g = {};
   if (n > 0)

@@ -19,12 +19,12 @@ count_macs = True  # the reference returns the multiply-add count of every conv;
 
 
 class LazyMacs(object):
-    """Sum of (device rule-count tensor, multiplier) terms that behaves like the float the
+    """Sum of (device rule-total scalar, multiplier) terms that behaves like the float the
     reference returns (`sparseconvnet.forward_pass_multiplyAdd_count += ...`,
     submanifoldConvolution.py:85-94) but performs the device->host read only when the value
     is actually looked at -- so counting costs no host synchronisation in the training loop.
-    Only the small per-offset count tensors are referenced (never the rule tables), and the
-    pending list is folded into the base value once it holds more than 256 terms."""
+    Only 0-dim totals are referenced (one reduction per rule book, cached on it; never the rule
+    tables), and the pending list is folded into the base value once it holds more than 1024 terms."""
     __slots__ = ("terms", "base")
 
     def __init__(self, terms=(), base=0.0):
@@ -32,11 +32,10 @@ class LazyMacs(object):
 
     def _value(self):
         if self.terms:
-            tot = None
-            for counts, mult in self.terms:
-                v = counts.sum(dtype=torch.float64) * mult
-                tot = v if tot is None else tot + v.to(tot.device)
-            self.base += float(tot.item())
+            # one gather kernel + one read-back for the whole pending list
+            dev = self.terms[0][0].device
+            vals = torch.stack([t.to(dev) for t, _ in self.terms]).tolist()
+            self.base += sum(v * m for v, (_, m) in zip(vals, self.terms))
             self.terms = []
         return self.base
 
@@ -45,7 +44,7 @@ class LazyMacs(object):
             r = LazyMacs(self.terms + other.terms, self.base + other.base)
         else:
             r = LazyMacs(self.terms, self.base + float(other))
-        if len(r.terms) > 256:
+        if len(r.terms) > 1024:
             r._value()
         return r
 
@@ -57,7 +56,7 @@ class LazyMacs(object):
             self.base += other.base
         else:
             self.base += float(other)
-        if len(self.terms) > 256:
+        if len(self.terms) > 1024:
             self._value()
         return self
 
@@ -126,11 +125,17 @@ class _Grid(object):
 
 class _Gather(object):
     """one gather table [vol, rows] + its compiled streaming forms (built lazily, cached)"""
-    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_pairs", "_host_counts")
+    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_pairs", "_host_counts", "_total")
 
     def __init__(self, table, counts, vol, rows):
         self.table, self.counts, self.vol, self.rows = table, counts, vol, rows
-        self._blocks = self._pairs = self._host_counts = None
+        self._blocks = self._pairs = self._host_counts = self._total = None
+
+    def total_dev(self):
+        """number of rules as a 0-dim float64 device tensor (one reduction per rule book, cached)"""
+        if self._total is None:
+            self._total = self._ensure_counts().sum(dtype=torch.float64)
+        return self._total
 
     def _ensure_counts(self):
         if self.counts is None:  # table built without counts (input side of a strided book)
@@ -262,12 +267,14 @@ class Metadata_3(object):
         cap = _hip.next_pow2(2 * n)
         nblk = (max(n, 1) + 1023) // 1024
         n1 = max(n, 1)
-        # int32 words: keys(2*cap) | vals(cap) | point_site(n) | site_coords(4*n1) | site_off(n+1) |
-        #              site_pts(n1) | meta(8) | scratch(3*cap + 2n + 4*nblk + 16); 16-byte aligned pieces
-        sizes = [2 * cap, cap, n, 4 * n1, n + 1, n1, _hip.META_WORDS, 3 * cap + 2 * n + 4 * nblk + 16]
-        offs, tot = [], 0
-        for sz in sizes:
-            offs.append(tot)
+        # int32 words: keys(2*cap) | scratch(3*cap + 2n + 4*nblk + 16) | vals(cap) | point_site(n) |
+        #              site_coords(4*n1) | site_off(n+1) | site_pts(n1) | meta(8); 16-byte aligned pieces.
+        # scratch sits right behind keys so the library clears both with one fill.
+        order = [(0, 2 * cap), (7, 3 * cap + 2 * n + 4 * nblk + 16), (1, cap), (2, n), (3, 4 * n1), (4, n + 1),
+                 (5, n1), (6, _hip.META_WORDS)]
+        offs, tot = [0] * 8, 0
+        for idx, sz in order:
+            offs[idx] = tot
             tot += (sz + 3) & ~3
         buf = torch.empty(tot, dtype=torch.int32, device=device)
         keys = buf[offs[0]:offs[0] + 2 * cap].view(torch.int64)
@@ -460,7 +467,10 @@ def InputLayer_updateGradInput(metadata, d_input_features, d_output_features):
 # ------------------------------------------------------------------------------------------------
 # the shared gather-GEMM
 # ------------------------------------------------------------------------------------------------
-def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags):
+def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
+    """`pack_t` (extension): a list owned by the autograd node.  The forward call (flags bit0 = 0) packs
+    the weights in both orientations with one launch and leaves the input-gradient layout in it; the
+    backward call (bit0 = 1) finds it there and runs without a pack launch of its own."""
     lib = _hip.load()
     n_in = inp.size(1)
     w = weight.contiguous()
@@ -476,17 +486,25 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags):
     out.resize_(n_rows_out, n_out)
     if w.dtype != torch.float32:
         raise TypeError("convolution weights are fp32 master parameters, got %s" % w.dtype)
-    if inp.dtype == torch.bfloat16:
-        wpack = _hip.workspace("wpack16", lib.aabr_conv_wpack_bf16_elems(gather.vol, w.size(2), w.size(3)),
-                               torch.bfloat16, inp.device)
-        check(lib.aabr_conv_forward_bf16(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
-                                         ptr(gather.blocks()), gather.vol, ptr(w), ptr(_opt(bias)), flags,
-                                         ptr(wpack), stream()))
-        return n_out
-    wpack = _hip.workspace("wpack", lib.aabr_conv_wpack_floats(gather.vol, w.size(2), w.size(3)), torch.float32,
-                           inp.device)
-    check(lib.aabr_conv_forward(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
-                                ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
+    bf16 = inp.dtype == torch.bfloat16
+    if bf16:
+        elems, name, dt = lib.aabr_conv_wpack_bf16_elems(gather.vol, w.size(2), w.size(3)), "wpack16", torch.bfloat16
+        conv, pack2 = lib.aabr_conv_forward_bf16, lib.aabr_conv_pack_weights2_bf16
+    else:
+        elems, name, dt = lib.aabr_conv_wpack_floats(gather.vol, w.size(2), w.size(3)), "wpack", torch.float32
+        conv, pack2 = lib.aabr_conv_forward, lib.aabr_conv_pack_weights2
+    if pack_t is not None and (flags & 1) and len(pack_t) == 1 and pack_t[0].dtype == dt:
+        wpack, flags = pack_t[0], flags | 4
+    else:
+        wpack = _hip.workspace(name, elems, dt, inp.device)
+        if pack_t is not None and not (flags & 1) and n_rows_out > 0:
+            wt = torch.empty(elems, dtype=dt, device=inp.device)
+            check(pack2(ptr(w), gather.vol, w.size(2), w.size(3), ptr(wpack), ptr(wt), stream()))
+            del pack_t[:]
+            pack_t.append(wt)
+            flags |= 4
+    check(conv(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
+               ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
     return n_out
 
 
@@ -507,62 +525,64 @@ def _conv_dw(inp, d_out, gather, d_weight, d_bias):
 def _macs(tb, weight):
     if not count_macs:
         return 0.0
-    return LazyMacs([(tb.out._ensure_counts(), float(weight.size(2) * weight.size(3) * weight.size(1)))])
+    return LazyMacs([(tb.out.total_dev(), float(weight.size(2) * weight.size(3) * weight.size(1)))])
 
 
 # SubmanifoldConvolution (pybind.cpp:134-143)
 def SubmanifoldConvolution_updateOutput(spatial_size, filter_size, metadata, input_features, output_features,
-                                        weight, bias):
+                                        weight, bias, pack_t=None):
     inp = _featc(input_features, "input_features")
     tb = metadata.getSubmanifoldRuleBook(spatial_size, filter_size)
-    _conv_fwd(inp, output_features, tb.V_out, tb.out, weight, bias, 0)
+    _conv_fwd(inp, output_features, tb.V_out, tb.out, weight, bias, 0, pack_t)
     return _macs(tb, weight)
 
 
 def SubmanifoldConvolution_backward(spatial_size, filter_size, metadata, input_features, d_input_features,
-                                    d_output_features, weight, d_weight, d_bias):
+                                    d_output_features, weight, d_weight, d_bias, pack_t=None, need_d_input=True):
     inp = _featc(input_features, "input_features")
     d_out = _featc(d_output_features, "d_output_features")
     tb = metadata.getSubmanifoldRuleBook(spatial_size, filter_size)
-    # d_in[u] = sum_k d_out[table[k'][u]] @ W[vol-1-k']^T  (flags: transpose | mirrored offset)
-    _conv_fwd(d_out, d_input_features, tb.V_in, tb.out, weight, None, 1 | 2)
+    if need_d_input:  # d_in[u] = sum_k d_out[table[k'][u]] @ W[vol-1-k']^T  (flags: transpose | mirrored offset)
+        _conv_fwd(d_out, d_input_features, tb.V_in, tb.out, weight, None, 1 | 2, pack_t)
     _conv_dw(inp, d_out, tb.out, d_weight, d_bias)
 
 
 # Convolution (pybind.cpp:54-65)
 def Convolution_updateOutput(input_size, output_size, filter_size, filter_stride, metadata, input_features,
-                             output_features, weight, bias):
+                             output_features, weight, bias, pack_t=None):
     inp = _featc(input_features, "input_features")
     tb = metadata.getRuleBook(input_size, output_size, filter_size, filter_stride)
-    _conv_fwd(inp, output_features, tb.V_out, tb.out, weight, bias, 0)
+    _conv_fwd(inp, output_features, tb.V_out, tb.out, weight, bias, 0, pack_t)
     return _macs(tb, weight)
 
 
 def Convolution_backward(input_size, output_size, filter_size, filter_stride, metadata, input_features,
-                         d_input_features, d_output_features, weight, d_weight, d_bias):
+                         d_input_features, d_output_features, weight, d_weight, d_bias, pack_t=None, need_d_input=True):
     inp = _featc(input_features, "input_features")
     d_out = _featc(d_output_features, "d_output_features")
     tb = metadata.getRuleBook(input_size, output_size, filter_size, filter_stride)
-    _conv_fwd(d_out, d_input_features, tb.V_in, tb.inn, weight, None, 1)
+    if need_d_input:
+        _conv_fwd(d_out, d_input_features, tb.V_in, tb.inn, weight, None, 1, pack_t)
     _conv_dw(inp, d_out, tb.out, d_weight, d_bias)
 
 
 # Deconvolution (pybind.cpp:78-89): the rule book is looked up as (outputSize, inputSize) with
 # the columns swapped (CPU/Deconvolution.cpp:15-16,34-37)
 def Deconvolution_updateOutput(input_size, output_size, filter_size, filter_stride, metadata, input_features,
-                               output_features, weight, bias):
+                               output_features, weight, bias, pack_t=None):
     inp = _featc(input_features, "input_features")
     tb = metadata.getRuleBook(output_size, input_size, filter_size, filter_stride)
-    _conv_fwd(inp, output_features, tb.V_in, tb.inn, weight, bias, 0)
+    _conv_fwd(inp, output_features, tb.V_in, tb.inn, weight, bias, 0, pack_t)
     return _macs(tb, weight)
 
 
 def Deconvolution_backward(input_size, output_size, filter_size, filter_stride, metadata, input_features,
-                           d_input_features, d_output_features, weight, d_weight, d_bias):
+                           d_input_features, d_output_features, weight, d_weight, d_bias, pack_t=None, need_d_input=True):
     inp = _featc(input_features, "input_features")
     d_out = _featc(d_output_features, "d_output_features")
     tb = metadata.getRuleBook(output_size, input_size, filter_size, filter_stride)
-    _conv_fwd(d_out, d_input_features, tb.V_out, tb.out, weight, None, 1)
+    if need_d_input:
+        _conv_fwd(d_out, d_input_features, tb.V_out, tb.out, weight, None, 1, pack_t)
     _conv_dw(inp, d_out, tb.inn, d_weight, d_bias)
 
 

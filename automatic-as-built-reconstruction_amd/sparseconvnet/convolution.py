@@ -57,13 +57,16 @@ class ConvolutionFunction(Function):
     def forward(ctx, input_features, weight, bias, input_metadata, input_spatial_size, output_spatial_size,
                 dimension, filter_size, filter_stride):
         output_features = input_features.new()
+        # the input-gradient layout of the weights is packed together with the forward one (one launch)
+        # when a backward pass through this layer will need it
+        ctx.pack_t = [] if ctx.needs_input_grad[0] else None
         ctx.input_metadata = input_metadata
         ctx.dimension = dimension
         ctx.geom = (input_spatial_size, output_spatial_size, filter_size, filter_stride)
         ctx.save_for_backward(input_features, weight, bias)
         sparseconvnet.forward_pass_multiplyAdd_count += SCN.Convolution_updateOutput(
             input_spatial_size, output_spatial_size, filter_size, filter_stride, input_metadata, input_features,
-            output_features, weight, bias)
+            output_features, weight, bias, pack_t=ctx.pack_t)
         sparseconvnet.forward_pass_hidden_states += output_features.nelement()
         return output_features
 
@@ -78,5 +81,5 @@ class ConvolutionFunction(Function):
         grad_bias = torch.zeros_like(bias)
         SCN.Convolution_backward(input_spatial_size, output_spatial_size, filter_size, filter_stride,
                                  ctx.input_metadata, input_features, grad_input, grad_output.contiguous(), weight,
-                                 grad_weight, grad_bias)
-        return grad_input, grad_weight, optionalTensorReturn(grad_bias), None, None, None, None, None, None
+                                 grad_weight, grad_bias, pack_t=ctx.pack_t, need_d_input=ctx.needs_input_grad[0])
+        return (grad_input if ctx.needs_input_grad[0] else None), grad_weight, optionalTensorReturn(grad_bias), None, None, None, None, None, None

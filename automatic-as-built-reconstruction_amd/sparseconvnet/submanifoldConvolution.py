@@ -58,9 +58,12 @@ class SubmanifoldConvolutionFunction(Function):
         ctx.spatial_size = spatial_size
         ctx.filter_size = filter_size
         output_features = input_features.new()
+        # the input-gradient layout of the weights is packed together with the forward one (one launch)
+        # when a backward pass through this layer will need it
+        ctx.pack_t = [] if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(input_features, weight, bias)
         sparseconvnet.forward_pass_multiplyAdd_count += SCN.SubmanifoldConvolution_updateOutput(
-            spatial_size, filter_size, input_metadata, input_features, output_features, weight, bias)
+            spatial_size, filter_size, input_metadata, input_features, output_features, weight, bias, pack_t=ctx.pack_t)
         sparseconvnet.forward_pass_hidden_states += output_features.nelement()
         return output_features
 
@@ -73,5 +76,5 @@ class SubmanifoldConvolutionFunction(Function):
         grad_weight = torch.empty_like(weight)
         grad_bias = torch.zeros_like(bias)
         SCN.SubmanifoldConvolution_backward(ctx.spatial_size, ctx.filter_size, ctx.input_metadata, input_features,
-                                            grad_input, grad_output.contiguous(), weight, grad_weight, grad_bias)
-        return grad_input, grad_weight, optionalTensorReturn(grad_bias), None, None, None, None
+                                            grad_input, grad_output.contiguous(), weight, grad_weight, grad_bias, pack_t=ctx.pack_t, need_d_input=ctx.needs_input_grad[0])
+        return (grad_input if ctx.needs_input_grad[0] else None), grad_weight, optionalTensorReturn(grad_bias), None, None, None, None

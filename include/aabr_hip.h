@@ -160,6 +160,14 @@ int64_t aabr_conv_wpack_floats(int vol, int n_in, int n_out);
 int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
                       int64_t V_out, const int32_t *blocks, int vol, const float *W,
                       const float *bias, int flags, float *wpack, void *stream);
+/* Training steps need W packed in both orientations once per weight version: this fills the forward
+ * layout (what aabr_conv_forward builds for flags bit0 = 0) and the input-gradient layout (bit0 = 1)
+ * in one launch; the conv calls then pass flags bit2.  Each pack holds
+ * aabr_conv_wpack_floats(vol,nIn,nOut) elements (float32 / bf16 bit patterns).                   */
+int aabr_conv_pack_weights2(const float *W, int vol, int n_in, int n_out, float *wpack_fwd,
+                            float *wpack_t, void *stream);
+int aabr_conv_pack_weights2_bf16(const float *W, int vol, int n_in, int n_out, uint16_t *wpack_fwd,
+                                 uint16_t *wpack_t, void *stream);
 /* dW[k] = sum over offset k's pairs (t, o) of in[t]^T (x) d_out[o]; d_bias (optional) = column
  * sums of d_out.  max_chunks bounds the number of 1024-pair chunks: sum_k ceil(R_k/1024) when the
  * rule counts are known on the host, else ceil(vol*V/1024) + vol; scratch float32

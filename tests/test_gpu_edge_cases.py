@@ -279,3 +279,54 @@ def test_sparse_to_dense_and_rotated_roi_align_3d():
     out2 = ROIAlignRotated3D((2, 2, 2), 0.5, 0)(x, _t(rois * np.array([1, 2, 2, 2, 2, 2, 2, 1], np.float32)))
     want2 = O.roi_align_rot3d_fwd(crop, rois * np.array([1, 2, 2, 2, 2, 2, 2, 1], np.float32), 0.5, (2, 2, 2), 0)
     np.testing.assert_allclose(out2.detach().cpu().numpy(), want2, rtol=1e-4, atol=1e-5)
+
+
+def test_conv_backward_without_input_gradient_and_prepacked_weights():
+    """autograd contract of the three convolution modules: when the input does not require a gradient the
+    input-gradient pass is skipped (grad is None) and dW is unchanged; when it does, the backward pass
+    reuses the weight pack made at forward time -- same bits as a stand-alone pack"""
+    scn = _scn()
+    rng = np.random.default_rng(77)
+    n = 3000
+    coords = np.stack([rng.integers(0, 16, n), rng.integers(0, 16, n), rng.integers(0, 8, n),
+                       np.sort(rng.integers(0, 2, n))], 1).astype(np.int64)
+    feats = rng.standard_normal((n, 32)).astype(np.float32)
+    mods = [scn.SubmanifoldConvolution(3, 32, 64, 3, False), scn.Convolution(3, 64, 32, [2, 2, 2], [2, 2, 2], False),
+            scn.Deconvolution(3, 32, 32, [2, 2, 2], [2, 2, 2], False)]
+    mods = [m.to(DEV) for m in mods]
+    results = []
+    for need in (True, False):
+        f = _t(feats).requires_grad_(need)
+        x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), f])
+        y = x
+        for m in mods:
+            m.zero_grad()
+            y = m(y)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        y.features.backward(torch.randn(y.features.shape, device=DEV, generator=g))
+        results.append(([m.weight.grad.clone() for m in mods], f.grad, y.features.detach().clone()))
+    (dw_a, gin_a, out_a), (dw_b, gin_b, out_b) = results
+    assert gin_a is not None and gin_b is None
+    assert torch.equal(out_a, out_b)
+    # layers 2 and 3 still propagate (their inputs come from a layer with parameters); only the first
+    # layer's input-gradient pass disappears, and no weight gradient changes by a bit
+    for a, b in zip(dw_a, dw_b):
+        assert torch.equal(a, b)
+    # the reference-named entry point without the holder packs on its own: identical result
+    import sparseconvnet.SCN as SCN
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(feats)])
+    d_out = torch.randn(x.features.shape[0], 64, device=DEV)
+    w = mods[0].weight.detach()
+    d_in_plain, d_in_held = torch.empty(0, device=DEV), torch.empty(0, device=DEV)
+    dW1, dW2 = torch.empty_like(w), torch.empty_like(w)
+    empty = torch.empty(0, device=DEV)
+    SCN.SubmanifoldConvolution_backward(x.spatial_size, mods[0].filter_size, x.metadata, x.features, d_in_plain,
+                                        d_out, w, dW1, empty)
+    holder = []
+    out = torch.empty(0, device=DEV)
+    SCN.SubmanifoldConvolution_updateOutput(x.spatial_size, mods[0].filter_size, x.metadata, x.features, out, w,
+                                            empty, pack_t=holder)
+    assert len(holder) == 1
+    SCN.SubmanifoldConvolution_backward(x.spatial_size, mods[0].filter_size, x.metadata, x.features, d_in_held,
+                                        d_out, w, dW2, empty, pack_t=holder)
+    assert torch.equal(d_in_plain, d_in_held) and torch.equal(dW1, dW2)
