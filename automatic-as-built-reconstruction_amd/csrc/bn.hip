@@ -111,6 +111,7 @@ __device__ inline void reduce_partials(const double *__restrict__ part, int npar
   const int pl = threadIdx.x % kFinPlanes, sl = threadIdx.x / kFinPlanes;
   double a = 0.0, b = 0.0;
   if (p < planes)
+#pragma unroll 8
     for (int j = sl; j < nparts; j += kFinSlices) {
       a += part[((int64_t)j * 2 + 0) * planes + p];
       b += part[((int64_t)j * 2 + 1) * planes + p];

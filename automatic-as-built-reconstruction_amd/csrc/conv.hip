@@ -1114,8 +1114,16 @@ __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_bf16(
 // Offset-major compacted pairs (the reference's RuleBook layout: for offset k the (in, out)
 // pairs in ascending out order, Metadata.h:34) for the weight-gradient pass, whose reduction
 // runs over the pairs of ONE offset.
-//   words: [vol] R_k | [vol+1] first chunk of offset k | [vol][nb256] block bases | [vol][V][2] pairs
-constexpr int kDwChunk = 1024; // pairs per weight-gradient chunk (one workgroup = 4 waves x 256)
+//   words: [vol] R_k | [vol+1] first 1024-pair chunk of offset k | [vol+1] first 256-pair chunk |
+//          [vol][nb256] block bases | [vol][V][2] pairs
+// pairs per weight-gradient chunk (one workgroup = 4 waves x chunk/4).  1024 keeps the partial-sum
+// traffic small (a partial is nIn*nOut floats per chunk); 256 gives a small rule book ~4x more workgroups
+// than CUs -- at 1024 the S80k launch ran one wave per SIMD and was pure gather latency.  Both chunk tables
+// are compiled into the pair list; the launch picks by rule-book size and layer width.
+__host__ __device__ inline int dw_chunk(int64_t V, int vol, int n_in, int n_out) {
+  return ((int64_t)vol * V <= (1ll << 21) && (int64_t)n_in * n_out <= 64 * 64) ? 256 : 1024;
+}
+__host__ __device__ inline int64_t op_hdr(int vol) { return (int64_t)vol + 2 * (vol + 1); }
 __host__ __device__ inline int64_t op_nb256(int64_t V) { return (V + 255) / 256; }
 
 // one block per offset: exclusive scan of the per-256-row hit counts
@@ -1124,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_offset_bases(const int32_t *__restrict_
   __shared__ int ws[4];
   __shared__ int carry_s;
   const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int32_t *bases = words + vol + (vol + 1) + (int64_t)k * nb;
+  int32_t *bases = words + op_hdr(vol) + (int64_t)k * nb;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   for (int64_t base = 0; base < nb; base += 256) {
@@ -1154,32 +1162,35 @@ __global__ __launch_bounds__(256) void k_fill_offset_pairs(const int32_t *__rest
   const int k = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nb = op_nb256(V);
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // chunk layout (one thread of the grid): offset k owns chunks [cstart[k], cstart[k+1]) of kDwChunk
+  // chunk layouts (one thread of the grid): offset k owns chunks [cstart[k], cstart[k+1]) of 1024 resp. 256
   // pairs each; the R_k were written by k_offset_bases, the previous launch on this stream
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    int c = 0;
+    int c = 0, c4 = 0;
     for (int kk = 0; kk < vol; ++kk) {
       words[vol + kk] = c;
-      c += (words[kk] + kDwChunk - 1) / kDwChunk;
+      words[vol + (vol + 1) + kk] = c4;
+      c += (words[kk] + 1023) / 1024;
+      c4 += (words[kk] + 255) / 256;
     }
     words[vol + vol] = c;
+    words[vol + (vol + 1) + vol] = c4;
   }
   const int t = (row < V) ? table[(int64_t)k * V + row] : -1;
   const unsigned long long m = __ballot(t >= 0);
   if (lane == 0) ws[wave] = (int)__popcll(m);
   __syncthreads();
-  int pre = words[vol + (vol + 1) + (int64_t)k * nb + blockIdx.x];
+  int pre = words[op_hdr(vol) + (int64_t)k * nb + blockIdx.x];
   for (int j = 0; j < wave; ++j) pre += ws[j];
   if (t >= 0) {
     int pos = pre + (int)__popcll(m & ((1ull << lane) - 1ull));
-    int2 *pairs = reinterpret_cast<int2 *>(words + vol + (vol + 1) + (int64_t)vol * nb) + (int64_t)k * V;
+    int2 *pairs = reinterpret_cast<int2 *>(words + op_hdr(vol) + (int64_t)vol * nb) + (int64_t)k * V;
     pairs[pos] = make_int2(t, (int)row);
   }
 }
 
 // ----------------------------------------------------------------------------- dW
 // partial[chunk][c][n] = sum over the chunk's pairs (t, o) of in[t][c] * d_out[o][n]; one workgroup
-// per chunk of kDwChunk pairs of one offset (each wave a quarter), MFMA with the pair index as the
+// per chunk of dw_chunk(V, vol) pairs of one offset (each wave a quarter), MFMA with the pair index as the
 // reduction dimension.  Pair indices are loaded 64 at a time (coalesced) and handed to the lane
 // groups by shuffles; 16 pairs are gathered per step before their MFMAs issue.  The four waves'
 // accumulators are summed through LDS in wave order (deterministic).  CB x NB blocks of 16.
@@ -1190,7 +1201,7 @@ template <int CB, int NB, typename T>
 __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in, int ci,
                                                        const T *__restrict__ d_out, int co, int64_t V,
                                                        const int32_t *__restrict__ words, int vol,
-                                                       float *__restrict__ partial) {
+                                                       int chunk_pairs, float *__restrict__ partial) {
   __shared__ f32x4 red[CB * NB][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
@@ -1199,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in,
   const int tile = blockIdx.y;
   const int cb0 = (tile / tiles_n) * CB, nb0 = (tile % tiles_n) * NB;
   const int chunk = blockIdx.x;
-  const int32_t *cstart = words + vol;
+  const int32_t *cstart = words + vol + (chunk_pairs == 256 ? vol + 1 : 0);
   if (chunk >= cstart[vol]) return;                        // workgroup-uniform
   // which offset owns this chunk (cstart is non-decreasing)
   int k = 0;
@@ -1210,10 +1221,10 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in,
     if (m) { k = k0 + (__ffsll((long long)m) - 1); break; }
   }
   const int rk = words[k];
-  const int p0 = (chunk - cstart[k]) * kDwChunk + wave * (kDwChunk / 4);
-  int p1 = p0 + kDwChunk / 4;
+  const int p0 = (chunk - cstart[k]) * chunk_pairs + wave * (chunk_pairs / 4);
+  int p1 = p0 + chunk_pairs / 4;
   if (p1 > rk) p1 = rk;
-  const int2 *pairs = reinterpret_cast<const int2 *>(words + vol + (vol + 1) + (int64_t)vol * op_nb256(V)) +
+  const int2 *pairs = reinterpret_cast<const int2 *>(words + op_hdr(vol) + (int64_t)vol * op_nb256(V)) +
                       (int64_t)k * V;
   f32x4 acc[CB][NB];
 #pragma unroll
@@ -1285,18 +1296,25 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in,
     }
 }
 
-// dW[k][i] = sum of the partials of offset k's chunks, in chunk order (deterministic)
+// dW[k][i] = sum of the partials of offset k's chunks (fixed order => deterministic): a block takes 64
+// consecutive elements i and deals the chunks to 4 slices (chunk c0+s, c0+s+4, ...), several loads in
+// flight per thread; the slices are combined in slice order through LDS
 __global__ __launch_bounds__(256) void k_conv_dw_reduce(const float *__restrict__ partial,
                                                         const int32_t *__restrict__ words, int vol,
-                                                        int64_t cico, float *__restrict__ dW) {
-  const int k = blockIdx.y;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= cico) return;
-  const int c0 = words[vol + k], c1 = words[vol + k + 1];
+                                                        int chunk_pairs, int64_t cico, float *__restrict__ dW) {
+  __shared__ float red[4][64];
+  const int k = blockIdx.y, col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + col;
+  const int32_t *cstart = words + vol + (chunk_pairs == 256 ? vol + 1 : 0);
+  const int c0 = cstart[k], c1 = cstart[k + 1];
   float s = 0.0f;
-#pragma unroll 4
-  for (int c = c0; c < c1; ++c) s += partial[(int64_t)c * cico + i];
-  dW[(int64_t)k * cico + i] = s;
+  if (i < cico) {
+#pragma unroll 8
+    for (int c = c0 + sl; c < c1; c += 4) s += partial[(int64_t)c * cico + i];
+  }
+  red[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < cico) dW[(int64_t)k * cico + i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // d_bias[n] = sum_rows d_out[row][n] (at::sum_out, CPU/Convolution.cpp:100-101); one block per
@@ -1352,7 +1370,7 @@ extern "C" int aabr_build_tile_blocks(const int32_t *table, int64_t V, int vol, 
 }
 
 extern "C" int64_t aabr_offset_pairs_words(int64_t V, int vol) {
-  return (int64_t)vol + (vol + 1) + (int64_t)vol * op_nb256(V) + 2 * (int64_t)vol * V;
+  return op_hdr(vol) + (int64_t)vol * op_nb256(V) + 2 * (int64_t)vol * V;
 }
 
 extern "C" int aabr_build_offset_pairs(const int32_t *table, const int32_t *block_counts, int64_t V, int vol,
@@ -1360,7 +1378,7 @@ extern "C" int aabr_build_offset_pairs(const int32_t *table, const int32_t *bloc
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(V >= 0 && vol > 0 && vol <= 65535 && pairs, "bad arguments");
   if (V == 0) {
-    hipMemsetAsync(pairs, 0, (size_t)(2 * vol + 1) * sizeof(int32_t), st);
+    hipMemsetAsync(pairs, 0, (size_t)op_hdr(vol) * sizeof(int32_t), st);
     return AABR_OK;
   }
   AABR_CHECK_ARG(table && block_counts, "null pointer");
@@ -1528,9 +1546,10 @@ static int conv_backward_weight_t(const T *in_feats, int n_in, const T *d_out, i
   dw_tiling(n_in, n_out, cb, nb, tiles);
   AABR_CHECK_ARG(tiles <= 65535, "too many tiles");
   dim3 grid((unsigned)max_chunks, (unsigned)tiles);
+  const int chunk_pairs = dw_chunk(V_out, vol, n_in, n_out);
 #define AABR_LAUNCH_DW(CB, NB)                                                                           \
   hipLaunchKernelGGL((k_conv_dw_pairs<CB, NB, T>), grid, dim3(256), 0, st, in_feats, n_in, d_out, n_out, \
-                     V_out, pairs, vol, scratch)
+                     V_out, pairs, vol, chunk_pairs, scratch)
   if (cb == 1 && nb == 1) AABR_LAUNCH_DW(1, 1);
   else if (cb == 1 && nb == 2) AABR_LAUNCH_DW(1, 2);
   else if (cb == 1 && nb == 4) AABR_LAUNCH_DW(1, 4);
@@ -1541,8 +1560,8 @@ static int conv_backward_weight_t(const T *in_feats, int n_in, const T *d_out, i
   else if (cb == 4 && nb == 2) AABR_LAUNCH_DW(4, 2);
   else AABR_LAUNCH_DW(4, 4);
 #undef AABR_LAUNCH_DW
-  hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 256), (unsigned)vol), dim3(256), 0, st,
-                     scratch, pairs, vol, cico, dW);
+  hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
+                     scratch, pairs, vol, chunk_pairs, cico, dW);
   if (d_bias)
     hipLaunchKernelGGL((k_col_sum<T>), dim3((unsigned)ceil_div(n_out, 64)), dim3(256), 0, st, d_out, V_out,
                        n_out, d_bias);
@@ -1665,4 +1684,8 @@ extern "C" int aabr_conv_pack_weights2_bf16(const float *W, int vol, int n_in, i
                                             uint16_t *wpack_t, void *stream_) {
   return conv_pack_weights2_t<__bf16>(W, vol, n_in, n_out, reinterpret_cast<__bf16 *>(wpack_fwd),
                                       reinterpret_cast<__bf16 *>(wpack_t), stream_);
+}
+
+extern "C" int aabr_conv_dw_chunk_pairs(int64_t V_out, int vol, int n_in, int n_out) {
+  return dw_chunk(V_out, vol, n_in, n_out);
 }

@@ -175,11 +175,12 @@ class _Gather(object):
             self._host_counts = c.view(self.vol, -1).sum(1).tolist() if c.numel() else [0] * self.vol
         return self._host_counts
 
-    def max_chunks(self):
-        """upper bound on the 1024-pair chunks of the weight-gradient pass"""
+    def max_chunks(self, n_in, n_out):
+        """upper bound on the chunks of the weight-gradient pass"""
+        cp = _hip.load().aabr_conv_dw_chunk_pairs(self.rows, self.vol, n_in, n_out)
         if self._host_counts is not None:
-            return sum((c + 1023) // 1024 for c in self._host_counts)
-        return (self.vol * self.rows + 1023) // 1024 + self.vol
+            return sum((c + cp - 1) // cp for c in self._host_counts)
+        return (self.vol * self.rows + cp - 1) // cp + self.vol
 
 
 class _Table(object):
@@ -514,7 +515,7 @@ def _conv_dw(inp, d_out, gather, d_weight, d_bias):
     assert gather.rows == V_out
     assert d_weight.is_contiguous() and d_weight.numel() == gather.vol * n_in * n_out
     pairs = gather.pairs()
-    mc = gather.max_chunks()
+    mc = gather.max_chunks(n_in, n_out)
     scratch = _hip.workspace("dw", lib.aabr_conv_dw_scratch_floats(mc, n_in, n_out), torch.float32, inp.device)
     _same_dtype(inp, d_out, "convolution backward")
     fn = lib.aabr_conv_backward_weight_bf16 if inp.dtype == torch.bfloat16 else lib.aabr_conv_backward_weight

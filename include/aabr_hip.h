@@ -169,12 +169,13 @@ int aabr_conv_pack_weights2(const float *W, int vol, int n_in, int n_out, float 
 int aabr_conv_pack_weights2_bf16(const float *W, int vol, int n_in, int n_out, uint16_t *wpack_fwd,
                                  uint16_t *wpack_t, void *stream);
 /* dW[k] = sum over offset k's pairs (t, o) of in[t]^T (x) d_out[o]; d_bias (optional) = column
- * sums of d_out.  max_chunks bounds the number of 1024-pair chunks: sum_k ceil(R_k/1024) when the
- * rule counts are known on the host, else ceil(vol*V/1024) + vol; scratch float32
+ * sums of d_out.  max_chunks bounds the number of chunks of c = aabr_conv_dw_chunk_pairs(V, vol, nIn, nOut) pairs:
+ * sum_k ceil(R_k/c) when the rule counts are known on the host, else ceil(vol*V/c) + vol; scratch float32
  * [aabr_conv_dw_scratch_floats(max_chunks, nIn, nOut)].  Deterministic (no atomics).
  * Replaces the dW half of *_backward (CPU/Convolution.cpp:81-115,151-185;
  * CUDA/Convolution.cu:249-441,526-667).                                                     */
 int64_t aabr_conv_dw_scratch_floats(int64_t max_chunks, int n_in, int n_out);
+int aabr_conv_dw_chunk_pairs(int64_t V_out, int vol, int n_in, int n_out); /* 256 or 1024 */
 int aabr_conv_backward_weight(const float *in_feats, int n_in, const float *d_out, int n_out,
                               int64_t V_out, const int32_t *pairs, int vol, int64_t max_chunks,
                               float *dW, float *d_bias, float *scratch, void *stream);

@@ -20,7 +20,6 @@ V = tb.V_out
 R = tb.total_rules()
 lib = _hip.load()
 blocks, pairs = tb.out.blocks(), tb.out.pairs()
-mc = tb.out.max_chunks()
 print("V=%d R=%d" % (V, R))
 for ci, co in ((9, 32), (32, 32), (32, 64), (64, 32), (64, 64), (128, 128), (256, 256), (32, 128), (128, 32)):
     inp = torch.randn(V, ci, device=dev)
@@ -44,6 +43,7 @@ for ci, co in ((9, 32), (32, 32), (32, 64), (64, 32), (64, 64), (128, 128), (256
         b.record(); torch.cuda.synchronize()
         extra.append(a.elapsed_time(b) / n * 1e3)
     print("   fwd variants (flat kernel): no-MFMA %.1f us, no-gather %.1f us, neither %.1f us, no main loop %.1f us" % tuple(extra))
+    mc = tb.out.max_chunks(ci, co)
     dW = torch.empty_like(w)
     scratch = torch.empty(lib.aabr_conv_dw_scratch_floats(mc, ci, co), device=dev)
     dout = torch.randn(V, co, device=dev)
@@ -73,6 +73,7 @@ for ci, co in ((32, 32), (64, 64), (128, 128), (256, 256), (32, 128), (128, 32))
         check(lib.aabr_conv_forward_bf16(ptr(inp), ci, V, ptr(out), co, V, ptr(blocks), 27, ptr(w), None, 4, ptr(wpack), stream()))
     b.record(); torch.cuda.synchronize()
     t = a.elapsed_time(b) / n * 1e-3
+    mc = tb.out.max_chunks(ci, co)
     dW = torch.empty_like(w)
     scratch = torch.empty(lib.aabr_conv_dw_scratch_floats(mc, ci, co), device=dev)
     dout = torch.randn(V, co, device=dev).to(torch.bfloat16)
