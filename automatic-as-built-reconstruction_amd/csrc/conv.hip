@@ -1488,7 +1488,11 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
       hipLaunchKernelGGL((k_conv_blocks_mfma<NBW, WPB, false>), grid, dim3(64 * (WPB)), lds, st,        \
                          in_feats, n_in, out_feats, n_out, V_out, blocks, vol, flip, wpack, bias);      \
   } while (0)
-  const int nbw = nnb <= 1 ? 1 : (nnb == 2 ? 2 : 4);
+  // widest column slab the layer allows (fewest re-gathers of the input rows) -- unless the rule book is so
+  // small that the launch would leave most CUs idle (the coarse FPN scales: 1-50 tiles): then narrower
+  // slabs, i.e. more and shorter workgroups; at that size the gathers are latency, not bandwidth
+  int nbw = nnb <= 1 ? 1 : (nnb == 2 ? 2 : 4);
+  while (nbw > 1 && ceil_div(V_out, 64) * ceil_div(nnb, nbw) < 512) nbw >>= 1;
   const int64_t wgs = ceil_div(V_out, 64) * ceil_div(nnb, nbw);
   int best_wpb = 2;
   int64_t best_cost = -1;
