@@ -1296,6 +1296,149 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in,
     }
 }
 
+// bf16 features: the same chunked scheme on v_mfma_f32_16x16x32_bf16 with the PAIR index as K.
+// The MFMA wants, per lane, 8 consecutive pairs of ONE channel -- a transpose of the row-major
+// feature matrices.  Each wave stages 32 gathered rows (16-byte global loads, 16-byte LDS writes, rows
+// padded by 16 B) and reads the operands back with ds_read_b64_tr_b16 (hardware 4x16 transpose: lane L
+// of a 16-lane group receives column L of 4 rows): two reads per 16-channel fragment.  The next batch's
+// rows are loaded into registers while the current batch's MFMAs run.  CB, NB in {2, 4}.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int CB, int NB>
+__global__ __launch_bounds__(256) void k_conv_dw_pairs_bf16(const __bf16 *__restrict__ in, int ci,
+                                                            const __bf16 *__restrict__ d_out, int co, int64_t V,
+                                                            const int32_t *__restrict__ words, int vol,
+                                                            int chunk_pairs, float *__restrict__ partial) {
+  constexpr int SX = CB * 32 + 16, SG = NB * 32 + 16; // LDS row strides (bytes)
+  constexpr int XCH = CB * 2, GCH = NB * 2;           // 16-byte chunks per row
+  constexpr int XIT = (32 * XCH) / 64, GIT = (32 * GCH) / 64; // chunks per lane and batch
+  __shared__ f32x4 red[CB * NB][64];
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][32 * (SX + SG)];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int nnb = nnb_of(co);
+  const int tiles_n = (nnb + NB - 1) / NB;
+  const int tile = blockIdx.y;
+  const int cb0 = (tile / tiles_n) * CB, nb0 = (tile % tiles_n) * NB;
+  const int chunk = blockIdx.x;
+  const int32_t *cstart = words + vol + (chunk_pairs == 256 ? vol + 1 : 0);
+  if (chunk >= cstart[vol]) return;                        // workgroup-uniform
+  int k = 0;
+  for (int k0 = 0; k0 < vol; k0 += 64) {
+    int kk = k0 + lane;
+    bool mine = kk < vol && cstart[kk] <= chunk && chunk < cstart[kk + 1];
+    unsigned long long m = __ballot(mine);
+    if (m) { k = k0 + (__ffsll((long long)m) - 1); break; }
+  }
+  const int rk = words[k];
+  const int p0 = (chunk - cstart[k]) * chunk_pairs + wave * (chunk_pairs / 4);
+  int p1 = p0 + chunk_pairs / 4;
+  if (p1 > rk) p1 = rk;
+  const int2 *pairs = reinterpret_cast<const int2 *>(words + op_hdr(vol) + (int64_t)vol * op_nb256(V)) +
+                      (int64_t)k * V;
+  unsigned char *xs = stage[wave], *gs = stage[wave] + 32 * SX;
+  f32x4 acc[CB][NB];
+#pragma unroll
+  for (int a = 0; a < CB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // register staging of one batch: XIT + GIT 16-byte chunks per lane (rows past the range: zeros)
+  u32x4 xr[XIT], gr[GIT];
+  auto load_batch = [&](int q32) {
+    const int q = q32 + (lane & 31);
+    const int2 pr = (q < p1) ? pairs[q] : make_int2(-1, -1);
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int id = it * 64 + lane, row = id / XCH, ch = id - row * XCH;
+      const int t = __shfl(pr.x, row);
+      xr[it] = (u32x4){0u, 0u, 0u, 0u};
+      if (t >= 0 && cb0 * 16 + ch * 8 < ci) // planes past the layer width (last tile): zeros, never read out of the row
+        xr[it] = *reinterpret_cast<const u32x4 *>(in + (int64_t)t * ci + cb0 * 16 + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < GIT; ++it) {
+      const int id = it * 64 + lane, row = id / GCH, ch = id - row * GCH;
+      const int o = __shfl(pr.y, row);
+      gr[it] = (u32x4){0u, 0u, 0u, 0u};
+      if (o >= 0 && nb0 * 16 + ch * 8 < co)
+        gr[it] = *reinterpret_cast<const u32x4 *>(d_out + (int64_t)o * co + nb0 * 16 + ch * 8);
+    }
+  };
+  auto store_batch = [&]() {
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int id = it * 64 + lane, row = id / XCH, ch = id - row * XCH;
+      *reinterpret_cast<u32x4 *>(xs + row * SX + ch * 16) = xr[it];
+    }
+#pragma unroll
+    for (int it = 0; it < GIT; ++it) {
+      const int id = it * 64 + lane, row = id / GCH, ch = id - row * GCH;
+      *reinterpret_cast<u32x4 *>(gs + row * SG + ch * 16) = gr[it];
+    }
+  };
+  // transposed operand: rows (pairs) g*8 .. g*8+7 of 16-bit column (blk*16 + c16)
+  const int q4 = c16 >> 2, p4 = c16 & 3;
+  auto tr_frag = [&](const unsigned char *base, int stride, int blk) {
+    const unsigned char *a0 = base + (g * 8 + q4) * stride + (blk * 16 + 4 * p4) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a0);
+    const s16x4 hi =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a0 + 4 * stride));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  if (p0 < p1) { // wave-uniform: the tr reads below always run with all 64 lanes active
+    load_batch(p0);
+    for (int q32 = p0; q32 < p1; q32 += 32) {
+      store_batch();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (q32 + 32 < p1) load_batch(q32 + 32);
+      bf16x8 af[CB], bf[NB];
+#pragma unroll
+      for (int a = 0; a < CB; ++a) af[a] = tr_frag(xs, SX, a);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) bf[b] = tr_frag(gs, SG, b);
+#pragma unroll
+      for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // reads done before the next batch overwrites
+    }
+  }
+  // sum the four waves' accumulators in wave order: w0 + w1 + w2 + w3
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (w == 0) red[a * NB + b][lane] = acc[a][b];
+          else {
+            f32x4 t = red[a * NB + b][lane];
+            t[0] += acc[a][b][0]; t[1] += acc[a][b][1]; t[2] += acc[a][b][2]; t[3] += acc[a][b][3];
+            red[a * NB + b][lane] = t;
+          }
+        }
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+  float *P = partial + (int64_t)chunk * ci * co;
+#pragma unroll
+  for (int a = 0; a < CB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      f32x4 t = red[a * NB + b][lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int c = (cb0 + a) * 16 + g * 4 + r, n = (nb0 + b) * 16 + c16;
+        if (c < ci && n < co) P[(int64_t)c * co + n] = t[r];
+      }
+    }
+}
+
 // dW[k][i] = sum of the partials of offset k's chunks (fixed order => deterministic): a block takes 64
 // consecutive elements i and deals the chunks to 4 slices (chunk c0+s, c0+s+4, ...), several loads in
 // flight per thread; the slices are combined in slice order through LDS
@@ -1584,6 +1727,36 @@ extern "C" int aabr_conv_backward_weight_bf16(const uint16_t *in_feats, int n_in
                                               int n_out, int64_t V_out, const int32_t *pairs, int vol,
                                               int64_t max_chunks, float *dW, float *d_bias, float *scratch,
                                               void *stream_) {
+  if (n_in > 0 && n_out > 0 && n_in % 32 == 0 && n_out % 32 == 0 && V_out > 0 && max_chunks > 0 &&
+      ((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)d_out & 15) == 0) {
+    // bf16 MFMA with LDS-transposed operands
+    hipStream_t st = (hipStream_t)stream_;
+    AABR_CHECK_ARG(vol > 0 && vol <= 65535 && n_in <= 4096 && n_out <= 4096, "bad sizes");
+    AABR_CHECK_ARG(in_feats && d_out && pairs && scratch && dW, "null pointer");
+    const __bf16 *in16 = reinterpret_cast<const __bf16 *>(in_feats), *do16 = reinterpret_cast<const __bf16 *>(d_out);
+    const int ncb = nnb_of(n_in), nnb = nnb_of(n_out);
+    const int cb = ncb >= 4 ? 4 : 2, nb = nnb >= 4 ? 4 : 2; // plane counts are multiples of 32
+    const int tiles = (int)(ceil_div(ncb, cb) * ceil_div(nnb, nb));
+    AABR_CHECK_ARG(tiles <= 65535, "too many tiles");
+    const int chunk_pairs = dw_chunk(V_out, vol, n_in, n_out);
+    const int64_t cico = (int64_t)n_in * n_out;
+    dim3 grid((unsigned)max_chunks, (unsigned)tiles);
+#define AABR_LAUNCH_DW16(CB, NB)                                                                          \
+  hipLaunchKernelGGL((k_conv_dw_pairs_bf16<CB, NB>), grid, dim3(256), 0, st, in16, n_in, do16, n_out, V_out, \
+                     pairs, vol, chunk_pairs, scratch)
+    if (cb == 2 && nb == 2) AABR_LAUNCH_DW16(2, 2);
+    else if (cb == 2 && nb == 4) AABR_LAUNCH_DW16(2, 4);
+    else if (cb == 4 && nb == 2) AABR_LAUNCH_DW16(4, 2);
+    else AABR_LAUNCH_DW16(4, 4);
+#undef AABR_LAUNCH_DW16
+    hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
+                       scratch, pairs, vol, chunk_pairs, cico, dW);
+    if (d_bias)
+      hipLaunchKernelGGL((k_col_sum<__bf16>), dim3((unsigned)ceil_div(n_out, 64)), dim3(256), 0, st, do16, V_out,
+                         n_out, d_bias);
+    AABR_CHECK_LAUNCH();
+    return AABR_OK;
+  }
   return conv_backward_weight_t<__bf16>(reinterpret_cast<const __bf16 *>(in_feats), n_in,
                                         reinterpret_cast<const __bf16 *>(d_out), n_out, V_out, pairs, vol,
                                         max_chunks, dW, d_bias, scratch, stream_);
