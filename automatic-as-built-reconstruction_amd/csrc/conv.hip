@@ -1789,7 +1789,8 @@ extern "C" int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_
   if (!(flags & 4))
     hipLaunchKernelGGL(k_pack_weights_bf16, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, W, vol, n_in,
                        n_out, transpose, wp);
-  const int nbw = nnb == 2 ? 2 : 4;
+  int nbw = nnb == 2 ? 2 : 4;
+  if (nbw == 4 && ceil_div(V_out, 64) * ceil_div(nnb, 4) < 512) nbw = 2; // small rule book: more, shorter workgroups
   const int kg = nkc >= 3 ? 4 : nkc;
   const int64_t wgs = ceil_div(V_out, 64) * ceil_div(nnb, nbw);
   int best_wpb = 2;

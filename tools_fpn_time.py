@@ -11,9 +11,10 @@ from test_cabi_and_host import default_fpn
 npts = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
 vs = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 bs = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+fdt = torch.bfloat16 if (len(sys.argv) > 4 and sys.argv[4] == "bf16") else torch.float32
 dev = "cuda:0"
 torch.manual_seed(0)
-net = default_fpn().to(dev)
+net = default_fpn(feature_dtype=fdt).to(dev)
 locs, feats = S.make_batch(bs, npts, 0, vs)
 l, f = torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)
 
@@ -36,7 +37,7 @@ for bwd in (False, True):
     for _ in range(n):
         r = run(bwd)
     torch.cuda.synchronize()
-    print("FPN_Net %d pts x bs%d @scale %d  %s: %.2f ms/iter  (V0=%d, MACs=%.3g)" % (
-        npts, bs, vs, "fwd+bwd" if bwd else "fwd", (time.perf_counter() - t0) / n * 1e3,
+    print("FPN_Net[%s] %d pts x bs%d @scale %d  %s: %.2f ms/iter  (V0=%d, MACs=%.3g)" % (
+        str(fdt).split(".")[-1], npts, bs, vs, "fwd+bwd" if bwd else "fwd", (time.perf_counter() - t0) / n * 1e3,
         r[0].metadata.input["V"], float(scn.forward_pass_multiplyAdd_count)))
 print("max mem GB", torch.cuda.max_memory_allocated() / 1e9)
