@@ -740,6 +740,115 @@ __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_wpipe(
   }
 }
 
+// ------------------------------------------------------------------ tiny rule books
+// The coarse FPN scales have 1-50 tiles and 128-256 planes: a launch of the kernels above is a handful of
+// workgroups walking 30-40 dependent (pair, channel-chunk) steps each (60 us for ~50 M MACs).  This variant
+// cuts the work finer: 16 output columns per workgroup, 8 waves, and the unit dealt to a wave is one
+// 32-channel chunk of one block pair, so a tile's ~15 pairs x 4-8 chunks spread over 8 waves x (co/16)
+// workgroups.  Every item ends with its own LDS accumulate (private tile per wave, summed in wave order:
+// still deterministic).  Gathers and weights are prefetched one item ahead (fixed register sets).
+struct ItemEnt { int eA, eB, kA, kB; };
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64, 1) void k_conv_blocks_mfma_small(
+    const float *__restrict__ in, int ci, int64_t in_bytes, float *__restrict__ out, int co, int64_t V_out,
+    const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const float *__restrict__ Wp,
+    int64_t wp_bytes, const float *__restrict__ bias) {
+  constexpr int WS = 16, TILE = 64 * WS;
+  extern __shared__ __align__(16) float smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  float *Ct = smem + (size_t)wave * TILE;
+  const int maxb = tb_maxb(vol);
+  const int nkc = ci >> 5, nnb = nnb_of(co);
+  const int nb0 = blockIdx.y;
+  const int64_t tile = blockIdx.x, row0 = tile * 64;
+  const int64_t ntiles = tb_ntiles(V_out);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, (int)wp_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwords =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(words), 0, (int)words_bytes, 0x00020000);
+  const int nblk = words[tile];
+  const unsigned kbase = (unsigned)((ntiles + tile * maxb) * 4);
+  const unsigned ebase = (unsigned)((ntiles + ntiles * maxb + tile * maxb * 16) * 4);
+  const unsigned rowbytes = (unsigned)ci * 4u, g32 = (unsigned)g * 32u, lane32 = (unsigned)lane * 32u;
+  const unsigned wk_bytes = (unsigned)nkc * (unsigned)nnb * 2048u, kc_bytes = (unsigned)nnb * 2048u;
+  const unsigned c16x4 = (unsigned)c16 * 4u;
+
+  for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
+
+  const int nitems = ((nblk + 1) >> 1) * nkc;               // (block pair, channel chunk)
+  const int nmine = wave < nitems ? (nitems - wave + WPB - 1) / WPB : 0;
+  auto load_item = [&](int j) {                             // this wave's j-th item
+    ItemEnt p;
+    int it = wave + j * WPB;
+    if (it >= nitems) it = nitems > 0 ? nitems - 1 : 0;     // past the end: harmless re-read, never consumed
+    int bA = 2 * (it / nkc);
+    if (bA >= nblk) bA = 0;
+    int bB = bA + 1;
+    const bool hasB = bB < nblk;
+    if (!hasB) bB = bA;
+    p.eA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bA * 64u, 0);
+    p.eB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bB * 64u, 0);
+    if (!hasB) p.eB |= (int)0x80000000;
+    p.kA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bA * 4u, 0);
+    p.kB = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, 0u, kbase + (unsigned)bB * 4u, 0);
+    return p;
+  };
+  auto kc_of = [&](int j) {
+    int it = wave + j * WPB;
+    if (it >= nitems) it = nitems > 0 ? nitems - 1 : 0;
+    return it % nkc;
+  };
+  auto fetch = [&](GStep &q, WSet<1> &w, const ItemEnt &p, int kc) {
+    const unsigned va = (((unsigned)p.eA & 0x7fffffffu) >> 6) * rowbytes + g32;
+    const unsigned vb = (((unsigned)p.eB & 0x7fffffffu) >> 6) * rowbytes + g32;
+    const unsigned so = (unsigned)kc * 128u;
+    q.a0 = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
+    q.a1 = __builtin_amdgcn_raw_buffer_load_b128(rin, va + 16u, so, 0);
+    q.b0 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb, so, 0);
+    q.b1 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb + 16u, so, 0);
+    int kA = __builtin_amdgcn_readfirstlane(p.kA), kB = __builtin_amdgcn_readfirstlane(p.kB);
+    if (wflip) { kA = vol - 1 - kA; kB = vol - 1 - kB; }
+    const unsigned off = (unsigned)kc * kc_bytes + (unsigned)nb0 * 2048u;
+    conv_load_w<1>(w, rw, lane32, (unsigned)kA * wk_bytes + off, (unsigned)kB * wk_bytes + off, 1);
+  };
+  auto compute = [&](const GStep &q, const WSet<1> &w, const ItemEnt &p) {
+    f32x4 accA[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, accB[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    conv_step_mfma_w<1>(q, w, 1, accA, accB);
+    conv_block_accumulate<1, WS>(Ct, p.eA, g, accA);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // A and B may hit the same row
+    conv_block_accumulate<1, WS>(Ct, p.eB, g, accB);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+  ItemEnt e0 = load_item(0), e1 = load_item(1), e2 = load_item(2);
+  GStep s0, s1;
+  WSet<1> w0, w1;
+  if (nmine > 0) fetch(s0, w0, e0, kc_of(0));
+  for (int j = 0; j < nmine; j += 2) {
+    if (j + 1 < nmine) fetch(s1, w1, e1, kc_of(j + 1));
+    compute(s0, w0, e0);
+    ItemEnt e3 = load_item(j + 3);
+    if (j + 1 < nmine) {
+      if (j + 2 < nmine) fetch(s0, w0, e2, kc_of(j + 2));
+      compute(s1, w1, e1);
+    }
+    ItemEnt e4 = load_item(j + 4);
+    e0 = e2; e1 = e3; e2 = e4;
+  }
+  __syncthreads();
+  const int nrows = (int)((V_out - row0) < 64 ? (V_out - row0) : 64);
+  const int wcols = (co - nb0 * 16) < 16 ? (co - nb0 * 16) : 16;
+  for (int i = threadIdx.x; i < nrows * wcols; i += WPB * 64) {
+    const int r = i / wcols, cc = i - r * wcols;
+    float v = smem[r * WS + cc];
+#pragma unroll
+    for (int w = 1; w < WPB; ++w) v += smem[(size_t)w * TILE + r * WS + cc];
+    if (bias) v += bias[nb0 * 16 + cc];
+    out[(row0 + r) * co + nb0 * 16 + cc] = v;
+  }
+}
+
 // ------------------------------------------------------------------ LDS-resident weights
 // For layers whose whole packed filter bank fits in LDS next to the output tiles
 // (vol * ceil(ci/32) * ceil(co/16) * 2 KiB <= ~110 KiB: 3x3x3 at <=32->32 planes, the 2x2x2 strided
@@ -1608,6 +1717,18 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
       else AABR_LAUNCH_WLDS_K(4);
 #undef AABR_LAUNCH_WLDS_K
 #undef AABR_LAUNCH_WLDS
+      AABR_CHECK_LAUNCH();
+      return AABR_OK;
+    }
+  }
+  // tiny rule books with wide layers (coarse FPN scales): (pair, chunk) items over 8 waves x 16-column slabs
+  if (lean && nkc >= 2 && ceil_div(V_out, 64) * nnb < 512) {
+    const char *ov = getenv("AABR_CONV_SMALL"); // tuning experiments only: 0 disables
+    if (!(ov && ov[0] == '0')) {
+      constexpr int kW = 8;
+      hipLaunchKernelGGL((k_conv_blocks_mfma_small<kW>), dim3((unsigned)ceil_div(V_out, 64), (unsigned)nnb),
+                         dim3(64 * kW), (size_t)kW * 64 * 16 * sizeof(float), st, in_feats, n_in, in_bytes, out_feats,
+                         n_out, V_out, blocks, words_bytes, vol, flip & 1, wpack, wp_bytes, bias);
       AABR_CHECK_LAUNCH();
       return AABR_OK;
     }
