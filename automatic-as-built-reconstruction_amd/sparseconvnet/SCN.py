@@ -19,12 +19,13 @@ count_macs = True  # the reference returns the multiply-add count of every conv;
 
 
 class LazyMacs(object):
-    """Sum of (device rule-total scalar, multiplier) terms that behaves like the float the
+    """Sum of (device rule-count tensor, multiplier) terms that behaves like the float the
     reference returns (`sparseconvnet.forward_pass_multiplyAdd_count += ...`,
     submanifoldConvolution.py:85-94) but performs the device->host read only when the value
     is actually looked at -- so counting costs no host synchronisation in the training loop.
-    Only 0-dim totals are referenced (one reduction per rule book, cached on it; never the rule
-    tables), and the pending list is folded into the base value once it holds more than 1024 terms."""
+    Only the small per-(offset, 256-row block) count tensors are referenced (never the rule tables);
+    nothing is launched per layer, and the pending list is folded into the base value (three launches,
+    one read-back) once it holds more than 1024 terms."""
     __slots__ = ("terms", "base")
 
     def __init__(self, terms=(), base=0.0):
@@ -32,10 +33,22 @@ class LazyMacs(object):
 
     def _value(self):
         if self.terms:
-            # one gather kernel + one read-back for the whole pending list
-            dev = self.terms[0][0].device
-            vals = torch.stack([t.to(dev) for t, _ in self.terms]).tolist()
-            self.base += sum(v * m for v, (_, m) in zip(vals, self.terms))
+            # the whole pending list in three launches and one read-back: concatenate the (small) count
+            # tensors of the distinct rule books, prefix-sum, pick the segment ends
+            uniq, order = {}, []
+            for c, _ in self.terms:
+                if id(c) not in uniq:
+                    uniq[id(c)] = len(order)
+                    order.append(c)
+            dev = order[0].device
+            ends, tot = [], 0
+            for c in order:
+                tot += c.numel()
+                ends.append(tot - 1)
+            cs = torch.cat([c.to(dev).reshape(-1) for c in order]).cumsum(0, dtype=torch.int64)
+            pref = cs[torch.tensor(ends, device=dev)].tolist()
+            sums = [pref[i] - (pref[i - 1] if i else 0) for i in range(len(pref))]
+            self.base += sum(float(sums[uniq[id(c)]]) * m for c, m in self.terms)
             self.terms = []
         return self.base
 
@@ -125,17 +138,11 @@ class _Grid(object):
 
 class _Gather(object):
     """one gather table [vol, rows] + its compiled streaming forms (built lazily, cached)"""
-    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_pairs", "_host_counts", "_total")
+    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_pairs", "_host_counts")
 
     def __init__(self, table, counts, vol, rows):
         self.table, self.counts, self.vol, self.rows = table, counts, vol, rows
-        self._blocks = self._pairs = self._host_counts = self._total = None
-
-    def total_dev(self):
-        """number of rules as a 0-dim float64 device tensor (one reduction per rule book, cached)"""
-        if self._total is None:
-            self._total = self._ensure_counts().sum(dtype=torch.float64)
-        return self._total
+        self._blocks = self._pairs = self._host_counts = None
 
     def _ensure_counts(self):
         if self.counts is None:  # table built without counts (input side of a strided book)
@@ -526,7 +533,7 @@ def _conv_dw(inp, d_out, gather, d_weight, d_bias):
 def _macs(tb, weight):
     if not count_macs:
         return 0.0
-    return LazyMacs([(tb.out.total_dev(), float(weight.size(2) * weight.size(3) * weight.size(1)))])
+    return LazyMacs([(tb.out._ensure_counts(), float(weight.size(2) * weight.size(3) * weight.size(1)))])
 
 
 # SubmanifoldConvolution (pybind.cpp:134-143)
