@@ -11,21 +11,61 @@ runs on the current PyTorch HIP stream.
 """
 import torch
 
+import os
+
 import _hip
 from _hip import ptr, stream, check
 
-count_macs = True  # the reference returns the multiply-add count of every conv; here the count is
+count_macs = os.environ.get("AABR_COUNT_MACS", "1") != "0"  # the reference returns the multiply-add count of every conv; here the count is
                    # a LAZY number: the rule counts stay on the device until somebody reads it
 
 
+class _TotalsRing(object):
+    """Device buffer of per-rule-book rule totals (float64).  A rule book writes its total into the next free
+    slot with ONE reduction launch when a layer first asks for it; reading values back is one copy of the
+    whole buffer.  When the buffer is full it is read back once, kept on the host under its generation
+    number, and reused."""
+    CAP = 4096
+
+    def __init__(self, device):
+        self.buf = torch.zeros(self.CAP, dtype=torch.float64, device=device)
+        self.gen, self.n, self.retired, self._snap = 0, 0, {}, None
+
+    def alloc(self):
+        if self.n == self.CAP:
+            self.retired[self.gen] = self.buf.tolist()
+            self.retired.pop(self.gen - 8, None)
+            self.gen, self.n, self._snap = self.gen + 1, 0, None
+        self.n += 1
+        self._snap = None
+        return self.gen, self.n - 1
+
+    def value(self, gen, idx):
+        if gen == self.gen:
+            if self._snap is None:
+                self._snap = self.buf[:self.n].tolist()  # the one read-back (host sync) of a fold
+            return self._snap[idx]
+        return self.retired[gen][idx]
+
+
+_rings = {}
+
+
+def _ring(device):
+    r = _rings.get(device)
+    if r is None:
+        r = _rings[device] = _TotalsRing(device)
+    return r
+
+
 class LazyMacs(object):
-    """Sum of (device rule-count tensor, multiplier) terms that behaves like the float the
+    """Sum of (rule-total slot, multiplier) terms that behaves like the float the
     reference returns (`sparseconvnet.forward_pass_multiplyAdd_count += ...`,
     submanifoldConvolution.py:85-94) but performs the device->host read only when the value
     is actually looked at -- so counting costs no host synchronisation in the training loop.
-    Only the small per-(offset, 256-row block) count tensors are referenced (never the rule tables);
-    nothing is launched per layer, and the pending list is folded into the base value (three launches,
-    one read-back) once it holds more than 1024 terms."""
+    A term references a slot of the per-device totals buffer (never a rule table); a rule book costs
+    one small reduction launch however many layers use it, and the pending list is folded into the
+    base value (one read-back) once it holds more than 1024 terms."""
     __slots__ = ("terms", "base")
 
     def __init__(self, terms=(), base=0.0):
@@ -33,22 +73,7 @@ class LazyMacs(object):
 
     def _value(self):
         if self.terms:
-            # the whole pending list in three launches and one read-back: concatenate the (small) count
-            # tensors of the distinct rule books, prefix-sum, pick the segment ends
-            uniq, order = {}, []
-            for c, _ in self.terms:
-                if id(c) not in uniq:
-                    uniq[id(c)] = len(order)
-                    order.append(c)
-            dev = order[0].device
-            ends, tot = [], 0
-            for c in order:
-                tot += c.numel()
-                ends.append(tot - 1)
-            cs = torch.cat([c.to(dev).reshape(-1) for c in order]).cumsum(0, dtype=torch.int64)
-            pref = cs[torch.tensor(ends, device=dev)].tolist()
-            sums = [pref[i] - (pref[i - 1] if i else 0) for i in range(len(pref))]
-            self.base += sum(float(sums[uniq[id(c)]]) * m for c, m in self.terms)
+            self.base += sum(ring.value(gen, idx) * m for ring, gen, idx, m in self.terms)
             self.terms = []
         return self.base
 
@@ -138,11 +163,20 @@ class _Grid(object):
 
 class _Gather(object):
     """one gather table [vol, rows] + its compiled streaming forms (built lazily, cached)"""
-    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_pairs", "_host_counts")
+    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_pairs", "_host_counts", "_total")
 
     def __init__(self, table, counts, vol, rows):
         self.table, self.counts, self.vol, self.rows = table, counts, vol, rows
-        self._blocks = self._pairs = self._host_counts = None
+        self._blocks = self._pairs = self._host_counts = self._total = None
+
+    def total_slot(self):
+        """(ring, generation, index) of this rule book's rule total on the device"""
+        if self._total is None:
+            ring = _ring(self.table.device)
+            gen, idx = ring.alloc()
+            torch.sum(self._ensure_counts(), (0,), dtype=torch.float64, out=ring.buf[idx])
+            self._total = (ring, gen, idx)
+        return self._total
 
     def _ensure_counts(self):
         if self.counts is None:  # table built without counts (input side of a strided book)
@@ -533,7 +567,7 @@ def _conv_dw(inp, d_out, gather, d_weight, d_bias):
 def _macs(tb, weight):
     if not count_macs:
         return 0.0
-    return LazyMacs([(tb.out._ensure_counts(), float(weight.size(2) * weight.size(3) * weight.size(1)))])
+    return LazyMacs([tb.out.total_slot() + (float(weight.size(2) * weight.size(3) * weight.size(1)),)])
 
 
 # SubmanifoldConvolution (pybind.cpp:134-143)

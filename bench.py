@@ -126,6 +126,42 @@ def time_stage(fn, reps=10):
     return a.elapsed_time(b) * 1e-3 / reps
 
 
+def pin_host_threads(local_rank, ncores=4):
+    """Bind this process (launch thread + autograd thread) to a few cores of the GPU's NUMA node.  On a
+    2-socket host the unbound process wanders over 256 hardware threads and the launch-bound step time
+    moves by 10-30 % from run to run (measured: 1,890-2,010 scenes/s unbound, 2,140-2,190 bound).
+    Best effort: any failure leaves the affinity untouched."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if len(allowed) <= ncores:
+            return None
+        cand = allowed
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            bdf = None
+        if bdf:
+            node_file = "/sys/bus/pci/devices/%s/numa_node" % str(bdf).lower()
+            if os.path.exists(node_file):
+                node = int(open(node_file).read().strip())
+                if node >= 0:
+                    cl = open("/sys/devices/system/node/node%d/cpulist" % node).read().strip()
+                    cpus = []
+                    for part in cl.split(","):
+                        a, _, b = part.partition("-")
+                        cpus += list(range(int(a), int(b or a) + 1))
+                    cand = [c for c in cpus if c in set(allowed)] or allowed
+        # distinct blocks for the ranks sharing a node: stride by rank modulo the blocks that fit
+        nblocks = max(1, len(cand) // ncores)
+        b0 = (local_rank % nblocks) * ncores
+        cores = set(cand[b0:b0 + ncores])
+        os.sched_setaffinity(0, cores)
+        return sorted(cores)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +190,8 @@ def main():
     backend = os.environ.get("AABR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if os.environ.get("AABR_BENCH_PIN", "1") != "0":
+        pin_host_threads(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
