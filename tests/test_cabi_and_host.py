@@ -133,3 +133,45 @@ def test_kernel_iou_arithmetic_on_host_matches_oracle(tmp_path):
     got = np.zeros((4, 4), np.float32)
     L.host_iou_eval(g["t_boxes"], 4, g["t_boxes"], 4, -1, got)
     np.testing.assert_array_equal(got, g["t_iou"])
+
+
+def test_lazy_mac_counter_ring_logic():
+    """host logic of the lazily evaluated multiply-add counter: slots, generations, folding"""
+    import sparseconvnet.SCN as SCN
+    ring = SCN._TotalsRing(torch.device("cpu"))
+    ring.CAP = 8
+    ring.buf = torch.zeros(8, dtype=torch.float64)
+    acc = SCN.LazyMacs()
+    want = 0.0
+    slots = []
+    for i in range(29):  # wraps the 8-slot ring three times
+        gen, idx = ring.alloc()
+        ring.buf[idx] = float(i + 1)
+        slots.append((ring, gen, idx))
+        acc += SCN.LazyMacs([(ring, gen, idx, 2.0)])
+        want += 2.0 * (i + 1)
+        if i % 5 == 4:  # read in the middle: folds what is pending, keeps counting afterwards
+            assert float(acc) == want
+    assert float(acc) == want and int(acc) == int(want)
+    assert acc == want and acc > want - 1 and acc <= want
+    assert "%d" % acc == "%d" % want
+    # terms of a retired generation are still readable (the buffer was read back when it wrapped)
+    old = SCN.LazyMacs([slots[17] + (1.0,)])
+    assert float(old) == 18.0
+    # plain numbers mix in
+    acc2 = SCN.LazyMacs() + 5
+    acc2 += 7.0
+    assert float(acc2 + SCN.LazyMacs([slots[28] + (3.0,)])) == 12.0 + 3.0 * 29
+
+
+def test_dw_chunk_policy_is_consistent_with_the_library():
+    import _hip
+    lib = _hip.load()
+    assert lib.aabr_conv_dw_chunk_pairs(66094, 27, 32, 32) == 256      # S80k rule book, narrow layer
+    assert lib.aabr_conv_dw_chunk_pairs(66094, 27, 128, 128) == 1024   # wide layer: fewer, larger partials
+    assert lib.aabr_conv_dw_chunk_pairs(1000000, 27, 32, 32) == 1024   # large rule book
+    import sparseconvnet.SCN as SCN
+    g = SCN._Gather(None, None, 27, 66094)
+    assert g.max_chunks(32, 32) == (27 * 66094 + 255) // 256 + 27
+    g._host_counts = [300] * 27
+    assert g.max_chunks(32, 32) == 27 * 2 and g.max_chunks(256, 256) == 27
