@@ -53,6 +53,26 @@ class FlatParams(object):
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
             self.flat_grad.mul_(1.0 / world_size)
 
+    def start_allreduce(self, group=None):
+        """Pack the gradients and launch the gradient all-reduce WITHOUT waiting for it: the collective runs
+        on the backend's communication stream while the caller enqueues work that does not read the
+        parameters (the next scene's hash grid and rule books).  `finish_update` must run before the
+        parameters are used again."""
+        assert getattr(self, "_pending", None) is None, "previous all-reduce not finished"
+        self.pack_grads()
+        self._pending = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def finish_update(self, lr, world_size):
+        """wait (stream-ordered for nccl) for the pending all-reduce and apply the SGD update with the mean
+        gradient; no-op when nothing is pending"""
+        work = getattr(self, "_pending", None)
+        if work is None:
+            return False
+        work.wait()
+        self._pending = None
+        self.flat.add_(self.flat_grad, alpha=-lr / world_size)
+        return True
+
     def sgd_step(self, lr, world_size=1):
         """fused SGD update.  With one rank the gradients are consumed where autograd left them (one
         multi-tensor launch, no packing); with several ranks the all-reduced flat buffer is used."""

@@ -240,6 +240,9 @@ class _Table(object):
         return float(sum(self.rule_counts()))
 
 
+_pinned_pool = []  # (pinned int32[META_WORDS], event) pairs of finished asynchronous read-backs
+
+
 class Metadata_3(object):
     """Replaces Metadata<3> (SCN/Metadata/Metadata.h:44-163, pybind class Metadata_3,
     pybind.cpp:12-32,205).  Caches are keyed exactly like the reference's: grids by spatial
@@ -333,9 +336,11 @@ class Metadata_3(object):
                                              base + 4 * offs[7], base + 4 * offs[2], base + 4 * offs[3],
                                              base + 4 * offs[4], base + 4 * offs[5], base + 4 * offs[6], stream()))
             if asynchronous:
-                host = torch.empty(_hip.META_WORDS, dtype=torch.int32, pin_memory=True)
+                # pinned read-back buffer + event from a small recycling pool (allocating pinned memory
+                # per scene costs more than the whole enqueue)
+                host, ev = _pinned_pool.pop() if _pinned_pool else (
+                    torch.empty(_hip.META_WORDS, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
                 host.copy_(meta, non_blocking=True)
-                ev = torch.cuda.Event()
                 ev.record()
         else:  # empty scene: an empty grid (all keys EMPTY), nothing to launch
             keys.fill_(-1)
@@ -353,6 +358,8 @@ class Metadata_3(object):
             if pend["event"] is not None:
                 pend["event"].synchronize()
                 m = pend["host"].tolist()
+                if len(_pinned_pool) < 16:
+                    _pinned_pool.append((pend["host"], pend["event"]))
             else:
                 m = pend["meta"].tolist()  # synchronous read-back
             self._pending = None

@@ -28,8 +28,18 @@ def _worker(rank, world, port, q):
     fp.pack_grads()
     local = fp.flat_grad.clone()
     fp.allreduce_mean(world)
+    g_mean = fp.flat_grad.clone()
     fp.sgd_step(0.1, world)
-    q.put((rank, mine, local, fp.flat_grad.clone(), fp.flat.clone()))
+    # the overlapped form used by bench.py: launch the all-reduce, do parameter-independent work, finish
+    w_before = fp.flat.clone()
+    fp.zero_grad()
+    for s in mine:
+        lin(torch.full((2, 4), float(s + 2))).sum().backward()
+    fp.pack_grads()
+    local2 = fp.flat_grad.clone()
+    fp.start_allreduce()
+    assert fp.finish_update(0.1, world) is True and fp.finish_update(0.1, world) is False
+    q.put((rank, mine, local, g_mean, w_before, local2, fp.flat.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -45,10 +55,13 @@ def test_two_rank_gloo_allreduce_and_sharding():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, s0, l0, g0, w0), (_, s1, l1, g1, w1) = res
+    (_, s0, l0, g0, w0, m0, v0), (_, s1, l1, g1, w1, m1, v1) = res
     assert sorted(s0 + s1) == list(range(6)) and not set(s0) & set(s1)
     # balanced by size: 60+30+20 vs 50+40+10
     assert s0 == [1, 4, 2] and s1 == [3, 5, 0]
     torch.testing.assert_close(g0, (l0 + l1) / 2)
     torch.testing.assert_close(g0, g1)
     torch.testing.assert_close(w0, w1)  # replicas stay in lock-step after the update
+    # overlapped all-reduce + update: same result as the mean-gradient SGD step
+    torch.testing.assert_close(v0, w0 - 0.1 * (m0 + m1) / 2)
+    torch.testing.assert_close(v0, v1)
