@@ -59,3 +59,30 @@ def rpn_proposals_single_map(tensor, objectness, box_regression, base_anchors, v
         out.append((boxes[keep], score[keep]))
         s = e
     return out
+
+
+def cat_scales_obj_reg(objectness, rpn_box_regression, examples_idxscope):
+    """`cat_scales_obj_reg` (modeling/rpn/rpn_sparse3d.py:19-77) on plain tensors: the RPN head emits, per
+    scale, the objectness / regression rows of all examples back to back; the loss and the post-processor
+    want them regrouped example-major ([example][scale][row]).  `objectness[s]` reshapes to [rows_s, sep],
+    `rpn_box_regression[s]` to [rows_s, 7*sep]; `examples_idxscope[s][b] = (begin, end)` is the row range
+    of example b at scale s (the reference keeps it on its anchor BoxList3D).  Stays on the device; the
+    regrouping is two `torch.cat`s of views."""
+    scale_num = len(objectness)
+    assert scale_num == len(rpn_box_regression) == len(examples_idxscope)
+    batch_size = len(examples_idxscope[0])
+    obj_new = [[] for _ in range(batch_size)]
+    reg_new = [[] for _ in range(batch_size)]
+    for s in range(scale_num):
+        assert objectness[s].shape[0] == 1 and rpn_box_regression[s].shape[0] == 1
+        sep = objectness[s].shape[-1]
+        assert rpn_box_regression[s].shape[-1] == 7 * sep
+        obj_s = objectness[s].reshape(-1, sep)
+        reg_s = rpn_box_regression[s].reshape(-1, 7 * sep)
+        for b in range(batch_size):
+            begin, end = examples_idxscope[s][b]
+            obj_new[b].append(obj_s[begin:end])
+            reg_new[b].append(reg_s[begin:end])
+    obj = torch.cat([torch.cat(o, 0) for o in obj_new], 0)
+    reg = torch.cat([torch.cat(r, 0) for r in reg_new], 0)
+    return obj, reg

@@ -175,3 +175,21 @@ def test_dw_chunk_policy_is_consistent_with_the_library():
     assert g.max_chunks(32, 32) == (27 * 66094 + 255) // 256 + 27
     g._host_counts = [300] * 27
     assert g.max_chunks(32, 32) == 27 * 2 and g.max_chunks(256, 256) == 27
+
+
+def test_cat_scales_obj_reg_regroups_example_major():
+    """SURVEY §8(f) rank 1 glue (rpn_sparse3d.py:19-77): [scale][example] row blocks -> [example][scale]"""
+    import rpn_glue
+    rng = np.random.default_rng(4)
+    scopes = [[(0, 5), (5, 12)], [(0, 2), (2, 3)], [(0, 0), (0, 4)]]  # 3 scales x 2 examples (one empty block)
+    obj = [torch.as_tensor(rng.standard_normal((1, 1, sc[-1][1], 1)).astype(np.float32)) for sc in scopes]
+    reg = [torch.as_tensor(rng.standard_normal((1, 1, sc[-1][1], 7)).astype(np.float32)) for sc in scopes]
+    o, r = rpn_glue.cat_scales_obj_reg(obj, reg, scopes)
+    assert o.shape == (19, 1) and r.shape == (19, 7)
+    want_o, want_r = [], []
+    for b in range(2):
+        for s in range(3):
+            a, e = scopes[s][b]
+            want_o.append(obj[s].reshape(-1, 1)[a:e])
+            want_r.append(reg[s].reshape(-1, 7)[a:e])
+    assert torch.equal(o, torch.cat(want_o)) and torch.equal(r, torch.cat(want_r))
