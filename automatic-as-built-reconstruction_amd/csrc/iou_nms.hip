@@ -5,8 +5,8 @@
 // (nms_postprocess :109-126, check_same_boxes :706-717) and the third-party CPU suppression
 // loop the reference's 3-D path ends in (nms_cpu.py:32-44 -> spconv rotate_non_max_suppression_cpu).
 // VALU / latency bound (56 KB of boxes, ~2 M branchy pair evaluations), not HBM bound.
-//   mask kernel : one wave per 64x64 tile of the upper triangle, boxes staged in LDS,
-//                 64-bit suppression words written straight from registers.
+//   mask kernel : one PAIR per lane, one wave per (row, 64-column block) of the upper triangle; the 64
+//                 verdicts become the suppression word with one ballot.
 //   scan kernel : one workgroup walks the 64-row blocks; the in-block dependency chain is
 //                 resolved on the diagonal 64x64 bit block by one wave in registers
 //                 (wavefront-level), then the kept rows' words are OR-reduced in parallel.
@@ -17,25 +17,20 @@
 namespace aabr {
 using namespace aabr_iou;
 
-__global__ __launch_bounds__(64) void k_rotate_iou_eval(const float *__restrict__ boxes, int64_t N,
-                                                        const float *__restrict__ query, int64_t K,
-                                                        int criterion, float *__restrict__ iou) {
-  __shared__ float sq[64 * 5], sb[64 * 5];
-  const int tx = threadIdx.x;
-  const int64_t n0 = (int64_t)blockIdx.x * 64, k0 = (int64_t)blockIdx.y * 64;
-  const int rows = (int)((N - n0) < 64 ? (N - n0) : 64), cols = (int)((K - k0) < 64 ? (K - k0) : 64);
-  for (int i = tx; i < cols * 5; i += 64) sq[i] = query[k0 * 5 + i];
-  for (int i = tx; i < rows * 5; i += 64) sb[i] = boxes[n0 * 5 + i];
-  __syncthreads();
-  if (tx < rows) {
-    float b[5];
-    for (int d = 0; d < 5; ++d) b[d] = sb[tx * 5 + d];
-    for (int j = 0; j < cols; ++j) {
-      float q[5];
-      for (int d = 0; d < 5; ++d) q[d] = sq[j * 5 + d];
-      iou[(n0 + tx) * K + k0 + j] = iou_eval_entry(b, q, criterion);
-    }
-  }
+// one pair per lane: a wave takes one box row and 64 consecutive queries (coalesced row of the output);
+// four rows per workgroup.  (A thread that walks 64 pairs in a loop -- the usual CUDA shape of this kernel
+// -- is a 64-long serial chain of a ~5 us, branchy, scratch-heavy evaluation: 300 us whatever the size.)
+__global__ __launch_bounds__(256) void k_rotate_iou_eval(const float *__restrict__ boxes, int64_t N,
+                                                         const float *__restrict__ query, int64_t K,
+                                                         int criterion, float *__restrict__ iou) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t k = (int64_t)blockIdx.y * 64 + lane;
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  if (n >= N || k >= K) return;
+  float b[5], q[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) { b[d] = boxes[n * 5 + d]; q[d] = query[k * 5 + d]; }
+  iou[n * K + k] = iou_eval_entry(b, q, criterion);
 }
 
 // [.,7] yx_zb -> 5-parameter 2-D box + z interval, with the reference's thickness clamps
@@ -116,56 +111,44 @@ __global__ __launch_bounds__(256) void k_rpn_decode(const int32_t *__restrict__ 
   for (int d = 0; d < 7; ++d) boxes[7 * i + d] = o[d];
 }
 
-// KIND 0: rotated 3-D boxes [n,7] (2-D IoU, optionally times z-IoU); KIND 1: axis-aligned [n,4]
+// KIND 0: rotated 3-D boxes [n,7] (2-D IoU, optionally times z-IoU); KIND 1: axis-aligned [n,4].
+// One pair per lane: a wave owns one row i and one block of 64 columns; the 64 verdicts become the
+// suppression word with a single ballot (no loop over columns, no shared-memory staging).  Four rows per
+// workgroup.  Blocks below the diagonal are never launched with work: a lower-scored box suppresses nothing.
 template <int KIND>
-__global__ __launch_bounds__(64) void k_nms_mask(const float *__restrict__ boxes, int64_t n, float thresh,
-                                                 int only_xy, int colblocks,
-                                                 unsigned long long *__restrict__ mask) {
+__global__ __launch_bounds__(256) void k_nms_mask(const float *__restrict__ boxes, int64_t n, float thresh,
+                                                  int only_xy, int colblocks,
+                                                  unsigned long long *__restrict__ mask) {
   constexpr int W = KIND == 0 ? 7 : 4;
-  __shared__ float sc[64 * W];
-  const int tx = threadIdx.x;
-  const int cb = blockIdx.x, rb = blockIdx.y;
-  const int64_t i = (int64_t)rb * 64 + tx;
-  if (cb < rb) { // below the diagonal: nothing can be suppressed by a lower-scored box
-    if (i < n) mask[i * colblocks + cb] = 0ull;
-    return;
-  }
-  const int64_t c0 = (int64_t)cb * 64;
-  const int cols = (int)((n - c0) < 64 ? (n - c0) : 64);
-  for (int t = tx; t < cols * W; t += 64) sc[t] = boxes[c0 * W + t];
-  __syncthreads();
-  if (i >= n) return;
-  unsigned long long bits = 0ull;
-  if (KIND == 0) {
-    const float *b = boxes + i * 7;
-    const float bi[5] = {b[0], b[1], b[3], b[4], b[6]};
-    const float z0 = b[2], z1 = b[2] + b[5];
-    for (int j = (cb == rb ? tx + 1 : 0); j < cols; ++j) {
-      const float *c = sc + j * 7;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cb = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;                                  // wave-uniform
+  const int64_t j = (int64_t)cb * 64 + lane;
+  bool hit = false;
+  if (cb >= (int)(i >> 6) && j < n && j > i) {         // strictly above the diagonal
+    const float *b = boxes + i * W, *c = boxes + j * W;
+    if (KIND == 0) {
+      const float bi[5] = {b[0], b[1], b[3], b[4], b[6]};
       const float bj[5] = {c[0], c[1], c[3], c[4], c[6]};
       // matrix entry [i][j] of boxes_iou_3d(dets, dets): box = i, query = j
       float v = iou_eval_entry(bi, bj, -1);
       if (!only_xy) {
-        const float a0 = c[2], a1 = c[2] + c[5];
+        const float z0 = b[2], z1 = b[2] + b[5], a0 = c[2], a1 = c[2] + c[5];
         v = v * ((fminf(a1, z1) - fmaxf(a0, z0)) / (fmaxf(a1, z1) - fminf(a0, z0)));
       }
-      if (v > 0.0f && v >= thresh) bits |= 1ull << j;
-    }
-  } else {
-    const float *b = boxes + i * 4;
-    const float ix1 = b[0], iy1 = b[1], ix2 = b[2], iy2 = b[3];
-    const float iarea = (ix2 - ix1 + 1) * (iy2 - iy1 + 1);
-    for (int j = (cb == rb ? tx + 1 : 0); j < cols; ++j) {
-      const float *c = sc + j * 4;
-      const float xx1 = fmaxf(ix1, c[0]), yy1 = fmaxf(iy1, c[1]);
-      const float xx2 = fminf(ix2, c[2]), yy2 = fminf(iy2, c[3]);
+      hit = v > 0.0f && v >= thresh;
+    } else {
+      const float xx1 = fmaxf(b[0], c[0]), yy1 = fmaxf(b[1], c[1]);
+      const float xx2 = fminf(b[2], c[2]), yy2 = fminf(b[3], c[3]);
       const float w = fmaxf(0.0f, xx2 - xx1 + 1), h = fmaxf(0.0f, yy2 - yy1 + 1);
       const float inter = w * h;
-      const float jarea = (c[2] - c[0] + 1) * (c[3] - c[1] + 1);
-      if (inter / (iarea + jarea - inter) >= thresh) bits |= 1ull << j;
+      const float iarea = (b[2] - b[0] + 1) * (b[3] - b[1] + 1), jarea = (c[2] - c[0] + 1) * (c[3] - c[1] + 1);
+      hit = inter / (iarea + jarea - inter) >= thresh;
     }
   }
-  mask[i * colblocks + cb] = bits;
+  const unsigned long long bits = __ballot(hit);
+  if (lane == 0) mask[i * colblocks + cb] = bits;
 }
 
 // Greedy scan.  remv words live in LDS (colblocks <= 8192 -> n <= 524288).
@@ -227,7 +210,7 @@ extern "C" int aabr_rotate_iou_eval(const float *boxes, int64_t N, const float *
   if (N == 0 || K == 0) return AABR_OK;
   AABR_CHECK_ARG(boxes && query && iou, "null pointer");
   AABR_CHECK_ARG(ceil_div(K, 64) <= 65535, "too many query boxes");
-  hipLaunchKernelGGL(k_rotate_iou_eval, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(K, 64)), dim3(64), 0,
+  hipLaunchKernelGGL(k_rotate_iou_eval, dim3((unsigned)ceil_div(N, 4), (unsigned)ceil_div(K, 64)), dim3(256), 0,
                      (hipStream_t)stream_, boxes, N, query, K, criterion, iou);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
@@ -252,7 +235,7 @@ extern "C" int aabr_boxes_iou_3d(const float *targets, int64_t M, const float *a
                      aug_host[1], t5, tz);
   hipLaunchKernelGGL(k_box7_to_2d, dim3((unsigned)ceil_div(K, 256)), dim3(256), 0, st, anchors, K, aug_host[2],
                      aug_host[3], a5, az);
-  hipLaunchKernelGGL(k_rotate_iou_eval, dim3((unsigned)ceil_div(M, 64), (unsigned)ceil_div(K, 64)), dim3(64), 0,
+  hipLaunchKernelGGL(k_rotate_iou_eval, dim3((unsigned)ceil_div(M, 4), (unsigned)ceil_div(K, 64)), dim3(256), 0,
                      st, t5, M, a5, K, criterion, iou);
   if (!only_xy)
     hipLaunchKernelGGL(k_scale_by_z, dim3((unsigned)ceil_div(M * K, 256)), dim3(256), 0, st, iou, M, K, tz, az);
@@ -291,8 +274,8 @@ static int nms_sorted_impl(const float *boxes, int64_t n, float thresh, int only
   if (!boxes || !mask || !keep) { set_error("%s: null pointer", fn); return AABR_EINVAL; }
   int64_t colblocks = ceil_div(n, 64);
   if (colblocks > 8192) { set_error("%s: n too large (max 524288)", fn); return AABR_EINVAL; }
-  hipLaunchKernelGGL((k_nms_mask<KIND>), dim3((unsigned)colblocks, (unsigned)colblocks), dim3(64), 0, st, boxes,
-                     n, thresh, only_xy, (int)colblocks, (unsigned long long *)mask);
+  hipLaunchKernelGGL((k_nms_mask<KIND>), dim3((unsigned)ceil_div(n, 4), (unsigned)colblocks), dim3(256), 0, st,
+                     boxes, n, thresh, only_xy, (int)colblocks, (unsigned long long *)mask);
   hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), (size_t)colblocks * 8, st,
                      (const unsigned long long *)mask, n, (int)colblocks, post_max, keep, meta);
   hipError_t e = hipGetLastError();
