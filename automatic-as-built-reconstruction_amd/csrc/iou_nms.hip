@@ -172,29 +172,35 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long *__re
         unsigned long long db = __shfl(diag, b); // wave-uniform trip
         if (!((cur >> b) & 1ull)) { kept |= 1ull << b; cur |= db; }
       }
+      // kept rows go to the list at their rank (all lanes at once)
+      const int nk0 = s_nk;
+      if ((kept >> tid) & 1ull) {
+        const int64_t pos = nk0 + __popcll(kept & ((1ull << tid) - 1ull));
+        if (pos < post_max) keep[pos] = r0 + tid;
+      }
       if (tid == 0) {
-        int nk = s_nk;
-        for (int b = 0; b < rows; ++b)
-          if ((kept >> b) & 1ull) {
-            if (nk < post_max) keep[nk] = r0 + b;
-            ++nk;
-          }
-        s_nk = nk;
+        s_nk = nk0 + (int)__popcll(kept);
         s_kept = kept;
       }
     }
     __syncthreads();
     const unsigned long long kept = s_kept;
     if (s_nk >= post_max) break; // uniform
-    for (int w = rb + 1 + tid; w < colblocks; w += blockDim.x) {
-      unsigned long long acc = remv[w];
-      unsigned long long kb = kept;
-      while (kb) {
-        int b = __ffsll((long long)kb) - 1;
-        kb &= kb - 1;
-        acc |= mask[(r0 + b) * colblocks + w];
-      }
-      remv[w] = acc;
+    // OR the kept rows' words into remv: 32 words x 8 row slices per pass (rows b = slice mod 8), loads of
+    // a thread are independent; slices meet in LDS with a 64-bit atomic OR
+    {
+      const int wl = tid & 31, slice = tid >> 5;
+      const unsigned long long mine = kept & (0x0101010101010101ull << slice);
+      if (mine)
+        for (int w = rb + 1 + wl; w < colblocks; w += 32) {
+          unsigned long long acc = 0ull, kb = mine;
+          while (kb) {
+            const int b = __ffsll((long long)kb) - 1;
+            kb &= kb - 1;
+            acc |= mask[(r0 + b) * colblocks + w];
+          }
+          if (acc) atomicOr(&remv[w], acc);
+        }
     }
     __syncthreads();
   }
