@@ -109,8 +109,15 @@ __global__ __launch_bounds__(256) void k_build_tile_blocks(const int32_t *__rest
   const int64_t row = tile * 64 + lane;
   const bool valid = row < V;
   int b0 = 0;
-  for (int k = 0; k < vol; ++k) {
-    const int t = valid ? table[(int64_t)k * V + row] : -1;
+  constexpr int B = 9; // table rows fetched per batch: nine independent loads in flight, then nine ballots
+  for (int k0 = 0; k0 < vol; k0 += B) {
+    int tv[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) tv[j] = (valid && k0 + j < vol) ? table[(int64_t)(k0 + j) * V + row] : -1;
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+    const int k = k0 + j;
+    const int t = tv[j];
     const unsigned long long m = __ballot(t >= 0);
     if (m == 0) continue;
     const int cnt = __popcll(m);
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(256) void k_build_tile_blocks(const int32_t *__rest
     if (lane < nmb * 16 - cnt) ent[b0 * 16 + cnt + lane] = e_first | (int)0x80000000;
     if (lane < nmb) blk_k[b0 + lane] = k;
     b0 += nmb;
+    }
   }
   if (lane == 0) nblk[tile] = b0;
 }
