@@ -41,8 +41,9 @@ __device__ inline void block_exscan2(int a, int b, int &ea, int &eb, int &ta, in
 }
 
 constexpr int kScanThreads = 256;
-constexpr int kScanItems = 4;
-constexpr int kScanTile = kScanThreads * kScanItems; // 1024 items per block
+constexpr int kScanItems = 1; // one item per thread: the flag lookups are dependent random loads, so more,
+                              // smaller blocks beat longer per-thread chains (80k points: 313 blocks, not 79)
+constexpr int kScanTile = kScanThreads * kScanItems; // 256 items per block
 
 // "first" flag of encounter e: it won the atomicMin on its slot.
 __device__ inline void first_flag(const int32_t *slot, const uint32_t *minidx, const uint32_t *slotcnt,
@@ -168,7 +169,16 @@ __global__ __launch_bounds__(kScanThreads) void k_assign_sites(
       int o = __shfl_xor(maxc, d);
       maxc = o > maxc ? o : maxc;
     }
-    if ((threadIdx.x & 63) == 0 && maxc > 0) atomicMax(&meta[1], maxc);
+    // one atomic per BLOCK, and none when the running maximum already covers it (meta[1] only grows, so a
+    // stale read can only cause a redundant atomic): same-address atomics serialise at ~14 ns each
+    __shared__ int wmax[kScanThreads / 64];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = maxc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int m = wmax[0];
+      for (int w = 1; w < kScanThreads / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
+      if (m > 0 && m > __builtin_nontemporal_load(&meta[1])) atomicMax(&meta[1], m);
+    }
   }
 }
 

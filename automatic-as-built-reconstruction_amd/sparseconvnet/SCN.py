@@ -310,7 +310,7 @@ class Metadata_3(object):
         coords = coords.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
         n, ncols = coords.shape
         cap = _hip.next_pow2(2 * n)
-        nblk = (max(n, 1) + 1023) // 1024
+        nblk = (max(n, 1) + 255) // 256
         n1 = max(n, 1)
         # int32 words: keys(2*cap) | scratch(3*cap + 2n + 4*nblk + 16) | vals(cap) | point_site(n) |
         #              site_coords(4*n1) | site_off(n+1) | site_pts(n1) | meta(8); 16-byte aligned pieces.
@@ -409,7 +409,7 @@ class Metadata_3(object):
                 maxout *= (a + b - 1) // b
             E = gi.V * maxout
             cap = _hip.next_pow2(2 * E)
-            nblk = (max(E, 1) + 1023) // 1024
+            nblk = (max(E, 1) + 255) // 256
             keys = torch.empty(cap, dtype=torch.int64, device=dev)
             vals = torch.empty(cap, dtype=torch.int32, device=dev)
             scratch = torch.empty(3 * cap + 2 * E + 4 * nblk + 16, dtype=torch.int32, device=dev)

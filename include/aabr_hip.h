@@ -59,7 +59,7 @@ int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale
  * (SCN/Metadata/Metadata.cpp:405-417, IOLayersRules.h:18-125), modes 1..4.
  *   coords       int64 [n, ncols] (ncols 3 or 4; 4th column = batch index)   (API layout)
  *   keys, vals   hash grid storage, capacity cap (contents overwritten)
- *   scratch      int32 [3*cap + 2*n + 4*nblk + 16] where nblk = ceil(n/1024)
+ *   scratch      int32 [3*cap + 2*n + 4*nblk + 16] where nblk = ceil(n/256)
  *   point_site   int32 [n]   out: output row of every input row
  *   site_coords  int32 [n,4] out: first V rows valid, first-seen order
  *   site_off     int32 [n+1] out: CSR offsets of the per-site point lists (first V+1 valid)
@@ -99,7 +99,7 @@ int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t
  * Convolution_InputSgToRulesAndOutputSg (Metadata.cpp:484-510, ConvolutionRules.h:11-34,
  * RectangularRegions.h:95-119).  Creates the output grid (sites numbered in first-seen order
  * over input rows ascending, then output-region order) and reports V_out in meta[0].
- *   scratch int32 [3*out_cap + 2*E + 4*ceil(E/1024) + 16], E = V_in * max_out_per_in,
+ *   scratch int32 [3*out_cap + 2*E + 4*ceil(E/256) + 16], E = V_in * max_out_per_in,
  *   max_out_per_in = prod(ceil(size/stride)); out_site_coords int32 [E,4].                  */
 int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, const int32_t *size_host,
                            const int32_t *stride_host, const int32_t *out_spatial_host,
