@@ -330,3 +330,34 @@ def test_conv_backward_without_input_gradient_and_prepacked_weights():
     SCN.SubmanifoldConvolution_backward(x.spatial_size, mods[0].filter_size, x.metadata, x.features, d_in_held,
                                         d_out, w, dW2, empty, pack_t=holder)
     assert torch.equal(d_in_plain, d_in_held) and torch.equal(dW1, dW2)
+
+
+@pytest.mark.parametrize("nIn,nOut,npts", [(128, 128, 30000), (96, 256, 30000), (32, 64, 400000), (64, 64, 400000)])
+def test_large_rule_book_kernel_variants_match_oracle(nIn, nOut, npts):
+    """The dispatch in aabr_conv_forward picks by shape AND size: the weight-prefetching 64-column kernel
+    needs >= 512 (tile, slab) workgroups, the LDS-resident-weight kernel only loops over several tiles
+    per wave above ~130k sites.  Small parity scenes never reach those paths; these do (forward and the
+    transposed input-gradient pass, against the oracle on the same rule book)."""
+    scn = _scn()
+    rng = np.random.default_rng(nIn + nOut)
+    locs, _ = S.make_batch(1, npts, 21, 50 if npts > 100000 else 20)
+    feats = rng.standard_normal((locs.shape[0], 4)).astype(np.float32)
+    x = scn.InputLayer(3, list(S.FULL_SCALE), mode=4)([_t(locs), _t(feats)])
+    V = x.features.shape[0]
+    assert V > (130000 if npts > 100000 else 16000)
+    il = O.input_layer(locs, feats, 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    fin = rng.standard_normal((V, nIn)).astype(np.float32)
+    xin = scn.SparseConvNetTensor(_t(fin).requires_grad_(True), x.metadata, x.spatial_size)
+    conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, False).to(DEV)
+    y = conv(xin)
+    W = conv.weight.detach().cpu().numpy().reshape(27, nIn, nOut)
+    ref, _ = O.conv_fwd(fin, W, rb, V)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=2e-6 * np.abs(ref).max() * nIn)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(_t(g))
+    d_in, dW, _ = O.conv_bwd(fin, g, W, rb)
+    np.testing.assert_allclose(xin.features.grad.cpu().numpy(), d_in, rtol=1e-4,
+                               atol=2e-6 * np.abs(d_in).max() * nOut)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(27, nIn, nOut), dW, rtol=2e-4,
+                               atol=2e-5 * np.abs(dW).max())
