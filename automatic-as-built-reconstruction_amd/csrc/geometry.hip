@@ -44,6 +44,7 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 1; // one item per thread: the flag lookups are dependent random loads, so more,
                               // smaller blocks beat longer per-thread chains (80k points: 313 blocks, not 79)
 constexpr int kScanTile = kScanThreads * kScanItems; // 256 items per block
+constexpr int kInlinePrefixBlocks = 2048;            // up to 512k items: block prefix summed in k_assign_sites
 
 // "first" flag of encounter e: it won the atomicMin on its slot.
 __device__ inline void first_flag(const int32_t *slot, const uint32_t *minidx, const uint32_t *slotcnt,
@@ -127,7 +128,7 @@ template <int MODE>
 __global__ __launch_bounds__(kScanThreads) void k_assign_sites(
     const int32_t *__restrict__ slot, const uint32_t *__restrict__ minidx,
     const uint32_t *__restrict__ slotcnt, int64_t n, const int32_t *__restrict__ prefix,
-    int32_t *__restrict__ vals, int32_t *__restrict__ site_coords, int32_t *__restrict__ site_off,
+    const int32_t *__restrict__ blocksums, int32_t *__restrict__ vals, int32_t *__restrict__ site_coords, int32_t *__restrict__ site_off,
     int32_t *__restrict__ meta, const int64_t *__restrict__ coords64, int ncols,
     const int32_t *__restrict__ in_coords, ConvGeom g) {
   int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -139,7 +140,29 @@ __global__ __launch_bounds__(kScanThreads) void k_assign_sites(
   }
   int ea, eb, ta, tb;
   block_exscan2<kScanThreads>(a, b, ea, eb, ta, tb);
-  int ra = prefix[2 * blockIdx.x] + ea, rb = prefix[2 * blockIdx.x + 1] + eb;
+  int pa, pb;
+  if (blocksums) {
+    // few blocks (<= kInlinePrefixBlocks): every block sums the block totals in front of it itself -- a
+    // couple of KB from L2 -- instead of waiting for a one-block prefix kernel in between
+    __shared__ int wsa[kScanThreads / 64], wsb[kScanThreads / 64];
+    int sa = 0, sb = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += kScanThreads) { sa += blocksums[2 * i]; sb += blocksums[2 * i + 1]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+    if ((threadIdx.x & 63) == 0) { wsa[threadIdx.x >> 6] = sa; wsb[threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    pa = 0; pb = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) { pa += wsa[w]; pb += wsb[w]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { // totals, as k_scan_blockprefix writes them
+      meta[0] = pa + ta;
+      meta[3] = pb + tb;
+      if (MODE == 0 && site_off) site_off[pa + ta] = pb + tb; // CSR terminator
+    }
+  } else {
+    pa = prefix[2 * blockIdx.x]; pb = prefix[2 * blockIdx.x + 1];
+  }
+  int ra = pa + ea, rb = pb + eb;
   int maxc = 0;
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
@@ -503,9 +526,11 @@ extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncol
                        (uint64_t)(cap - 1), minidx, slotcnt, slot, meta);
   hipLaunchKernelGGL(k_scan_blocksums, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx, slotcnt,
                      n, blocksums);
-  hipLaunchKernelGGL(k_scan_blockprefix, dim3(1), dim3(1024), 0, st, blocksums, nblk, prefix, meta, site_off);
+  const bool inline_prefix = nblk <= kInlinePrefixBlocks;
+  if (!inline_prefix)
+    hipLaunchKernelGGL(k_scan_blockprefix, dim3(1), dim3(1024), 0, st, blocksums, nblk, prefix, meta, site_off);
   hipLaunchKernelGGL(k_assign_sites<0>, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx, slotcnt,
-                     n, prefix, vals, site_coords, site_off, meta, coords, ncols, (const int32_t *)nullptr, g);
+                     n, prefix, inline_prefix ? (const int32_t *)blocksums : (const int32_t *)nullptr, vals, site_coords, site_off, meta, coords, ncols, (const int32_t *)nullptr, g);
   if (n > 0) {
     hipLaunchKernelGGL(k_point_site_fill, grid1(n, 256), dim3(256), 0, st, slot, n, vals, slotcnt, site_off,
                        point_site, seg);
@@ -609,10 +634,13 @@ extern "C" int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, co
                        (uint64_t)(out_cap - 1), minidx, slot);
   hipLaunchKernelGGL(k_scan_blocksums, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx,
                      (const uint32_t *)nullptr, E, blocksums);
-  hipLaunchKernelGGL(k_scan_blockprefix, dim3(1), dim3(1024), 0, st, blocksums, nblk, prefix, meta,
-                     (int32_t *)nullptr);
+  const bool inline_prefix = nblk <= kInlinePrefixBlocks;
+  if (!inline_prefix)
+    hipLaunchKernelGGL(k_scan_blockprefix, dim3(1), dim3(1024), 0, st, blocksums, nblk, prefix, meta,
+                       (int32_t *)nullptr);
   hipLaunchKernelGGL(k_assign_sites<1>, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx,
-                     (const uint32_t *)nullptr, E, prefix, out_vals, out_site_coords, (int32_t *)nullptr, meta,
+                     (const uint32_t *)nullptr, E, prefix,
+                     inline_prefix ? (const int32_t *)blocksums : (const int32_t *)nullptr, out_vals, out_site_coords, (int32_t *)nullptr, meta,
                      (const int64_t *)nullptr, 0, in_coords, g);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
