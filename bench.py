@@ -60,6 +60,12 @@ def cpu_baseline(n_scenes_budget_s=15.0):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_lib as O
     import ref_net
+    # the CPU leg runs on the cores the process was given, not on the four the GPU leg pinned itself to
+    if _ORIG_AFFINITY:
+        try:
+            os.sched_setaffinity(0, _ORIG_AFFINITY)
+        except Exception:
+            pass
     # host cores this process may use (a 1-GPU box exposes a 16-core share of the host)
     try:
         ncpu = len(os.sched_getaffinity(0))
@@ -128,13 +134,18 @@ def time_stage(fn, reps=10):
     return a.elapsed_time(b) * 1e-3 / reps
 
 
+_ORIG_AFFINITY = None
+
+
 def pin_host_threads(local_rank, ncores=4):
     """Bind this process (launch thread + autograd thread) to a few cores of the GPU's NUMA node.  On a
     2-socket host the unbound process wanders over 256 hardware threads and the launch-bound step time
     moves by 10-30 % from run to run (measured: 1,890-2,010 scenes/s unbound, 2,140-2,190 bound).
     Best effort: any failure leaves the affinity untouched."""
+    global _ORIG_AFFINITY
     try:
         allowed = sorted(os.sched_getaffinity(0))
+        _ORIG_AFFINITY = set(allowed)
         if len(allowed) <= ncores:
             return None
         cand = allowed

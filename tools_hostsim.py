@@ -15,7 +15,8 @@ V_FAKE = 64
 class Fake(object):
     def __getattr__(self, name):
         fn = getattr(real, name)
-        if name.endswith("_floats") or name.endswith("_words") or name in ("aabr_version", "aabr_last_error"):
+        if name.endswith("_floats") or name.endswith("_words") or name.endswith("_elems") \
+                or name in ("aabr_version", "aabr_last_error", "aabr_conv_dw_chunk_pairs"):
             return fn
         if name == "aabr_input_layer_sites":
             def sites(*a):
