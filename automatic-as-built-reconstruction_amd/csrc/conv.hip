@@ -548,6 +548,61 @@ __device__ inline void conv_step_mfma_w(const GStep &q, const WSet<JG> &w, int n
   }
 }
 
+// the two blocks of a pair are ADJACENT in the tile's (offset-sorted) list in the weight-prefetching
+// kernel, so they often share the filter offset (the centre offset alone fills four blocks of a 64-row
+// tile): then one set of weight fragments feeds both MFMA chains and the second fetch is skipped
+template <int JG>
+__device__ inline void conv_load_w_shared(WSet<JG> &w, __amdgpu_buffer_rsrc_t rw, unsigned lane32, unsigned soA,
+                                          unsigned soB, int nvalid) {
+#pragma unroll
+  for (int j = 0; j < JG; ++j) {
+    if (j < nvalid) {
+      w.a0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soA + j * 2048, 0);
+      w.a1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soA + j * 2048, 0);
+      if (soA != soB) { // wave-uniform
+        w.b0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soB + j * 2048, 0);
+        w.b1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soB + j * 2048, 0);
+      }
+    }
+  }
+}
+
+template <int JG, bool ADJ>
+__device__ inline void conv_load_w_sel(WSet<JG> &w, __amdgpu_buffer_rsrc_t rw, unsigned lane32, unsigned soA,
+                                       unsigned soB, int nvalid) {
+  if (ADJ) conv_load_w_shared<JG>(w, rw, lane32, soA, soB, nvalid);
+  else conv_load_w<JG>(w, rw, lane32, soA, soB, nvalid);
+}
+
+#define AABR_MFMA8(ACC, W0, W1, X0, X1)                                            \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(W0[0]), bcf(X0[0]), ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(W0[1]), bcf(X0[1]), ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(W0[2]), bcf(X0[2]), ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(W0[3]), bcf(X0[3]), ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(W1[0]), bcf(X1[0]), ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(W1[1]), bcf(X1[1]), ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(W1[2]), bcf(X1[2]), ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf(W1[3]), bcf(X1[3]), ACC, 0, 0, 0)
+
+template <int JG>
+__device__ inline void conv_step_mfma_w_shared(const GStep &q, const WSet<JG> &w, bool same, int nvalid, f32x4 *accA,
+                                               f32x4 *accB) {
+  if (!same) {
+    conv_step_mfma_w<JG>(q, w, nvalid, accA, accB);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < JG; ++j) {
+    if (j < nvalid) {
+      f32x4 ca = accA[j], cb = accB[j];
+      // same weights for both blocks: the two chains stay interleaved through the scheduler
+      AABR_MFMA8(ca, w.a0[j], w.a1[j], q.a0, q.a1);
+      AABR_MFMA8(cb, w.a0[j], w.a1[j], q.b0, q.b1);
+      accA[j] = ca; accB[j] = cb;
+    }
+  }
+}
+
 // weights streamed right before their MFMAs, one column block at a time (16 VGPRs live)
 template <int NBW>
 __device__ inline void conv_step_mfma_stream(const GStep &q, __amdgpu_buffer_rsrc_t rw, unsigned lane32,
@@ -566,7 +621,10 @@ __device__ inline void conv_step_mfma_stream(const GStep &q, __amdgpu_buffer_rsr
 // step that issues it.
 // WPIPE: prefetch the packed weights one micro-step ahead (pays for wide slabs, NBW = 4; with narrow
 // slabs the extra 32-64 VGPRs cost a wave of occupancy and the step is too short to need it).
-template <int NBW, int WPB, bool WPIPE>
+// ADJ: pairs are ADJACENT blocks of the tile's list and share their weight fragments when they share the
+// offset (less L2->CU traffic: pays when the launch is throughput-bound, i.e. thousands of workgroups;
+// on small launches the longer loop body costs more than it saves)
+template <int NBW, int WPB, bool WPIPE, bool ADJ>
 __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_wpipe(
     const float *__restrict__ in, int ci, int64_t in_bytes, float *__restrict__ out, int co, int64_t V_out,
     const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const float *__restrict__ Wp,
@@ -599,13 +657,16 @@ __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_wpipe(
 
   for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
 
+  // ADJ: pairs of adjacent blocks (2j, 2j+1) dealt to the waves round-robin; else blocks dealt round-robin
+  // and a wave pairs its own consecutive ones
+  const int tpairs = (nblk + 1) >> 1;
   const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
-  const int npairs = (nmine + 1) >> 1;
+  const int npairs = ADJ ? (wave < tpairs ? (tpairs - wave + WPB - 1) / WPB : 0) : ((nmine + 1) >> 1);
   auto load_pair = [&](int pr) {
     PairEnt p;
-    int bA = wave + (2 * pr) * WPB;
-    if (bA >= nblk) bA = nblk > 0 ? nblk - 1 : 0;      // past the end: harmless re-read, never consumed
-    int bB = bA + WPB;
+    int bA = ADJ ? 2 * (wave + pr * WPB) : wave + (2 * pr) * WPB;
+    if (bA >= nblk) bA = nblk > 0 ? (ADJ ? ((nblk - 1) & ~1) : nblk - 1) : 0; // past the end: harmless re-read
+    int bB = bA + (ADJ ? 1 : WPB);
     const bool hasB = bB < nblk;
     if (!hasB) bB = bA;
     p.eA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bA * 64u, 0);
@@ -644,7 +705,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_wpipe(
   }
   if (npairs > 0) {
     gather(s0, p0, 0);
-    if (WPIPE) conv_load_w<JG>(w0, rw, lane32, soA, soB, nvalid);
+    if (WPIPE) conv_load_w_sel<JG, ADJ>(w0, rw, lane32, soA, soB, nvalid);
   }
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
@@ -672,14 +733,15 @@ __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_wpipe(
       soA1 = __builtin_amdgcn_readfirstlane(soA1); soB1 = __builtin_amdgcn_readfirstlane(soB1);
       const unsigned nA = last_kc ? soA1 : cA + kc_bytes; // first weight set of the next step
       const unsigned nB = last_kc ? soB1 : cB + kc_bytes;
+      const bool same = ADJ && soA == soB; // both blocks of the pair use the same filter offset (wave-uniform)
       if (NJG == 1) {
-        if (more) conv_load_w<JG>(wo, rw, lane32, nA, nB, nvalid);
-        conv_step_mfma_w<JG>(xc, wc, nvalid, accA, accB);
+        if (more) conv_load_w_sel<JG, ADJ>(wo, rw, lane32, nA, nB, nvalid);
+        conv_step_mfma_w_shared<JG>(xc, wc, same, nvalid, accA, accB);
       } else {
-        conv_load_w<JG>(wo, rw, lane32, cA + JG * 2048u, cB + JG * 2048u, nvalid - JG);
-        conv_step_mfma_w<JG>(xc, wc, nvalid, accA, accB);
-        if (more) conv_load_w<JG>(wc, rw, lane32, nA, nB, nvalid);
-        conv_step_mfma_w<JG>(xc, wo, nvalid - JG, accA + JG, accB + JG);
+        conv_load_w_sel<JG, ADJ>(wo, rw, lane32, cA + JG * 2048u, cB + JG * 2048u, nvalid - JG);
+        conv_step_mfma_w_shared<JG>(xc, wc, same, nvalid, accA, accB);
+        if (more) conv_load_w_sel<JG, ADJ>(wc, rw, lane32, nA, nB, nvalid);
+        conv_step_mfma_w_shared<JG>(xc, wo, same, nvalid - JG, accA + JG, accB + JG);
       }
     }
     if (last_kc) {
@@ -1745,8 +1807,12 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
   do {                                                                                                  \
     size_t lds = (size_t)(WPB) * 64 * ((NBW)*16) * sizeof(float);                                       \
     dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                           \
-    if (lean && (NBW) == 4)                                                                             \
-      hipLaunchKernelGGL((k_conv_blocks_mfma_wpipe<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,   \
+    if (lean && (NBW) == 4 && wgs >= 8192)                                                              \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_wpipe<NBW, WPB, true, true>), grid, dim3(64 * (WPB)), lds, st, \
+                         in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
+                         flip & 1, wpack, wp_bytes, bias);                                              \
+    else if (lean && (NBW) == 4)                                                                        \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_wpipe<NBW, WPB, true, false>), grid, dim3(64 * (WPB)), lds, st, \
                          in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
                          flip & 1, wpack, wp_bytes, bias);                                              \
     else if (lean)                                                                                      \

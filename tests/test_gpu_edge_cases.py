@@ -332,15 +332,17 @@ def test_conv_backward_without_input_gradient_and_prepacked_weights():
     assert torch.equal(d_in_plain, d_in_held) and torch.equal(dW1, dW2)
 
 
-@pytest.mark.parametrize("nIn,nOut,npts", [(128, 128, 30000), (96, 256, 30000), (32, 64, 400000), (64, 64, 400000)])
+@pytest.mark.parametrize("nIn,nOut,npts", [(128, 128, 30000), (96, 256, 30000), (32, 64, 400000), (64, 64, 400000),
+                                           (96, 256, 160000)])
 def test_large_rule_book_kernel_variants_match_oracle(nIn, nOut, npts):
     """The dispatch in aabr_conv_forward picks by shape AND size: the weight-prefetching 64-column kernel
     needs >= 512 (tile, slab) workgroups, the LDS-resident-weight kernel only loops over several tiles
-    per wave above ~130k sites.  Small parity scenes never reach those paths; these do (forward and the
+    per wave above ~130k sites, adjacent block pairs share their weight fragments above 8192 workgroups
+    (the 160k-point, 256-plane case: 2,300 tiles x 4 slabs).  Small parity scenes never reach those paths; these do (forward and the
     transposed input-gradient pass, against the oracle on the same rule book)."""
     scn = _scn()
     rng = np.random.default_rng(nIn + nOut)
-    locs, _ = S.make_batch(1, npts, 21, 50 if npts > 100000 else 20)
+    locs, _ = S.make_batch(1, npts, 21, 50 if npts > 100000 else 20)  # 2 cm voxels: ~0.9 sites per point
     feats = rng.standard_normal((locs.shape[0], 4)).astype(np.float32)
     x = scn.InputLayer(3, list(S.FULL_SCALE), mode=4)([_t(locs), _t(feats)])
     V = x.features.shape[0]
