@@ -343,10 +343,11 @@ struct GStep { u32x4 a0, a1, b0, b1; };
 
 __device__ inline float bcf(unsigned int v) { return __builtin_bit_cast(float, v); }
 
-template <int NBW>
+template <int NBW, bool ADJ>
 __device__ inline void conv_step_mfma_buf(const GStep &q, __amdgpu_buffer_rsrc_t rw, unsigned lane32,
                                           unsigned soA, unsigned soB, int nvalid, f32x4 (&accA)[NBW],
                                           f32x4 (&accB)[NBW]) {
+  const bool same = ADJ && soA == soB; // adjacent blocks of one offset: one set of weight fragments (wave-uniform)
   // all of the step's weight loads go out before its first MFMA: the L2 latency is paid once per
   // step, not once per column block (the last column slab may hold fewer than NBW blocks)
   u32x4 w0[NBW], w1[NBW], u0[NBW], u1[NBW];
@@ -355,9 +356,16 @@ __device__ inline void conv_step_mfma_buf(const GStep &q, __amdgpu_buffer_rsrc_t
     if (j < nvalid) {
       w0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soA + j * 2048, 0);
       w1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soA + j * 2048, 0);
-      u0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soB + j * 2048, 0);
-      u1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soB + j * 2048, 0);
+      if (!same) {
+        u0[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, soB + j * 2048, 0);
+        u1[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16, soB + j * 2048, 0);
+      }
     }
+  }
+  if (same) {
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+      if (j < nvalid) { u0[j] = w0[j]; u1[j] = w1[j]; }
   }
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
@@ -384,7 +392,7 @@ __device__ inline void conv_step_mfma_buf(const GStep &q, __amdgpu_buffer_rsrc_t
   }
 }
 
-template <int NBW, int WPB>
+template <int NBW, int WPB, bool ADJ>
 __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mfma_buf(
     const float *__restrict__ in, int ci, int64_t in_bytes, float *__restrict__ out, int co, int64_t V_out,
     const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const float *__restrict__ Wp,
@@ -414,13 +422,16 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
 
   for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
 
+  // ADJ (throughput-bound launches): pairs of adjacent blocks dealt round-robin, same-offset pairs share
+  // their weight fragments; else blocks dealt round-robin and a wave pairs its own consecutive ones
   const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
-  const int npairs = (nmine + 1) >> 1;
+  const int tpairs = (nblk + 1) >> 1;
+  const int npairs = ADJ ? (wave < tpairs ? (tpairs - wave + WPB - 1) / WPB : 0) : ((nmine + 1) >> 1);
   auto load_pair = [&](int pr) {
     PairEnt p;
-    int bA = wave + (2 * pr) * WPB;
-    if (bA >= nblk) bA = nblk > 0 ? nblk - 1 : 0;      // past the end: harmless re-read, never consumed
-    int bB = bA + WPB;
+    int bA = ADJ ? 2 * (wave + pr * WPB) : wave + (2 * pr) * WPB;
+    if (bA >= nblk) bA = nblk > 0 ? (ADJ ? ((nblk - 1) & ~1) : nblk - 1) : 0; // past the end: harmless re-read
+    int bB = bA + (ADJ ? 1 : WPB);
     const bool hasB = bB < nblk;
     if (!hasB) bB = bA;
     p.eA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bA * 64u, 0);
@@ -461,10 +472,10 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
       const unsigned so = (unsigned)kc * (unsigned)nnb * 2048u;
       if (step & 1) {
         if (more) gather(s0, pn, kcn);
-        conv_step_mfma_buf<NBW>(s1, rw, lane32, soA0 + so, soB0 + so, nvalid, accA, accB);
+        conv_step_mfma_buf<NBW, ADJ>(s1, rw, lane32, soA0 + so, soB0 + so, nvalid, accA, accB);
       } else {
         if (more) gather(s1, pn, kcn);
-        conv_step_mfma_buf<NBW>(s0, rw, lane32, soA0 + so, soB0 + so, nvalid, accA, accB);
+        conv_step_mfma_buf<NBW, ADJ>(s0, rw, lane32, soA0 + so, soB0 + so, nvalid, accA, accB);
       }
     }
     conv_block_accumulate<NBW, WS>(Ct, p0.eA, g, accA);
@@ -1815,10 +1826,14 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
       hipLaunchKernelGGL((k_conv_blocks_mfma_wpipe<NBW, WPB, true, false>), grid, dim3(64 * (WPB)), lds, st, \
                          in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
                          flip & 1, wpack, wp_bytes, bias);                                              \
+    else if (lean && wgs >= 8192)                                                                       \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,     \
+                         in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
+                         flip & 1, wpack, wp_bytes, bias);                                              \
     else if (lean)                                                                                      \
-      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB>), grid, dim3(64 * (WPB)), lds, st, in_feats, \
-                         n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip & 1,   \
-                         wpack, wp_bytes, bias);                                                        \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB, false>), grid, dim3(64 * (WPB)), lds, st,    \
+                         in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
+                         flip & 1, wpack, wp_bytes, bias);                                              \
     else if (aligned)                                                                                   \
       hipLaunchKernelGGL((k_conv_blocks_mfma<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,         \
                          in_feats, n_in, out_feats, n_out, V_out, blocks, vol, flip, wpack, bias);      \
