@@ -1,8 +1,8 @@
 """Summarise the two PMC passes of tools_pmc.sh into profiles/r01_pmc_fetch_write_per_kernel.json"""
-import collections, csv, glob, json
+import collections, csv, glob, json, os
 def agg(pat):
     d = collections.defaultdict(list)
-    for r in csv.DictReader(open(sorted(glob.glob(pat))[-1])):
+    for r in csv.DictReader(open(max(glob.glob(pat), key=os.path.getmtime))):  # newest pass
         d[r['Kernel_Name']].append(float(r['Counter_Value']))
     return d
 f = agg('gpurun_out/pmc_FETCH_SIZE/*/*counter_collection.csv')
