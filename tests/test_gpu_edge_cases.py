@@ -363,3 +363,47 @@ def test_large_rule_book_kernel_variants_match_oracle(nIn, nOut, npts):
                                atol=2e-6 * np.abs(d_in).max() * nOut)
     np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(27, nIn, nOut), dW, rtol=2e-4,
                                atol=2e-5 * np.abs(dW).max())
+
+
+def test_randomised_conv_shapes_against_oracle():
+    """seeded sweep over plane counts (aligned and not), site counts around the 64-row tile boundaries and
+    all three layer types: whatever kernel variant the dispatch picks must agree with the oracle"""
+    scn = _scn()
+    rng = np.random.default_rng(2024)
+    plane_choices = [1, 3, 9, 16, 31, 32, 33, 48, 64, 65, 96, 128, 160]
+    for trial in range(14):
+        nIn, nOut = int(rng.choice(plane_choices)), int(rng.choice(plane_choices))
+        n = int(rng.choice([1, 2, 63, 64, 65, 200, 700, 1500]))
+        size = (9, 7, 5)
+        coords = np.stack([rng.integers(0, s, n) for s in size] + [np.sort(rng.integers(0, 2, n))], 1).astype(np.int64)
+        feats = rng.standard_normal((n, nIn)).astype(np.float32)
+        f = _t(feats).requires_grad_(True)
+        x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), f])
+        il = O.input_layer(coords, feats, 4)
+        kind = trial % 3
+        if kind == 0:
+            mod = scn.SubmanifoldConvolution(3, nIn, nOut, 3, bool(trial & 1)).to(DEV)
+            rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+            n_out_rows, in_col = il["V"], 0
+        else:
+            mod = scn.Convolution(3, nIn, nOut, [2, 2, 2], [2, 2, 2], False).to(DEV)
+            rb, oc = O.convolution_rules(il["coords"], [2, 2, 2], [2, 2, 2], np.array([8, 8, 4]))
+            n_out_rows, in_col = oc.shape[0], 0
+        if hasattr(mod, "bias"):
+            mod.bias.data.normal_()
+        y = mod(x)
+        W = mod.weight.detach().cpu().numpy().reshape(rb.vol, nIn, nOut)
+        bias = mod.bias.detach().cpu().numpy() if hasattr(mod, "bias") else None
+        ref, _ = O.conv_fwd(il["out"], W, rb, n_out_rows, bias, in_col=in_col)
+        tag = "trial %d: %s %d->%d, %d points" % (trial, type(mod).__name__, nIn, nOut, n)
+        np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4,
+                                   atol=3e-6 * max(np.abs(ref).max(), 1e-3) * nIn, err_msg=tag)
+        g = rng.standard_normal(ref.shape).astype(np.float32)
+        y.features.backward(_t(g))
+        d_in, dW, db = O.conv_bwd(il["out"], g, W, rb, in_col=in_col, want_bias=bias is not None)
+        np.testing.assert_allclose(f.grad.cpu().numpy(), O.input_layer_bwd(il, d_in), rtol=1e-4,
+                                   atol=3e-6 * max(np.abs(d_in).max(), 1e-3) * nOut, err_msg=tag)
+        np.testing.assert_allclose(mod.weight.grad.cpu().numpy().reshape(W.shape), dW, rtol=2e-4,
+                                   atol=2e-5 * max(np.abs(dW).max(), 1e-3), err_msg=tag)
+        if bias is not None:
+            np.testing.assert_allclose(mod.bias.grad.cpu().numpy(), db, rtol=1e-4, atol=1e-4, err_msg=tag)
