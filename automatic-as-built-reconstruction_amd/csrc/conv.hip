@@ -1846,6 +1846,14 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
   // slabs, i.e. more and shorter workgroups; at that size the gathers are latency, not bandwidth
   int nbw = nnb <= 1 ? 1 : (nnb == 2 ? 2 : 4);
   while (nbw > 1 && ceil_div(V_out, 64) * ceil_div(nnb, nbw) < 512) nbw >>= 1;
+  // throughput-bound launches: 32-column slabs of the streaming kernel (twice the waves per CU beside half
+  // the private LDS tile) edge out the 64-column weight-prefetch kernel: 39.4 -> 40.3 % / 41.9 -> 42.8 % of
+  // the fp32 MFMA peak at 128 / 256 planes, 1.5 M points
+  if (nbw == 4 && ceil_div(V_out, 64) * ceil_div(nnb, 4) >= 8192) nbw = 2;
+  if (const char *ov = getenv("AABR_CONV_NBW")) { // tuning experiments only
+    int v = atoi(ov);
+    if ((v == 1 || v == 2 || v == 4) && v <= nbw) nbw = v;
+  }
   const int64_t wgs = ceil_div(V_out, 64) * ceil_div(nnb, nbw);
   int best_wpb = 2;
   int64_t best_cost = -1;
