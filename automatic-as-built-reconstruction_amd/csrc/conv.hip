@@ -1826,12 +1826,8 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
       hipLaunchKernelGGL((k_conv_blocks_mfma_wpipe<NBW, WPB, true, false>), grid, dim3(64 * (WPB)), lds, st, \
                          in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
                          flip & 1, wpack, wp_bytes, bias);                                              \
-    else if (lean && wgs >= 8192)                                                                       \
+    else if (lean) /* adjacent-pair weight sharing pays at every size in the streaming kernel */        \
       hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,     \
-                         in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
-                         flip & 1, wpack, wp_bytes, bias);                                              \
-    else if (lean)                                                                                      \
-      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB, false>), grid, dim3(64 * (WPB)), lds, st,    \
                          in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
                          flip & 1, wpack, wp_bytes, bias);                                              \
     else if (aligned)                                                                                   \
