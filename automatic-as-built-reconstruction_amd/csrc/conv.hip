@@ -392,7 +392,7 @@ __device__ inline void conv_step_mfma_buf(const GStep &q, __amdgpu_buffer_rsrc_t
   }
 }
 
-template <int NBW, int WPB, bool ADJ>
+template <int NBW, int WPB, bool ADJ, bool ALIGNED>
 __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mfma_buf(
     const float *__restrict__ in, int ci, int64_t in_bytes, float *__restrict__ out, int co, int64_t V_out,
     const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const float *__restrict__ Wp,
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
   const int g = lane >> 4, c16 = lane & 15;
   float *Ct = smem + (size_t)wave * TILE;
   const int maxb = tb_maxb(vol);
-  const int nkc = ci >> 5, nnb = nnb_of(co);
+  const int nkc = ALIGNED ? (ci >> 5) : nkc_of(ci), nnb = nnb_of(co);
   const int nb0 = blockIdx.y * NBW;
   const int64_t tile = blockIdx.x, row0 = tile * 64;
   const int64_t ntiles = tb_ntiles(V_out);
@@ -445,10 +445,24 @@ __global__ __launch_bounds__(WPB * 64, (NBW <= 2 ? 3 : 2)) void k_conv_blocks_mf
     const unsigned va = (((unsigned)p.eA & 0x7fffffffu) >> 6) * rowbytes + g32;
     const unsigned vb = (((unsigned)p.eB & 0x7fffffffu) >> 6) * rowbytes + g32;
     const unsigned so = (unsigned)kc * 128u;
-    q.a0 = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
-    q.a1 = __builtin_amdgcn_raw_buffer_load_b128(rin, va + 16u, so, 0);
-    q.b0 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb, so, 0);
-    q.b1 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb + 16u, so, 0);
+    if (ALIGNED) {
+      q.a0 = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
+      q.a1 = __builtin_amdgcn_raw_buffer_load_b128(rin, va + 16u, so, 0);
+      q.b0 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb, so, 0);
+      q.b1 = __builtin_amdgcn_raw_buffer_load_b128(rin, vb + 16u, so, 0);
+    } else {
+      // any plane count (the 9-plane first layer): element loads, planes past ci read as zero (their packed
+      // weights are zero too); rows are ci*4 bytes apart, not 16-byte aligned
+      const int c0 = kc * kKC + g * 8;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool ok0 = c0 + t < ci, ok1 = c0 + 4 + t < ci;
+        q.a0[t] = ok0 ? __builtin_amdgcn_raw_buffer_load_b32(rin, va + 4u * t, so, 0) : 0u;
+        q.a1[t] = ok1 ? __builtin_amdgcn_raw_buffer_load_b32(rin, va + 16u + 4u * t, so, 0) : 0u;
+        q.b0[t] = ok0 ? __builtin_amdgcn_raw_buffer_load_b32(rin, vb + 4u * t, so, 0) : 0u;
+        q.b1[t] = ok1 ? __builtin_amdgcn_raw_buffer_load_b32(rin, vb + 16u + 4u * t, so, 0) : 0u;
+      }
+    }
   };
   PairEnt p0 = load_pair(0), p1 = load_pair(1), p2 = load_pair(2);
   GStep s0, s1;
@@ -1746,8 +1760,8 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
   // lean buffer-descriptor kernel: aligned channels and every buffer below 2 GiB (32-bit offsets)
   const int64_t in_bytes = rows_in * n_in * 4, wp_bytes = total * 4,
                 words_bytes = aabr_tile_blocks_words(V_out, vol) * 4;
-  const bool lean = aligned && in_bytes < (1ll << 31) && wp_bytes < (1ll << 31) && words_bytes < (1ll << 31) &&
-                    !(flags >> 8);
+  const bool lean_any = in_bytes < (1ll << 31) && wp_bytes < (1ll << 31) && words_bytes < (1ll << 31) && !(flags >> 8);
+  const bool lean = aligned && lean_any;
   // LDS-resident weights: the slab's packed filter bank + enough per-wave output tiles fit in 160 KiB
   if (nkc <= 2 && in_bytes < (1ll << 31) && words_bytes < (1ll << 31) && !(flags >> 8)) {
     const char *ov = getenv("AABR_CONV_WLDS"); // tuning experiments only: 0 disables, 1/2/4 forces the slab width
@@ -1827,7 +1841,11 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
                          in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
                          flip & 1, wpack, wp_bytes, bias);                                              \
     else if (lean) /* adjacent-pair weight sharing pays at every size in the streaming kernel */        \
-      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB, true>), grid, dim3(64 * (WPB)), lds, st,     \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB, true, true>), grid, dim3(64 * (WPB)), lds, st, \
+                         in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
+                         flip & 1, wpack, wp_bytes, bias);                                              \
+    else if (lean_any) /* same kernel with element gathers: plane counts that are not multiples of 32 */ \
+      hipLaunchKernelGGL((k_conv_blocks_mfma_buf<NBW, WPB, true, false>), grid, dim3(64 * (WPB)), lds, st, \
                          in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
                          flip & 1, wpack, wp_bytes, bias);                                              \
     else if (aligned)                                                                                   \

@@ -310,7 +310,7 @@ def main():
                     traffic = int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
         except Exception:
             traffic = None
-        roof = dict(kernel="k_conv_blocks_mfma_buf<2,4,true> (SubmConv3 32->32 forward)", bound="mfma",
+        roof = dict(kernel="k_conv_blocks_mfma_buf<2,4,true,true> (SubmConv3 32->32 forward)", bound="mfma",
                     achieved=round(flops / ksec / 1e12, 4), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                     frac=round(flops / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5), traffic=traffic,
                     launch_us=round(ksec * 1e6, 2), rules=int(R), sites=int(V),
