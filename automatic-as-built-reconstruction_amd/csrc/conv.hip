@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16(const float *__restri
 }
 
 // KG = channel chunks (of 32) gathered per work item; an item is (pair of blocks, chunk group).
-template <int NBW, int WPB, int KG>
+template <int NBW, int WPB, int KG, bool ADJ>
 __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_bf16(
     const __bf16 *__restrict__ in, int ci, int64_t in_bytes, __bf16 *__restrict__ out, int co, int64_t V_out,
     const int32_t *__restrict__ words, int64_t words_bytes, int vol, int wflip, const __bf16 *__restrict__ Wp,
@@ -1200,17 +1200,19 @@ __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_bf16(
 
   for (int i = lane; i < TILE; i += 64) Ct[i] = 0.0f;
 
+  // ADJ (throughput-bound launches): pairs of adjacent blocks, same-offset pairs share their weights
   const int nmine = wave < nblk ? (nblk - wave + WPB - 1) / WPB : 0;
-  const int npairs = (nmine + 1) >> 1;
+  const int tpairs = (nblk + 1) >> 1;
+  const int npairs = ADJ ? (wave < tpairs ? (tpairs - wave + WPB - 1) / WPB : 0) : ((nmine + 1) >> 1);
   const int nitems = npairs * ngrp;
   struct Item { int eA, eB, kA, kB, kc0; };
   auto load_item = [&](int it) {
     Item p;
     const int pr = it / ngrp;
     p.kc0 = (it - pr * ngrp) * KG;
-    int bA = wave + (2 * pr) * WPB;
-    if (bA >= nblk) bA = nblk > 0 ? nblk - 1 : 0;
-    int bB = bA + WPB;
+    int bA = ADJ ? 2 * (wave + pr * WPB) : wave + (2 * pr) * WPB;
+    if (bA >= nblk) bA = nblk > 0 ? (ADJ ? ((nblk - 1) & ~1) : nblk - 1) : 0;
+    int bB = bA + (ADJ ? 1 : WPB);
     const bool hasB = bB < nblk;
     if (!hasB) bB = bA;
     p.eA = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, c16x4, ebase + (unsigned)bA * 64u, 0);
@@ -1244,19 +1246,44 @@ __global__ __launch_bounds__(WPB * 64, 2) void k_conv_blocks_mfma_bf16(
       accA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       accB[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // weight fragments of chunk t+1 are in flight while chunk t's MFMAs issue (two register sets, picked by
+    // the unrolled index); a pair of adjacent same-offset blocks fetches one set for both chains
+    const bool same = ADJ && kA == kB; // wave-uniform
+    u32x4 wA[2][NBW], wB[2][NBW];
+    auto loadw = [&](int set, int t) {
+      const unsigned so = (unsigned)(p.kc0 + t) * (unsigned)nnb * 1024u;
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        if (j < nvalid) {
+          wA[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, soA0 + so + j * 1024, 0);
+          if (!same) wB[set][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, soB0 + so + j * 1024, 0);
+        }
+      }
+    };
+    if (p.kc0 < nkc) loadw(0, 0);
 #pragma unroll
     for (int t = 0; t < KG; ++t) {
       if (p.kc0 + t < nkc) {
-        const unsigned so = (unsigned)(p.kc0 + t) * (unsigned)nnb * 1024u;
+        if (t + 1 < KG && p.kc0 + t + 1 < nkc) loadw((t + 1) & 1, t + 1);
+        if (same) {
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-          if (j < nvalid) {
-            const u32x4 wa = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, soA0 + so + j * 1024, 0);
-            const u32x4 wb = __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, soB0 + so + j * 1024, 0);
-            accA[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa),
-                                                              __builtin_bit_cast(bf16x8, q.a[t]), accA[j], 0, 0, 0);
-            accB[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb),
-                                                              __builtin_bit_cast(bf16x8, q.b[t]), accB[j], 0, 0, 0);
+          for (int j = 0; j < NBW; ++j) {
+            if (j < nvalid) {
+              accA[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wA[t & 1][j]),
+                                                                __builtin_bit_cast(bf16x8, q.a[t]), accA[j], 0, 0, 0);
+              accB[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wA[t & 1][j]),
+                                                                __builtin_bit_cast(bf16x8, q.b[t]), accB[j], 0, 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NBW; ++j) {
+            if (j < nvalid) {
+              accA[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wA[t & 1][j]),
+                                                                __builtin_bit_cast(bf16x8, q.a[t]), accA[j], 0, 0, 0);
+              accB[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wB[t & 1][j]),
+                                                                __builtin_bit_cast(bf16x8, q.b[t]), accB[j], 0, 0, 0);
+            }
           }
         }
       }
@@ -2045,7 +2072,7 @@ extern "C" int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_
   do {                                                                                                   \
     size_t lds = (size_t)(WPB) * 64 * ((NBW)*16) * sizeof(float);                                        \
     dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                            \
-    hipLaunchKernelGGL((k_conv_blocks_mfma_bf16<NBW, WPB, KG>), grid, dim3(64 * (WPB)), lds, st,         \
+    hipLaunchKernelGGL((k_conv_blocks_mfma_bf16<NBW, WPB, KG, true>), grid, dim3(64 * (WPB)), lds, st,   \
                        reinterpret_cast<const __bf16 *>(in_feats), n_in, in_bytes,                       \
                        reinterpret_cast<__bf16 *>(out_feats), n_out, V_out, blocks, words_bytes, vol,    \
                        flip, wp, wp_bytes, bias);                                                        \
