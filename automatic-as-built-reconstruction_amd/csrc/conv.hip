@@ -2050,6 +2050,10 @@ extern "C" int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_
                        n_out, transpose, wp);
   int nbw = nnb == 2 ? 2 : 4;
   if (nbw == 4 && ceil_div(V_out, 64) * ceil_div(nnb, 4) < 512) nbw = 2; // small rule book: more, shorter workgroups
+  if (const char *ov = getenv("AABR_CONV_NBW")) { // tuning experiments only
+    int v = atoi(ov);
+    if ((v == 2 || v == 4) && v <= nbw) nbw = v;
+  }
   const int kg = nkc >= 3 ? 4 : nkc;
   const int64_t wgs = ceil_div(V_out, 64) * ceil_div(nnb, nbw);
   int best_wpb = 2;
