@@ -162,9 +162,22 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long *__re
   for (int w = tid; w < colblocks; w += blockDim.x) remv[w] = 0ull;
   if (tid == 0) s_nk = 0;
   __syncthreads();
+  const int wl = tid & 31, slice = tid >> 5;
   for (int rb = 0; rb < colblocks; ++rb) {
     const int64_t r0 = (int64_t)rb * 64;
     const int rows = (int)((n - r0) < 64 ? (n - r0) : 64);
+    // speculative fetch, before the block's kept set is known: this thread's 8 rows (b = slice mod 8) of the
+    // first 32 words to the right of the diagonal.  The loads overlap the serial chain below; rows that
+    // turn out suppressed are simply not OR-ed in.
+    unsigned long long pre[8];
+    {
+      const int w = rb + 1 + wl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t row = r0 + slice + 8 * i;
+        pre[i] = (w < colblocks && row < n) ? mask[row * colblocks + w] : 0ull;
+      }
+    }
     if (tid < 64) { // first wave: resolve the chain inside the block on the diagonal bits
       unsigned long long diag = (tid < rows) ? mask[(r0 + tid) * colblocks + rb] : 0ull;
       unsigned long long cur = remv[rb], kept = 0ull;
@@ -189,10 +202,16 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long *__re
     // OR the kept rows' words into remv: 32 words x 8 row slices per pass (rows b = slice mod 8), loads of
     // a thread are independent; slices meet in LDS with a 64-bit atomic OR
     {
-      const int wl = tid & 31, slice = tid >> 5;
       const unsigned long long mine = kept & (0x0101010101010101ull << slice);
+      if (mine) {
+        unsigned long long acc0 = 0ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if ((mine >> (slice + 8 * i)) & 1ull) acc0 |= pre[i];
+        if (acc0) atomicOr(&remv[rb + 1 + wl], acc0);
+      }
       if (mine)
-        for (int w = rb + 1 + wl; w < colblocks; w += 32) {
+        for (int w = rb + 1 + wl + 32; w < colblocks; w += 32) {
           unsigned long long acc = 0ull, kb = mine;
           while (kb) {
             const int b = __ffsll((long long)kb) - 1;
