@@ -1,6 +1,6 @@
 """Dev tool: time aabr_conv_forward / backward_weight for several channel counts on the S80k rule book."""
 import importlib, os, sys, time
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 importlib.import_module("automatic-as-built-reconstruction_amd")
 import torch

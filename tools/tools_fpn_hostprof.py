@@ -1,6 +1,6 @@
 """Dev tool: cProfile of FPN_Net forward (+backward) host time on the GPU box."""
 import cProfile, io, os, pstats, sys, importlib
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 importlib.import_module("automatic-as-built-reconstruction_amd")
 import torch

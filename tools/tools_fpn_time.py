@@ -1,6 +1,6 @@
 """Dev tool: time the default 9-scale FPN_Net (fwd, fwd+bwd) on a synthetic scene."""
 import importlib, os, sys, time
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 importlib.import_module("automatic-as-built-reconstruction_amd")
 import torch, numpy as np

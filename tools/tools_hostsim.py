@@ -1,7 +1,7 @@
 """Dev tool: measure the pure host-side (Python + autograd + ctypes) cost of a bench step with
 every kernel-launching C entry point replaced by a no-op, on CPU tensors (no GPU needed)."""
 import cProfile, ctypes, importlib, io, os, pstats, sys, time
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 importlib.import_module("automatic-as-built-reconstruction_amd")
 import torch

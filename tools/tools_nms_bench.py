@@ -1,6 +1,6 @@
 """Dev tool: time the rotated-IoU matrix (label generation shape) and the rotated-3D NMS at the RPN's sizes."""
 import importlib, os, sys, time
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 importlib.import_module("automatic-as-built-reconstruction_amd")
 import numpy as np, torch

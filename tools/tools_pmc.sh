@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools_pmc.sh   -- FETCH_SIZE and WRITE_SIZE in separate passes over bench.py
+# usage (GPU box, repo root): bash tools/tools_pmc.sh   -- FETCH_SIZE and WRITE_SIZE in separate passes over bench.py
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools_profile.sh <tag> [bench args...]
+# usage (on the GPU box, from the repo root): bash tools/tools_profile.sh <tag> [bench args...]
 # runs the GPU tests, a rocprofv3 kernel-trace of bench.py and an un-profiled bench line
 tag=$1; shift
 root=$GRAFT_REPO_ROOT

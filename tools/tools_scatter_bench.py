@@ -1,6 +1,6 @@
 """Dev tool: time the voxel scatter (InputLayer) and rule-book builds at several scene sizes."""
 import importlib, os, sys, time
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 importlib.import_module("automatic-as-built-reconstruction_amd")
 import torch

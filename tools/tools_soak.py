@@ -1,7 +1,7 @@
 """Dev tool: determinism soak.  Runs the bench's training step N times from fixed seeds and prints a checksum
 of the parameters; two invocations must print the same line (no float atomics, fixed summation orders)."""
 import hashlib, importlib, os, sys
-REPO = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 importlib.import_module("automatic-as-built-reconstruction_amd")
 import torch
