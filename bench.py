@@ -139,6 +139,46 @@ def time_stage(fn, reps=10):
     return a.elapsed_time(b) * 1e-3 / reps
 
 
+def fpn_net_extra(scn, dev):
+    """Not the headline: the whole FPN_Net backbone (BASELINE.json configs[2]-shaped input: 4 scenes @ 2 cm)
+    forward + backward in fp32 and with bf16 feature storage, so the bench output also carries the
+    full-network numbers.  Any failure here is reported in the object and never touches the main line."""
+    res = {}
+    try:
+        locs, feats = S.make_batch(4, 80000, 9000, 50)
+        l, f = torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)
+        for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            torch.manual_seed(0)
+            net = scn.FPN_Net([4096, 4096, 512], 3, ["xyz", "color", "normal"], 1,
+                              [32, 64, 64, 128, 128, 128, 256, 256, 256], 128, True, [4, 3, 2, 1], [4, 3, 2, 1],
+                              [[[2, 2, 2]] * 8, [[2, 2, 2]] * 8],
+                              [[256, 256, 32], [128, 128, 16], [64, 64, 8], [32, 32, 4]], [1, 2, 3, 4, 5, 6],
+                              leakiness=0, voxel_scale=50, bn_momentum=0.95, feature_dtype=dt).to(dev)
+
+            def run():
+                scn.forward_pass_multiplyAdd_count = 0
+                rpn, _ = net([l, f])
+                sum(m_.features.square().mean() for m_ in rpn).backward()
+                return rpn
+            for _ in range(6):
+                r = run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                r = run()
+            torch.cuda.synchronize()
+            dt_s = (time.perf_counter() - t0) / n
+            res[name] = {"ms_fwd_bwd": round(dt_s * 1e3, 2), "scenes_per_s": round(4 / dt_s, 1)}
+            res["sites"] = int(r[0].metadata.input["V"])
+            res["forward_macs"] = float(scn.forward_pass_multiplyAdd_count)
+            del net
+        res["workload"] = "FPN_Net (21.2 M parameters), 4 x S80k scenes @ 2 cm, forward + backward"
+    except Exception as e:  # pragma: no cover
+        res["error"] = repr(e)[:200]
+    return res
+
+
 _ORIG_AFFINITY = None
 
 
@@ -335,6 +375,7 @@ def main():
             "roofline": roof, "voxel_scatter": scatter,
         }
         if not args.no_cpu_baseline and world == 1:
+            line["fpn_net"] = fpn_net_extra(scn, dev)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
