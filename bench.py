@@ -309,6 +309,15 @@ def main():
     fpn_extra = None
     if not args.no_cpu_baseline and world == 1:
         fpn_extra = fpn_net_extra(scn, dev)
+    else:
+        # same purpose where the extra is not produced (N > 1, --no-cpu-baseline): ~0.4 s of untimed forward
+        # passes on every rank, so clocks are up before the W warm-up steps whatever W is
+        t_pre = time.perf_counter()
+        with torch.no_grad():
+            while time.perf_counter() - t_pre < 0.4:
+                for sc in scenes:
+                    forward(scn, m, sc[0], sc[1])
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     flat.finish_update(1e-4, world)
