@@ -63,6 +63,11 @@ _SIGS = {
                                                     _i32, _vp, _vp]),
     "aabr_roi_align_rotated_3d_backward": (C.c_int, [_vp, _vp, _i64, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                                      _i32, _i32, _vp, _vp]),
+    "aabr_roi_cellmap": (C.c_int, [_vp, _i64, _i32p, _i32, _vp, _vp]),
+    "aabr_roi_align_rotated_3d_sparse_forward": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _f32,
+                                                           _i32, _i32, _i32, _i32, _vp, _vp]),
+    "aabr_roi_align_rotated_3d_sparse_backward": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _f32,
+                                                            _i32, _i32, _i32, _i32, _i64, _vp, _vp]),
     "aabr_rpn_decode": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f32, _f32p, _f32p, _f32, _vp, _vp]),
     "aabr_rotate_nms_sorted": (C.c_int, [_vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "aabr_nms_sorted": (C.c_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),

@@ -278,6 +278,25 @@ int aabr_roi_align_rotated_3d_backward(const float *grad_output, const float *ro
                                        int batch_size, int channels, int height, int width, int zsize,
                                        int sampling_ratio, float *grad_input, void *stream);
 
+/* ---- fused sparse ROI-align (never densify) -----------------------------------------
+ * Same contract as sparse_3d_to_dense_2d + _C.roi_align_rotated_3d_* (tools_3d_2d.py:7-48,
+ * ROIAlignRotated3D_cuda.cu:16-346) without the dense [B,C,X,Y,Z] tensor: `cellmap` int32
+ * [B, height, width, zsize] over the occupied extent (max coordinate + 1 per axis) holds the site row or -1
+ * (aabr_roi_cellmap fills it); forward gathers feature rows [V, C] directly (bit-identical to the dense
+ * form), backward adds into d_feats [V, C] (zeroed here; fp32 atomics on active cells only).          */
+int aabr_roi_cellmap(const int32_t *site_coords, int64_t V, const int32_t *extent_host, int batch_size,
+                     int32_t *cellmap, void *stream);
+int aabr_roi_align_rotated_3d_sparse_forward(const float *feats, int channels, const int32_t *cellmap,
+                                             int batch_size, int height, int width, int zsize,
+                                             const float *rois, int64_t num_rois, float spatial_scale,
+                                             int pooled_h, int pooled_w, int pooled_z, int sampling_ratio,
+                                             float *output, void *stream);
+int aabr_roi_align_rotated_3d_sparse_backward(const float *grad_output, int channels, const int32_t *cellmap,
+                                              int batch_size, int height, int width, int zsize,
+                                              const float *rois, int64_t num_rois, float spatial_scale,
+                                              int pooled_h, int pooled_w, int pooled_z, int sampling_ratio,
+                                              int64_t V, float *d_feats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -407,3 +407,35 @@ def test_randomised_conv_shapes_against_oracle():
                                    atol=2e-5 * max(np.abs(dW).max(), 1e-3), err_msg=tag)
         if bias is not None:
             np.testing.assert_allclose(mod.bias.grad.cpu().numpy(), db, rtol=1e-4, atol=1e-4, err_msg=tag)
+
+
+def test_fused_sparse_roi_align_equals_the_dense_two_step_form():
+    """ROIAlignRotated3D gathers from the sparse rows through a cell map by default; with `fused = False` it
+    densifies, crops and calls `_C.roi_align_rotated_3d_*` like the reference.  Forward must agree bit for
+    bit (same statements, zeros for inactive cells); backward up to fp32 summation order (both use atomics)."""
+    scn = _scn()
+    from maskrcnn_benchmark.layers.roi_align_rotated_3d import ROIAlignRotated3D
+    rng = np.random.default_rng(11)
+    n = 4000
+    coords = np.unique(np.stack([rng.integers(0, 40, n), rng.integers(0, 33, n), rng.integers(0, 7, n),
+                                 np.sort(rng.integers(0, 3, n))], 1), axis=0)
+    coords = coords[np.argsort(coords[:, 3], kind="stable")].astype(np.int64)
+    feats = rng.standard_normal((coords.shape[0], 160)).astype(np.float32)  # 160 planes: two plane groups
+    nroi = 70
+    rois = np.stack([rng.integers(0, 3, nroi), rng.uniform(-2, 42, nroi), rng.uniform(-2, 35, nroi),
+                     rng.uniform(-1, 8, nroi), rng.uniform(0.3, 15, nroi), rng.uniform(0.3, 15, nroi),
+                     rng.uniform(0.3, 5, nroi), rng.uniform(-180, 180, nroi)], 1).astype(np.float32)
+    for out_size, sampling in (((7, 7, 3), 2), ((5, 6, 11), 0)):  # 330 bins: several LDS passes; adaptive grid
+        res = []
+        for fused in (True, False):
+            f = _t(feats).requires_grad_(True)
+            x = scn.InputLayer(3, [48, 48, 8], mode=4)([_t(coords), f])
+            layer = ROIAlignRotated3D(out_size, 0.9, sampling)
+            layer.fused = fused
+            out = layer(x, _t(rois))
+            g = torch.Generator(device=DEV).manual_seed(5)
+            out.backward(torch.randn(out.shape, device=DEV, generator=g))
+            res.append((out.detach(), f.grad.detach()))
+        assert res[0][0].shape == (nroi, 160) + out_size
+        assert torch.equal(res[0][0], res[1][0])
+        torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5)
