@@ -1691,22 +1691,44 @@ __global__ __launch_bounds__(256) void k_conv_dw_reduce(const float *__restrict_
   if (sl == 0 && i < cico) dW[(int64_t)k * cico + i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
-// d_bias[n] = sum_rows d_out[row][n] (at::sum_out, CPU/Convolution.cpp:100-101); one block per
-// 64 columns, fixed-order tree => deterministic.
+// d_bias[n] = sum_rows d_out[row][n] (at::sum_out, CPU/Convolution.cpp:100-101), two fixed-order stages:
+// S row slices x 64-column blocks of partial sums (rows s, s+S, ... per slice; 4 sub-slices per block
+// combined through LDS), then one thread per column adds the S partials in slice order => deterministic.
 template <typename T>
-__global__ __launch_bounds__(256) void k_col_sum(const T *__restrict__ x, int64_t rows, int co,
-                                                 float *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_col_sum_partial(const T *__restrict__ x, int64_t rows, int co, int S,
+                                                         float *__restrict__ part) {
   __shared__ float red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, sl = blockIdx.y;
   float s = 0.0f;
   if (col < co)
-    for (int64_t r = part; r < rows; r += 4) s += ldf(x, r * co + col);
-  red[part][threadIdx.x & 63] = s;
+    for (int64_t r = (int64_t)sl * 4 + sub; r < rows; r += (int64_t)S * 4) s += ldf(x, r * co + col);
+  red[sub][threadIdx.x & 63] = s;
   __syncthreads();
-  if (part == 0 && col < co)
-    out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (sub == 0 && col < co)
+    part[(int64_t)sl * co + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+__global__ __launch_bounds__(256) void k_col_sum_final(const float *__restrict__ part, int co, int S,
+                                                       float *__restrict__ out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= co) return;
+  float s = 0.0f;
+  for (int i = 0; i < S; ++i) s += part[(int64_t)i * co + col];
+  out[col] = s;
+}
+
+// scratch: the dW partial buffer, free again once the chunk reduction has been enqueued
+template <typename T>
+static void launch_col_sum(const T *d_out, int64_t rows, int co, float *d_bias, float *scratch, int64_t scratch_floats,
+                           hipStream_t st) {
+  int64_t S = scratch_floats / co;
+  if (S > 128) S = 128;
+  if (S > ceil_div(rows, 4)) S = ceil_div(rows, 4);
+  if (S < 1) S = 1;
+  hipLaunchKernelGGL((k_col_sum_partial<T>), dim3((unsigned)ceil_div(co, 64), (unsigned)S), dim3(256), 0, st, d_out,
+                     rows, co, (int)S, scratch);
+  hipLaunchKernelGGL(k_col_sum_final, dim3((unsigned)ceil_div(co, 256)), dim3(256), 0, st, scratch, co, (int)S, d_bias);
+}
 
 static void dw_tiling(int ci, int co, int &cb, int &nb, int &tiles) {
   int ncb = nnb_of(ci), nnb = nnb_of(co);
@@ -1968,9 +1990,7 @@ static int conv_backward_weight_t(const T *in_feats, int n_in, const T *d_out, i
 #undef AABR_LAUNCH_DW
   hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
                      scratch, pairs, vol, chunk_pairs, cico, dW);
-  if (d_bias)
-    hipLaunchKernelGGL((k_col_sum<T>), dim3((unsigned)ceil_div(n_out, 64)), dim3(256), 0, st, d_out, V_out,
-                       n_out, d_bias);
+  if (d_bias) launch_col_sum<T>(d_out, V_out, n_out, d_bias, scratch, max_chunks * cico, st);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -2010,9 +2030,7 @@ extern "C" int aabr_conv_backward_weight_bf16(const uint16_t *in_feats, int n_in
 #undef AABR_LAUNCH_DW16
     hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
                        scratch, pairs, vol, chunk_pairs, cico, dW);
-    if (d_bias)
-      hipLaunchKernelGGL((k_col_sum<__bf16>), dim3((unsigned)ceil_div(n_out, 64)), dim3(256), 0, st, do16, V_out,
-                         n_out, d_bias);
+    if (d_bias) launch_col_sum<__bf16>(do16, V_out, n_out, d_bias, scratch, max_chunks * cico, st);
     AABR_CHECK_LAUNCH();
     return AABR_OK;
   }
