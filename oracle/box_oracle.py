@@ -1,0 +1,62 @@
+"""box_oracle.py -- numpy float32 restatement of the reference's RPN box glue.
+
+TEST INFRASTRUCTURE ONLY (tests/, smoke, cpu_baseline): the product never imports this.
+Pinned by tests/golden/box_golden.npz, which tests/golden/gen_box_golden.py produced by importing and
+running the reference's own torch code (tests/test_oracle_golden.py::test_box_*).
+
+Restates (citations under /root/reference):
+  * BoxCoder3D.decode_centroid_box / encode_centroid_box  maskrcnn_benchmark/modeling/box_coder_3d.py:46-80
+  * second_box_decode / second_box_encode (smooth_dim)     second/pytorch/core/box_torch_ops.py:82-154
+  * limit_period                                           utils3d/geometric_torch.py:4-10
+  * AnchorGenerator.grid_anchors                           maskrcnn_benchmark/modeling/rpn/anchor_generator_sparse3d.py:88-104
+"""
+import numpy as np
+
+F = np.float32
+PI = F(np.pi)   # torch evaluates `val / math.pi` with the python double rounded to the tensor dtype
+
+
+def limit_period(val, offset, period):
+    val = val.astype(F)
+    return (val - np.floor(val / F(period) + F(offset)) * F(period)).astype(F)
+
+
+def decode_centroid_box(box_encodings, anchors, weights=(1.0,) * 7, bbox_xform_clip=10000.0):
+    enc = np.asarray(box_encodings, F)
+    anchors = np.asarray(anchors, F)
+    num_classes = enc.shape[1] // 7
+    n = enc.shape[0]
+    if num_classes != 1:
+        enc = enc.reshape(-1, 7)
+        anchors = np.repeat(anchors.reshape(n, 1, 7), num_classes, 1).reshape(-1, 7)
+    e = (enc / np.asarray(weights, F).reshape(1, 7)).astype(F)
+    e[:, 3:6] = np.minimum(e[:, 3:6], F(bbox_xform_clip))
+    xa, ya, za, wa, la, ha, ra = [anchors[:, i] for i in range(7)]
+    diag = np.sqrt((la * la + wa * wa).astype(F)).astype(F)
+    out = np.stack([e[:, 0] * diag + xa, e[:, 1] * diag + ya, e[:, 2] * ha + za, (e[:, 3] + F(1)) * wa,
+                    (e[:, 4] + F(1)) * la, (e[:, 5] + F(1)) * ha, e[:, 6] + ra], 1).astype(F)
+    out[:, 6] = limit_period(out[:, 6], 0.5, PI)
+    if num_classes != 1:
+        out = out.reshape(n, num_classes * 7)
+    return out
+
+
+def encode_centroid_box(targets, anchors, weights=(1.0,) * 7):
+    g = np.asarray(targets, F)
+    a = np.asarray(anchors, F)
+    xa, ya, za, wa, la, ha, ra = [a[:, i] for i in range(7)]
+    xg, yg, zg, wg, lg, hg, rg = [g[:, i] for i in range(7)]
+    diag = np.sqrt((la * la + wa * wa).astype(F)).astype(F)
+    enc = np.stack([(xg - xa) / diag, (yg - ya) / diag, (zg - za) / ha, wg / wa - F(1), lg / la - F(1),
+                    hg / ha - F(1), rg - ra], 1).astype(F)
+    enc[:, 6] = limit_period(enc[:, 6], 0.5, PI)
+    return (enc * np.asarray(weights, F).reshape(1, 7)).astype(F)
+
+
+def grid_anchors(site_coords, base_anchors, voxel_scale, stride):
+    """[V*A, 7], flatten order [site, yaw]"""
+    sc = np.asarray(site_coords)
+    base = np.asarray(base_anchors, F)
+    cen = (sc[:, :3].astype(F) / F(voxel_scale) * np.asarray(stride, F).reshape(1, 3)).astype(F)
+    cen = np.concatenate([cen, np.zeros((sc.shape[0], 4), F)], 1)
+    return (cen[:, None, :] + base[None]).reshape(-1, 7).astype(F)

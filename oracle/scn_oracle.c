@@ -17,11 +17,17 @@
  *     /root/reference into oracle/_ref/ (tests/test_oracle_ref_regions.py).
  *   - Voxel/rule counts are pinned against the reference-run statistics the
  *     survey recorded in BASELINE.md (V0=66,094 / R3=243,374 for S80k seed 0).
- *   - The SparseConvNet C++ compute path itself is UNBUILDABLE here (needs
- *     google sparsehash, absent, and no stand-in headers are allowed), and the
- *     reference holds no golden vectors for it: the numerical half of this
- *     oracle is "parity unpinned" against reference outputs; it is cross-checked
- *     against independent dense torch conv3d / closed-form BN in tests.
+ *   - Numerical kernels (InputLayer fwd/bwd, BatchNorm fwd/bwd, per-offset
+ *     gather -> matmul -> scatter-add of Convolution / Deconvolution fwd/bwd,
+ *     SparseToDense) are pinned against the reference's OWN raw-pointer CPU
+ *     kernels (SCN/CPU/{BatchNormalization,IOLayers,Convolution,SparseToDense}.cpp)
+ *     compiled from /root/reference into oracle/_ref/libref_kernels.so
+ *     (oracle/ref_kernels_harness.cpp, tests/test_oracle_ref_kernels.py):
+ *     BatchNorm and InputLayer BIT-EQUAL, conv/deconv within 1e-5 (at::matmul's
+ *     summation order is unspecified), SparseToDense exact.
+ *   - STILL UNPINNED: the rule-book BUILDERS (Metadata.h needs google sparsehash,
+ *     absent, no stand-in allowed: unbuildable here) beyond their region
+ *     geometry and the V/R counts above.
  *
  * Site-order convention: the reference numbers input-layer sites in first-seen
  * order of the point list (IOLayersRules.h:86-91) -- reproduced exactly.

@@ -187,17 +187,11 @@ def test_device_quantisation_pipeline_matches_host_rule():
 
 
 def _np_decode(reg, anchors, weights, clip):
-    """numpy float32 restatement of BoxCoder3D.decode_centroid_box (box_coder_3d.py:53-80) +
-    second_box_decode(smooth_dim=True) (box_torch_ops.py:118-154) + limit_period (geometric_torch.py:4-10)"""
-    e = (reg / np.asarray(weights, np.float32)).astype(np.float32)
-    e[:, 3:6] = np.minimum(e[:, 3:6], np.float32(clip))
-    xa, ya, za, wa, la, ha, ra = [anchors[:, i] for i in range(7)]
-    diag = np.sqrt(la * la + wa * wa).astype(np.float32)
-    out = np.stack([e[:, 0] * diag + xa, e[:, 1] * diag + ya, e[:, 2] * ha + za, (e[:, 3] + 1) * wa,
-                    (e[:, 4] + 1) * la, (e[:, 5] + 1) * ha, e[:, 6] + ra], 1).astype(np.float32)
-    pi = np.float32(np.pi)
-    out[:, 6] = out[:, 6] - np.floor(out[:, 6] / pi + np.float32(0.5)) * pi
-    return out
+    """oracle/box_oracle.py (pinned by tests/golden/box_golden.npz against the reference's BoxCoder3D)"""
+    import sys
+    sys.path.insert(0, O.ORACLE_DIR)
+    import box_oracle
+    return box_oracle.decode_centroid_box(reg, anchors, weights, clip)
 
 
 def test_rpn_glue_anchors_decode_nms_on_device():

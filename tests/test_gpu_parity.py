@@ -518,3 +518,39 @@ def test_axis_aligned_nms_matches_reference_cpu_rule():
     sc = rng.random(600).astype(np.float32)
     got = nms(_t(dets), _t(sc), 0.4).cpu().numpy()
     np.testing.assert_array_equal(got, O.nms_axis_aligned(dets, sc, 0.4))
+
+
+# ------------------------------------------------------------------------------------ reference-torch golden
+def test_rpn_decode_kernel_vs_reference_torch_golden(golden_dir):
+    """k_rpn_decode against BoxCoder3D.decode run from the reference (tests/golden/gen_box_golden.py): the 256
+    golden anchors ride as base anchors of a single site at the origin, so the kernel's anchor = base."""
+    import _hip
+    from _hip import ptr, stream, check
+    g = np.load(os.path.join(golden_dir, "box_golden.npz"))
+    lib = _hip.load()
+    n = g["dec_enc"].shape[0]
+    coords = torch.zeros((1, 4), dtype=torch.int32, device=DEV)
+    sel = torch.arange(n, dtype=torch.int64, device=DEV)
+    for w in ("w1", "w2"):
+        boxes = torch.empty((n, 7), dtype=torch.float32, device=DEV)
+        check(lib.aabr_rpn_decode(ptr(coords), 0, ptr(sel), n, ptr(_t(g["dec_enc"])), 0, ptr(_t(g["dec_anchors"])), n,
+                                  20.0, _hip.f32xn([4.0, 4.0, 2.0]), _hip.f32xn(g["weights_" + w].tolist()), 10000.0,
+                                  ptr(boxes), stream()))
+        # device division / sqrt are IEEE; floorf(x/pi + .5) is exact -> tolerance only for fma contraction
+        np.testing.assert_allclose(boxes.cpu().numpy(), g["dec_" + w], rtol=1e-6, atol=1e-6)
+
+
+def test_boxes_iou_3d_and_nms_vs_reference_torch_golden(golden_dir):
+    from utils3d.rotate_nms_3d_torch import boxes_iou_3d
+    from second.pytorch.core.box_torch_ops import rotate_nms_3d
+    g = np.load(os.path.join(golden_dir, "box_golden.npz"))
+    for flag in ("rpn_label_generation", "roi_label_generation", "eval", "rpn_post"):
+        a = g["iou3d_%s_aug" % flag]
+        aug = None if flag == "rpn_post" else {"target_Y": float(a[0]), "target_Z": float(a[1]),
+                                                "anchor_Y": float(a[2]), "anchor_Z": float(a[3])}
+        got = boxes_iou_3d(_t(g["iou3d_targets"]), _t(g["iou3d_anchors"]), aug, int(g["iou3d_%s_crit" % flag]),
+                           only_xy=False, flag=flag).cpu().numpy()
+        np.testing.assert_allclose(got, g["iou3d_" + flag], atol=2e-5)
+    for pre, post in ((100, 30), (2000, 1000)):
+        k = rotate_nms_3d(_t(g["nms3d_boxes"]), _t(g["nms3d_scores"]), pre, post, 0.5, flag="rpn_post").cpu().numpy()
+        np.testing.assert_array_equal(k, g["nms3d_keep_%d_%d" % (pre, post)])
