@@ -32,6 +32,7 @@ _SIGS = {
                                           _i32p, _vp, _vp, _vp, _vp]),
     "aabr_table_to_rulebook": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "aabr_spatial_locations": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "aabr_conv_last_variant": (C.c_char_p, []),
     "aabr_conv_wpack_floats": (C.c_int64, [_i32, _i32, _i32]),
     "aabr_conv_forward": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "aabr_conv_dw_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),
@@ -69,6 +70,8 @@ _SIGS = {
     "aabr_roi_align_rotated_3d_sparse_backward": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _f32,
                                                             _i32, _i32, _i32, _i32, _i64, _vp, _vp]),
     "aabr_rpn_decode": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f32, _f32p, _f32p, _f32, _vp, _vp]),
+    "aabr_rpn_decode_maps": (C.c_int, [_i32, _vp, _vp, _vp, _i32p, _i32p, _f32p, _vp, _i32, _f32, _f32p, _f32, _f32,
+                                       _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "aabr_rotate_nms_sorted": (C.c_int, [_vp, _i64, _f32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "aabr_nms_sorted": (C.c_int, [_vp, _i64, _f32, _vp, _vp, _vp, _vp]),
 }
@@ -160,6 +163,16 @@ except AttributeError:  # pragma: no cover
 
 def i32x3(v):
     return (C.c_int32 * 3)(*[int(x) for x in v])
+
+
+def i32xn(v):
+    v = [int(x) for x in v]
+    return (C.c_int32 * len(v))(*v)
+
+
+def ptrs(ts):
+    """host array of device pointers"""
+    return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None and t.numel() else None for t in ts])
 
 
 def f32x4(v):

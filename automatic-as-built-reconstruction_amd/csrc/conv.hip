@@ -1742,6 +1742,11 @@ static void dw_tiling(int ci, int co, int &cb, int &nb, int &tiles) {
 
 using namespace aabr;
 
+// name of the kernel instance the last conv / dW entry point dispatched on this thread (bench provenance:
+// `roofline.kernel` is what actually ran, not a string typed into the bench)
+static thread_local const char *g_last_variant = "";
+extern "C" const char *aabr_conv_last_variant(void) { return g_last_variant; }
+
 extern "C" int64_t aabr_conv_wpack_floats(int vol, int n_in, int n_out) {
   // sized for either orientation (forward uses ci=n_in, the transposed pass ci=n_out)
   int64_t a = (int64_t)vol * nkc_of(n_in) * nnb_of(n_out) * 512;
@@ -1847,6 +1852,7 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
       attr_set = true;                                                                                   \
     }                                                                                                    \
+    g_last_variant = "k_conv_blocks_mfma_wlds<" #NBW "," #NKC "," #AL ">";                                \
     hipLaunchKernelGGL((k_conv_blocks_mfma_wlds<NBW, NKC, AL>), dim3((unsigned)wgx, (unsigned)slabs),    \
                        dim3(64 * nw), lds, st, in_feats, n_in, in_bytes, out_feats, n_out, V_out,        \
                        blocks, words_bytes, vol, flip & 1, wpack, bias);                                 \
@@ -1870,6 +1876,7 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
     const char *ov = getenv("AABR_CONV_SMALL"); // tuning experiments only: 0 disables
     if (!(ov && ov[0] == '0')) {
       constexpr int kW = 8;
+      g_last_variant = "k_conv_blocks_mfma_small<8>";
       hipLaunchKernelGGL((k_conv_blocks_mfma_small<kW>), dim3((unsigned)ceil_div(V_out, 64), (unsigned)nnb),
                          dim3(64 * kW), (size_t)kW * 64 * 16 * sizeof(float), st, in_feats, n_in, in_bytes, out_feats,
                          n_out, V_out, blocks, words_bytes, vol, flip & 1, wpack, wp_bytes, bias);
@@ -1881,6 +1888,12 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
   do {                                                                                                  \
     size_t lds = (size_t)(WPB) * 64 * ((NBW)*16) * sizeof(float);                                       \
     dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                           \
+    g_last_variant = (lean && (NBW) == 4 && wgs >= 8192) ? "k_conv_blocks_mfma_wpipe<" #NBW "," #WPB ",true,true>" \
+                   : (lean && (NBW) == 4) ? "k_conv_blocks_mfma_wpipe<" #NBW "," #WPB ",true,false>"    \
+                   : lean ? "k_conv_blocks_mfma_buf<" #NBW "," #WPB ",true,true>"                       \
+                   : lean_any ? "k_conv_blocks_mfma_buf<" #NBW "," #WPB ",true,false>"                  \
+                   : aligned ? "k_conv_blocks_mfma<" #NBW "," #WPB ",true>"                             \
+                             : "k_conv_blocks_mfma<" #NBW "," #WPB ",false>";                           \
     if (lean && (NBW) == 4 && wgs >= 8192)                                                              \
       hipLaunchKernelGGL((k_conv_blocks_mfma_wpipe<NBW, WPB, true, true>), grid, dim3(64 * (WPB)), lds, st, \
                          in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol,   \
@@ -1976,8 +1989,11 @@ static int conv_backward_weight_t(const T *in_feats, int n_in, const T *d_out, i
   dim3 grid((unsigned)max_chunks, (unsigned)tiles);
   const int chunk_pairs = dw_chunk(V_out, vol, n_in, n_out);
 #define AABR_LAUNCH_DW(CB, NB)                                                                           \
-  hipLaunchKernelGGL((k_conv_dw_pairs<CB, NB, T>), grid, dim3(256), 0, st, in_feats, n_in, d_out, n_out, \
-                     V_out, pairs, vol, chunk_pairs, scratch)
+  do {                                                                                                   \
+    g_last_variant = sizeof(T) == 4 ? "k_conv_dw_pairs<" #CB "," #NB ",float>" : "k_conv_dw_pairs<" #CB "," #NB ",bf16>"; \
+    hipLaunchKernelGGL((k_conv_dw_pairs<CB, NB, T>), grid, dim3(256), 0, st, in_feats, n_in, d_out, n_out, \
+                       V_out, pairs, vol, chunk_pairs, scratch);                                         \
+  } while (0)
   if (cb == 1 && nb == 1) AABR_LAUNCH_DW(1, 1);
   else if (cb == 1 && nb == 2) AABR_LAUNCH_DW(1, 2);
   else if (cb == 1 && nb == 4) AABR_LAUNCH_DW(1, 4);
@@ -2021,8 +2037,11 @@ extern "C" int aabr_conv_backward_weight_bf16(const uint16_t *in_feats, int n_in
     const int64_t cico = (int64_t)n_in * n_out;
     dim3 grid((unsigned)max_chunks, (unsigned)tiles);
 #define AABR_LAUNCH_DW16(CB, NB)                                                                          \
-  hipLaunchKernelGGL((k_conv_dw_pairs_bf16<CB, NB>), grid, dim3(256), 0, st, in16, n_in, do16, n_out, V_out, \
-                     pairs, vol, chunk_pairs, scratch)
+  do {                                                                                                    \
+    g_last_variant = "k_conv_dw_pairs_bf16<" #CB "," #NB ">";                                             \
+    hipLaunchKernelGGL((k_conv_dw_pairs_bf16<CB, NB>), grid, dim3(256), 0, st, in16, n_in, do16, n_out, V_out, \
+                       pairs, vol, chunk_pairs, scratch);                                                 \
+  } while (0)
     if (cb == 2 && nb == 2) AABR_LAUNCH_DW16(2, 2);
     else if (cb == 2 && nb == 4) AABR_LAUNCH_DW16(2, 4);
     else if (cb == 4 && nb == 2) AABR_LAUNCH_DW16(4, 2);
@@ -2094,6 +2113,7 @@ extern "C" int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_
   do {                                                                                                   \
     size_t lds = (size_t)(WPB) * 64 * ((NBW)*16) * sizeof(float);                                        \
     dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)ceil_div(nnb, (NBW)));                            \
+    g_last_variant = "k_conv_blocks_mfma_bf16<" #NBW "," #WPB "," #KG ",true>";                          \
     hipLaunchKernelGGL((k_conv_blocks_mfma_bf16<NBW, WPB, KG, true>), grid, dim3(64 * (WPB)), lds, st,   \
                        reinterpret_cast<const __bf16 *>(in_feats), n_in, in_bytes,                       \
                        reinterpret_cast<__bf16 *>(out_feats), n_out, V_out, blocks, words_bytes, vol,    \

@@ -111,6 +111,76 @@ __global__ __launch_bounds__(256) void k_rpn_decode(const int32_t *__restrict__ 
   for (int d = 0; d < 7; ++d) boxes[7 * i + d] = o[d];
 }
 
+// Cross-scale form (the shape RPNPostProcessor actually runs in: cat_scales_obj_reg regroups the scales
+// example-major, rpn_sparse3d.py:19-77, then ONE top-k + decode + NMS per example, rpn/inference_3d.py:95-149).
+// `selected[i]` indexes the example's concatenated anchor list [map][site][yaw]; the segment table maps it
+// back to (map, site row, yaw) so neither the anchors nor the concatenated regression are ever materialised.
+// Also fused: objectness sigmoid of the selected logits and the boxlist_nms_3d thickness clamps
+// (structures/boxlist_ops_3d.py:42-44) into a second, NMS-only copy of the boxes.
+constexpr int kMaxRpnMaps = 8;
+struct RpnMapsParams {
+  const int32_t *coords[kMaxRpnMaps];   // [V_m,4] site lists
+  const float *logits[kMaxRpnMaps];     // [V_m*A]
+  const float *regression[kMaxRpnMaps]; // [V_m*A,7]
+  int32_t seg_begin[kMaxRpnMaps + 1];   // first local anchor index of map m in this example's list
+  int32_t site_begin[kMaxRpnMaps];      // first site row of this example in map m
+  float stride[kMaxRpnMaps][3];
+  int n_maps, A;
+  float voxel_scale, clip, nms_min_yx, nms_min_z;
+  float weights[7];
+};
+
+__global__ __launch_bounds__(256) void k_rpn_decode_maps(RpnMapsParams p, const int64_t *__restrict__ sel, int64_t k,
+                                                         const float *__restrict__ base_anchors /*[n_maps*A,7]*/,
+                                                         float *__restrict__ boxes, float *__restrict__ nms_boxes,
+                                                         float *__restrict__ scores) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const int32_t t = (int32_t)sel[i];
+  int m = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxRpnMaps; ++q)
+    if (q < p.n_maps && t >= p.seg_begin[q]) m = q;
+  const int32_t r = t - p.seg_begin[m];
+  const int64_t site = (int64_t)p.site_begin[m] + r / p.A;
+  const int a = r % p.A;
+  const int32_t *sc = p.coords[m] + 4 * site;
+  const float *ba = base_anchors + 7 * ((int64_t)m * p.A + a);
+  float an[7];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) an[d] = (float)sc[d] / p.voxel_scale * p.stride[m][d] + ba[d];
+#pragma unroll
+  for (int d = 3; d < 7; ++d) an[d] = 0.0f + ba[d];
+  const int64_t row = site * p.A + a;
+  const float *rg7 = p.regression[m] + 7 * row;
+  float e[7];
+#pragma unroll
+  for (int d = 0; d < 7; ++d) e[d] = rg7[d] / p.weights[d];
+#pragma unroll
+  for (int d = 3; d < 6; ++d) e[d] = e[d] > p.clip ? p.clip : e[d];
+  const float diagonal = sqrtf(an[4] * an[4] + an[3] * an[3]);
+  float o[7];
+  o[0] = e[0] * diagonal + an[0];
+  o[1] = e[1] * diagonal + an[1];
+  o[2] = e[2] * an[5] + an[2];
+  o[3] = (e[3] + 1) * an[3];
+  o[4] = (e[4] + 1) * an[4];
+  o[5] = (e[5] + 1) * an[5];
+  float rg = e[6] + an[6];
+  const float period = 3.14159265358979323846f;
+  o[6] = rg - floorf(rg / period + 0.5f) * period;
+#pragma unroll
+  for (int d = 0; d < 7; ++d) boxes[7 * i + d] = o[d];
+  if (nms_boxes) {
+    o[3] = o[3] < p.nms_min_yx ? p.nms_min_yx : o[3];
+    o[4] = o[4] < p.nms_min_yx ? p.nms_min_yx : o[4];
+    o[5] = o[5] < p.nms_min_z ? p.nms_min_z : o[5];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) nms_boxes[7 * i + d] = o[d];
+  }
+  if (scores) scores[i] = 1.0f / (1.0f + expf(-p.logits[m][row]));
+}
+
 // KIND 0: rotated 3-D boxes [n,7] (2-D IoU, optionally times z-IoU); KIND 1: axis-aligned [n,4].
 // One pair per lane: a wave owns one row i and one block of 64 columns; the 64 verdicts become the
 // suppression word with a single ballot (no loop over columns, no shared-memory staging).  Four rows per
@@ -285,6 +355,43 @@ extern "C" int aabr_rpn_decode(const int32_t *site_coords, int64_t site_begin, c
   hipLaunchKernelGGL(k_rpn_decode, dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, (hipStream_t)stream_,
                      site_coords, site_begin, selected, k, regression, reg_begin, base_anchors, num_anchors, p,
                      boxes);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_rpn_decode_maps(int n_maps, const void *const *coords_ptrs, const void *const *logit_ptrs,
+                                    const void *const *regression_ptrs, const int32_t *seg_begin_host,
+                                    const int32_t *site_begin_host, const float *strides_host,
+                                    const float *base_anchors, int num_anchors, float voxel_scale,
+                                    const float *weights_host, float clip, float nms_min_yx, float nms_min_z,
+                                    const int64_t *selected, int64_t k, float *boxes, float *nms_boxes,
+                                    float *scores, void *stream_) {
+  AABR_CHECK_ARG(n_maps >= 1 && n_maps <= kMaxRpnMaps && k >= 0 && num_anchors > 0 && voxel_scale > 0,
+                 "bad arguments");
+  AABR_CHECK_ARG(coords_ptrs && logit_ptrs && regression_ptrs && seg_begin_host && site_begin_host &&
+                     strides_host && weights_host, "null host table");
+  if (k == 0) return AABR_OK;
+  AABR_CHECK_ARG(selected && base_anchors && boxes, "null pointer");
+  RpnMapsParams p;
+  for (int m = 0; m < kMaxRpnMaps; ++m) {
+    const bool on = m < n_maps;
+    p.coords[m] = on ? (const int32_t *)coords_ptrs[m] : nullptr;
+    p.logits[m] = on ? (const float *)logit_ptrs[m] : nullptr;
+    p.regression[m] = on ? (const float *)regression_ptrs[m] : nullptr;
+    p.site_begin[m] = on ? site_begin_host[m] : 0;
+    for (int d = 0; d < 3; ++d) p.stride[m][d] = on ? strides_host[3 * m + d] : 0.f;
+  }
+  for (int m = 0; m <= kMaxRpnMaps; ++m) p.seg_begin[m] = seg_begin_host[m <= n_maps ? m : n_maps];
+  for (int m = 0; m < n_maps; ++m) {
+    AABR_CHECK_ARG(p.seg_begin[m + 1] >= p.seg_begin[m], "segment table must be non-decreasing");
+    AABR_CHECK_ARG(p.seg_begin[m + 1] == p.seg_begin[m] || (p.coords[m] && p.logits[m] && p.regression[m]),
+                   "null map pointer");
+  }
+  p.n_maps = n_maps; p.A = num_anchors; p.voxel_scale = voxel_scale; p.clip = clip;
+  p.nms_min_yx = nms_min_yx; p.nms_min_z = nms_min_z;
+  for (int d = 0; d < 7; ++d) p.weights[d] = weights_host[d];
+  hipLaunchKernelGGL(k_rpn_decode_maps, dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, (hipStream_t)stream_, p,
+                     selected, k, base_anchors, boxes, nms_boxes, scores);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

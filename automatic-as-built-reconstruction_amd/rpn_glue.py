@@ -61,6 +61,62 @@ def rpn_proposals_single_map(tensor, objectness, box_regression, base_anchors, v
     return out
 
 
+def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel_scale, pre_nms_top_n=2000,
+                  post_nms_top_n=1000, nms_thresh=0.5, nms_aug_thickness=(0.3, 0.3), weights=(1.0,) * 7,
+                  bbox_xform_clip=10000.0):
+    """Cross-scale proposals, the shape the reference runs in (RPNModule.forward, rpn_sparse3d.py:184-209):
+    `cat_scales_obj_reg` regroups the scales example-major and RPNPostProcessor then does, per example, ONE
+    sigmoid -> top-k(2000) -> decode -> boxlist_nms_3d(1000) over the anchors of all maps
+    (rpn/inference_3d.py:95-149).
+
+    maps: list of SparseConvNetTensor (sites batch-contiguous); objectness[m] [V_m*A] logits and
+    box_regression[m] [V_m*A,7] in the flatten order [site, yaw]; base_anchors[m] [A,7]; strides[m] (3).
+    Device-resident: neither the anchors nor the regrouped tensors are materialised -- the fused kernel maps a
+    selected index of the example's concatenated list back to (map, site, yaw).  The top-k runs on the logits
+    (sigmoid is monotone; it is applied to the k selected entries inside the kernel).  One small read-back
+    (sites per example and map) sizes the slices.  Returns a list over examples of (boxes [m,7], scores [m])."""
+    lib = _hip.load()
+    n_maps = len(maps)
+    assert n_maps == len(objectness) == len(box_regression) == len(base_anchors) == len(strides)
+    grids = [t.metadata.grids[tuple(int(v) for v in t.spatial_size.tolist())] for t in maps]
+    dev = objectness[0].device
+    A = int(base_anchors[0].shape[0])
+    ba = torch.cat([b.reshape(A, 7) for b in base_anchors], 0).to(device=dev, dtype=torch.float32).contiguous()
+    obj = [o.reshape(-1).contiguous().float() for o in objectness]
+    reg = [r.reshape(-1, 7).contiguous().float() for r in box_regression]
+    nb = max((int(g.coords[-1, 3].item()) + 1 if g.V else 0) for g in grids[:1])
+    counts = torch.stack([torch.bincount(g.coords[:, 3].long(), minlength=nb)[:nb] if g.V else
+                          torch.zeros(nb, dtype=torch.int64, device=dev) for g in grids]).tolist()   # [map][example]
+    coords_p, obj_p, reg_p = _hip.ptrs([g.coords for g in grids]), _hip.ptrs(obj), _hip.ptrs(reg)
+    strides_h = _hip.f32xn([v for st in strides for v in st])
+    weights_h = _hip.f32xn(weights)
+    site0 = [0] * n_maps
+    out = []
+    for bi in range(nb):
+        seg = [0]
+        for m in range(n_maps):
+            seg.append(seg[-1] + counts[m][bi] * A)
+        n_anchor = seg[-1]
+        if n_anchor == 0:
+            out.append((torch.zeros(0, 7, device=dev), torch.zeros(0, device=dev)))
+            continue
+        logit_b = torch.cat([obj[m][site0[m] * A:(site0[m] + counts[m][bi]) * A] for m in range(n_maps)])
+        k = min(pre_nms_top_n, n_anchor)
+        _, sel = logit_b.topk(k, dim=0, sorted=True)
+        boxes = torch.empty((k, 7), dtype=torch.float32, device=dev)
+        nms_boxes = torch.empty((k, 7), dtype=torch.float32, device=dev)
+        scores = torch.empty(k, dtype=torch.float32, device=dev)
+        check(lib.aabr_rpn_decode_maps(n_maps, coords_p, obj_p, reg_p, _hip.i32xn(seg), _hip.i32xn(site0), strides_h,
+                                       ptr(ba), A, float(voxel_scale), weights_h, float(bbox_xform_clip),
+                                       float(nms_aug_thickness[0]), float(nms_aug_thickness[1]), ptr(sel), k,
+                                       ptr(boxes), ptr(nms_boxes), ptr(scores), stream()))
+        keep = _nms.rotate_nms_sorted(nms_boxes, nms_thresh, post_nms_top_n, _nms.REFERENCE_DEBUG_ONLY_XY)
+        out.append((boxes[keep], scores[keep]))
+        for m in range(n_maps):
+            site0[m] += counts[m][bi]
+    return out
+
+
 def cat_scales_obj_reg(objectness, rpn_box_regression, examples_idxscope):
     """`cat_scales_obj_reg` (modeling/rpn/rpn_sparse3d.py:19-77) on plain tensors: the RPN head emits, per
     scale, the objectness / regression rows of all examples back to back; the loss and the post-processor

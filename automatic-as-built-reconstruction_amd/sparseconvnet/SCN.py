@@ -20,6 +20,10 @@ count_macs = os.environ.get("AABR_COUNT_MACS", "1") != "0"  # the reference retu
                    # a LAZY number: the rule counts stay on the device until somebody reads it
 
 
+trace = None  # measurement hook: when set to a list, every conv / dW launch appends
+              # (kind, n_in, n_out, gather, rows_in, flags, dtype) -- bench.py uses it to find the dominant kernel
+
+
 class _TotalsRing(object):
     """Device buffer of per-rule-book rule totals (float64).  A rule book writes its total into the next free
     slot with ONE reduction launch when a layer first asks for it; reading values back is one copy of the
@@ -219,9 +223,14 @@ class _Gather(object):
     def max_chunks(self, n_in, n_out):
         """upper bound on the chunks of the weight-gradient pass"""
         cp = _hip.load().aabr_conv_dw_chunk_pairs(self.rows, self.vol, n_in, n_out)
+        bound = (self.vol * self.rows + cp - 1) // cp + self.vol
+        # the geometric bound sizes a grow-only scratch of bound * n_in * n_out floats (256->256 on a 1.5 M-site
+        # book: ~10 GB); past 256 MB read the true per-offset counts once (one small D2H, cached) instead
+        if self._host_counts is None and bound * n_in * n_out * 4 > (256 << 20):
+            self.rule_counts()
         if self._host_counts is not None:
             return sum((c + cp - 1) // cp for c in self._host_counts)
-        return (self.vol * self.rows + cp - 1) // cp + self.vol
+        return bound
 
 
 class _Table(object):
@@ -293,9 +302,10 @@ class Metadata_3(object):
     # ---- builders ---------------------------------------------------------------------------
     def inputLayer(self, spatial_size, coords, batch_size, mode, device):
         """Metadata::inputLayer (Metadata.cpp:405-417)"""
-        if self.input is not None and self.input.get("coords_id") == (coords.data_ptr(), coords.shape[0]) \
-                and self.input["mode"] == int(mode):
-            return self.inputLayerFinish()  # prepared ahead of time (InputLayer.prepare)
+        if self.input is not None:
+            src = self.input.get("coords_src")
+            if src is not None and src[0] is coords and src[1] == coords._version and self.input["mode"] == int(mode):
+                return self.inputLayerFinish()  # prepared ahead of time (InputLayer.prepare)
         self.inputLayerEnqueue(spatial_size, coords, mode, device, asynchronous=False)
         return self.inputLayerFinish()
 
@@ -304,7 +314,7 @@ class Metadata_3(object):
         when `asynchronous`); all integer state of the input layer lives in ONE device allocation"""
         assert coords.dim() == 2 and coords.size(1) in (3, 4)
         assert self.input is None and len(self.grids) == 0, "Metadata already holds an input layer"
-        coords_id = (coords.data_ptr(), coords.shape[0])
+        coords_src = (coords, coords._version)   # identity + version of the caller's tensor (kept alive here)
         lib = _hip.load()
         self.device = device
         coords = coords.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
@@ -349,7 +359,7 @@ class Metadata_3(object):
         self._pending = dict(host=host, event=ev, meta=meta, site_coords=site_coords, keys=keys, vals=vals,
                              cap=cap, coords=coords, buf=buf)
         self.input = dict(point_site=point_site, site_off=site_off, site_pts=site_pts, n=n, V=None,
-                          mode=int(mode), max_active=None, spatial=_key(spatial_size), coords_id=coords_id)
+                          mode=int(mode), max_active=None, spatial=_key(spatial_size), coords_src=coords_src)
 
     def inputLayerFinish(self):
         """wait for the read-back (the one host sync of the input layer: V sizes every later tensor)"""
@@ -554,6 +564,8 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
             flags |= 4
     check(conv(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
                ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
+    if trace is not None:
+        trace.append(("fwd", n_in, n_out, gather, inp.size(0), flags & 3, inp.dtype))
     return n_out
 
 
@@ -569,6 +581,8 @@ def _conv_dw(inp, d_out, gather, d_weight, d_bias):
     fn = lib.aabr_conv_backward_weight_bf16 if inp.dtype == torch.bfloat16 else lib.aabr_conv_backward_weight
     check(fn(ptr(inp), n_in, ptr(d_out), n_out, V_out, ptr(pairs), gather.vol, mc,
              ptr(d_weight), ptr(_opt(d_bias)), ptr(scratch), stream()))
+    if trace is not None:
+        trace.append(("dw", n_in, n_out, gather, inp.size(0), 0, inp.dtype))
 
 
 def _macs(tb, weight):
@@ -646,6 +660,11 @@ def BatchNormalization_updateOutput(input_features, output_features, saveMean, s
     if inp.dim() != 2:
         return
     rows, planes = inp.shape
+    for t_, nm_ in ((saveMean, "saveMean"), (saveInvStd, "saveInvStd"), (runningMean, "runningMean"),
+                    (runningVar, "runningVar")):
+        if t_.dtype != torch.float32 or t_.numel() < planes:
+            raise TypeError("BatchNormalization: %s must hold %d float32 values, got %s[%d]"
+                            % (nm_, planes, t_.dtype, t_.numel()))
     scratch = _hip.workspace("bn", lib.aabr_bn_scratch_floats(planes), torch.float32, inp.device)
     _same_dtype(inp, output_features, "BatchNormalization")
     fn = lib.aabr_bn_forward_bf16 if inp.dtype == torch.bfloat16 else lib.aabr_bn_forward

@@ -36,8 +36,9 @@ class BatchNormalization(Module):
             _mean = self.running_mean
             _var = self.running_var
         else:
-            _mean = input.features.mean(0)
-            _var = input.features.var(0)
+            # statistics buffers are fp32 whatever the feature storage (the kernels read `planes` floats)
+            _mean = input.features.float().mean(0)
+            _var = input.features.float().var(0)
         output.features = BatchNormalizationFunction.apply(
             input.features, optionalTensor(self, "weight"), optionalTensor(self, "bias"), _mean, _var, self.eps,
             self.momentum, self.training, self.leakiness)

@@ -36,17 +36,25 @@ class InputLayer(Module):
             device = self.device if self.device is not None else coords.device
         md = Metadata(self.dimension)
         side = stream if stream is not None else torch.cuda.current_stream()
+        c64 = coords if coords.dtype == torch.int64 else coords.long()   # converted ONCE; forward reuses c64
         with torch.cuda.stream(side):
             # kernels + an asynchronous read-back of the site count; nothing blocks here
-            md.inputLayerEnqueue(self.spatial_size, coords.long(), self.mode if self.mode else 3, device)
+            md.inputLayerEnqueue(self.spatial_size, c64, self.mode if self.mode else 3, device)
             md.prepared_on = side
         if not hasattr(self, "_prepared"):
-            self._prepared = {}
-        self._prepared[(coords.data_ptr(), coords.shape[0])] = md
+            self._prepared = []
+        # matched by identity + version of the caller's tensor (held here, so its address cannot be recycled)
+        self._prepared.append((coords, coords._version, c64, md))
 
     def forward(self, input):
         prepared = getattr(self, "_prepared", None)
-        md = prepared.pop((input[0].data_ptr(), input[0].shape[0]), None) if prepared else None
+        md, c64 = None, None
+        if prepared:
+            for i, (src, ver, conv, m) in enumerate(prepared):
+                if src is input[0] and ver == input[0]._version:
+                    md, c64 = m, conv
+                    del prepared[i]
+                    break
         if md is not None:
             cur = torch.cuda.current_stream()
             if md.prepared_on != cur:
@@ -56,7 +64,7 @@ class InputLayer(Module):
         output = SparseConvNetTensor(metadata=md if md is not None else Metadata(self.dimension),
                                      spatial_size=self.spatial_size)
         output.features = InputLayerFunction.apply(
-            self.dimension, output.metadata, self.spatial_size, input[0].long(),
+            self.dimension, output.metadata, self.spatial_size, c64 if c64 is not None else input[0].long(),
             input[1].to(self.device) if self.device else input[1], 0 if len(input) == 2 else input[2],
             self.mode)
         return output

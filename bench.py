@@ -1,191 +1,337 @@
 #!/usr/bin/env python3
 """bench.py -- scenes/s (fwd+bwd) of the sparse-3D hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): one synthetic SUNCG-shaped scene per step (~80k points,
-5 cm voxels, C_in = 9, bs = 1) -> HIP voxel scatter (InputLayer mode 4, hash grid + rule table
-built on the device every step) -> 2-stage submanifold backbone (SubmConv3 9->32, residual
-block BNReLU-SubmConv3-BNReLU-SubmConv3 32->32, add), fp32, forward + backward (all weight
-gradients and the input-feature gradient) + gradient all-reduce (N > 1) + SGD update.
-Inputs are resident in HBM before the timed region.  One process per GPU; ranks take
-different scenes (weak scaling), the only collective is the gradient all-reduce.
+Headline workload = BASELINE.json configs[2] ("walls" config: the default FPN_Net backbone,
+maskrcnn_benchmark/config/defaults.py:48-57, SparseConvNet/sparseconvnet/fpn_net.py:13-203), per GPU and step:
+  4 synthetic SUNCG-shaped scenes (~80k points each) at 2 cm voxels, C_in = 9
+  -> HIP voxel scatter (InputLayer mode 4; hash grid, site numbering and every rule book rebuilt each step)
+  -> FPN_Net: 9 scales, 36 SubmanifoldConvolution + 12 Convolution + 8 Deconvolution + 35 BatchNorm(+ReLU)
+  -> RPN head (three dense 1x1 layers, torch plumbing as in the reference, rpn_sparse3d.py:81-131)
+  -> per scene: cross-scale top-k(2000) -> fused anchor + BoxCoder3D decode -> rotated-3D NMS (1000)
+  -> backward through head and backbone (all weight gradients + the input-feature gradient)
+  -> gradient all-reduce (N > 1: ONE flat RCCL all-reduce) -> SGD update.
+The headline runs in fp32, the reference's arithmetic; the same step with bf16 feature storage is reported
+beside it (`extras.bf16`).  Inputs are resident in HBM before the timed region.  One process per GPU
+(`--gpus N` spawns the ranks itself when not already under torchrun); ranks take different scenes of one global
+scene list (weak scaling: per-GPU work fixed); the only collective is the gradient all-reduce.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the output-stationary
-MFMA gather-GEMM, k_conv_blocks_mfma, 32->32 forward instance) timed with HIP events on the
-stream it is launched on; `cpu_baseline` is the oracle (CPU port of the reference path) timed
-on this box's host cores on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel instance with the largest share of the step among
+the convolution launches of this very workload, found and timed live (HIP events on the launching stream);
+`cpu_baseline` is the oracle (CPU port of the reference path) on a bounded sample of the same workload with the
+per-stage split of SURVEY 8(d).
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-importlib.import_module("automatic-as-built-reconstruction_amd")
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import synth_scenes as S  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+SCENES_PER_STEP = 4             # bs 4 per GPU (configs[2] / configs[3])
+VOXEL_SCALE = 50                # 2 cm
+N_POINTS = 80000
+MIN_TIMED_S = 0.2               # a timed region shorter than this is reported as such (`timed_region_short`)
+
+# RPN constants of the reference config (defaults.py:127-131,159-181)
+ANCHOR_SIZES_3D = [[0.4, 1.5, 1.5], [1.5, 1.5, 1.0], [4, 4, 1.5], [0.2, 0.5, 3], [0.4, 1.5, 3], [0.6, 2.5, 3]]
+YAWS = (0, -1.57, -0.785, 0.785)
 
 
-def build_model(scn, dev, c_in=9):
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(argv, n, script=None):
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (tools/train_net_sparse3d.py:183-190
+    is launched by torch.distributed.launch the same way).  This parent never touches the GPU and nothing is
+    re-exec'd; children inherit stdout, rank 0 prints the JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("AABR_BENCH_TIMEOUT", "1500"))
+    while procs:
+        for p in list(procs):
+            r = p.poll()
+            if r is None:
+                continue
+            procs.remove(p)
+            if r != 0:
+                rc = rc or r
+                for q in procs:   # one rank failed: the others would hang in the next collective
+                    q.terminate()
+        if time.time() > deadline:
+            for q in procs:
+                q.kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ workload
+def build_net(scn, torch, dev, dtype):
     torch.manual_seed(0)
-    m = dict(inp=scn.InputLayer(3, list(S.FULL_SCALE), mode=4),
-             conv1=scn.SubmanifoldConvolution(3, c_in, 32, 3, False).to(dev),
-             bn1=scn.BatchNormLeakyReLU(32, momentum=0.95, leakiness=0).to(dev),
-             conv2=scn.SubmanifoldConvolution(3, 32, 32, 3, False).to(dev),
-             bn2=scn.BatchNormLeakyReLU(32, momentum=0.95, leakiness=0).to(dev),
-             conv3=scn.SubmanifoldConvolution(3, 32, 32, 3, False).to(dev))
-    return m
+    net = scn.FPN_Net([4096, 4096, 512], 3, ["xyz", "color", "normal"], 1,
+                      [32, 64, 64, 128, 128, 128, 256, 256, 256], 128, True, [4, 3, 2, 1], [4, 3, 2, 1],
+                      [[[2, 2, 2]] * 8, [[2, 2, 2]] * 8],
+                      [[256, 256, 32], [128, 128, 16], [64, 64, 8], [32, 32, 4]], [1, 2, 3, 4, 5, 6],
+                      leakiness=0, voxel_scale=VOXEL_SCALE, bn_momentum=0.95, feature_dtype=dtype).to(dev)
+
+    class RpnHead(torch.nn.Module):
+        """SingleConvRPNHead_Sparse3D (rpn_sparse3d.py:81-131): 1x1 conv + ReLU, objectness and box heads --
+        dense torch layers in the reference too (nn.Conv2d on [1,C,N,1]); plumbing, not part of the HIP path."""
+
+        def __init__(self, c, a):
+            super().__init__()
+            self.conv, self.cls_logits, self.bbox_pred = (torch.nn.Linear(c, c), torch.nn.Linear(c, a),
+                                                          torch.nn.Linear(c, a * 7))
+            for l in (self.conv, self.cls_logits, self.bbox_pred):
+                torch.nn.init.normal_(l.weight, std=0.01)
+                torch.nn.init.constant_(l.bias, 0)
+
+        def forward(self, f):
+            t = torch.relu(self.conv(f))
+            return self.cls_logits(t).reshape(-1), self.bbox_pred(t).reshape(-1, 7)
+
+    head = RpnHead(128, len(YAWS)).to(dev)
+    return net, head
 
 
-def forward(scn, m, locs, feats, after_geometry=None):
-    x0 = m["inp"]([locs, feats])
-    if after_geometry is not None:
-        after_geometry()  # hook between the parameter-free geometry and the first layer with weights
-    x1 = m["conv1"](x0)
-    x3 = m["conv3"](m["bn2"](m["conv2"](m["bn1"](x1))))
-    return scn.add_feature_planes([x1, x3])
+def rpn_constants(torch):
+    base = []
+    for size in ANCHOR_SIZES_3D:   # generate_anchors_3d_yaws (anchor_generator_sparse3d.py:230-241)
+        base.append(torch.tensor([[0.0, 0.0, 0.0] + list(size) + [y] for y in YAWS], dtype=torch.float32))
+    # ANCHOR_STRIDE = cumulative SPARSE3D.STRIDE of each map's scale (train_net_sparse3d.py:287-305); rpn maps are
+    # the 3-D maps of scales 5,6,7 from the bottom and the z-collapsed maps of scales 4,5,6 (selector [1..6])
+    strides = [[2.0 ** s] * 3 for s in (5, 6, 7)] + [[2.0 ** s] * 3 for s in (4, 5, 6)]
+    return base, strides
 
 
-def cpu_baseline(n_scenes_budget_s=15.0):
-    """oracle (CPU port of the reference path) on the same workload, bounded sample"""
+class Workload(object):
+    def __init__(self, scn, torch, dp, dev, dtype, rank, world, n_batches):
+        import synth_scenes as S
+        self.scn, self.torch, self.dev, self.world = scn, torch, dev, world
+        self.net, self.head = build_net(scn, torch, dev, dtype)
+        self.flat = dp.FlatParams([self.net, self.head])
+        self.flat.broadcast(0)
+        self.base, self.strides = rpn_constants(torch)
+        # one global scene list, sharded over the ranks (dp.shard_scenes: the sampler the reference lacks)
+        n_global = world * n_batches * SCENES_PER_STEP
+        mine = dp.shard_scenes(n_global, rank, world, sizes=[N_POINTS] * n_global)
+        self.batches = []
+        for b in range(n_batches):
+            L, F = [], []
+            for j, sid in enumerate(mine[b * SCENES_PER_STEP:(b + 1) * SCENES_PER_STEP]):
+                l, f = S.make_scene(N_POINTS, 9000 + sid, VOXEL_SCALE)
+                import numpy as np
+                L.append(np.concatenate([l, np.full((l.shape[0], 1), j, np.int64)], 1))
+                F.append(f)
+            import numpy as np
+            self.batches.append((torch.as_tensor(np.concatenate(L, 0)).to(dev),
+                                 torch.as_tensor(np.concatenate(F, 0)).to(dev).requires_grad_(True)))
+        self.last = None
+
+    def forward_backward(self, i, proposals=True):
+        import rpn_glue
+        torch = self.torch
+        locs, feats = self.batches[i % len(self.batches)]
+        rpn_maps, _ = self.net([locs, feats])
+        loss, objs, regs = 0, [], []
+        for m in rpn_maps:
+            o, r = self.head(m.features)
+            objs.append(o)
+            regs.append(r)
+            loss = loss + o.square().mean() + r.square().mean()
+        loss.backward()
+        feats.grad = None
+        props = None
+        if proposals:
+            with torch.no_grad():
+                props = rpn_glue.rpn_proposals(rpn_maps, [o.detach() for o in objs], [r.detach() for r in regs],
+                                               self.base, self.strides, float(VOXEL_SCALE), 2000, 1000, 0.5, (0.3, 0.3))
+        self.last = (rpn_maps, props)
+        return loss
+
+    def step(self, i):
+        self.flat.zero_grad()
+        self.forward_backward(i)
+        self.flat.allreduce_mean(self.world)
+        self.flat.sgd_step(1e-5, self.world)
+
+
+# ------------------------------------------------------------------------------------------------ measurement
+def hip_time(torch, fn, group, reps):
+    """average duration of fn() from HIP events on the launching (current) stream; events bracket GROUPS of
+    back-to-back launches (an event pair around one ~20 us launch reads 2-3 us high)"""
+    fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        for _ in range(group):
+            fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) / group for a, b in evs)
+    ms = ms[: max(1, len(ms) * 3 // 4)]
+    return sum(ms) / len(ms) * 1e-3
+
+
+def conv_kernel_table(torch, wl, dtype):
+    """Every convolution launch of one training step (forward, input-gradient, weight-gradient), grouped by
+    (kernel kind, planes, rule book); each distinct instance re-launched alone and timed with HIP events.
+    Returns rows sorted by their share of the step."""
+    import _hip
+    from _hip import ptr, stream, check
+    from sparseconvnet import SCN
+    lib = _hip.load()
+    SCN.trace = []
+    wl.flat.zero_grad()
+    wl.forward_backward(0, proposals=False)
+    torch.cuda.synchronize()
+    tr, SCN.trace = SCN.trace, None
+    groups = {}
+    for kind, n_in, n_out, gather, rows_in, flags, dt in tr:
+        key = (kind, n_in, n_out, id(gather), flags, dt)
+        g = groups.setdefault(key, dict(kind=kind, n_in=n_in, n_out=n_out, gather=gather, rows_in=rows_in,
+                                        flags=flags, dtype=dt, calls=0))
+        g["calls"] += 1
+    rows = []
+    dev = wl.dev
+    for g in groups.values():
+        ga, n_in, n_out, rows_in = g["gather"], g["n_in"], g["n_out"], g["rows_in"]
+        R = float(sum(ga.rule_counts()))
+        bf = g["dtype"] == torch.bfloat16
+        fdt = torch.bfloat16 if bf else torch.float32
+        if g["kind"] == "fwd":
+            inp = torch.randn((rows_in, n_in), device=dev).to(fdt)
+            out = torch.empty((ga.rows, n_out), device=dev, dtype=fdt)
+            tr_ = g["flags"] & 1
+            w = torch.randn((ga.vol, 1, n_out, n_in) if tr_ else (ga.vol, 1, n_in, n_out), device=dev) * 0.05
+            if bf:
+                wpack = torch.empty(lib.aabr_conv_wpack_bf16_elems(ga.vol, w.size(2), w.size(3)), device=dev,
+                                    dtype=torch.bfloat16)
+                conv = lib.aabr_conv_forward_bf16
+            else:
+                wpack = torch.empty(lib.aabr_conv_wpack_floats(ga.vol, w.size(2), w.size(3)), device=dev)
+                conv = lib.aabr_conv_forward
+            blocks = ga.blocks()
+            check(conv(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks), ga.vol, ptr(w), None,
+                       g["flags"], ptr(wpack), stream()))   # packs the weights once
+
+            def fn():
+                check(conv(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks), ga.vol, ptr(w), None,
+                           g["flags"] | 4, ptr(wpack), stream()))
+        else:
+            inp = torch.randn((rows_in, n_in), device=dev).to(fdt)
+            d_out = torch.randn((ga.rows, n_out), device=dev).to(fdt)
+            dW = torch.empty((ga.vol, n_in, n_out), device=dev)
+            pairs = ga.pairs()
+            mc = ga.max_chunks(n_in, n_out)
+            scratch = torch.empty(max(1, lib.aabr_conv_dw_scratch_floats(mc, n_in, n_out)), device=dev)
+            fnc = lib.aabr_conv_backward_weight_bf16 if bf else lib.aabr_conv_backward_weight
+
+            def fn():
+                check(fnc(ptr(inp), n_in, ptr(d_out), n_out, ga.rows, ptr(pairs), ga.vol, mc, ptr(dW), None,
+                          ptr(scratch), stream()))
+        fn()
+        variant = lib.aabr_conv_last_variant().decode()
+        sec = hip_time(torch, fn, 4, 6)
+        flops = 2.0 * R * n_in * n_out
+        rows.append(dict(kind=g["kind"], kernel=variant, n_in=n_in, n_out=n_out, vol=ga.vol, rows_out=int(ga.rows),
+                         rules=int(R), calls_per_step=g["calls"], launch_us=round(sec * 1e6, 2),
+                         step_us=round(sec * 1e6 * g["calls"], 1), tflops=round(flops / sec / 1e12, 2),
+                         flops_per_launch=flops))
+        del inp
+    rows.sort(key=lambda r: -r["step_us"])
+    return rows
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes of THIS command (profiles/, separate
+    --pmc runs; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note of MI355X_MICROARCH.md).  Returns (bytes, source)
+    or (None, reason) -- never a number for a different kernel."""
+    path = os.path.join(REPO, "profiles", "r02_pmc_fetch_write_per_kernel.json")
+    try:
+        pm = json.load(open(path))["kernels"]
+    except Exception:
+        return None, "no committed PMC profile for this round"
+    base = kernel_name.replace(" ", "")
+    for kname, v in pm.items():
+        if kname.replace(" ", "").startswith(base.split("(")[0]):
+            return int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024), \
+                "committed profile profiles/r02_pmc_fetch_write_per_kernel.json (average over that kernel's launches)"
+    return None, "kernel not in the committed PMC profile (dispatch changed since it was taken)"
+
+
+def cpu_baseline(wl, torch, budget_s=25.0):
+    """oracle (CPU port of the reference path; contraction / BN / input kernels pinned to the reference's own
+    compiled CPU kernels, tests/test_oracle_ref_kernels.py) on a bounded sample of the same workload, with the
+    per-stage split of SURVEY 8(d)"""
     sys.path.insert(0, os.path.join(REPO, "tests"))
+    import numpy as np
     import oracle_lib as O
     import ref_net
-    # the CPU leg runs on the cores the process was given, not on the four the GPU leg pinned itself to
+    import synth_scenes as S
     if _ORIG_AFFINITY:
         try:
             os.sched_setaffinity(0, _ORIG_AFFINITY)
         except Exception:
             pass
-    # host cores this process may use (a 1-GPU box exposes a 16-core share of the host)
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
     O.set_threads(max(1, min(ncpu, int(os.environ.get("AABR_CPU_THREADS", "16")))))
-    rng = np.random.default_rng(0)
-    W1 = (rng.standard_normal((27, 9, 32)) * 0.09).astype(np.float32)
-    W2 = (rng.standard_normal((27, 32, 32)) * 0.05).astype(np.float32)
-    W3 = (rng.standard_normal((27, 32, 32)) * 0.05).astype(np.float32)
-    bn = dict(weight=np.ones(32, np.float32), bias=np.zeros(32, np.float32), running_mean=np.zeros(32),
-              running_var=np.ones(32))
-    locs, feats = S.make_batch(1, 80000, 0, 20)
-    done, t0 = 0, time.time()
+    P = ref_net.fpn_params(wl.net)
+    done, t0, stages = 0, time.perf_counter(), {}
     while True:
-        c = ref_net.two_stage_forward(locs, feats, W1, W2, W3, bn, bn)
-        ref_net.two_stage_backward(c, np.ones_like(c["out"]), W1, W2, W3, bn, bn)
+        l, f = S.make_scene(N_POINTS, 9000 + done, VOXEL_SCALE)
+        locs = np.concatenate([l, np.zeros((l.shape[0], 1), np.int64)], 1)
+        t_s = time.perf_counter()
+        fo = ref_net.FpnOracle(P, (4096, 4096, 512), [[2, 2, 2]] * 8, [[2, 2, 2]] * 8,
+                               [[256, 256, 32], [128, 128, 16], [64, 64, 8], [32, 32, 4]])
+        rpn, _ = fo.forward(locs, f)
+        t_f = time.perf_counter()
+        fo.backward([2.0 * m.v / m.v.size for m in rpn])
+        t_b = time.perf_counter()
+        for k, v in fo.timing.items():
+            stages[k] = stages.get(k, 0.0) + v
+        stages["backbone_fwd"] = stages.get("backbone_fwd", 0.0) + (t_f - t_s)
+        stages["backbone_fwd_bwd"] = stages.get("backbone_fwd_bwd", 0.0) + (t_b - t_s)
+        b7, sc = S.make_nms_boxes(2000, done)
+        t_n = time.perf_counter()
+        O.rotate_nms_3d(b7, sc, 2000, 1000, 0.5)
+        stages["iou_nms_2000"] = stages.get("iou_nms_2000", 0.0) + time.perf_counter() - t_n
         done += 1
-        el = time.time() - t0
-        if el > n_scenes_budget_s or done >= 64:
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 8:
             break
-    return dict(value=round(done / el, 3), unit="scenes/s", cores=O.num_threads(), kind="port",
-                sample="%d x S80k@5cm scene, voxel scatter + rule book + 2-stage fwd+bwd, %.1f s of CPU work, "
-                       "OpenMP over %d threads" % (done, el, O.num_threads()))
-
-
-def time_dominant_kernel(scn, m, scene, reps=30):
-    """average launch duration of k_conv_blocks_mfma (32->32 forward, S80k rule book) with HIP
-    events recorded on the stream the kernel is launched on (torch's current stream)."""
-    import _hip
-    from _hip import ptr, stream, check
-    lib = _hip.load()
-    with torch.no_grad():
-        x0 = m["inp"]([scene[0], scene[1]])
-        y1 = m["bn1"](m["conv1"](x0))
-        tb = x0.metadata.getSubmanifoldRuleBook(x0.spatial_size, torch.LongTensor([3, 3, 3]))
-        inp = y1.features.contiguous()
-        V = inp.size(0)
-        out = torch.empty((V, 32), device=inp.device)
-        w = m["conv2"].weight.detach().contiguous()
-        wpack = torch.empty(lib.aabr_conv_wpack_floats(27, 32, 32), device=inp.device)
-        check(lib.aabr_conv_forward(ptr(inp), 32, V, ptr(out), 32, V, ptr(tb.out.blocks()), 27, ptr(w), None, 0, ptr(wpack),
-                                    stream()))
-        torch.cuda.synchronize()
-        # events bracket GROUPS of back-to-back launches of the one kernel: an event pair around a single
-        # 20 us launch reads 2-3 us high (the record / completion-signal cost), which a rocprofv3 trace of the
-        # same launch does not contain
-        group = 8
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in evs:
-            a.record()
-            for _ in range(group):
-                check(lib.aabr_conv_forward(ptr(inp), 32, V, ptr(out), 32, V, ptr(tb.out.blocks()), 27, ptr(w), None,
-                                            4, ptr(wpack), stream()))
-            b.record()
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) / group for a, b in evs)
-        ms = ms[: max(1, len(ms) * 3 // 4)]  # drop the slow tail (first-touch / clock ramp)
-        R = tb.total_rules()
-        return sum(ms) / len(ms) * 1e-3, R, V
-
-
-def time_stage(fn, reps=10):
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) * 1e-3 / reps
-
-
-def fpn_net_extra(scn, dev):
-    """Not the headline: the whole FPN_Net backbone (BASELINE.json configs[2]-shaped input: 4 scenes @ 2 cm)
-    forward + backward in fp32 and with bf16 feature storage, so the bench output also carries the
-    full-network numbers.  Any failure here is reported in the object and never touches the main line."""
-    res = {}
-    try:
-        locs, feats = S.make_batch(4, 80000, 9000, 50)
-        l, f = torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)
-        for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
-            torch.manual_seed(0)
-            net = scn.FPN_Net([4096, 4096, 512], 3, ["xyz", "color", "normal"], 1,
-                              [32, 64, 64, 128, 128, 128, 256, 256, 256], 128, True, [4, 3, 2, 1], [4, 3, 2, 1],
-                              [[[2, 2, 2]] * 8, [[2, 2, 2]] * 8],
-                              [[256, 256, 32], [128, 128, 16], [64, 64, 8], [32, 32, 4]], [1, 2, 3, 4, 5, 6],
-                              leakiness=0, voxel_scale=50, bn_momentum=0.95, feature_dtype=dt).to(dev)
-
-            def run():
-                scn.forward_pass_multiplyAdd_count = 0
-                rpn, _ = net([l, f])
-                sum(m_.features.square().mean() for m_ in rpn).backward()
-                return rpn
-            for _ in range(6):
-                r = run()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 10
-            for _ in range(n):
-                r = run()
-            torch.cuda.synchronize()
-            dt_s = (time.perf_counter() - t0) / n
-            res[name] = {"ms_fwd_bwd": round(dt_s * 1e3, 2), "scenes_per_s": round(4 / dt_s, 1)}
-            res["sites"] = int(r[0].metadata.input["V"])
-            res["forward_macs"] = float(scn.forward_pass_multiplyAdd_count)
-            del net
-        res["workload"] = "FPN_Net (21.2 M parameters), 4 x S80k scenes @ 2 cm, forward + backward"
-    except Exception as e:  # pragma: no cover
-        res["error"] = repr(e)[:200]
-    return res
+    total = stages["backbone_fwd_bwd"] + stages["iou_nms_2000"]
+    return dict(value=round(done / total, 4), unit="scenes/s", cores=O.num_threads(), kind="port",
+                sample="%d x S80k@2cm scene through the whole FPN_Net fwd+bwd + one 2000-box rotated NMS, %.1f s of CPU "
+                       "work, OpenMP over %d threads (scene generation excluded)" % (done, total, O.num_threads()),
+                stage_seconds_per_scene={k: round(v / done, 4) for k, v in sorted(stages.items())})
 
 
 _ORIG_AFFINITY = None
 
 
-def pin_host_threads(local_rank, ncores=4):
-    """Bind this process (launch thread + autograd thread) to a few cores of the GPU's NUMA node.  On a
-    2-socket host the unbound process wanders over 256 hardware threads and the launch-bound step time
-    moves by 10-30 % from run to run (measured: 1,890-2,010 scenes/s unbound, 2,140-2,190 bound).
+def pin_host_threads(torch, local_rank, ncores=4):
+    """Bind this process (launch thread + autograd thread) to a few cores of the GPU's NUMA node: unbound, the
+    launch thread wanders over a 2-socket host and the host-bound part of a step moves by 10-30 % run to run.
     Best effort: any failure leaves the affinity untouched."""
     global _ORIG_AFFINITY
     try:
@@ -210,7 +356,6 @@ def pin_host_threads(local_rank, ncores=4):
                         a, _, b = part.partition("-")
                         cpus += list(range(int(a), int(b or a) + 1))
                     cand = [c for c in cpus if c in set(allowed)] or allowed
-        # distinct blocks for the ranks sharing a node: stride by rank modulo the blocks that fit
         nblocks = max(1, len(cand) // ncores)
         b0 = (local_rank % nblocks) * ncores
         cores = set(cand[b0:b0 + ncores])
@@ -220,36 +365,61 @@ def pin_host_threads(local_rank, ncores=4):
         return None
 
 
+def timed_steps(torch, dist, wl, steps, warmup, world, dev):
+    for i in range(warmup):
+        wl.step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        wl.step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults sized for steady state: the first few hundred steps of a fresh process run with the GPU
-    # and host clocks still ramping (measured on MI355X: 200 timed steps after 20 warm-up steps read
-    # ~0.8 ms/step, 2000 after 300 read ~0.55-0.6 ms/step); the whole default run is still ~3 s
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank, cycled")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batches", type=int, default=2, help="distinct resident 4-scene batches per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-profile", default="", help="write a cProfile of the timed loop to this file")
-    ap.add_argument("--prefetch", type=int, default=0,
-                    help="1: build the next scene's hash grid on a side stream while the current scene trains")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="feature storage of the HEADLINE loop")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(sys.argv[1:], args.gpus))   # before anything touches the GPU
+
+    importlib.import_module("automatic-as-built-reconstruction_amd")
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    # rehearsal knobs (1-GPU boxes): AABR_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
-    # AABR_BENCH_BACKEND=gloo runs the collective through the host, so the N>1 code path can be
-    # exercised where only one GPU exists.  Never set by the driver.
+    # rehearsal knobs (1-GPU boxes): AABR_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and AABR_BENCH_BACKEND=gloo
+    # runs the collective through the host, so the N>1 code path can be exercised where only one GPU exists.
     if os.environ.get("AABR_BENCH_SHARE_GPU") == "1":
         local = 0
     backend = os.environ.get("AABR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if os.environ.get("AABR_BENCH_PIN", "1") != "0":
-        pin_host_threads(local)
+        pin_host_threads(torch, local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -259,140 +429,74 @@ def main():
 
     import sparseconvnet as scn
     import dp
-    m = build_model(scn, dev)
-    flat = dp.FlatParams([v for k, v in m.items() if k != "inp"])
-    flat.broadcast(0)
-
-    # resident inputs: `scenes` distinct scenes per rank (different seeds on every rank)
-    scenes = []
-    for i in range(args.scenes):
-        locs, feats = S.make_batch(1, 80000, 1000 * rank + i, 20)
-        scenes.append((torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)))
-    grads = []
-    with torch.no_grad():
-        for sc in scenes:
-            o = forward(scn, m, sc[0], sc[1])
-            g = torch.Generator(device=dev).manual_seed(7)
-            grads.append(torch.randn(o.features.shape, device=dev, generator=g))
-    feats_req = [(sc[0], sc[1].clone().requires_grad_(True)) for sc in scenes]
-
-    side = torch.cuda.Stream()
-    overlap = world > 1 and os.environ.get("AABR_BENCH_OVERLAP", "0") == "1"
-
-    def step(i):
-        j = i % len(scenes)
-        flat.zero_grad()
-        # geometry of the NEXT scene (hash grid + site numbering; needs only its coordinates) is
-        # built on a side stream now, so its one host read-back overlaps this scene's compute
-        nj = (i + 1) % len(scenes)
-        if args.prefetch and i == 0:
-            m["inp"].prepare(feats_req[j][0], dev, side)
-        # AABR_BENCH_OVERLAP=1 (N > 1, not the default: it could not be measured on a multi-GPU node this
-        # round): this scene's geometry does not read the parameters, so it can overlap the previous step's
-        # gradient all-reduce; the collective is then waited for (stream-ordered) and the update applied
-        # right before the first convolution needs the weights
-        hook = (lambda: flat.finish_update(1e-4, world)) if overlap else None
-        out = forward(scn, m, feats_req[j][0], feats_req[j][1], hook)
-        out.features.backward(grads[j])
-        if args.prefetch:
-            m["inp"].prepare(feats_req[nj][0], dev, side)
-        feats_req[j][1].grad = None
-        if overlap:
-            flat.start_allreduce()
-        else:
-            flat.allreduce_mean(world)
-            flat.sgd_step(1e-4, world)
-
-    # The full-network extra (N = 1) runs BEFORE the headline loop: it is required output either way, and half a
-    # second of real work ahead of the warm-up steps means the timed region does not start on idle clocks when
-    # the caller asks for a short --warmup.
-    fpn_extra = None
-    if not args.no_cpu_baseline and world == 1:
-        fpn_extra = fpn_net_extra(scn, dev)
-    else:
-        # same purpose where the extra is not produced (N > 1, --no-cpu-baseline): ~0.4 s of untimed forward
-        # passes on every rank, so clocks are up before the W warm-up steps whatever W is
-        t_pre = time.perf_counter()
-        with torch.no_grad():
-            while time.perf_counter() - t_pre < 0.4:
-                for sc in scenes:
-                    forward(scn, m, sc[0], sc[1])
-        torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    flat.finish_update(1e-4, world)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    prof = None
-    if args.host_profile:
-        import cProfile
-        prof = cProfile.Profile()
-        prof.enable()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    flat.finish_update(1e-4, world)  # the last step's update belongs to the timed region
-    t_enq = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if prof is not None:
-        import io
-        import pstats
-        prof.disable()
-        buf = io.StringIO()
-        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(45)
-        open(args.host_profile, "w").write("enqueue s/step: %g\n" % (t_enq / args.steps) + buf.getvalue())
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    head_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    wl = Workload(scn, torch, dp, dev, head_dtype, rank, world, args.batches)
+    el = timed_steps(torch, dist, wl, args.steps, args.warmup, world, dev)
 
     if rank == 0:
-        ksec, R, V = time_dominant_kernel(scn, m, scenes[0])
-        flops = 2.0 * R * 32 * 32
-        # HBM traffic of that kernel from the committed PMC passes (profiles/, separate --pmc runs of
-        # this same command): FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_fetch_write_per_kernel.json")))["kernels"]
-            for kname, v in pm.items():
-                if "k_conv_blocks_mfma_buf<2, 4" in kname:  # <NBW, WPB[, ADJ]>
-                    traffic = int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
-        except Exception:
-            traffic = None
-        roof = dict(kernel="k_conv_blocks_mfma_buf<2,4,true,true> (SubmConv3 32->32 forward)", bound="mfma",
-                    achieved=round(flops / ksec / 1e12, 4), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(flops / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5), traffic=traffic,
-                    launch_us=round(ksec * 1e6, 2), rules=int(R), sites=int(V),
-                    algorithmic_flops_per_launch=flops)
-        # voxel scatter (A1+A2): N*(32 + 4*C_in) + V*(4*C_in + 16) algorithmic bytes
-        N = scenes[0][0].shape[0]
-        with torch.no_grad():
-            t_sc = time_stage(lambda: m["inp"]([scenes[0][0], scenes[0][1]]))
-        sc_bytes = N * (32 + 4 * 9) + V * (4 * 9 + 16)
-        scatter = dict(bytes=sc_bytes, seconds=round(t_sc, 7), achieved_gbs=round(sc_bytes / t_sc / 1e9, 2),
-                       frac_of_hbm_peak=round(sc_bytes / t_sc / 1e9 / PEAK_HBM_GBS, 5),
-                       note="whole InputLayer call incl. hash build, site numbering, host read of V")
+        n_pts = int(wl.batches[0][0].shape[0])
+        V0 = int(wl.last[0][0].metadata.input["V"])
+        n_prop = [int(b.shape[0]) for b, _ in wl.last[1]]
         line = {
-            "metric": "scenes/sec (fwd+bwd)", "value": round(world * args.steps / el, 2), "unit": "scenes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "S80k@5cm scene (79,998 pts -> ~66k voxels), voxel scatter + 2-stage "
-                                   "SubmanifoldConvolution backbone (9->32, residual 32->32 x2), fwd+bwd+SGD, "
-                                   "bs=1 per GPU (BASELINE.json configs[1])",
-                       "global_batch": world, "points_per_scene": int(N), "parallelism": "dp%d" % world},
-            "roofline": roof, "voxel_scatter": scatter,
+            "metric": "scenes/sec (fwd+bwd)", "value": round(world * args.steps * SCENES_PER_STEP / el, 2),
+            "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: 'walls' config = default FPN_Net (21.2 M parameters), "
+                                   "4 x S80k scenes @ 2 cm per GPU and step (%d points -> %d voxels), voxel scatter + "
+                                   "all rule books rebuilt every step, fwd + bwd + SGD, RPN head + cross-scale "
+                                   "top-2000 decode + rotated-3D NMS per scene%s" %
+                                   (n_pts, V0, "" if args.dtype == "f32" else ", bf16 feature storage"),
+                       "global_batch": world * SCENES_PER_STEP, "points_per_scene": N_POINTS,
+                       "voxel_scale": VOXEL_SCALE, "parallelism": "dp%d" % world,
+                       "proposals_per_scene": n_prop},
+            "timed_region_s": round(el, 3),
         }
+        if el < MIN_TIMED_S:
+            line["timed_region_short"] = True
+        if not args.no_extras:
+            table = conv_kernel_table(torch, wl, head_dtype)
+            top = table[0]
+            peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" and "bf16" in top["kernel"] else PEAK_FP32_MFMA_TFLOPS
+            traffic, src = pmc_traffic(top["kernel"])
+            line["roofline"] = dict(
+                kernel="%s (%s %d->%d, vol %d, %d output rows, %d rules; %d launches per step = %.0f us of the %.0f us step)"
+                       % (top["kernel"], top["kind"], top["n_in"], top["n_out"], top["vol"], top["rows_out"], top["rules"],
+                          top["calls_per_step"], top["step_us"], el / args.steps * 1e6),
+                bound="mfma", achieved=top["tflops"], peak=peak, unit="TFLOP/s", frac=round(top["tflops"] / peak, 5),
+                traffic=traffic, traffic_source=src, launch_us=top["launch_us"],
+                algorithmic_flops_per_launch=top["flops_per_launch"],
+                kernel_source="aabr_conv_last_variant() of the timed launch")
+            line["conv_kernels"] = [{k: v for k, v in r.items() if k != "flops_per_launch"} for r in table[:8]]
+            line["conv_step_us_total"] = round(sum(r["step_us"] for r in table), 1)
+            # voxel scatter (A1+A2): N*(32 + 4*C_in) + V*(4*C_in + 16) algorithmic bytes
+            locs, feats = wl.batches[0]
+            inp = scn.InputLayer(3, [4096, 4096, 512], mode=4)
+            with torch.no_grad():
+                t_sc = hip_time(torch, lambda: inp([locs, feats.detach()]), 1, 10)
+            sc_bytes = n_pts * (32 + 4 * 9) + V0 * (4 * 9 + 16)
+            line["voxel_scatter"] = dict(bytes=sc_bytes, seconds=round(t_sc, 7),
+                                         achieved_gbs=round(sc_bytes / t_sc / 1e9, 2),
+                                         frac_of_hbm_peak=round(sc_bytes / t_sc / 1e9 / PEAK_HBM_GBS, 5),
+                                         note="whole InputLayer call on the 4-scene batch")
+            if world == 1:
+                extras = {}
+                try:
+                    other = torch.float32 if args.dtype == "bf16" else torch.bfloat16
+                    wl2 = Workload(scn, torch, dp, dev, other, 0, 1, 1)
+                    n2 = max(5, min(args.steps, 20))
+                    el2 = timed_steps(torch, dist, wl2, n2, 5, 1, dev)
+                    extras["bf16" if other == torch.bfloat16 else "f32"] = {
+                        "ms_per_step": round(el2 / n2 * 1e3, 3), "scenes_per_s": round(n2 * SCENES_PER_STEP / el2, 2),
+                        "steps": n2, "workload": "same step with %s feature storage" % str(other).split(".")[1]}
+                    del wl2
+                except Exception as e:  # pragma: no cover
+                    extras["other_dtype_error"] = repr(e)[:200]
+                line["extras"] = extras
         if not args.no_cpu_baseline and world == 1:
-            line["fpn_net"] = fpn_extra
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(wl, torch)
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

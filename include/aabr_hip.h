@@ -142,6 +142,10 @@ int64_t aabr_offset_pairs_words(int64_t V, int vol);  /* int32 words of `pairs` 
 int aabr_build_offset_pairs(const int32_t *table, const int32_t *block_counts, int64_t V, int vol,
                             int32_t *pairs, void *stream);
 
+/* Name of the kernel instance (template arguments included) the last aabr_conv_forward[_bf16] /
+ * aabr_conv_backward_weight[_bf16] call on this thread dispatched -- measurement provenance only.   */
+const char *aabr_conv_last_variant(void);
+
 /* ---- sparse convolution (fp32 features, fp32 MFMA) ----------------------------------------
  * out[o] = bias + sum_k in[table[k][o]] @ W[wk(k)]      (rows with table == -1 contribute 0)
  * Replaces {Submanifold,}Convolution_updateOutput / Deconvolution_updateOutput
@@ -242,6 +246,25 @@ int aabr_rpn_decode(const int32_t *site_coords, int64_t site_begin, const int64_
                     const float *regression, int64_t reg_begin, const float *base_anchors,
                     int num_anchors, float voxel_scale, const float *stride_host,
                     const float *weights_host, float clip, float *boxes, void *stream);
+
+/* Cross-scale RPN proposals front end -- what RPNPostProcessor.forward_for_single_feature_map
+ * (modeling/rpn/inference_3d.py:82-163) does per example AFTER cat_scales_obj_reg (rpn_sparse3d.py:19-77)
+ * regrouped the scales example-major: for the k selected (top-k by objectness) entries of the example's
+ * concatenated anchor list [map][site][yaw] -- anchor from the site coordinates
+ * (anchor_generator_sparse3d.py:88-104) -> BoxCoder3D.decode_centroid_box (box_coder_3d.py:53-80) ->
+ * sigmoid of the logit (:113) -> the boxlist_nms_3d thickness clamps (structures/boxlist_ops_3d.py:42-44)
+ * into an NMS-only copy.  Host tables (n_maps <= 8): device pointers of each map's site list [V_m,4] int32,
+ * logits [V_m*A] and regression [V_m*A,7]; seg_begin_host[n_maps+1] = first local anchor index of each map in
+ * this example's list; site_begin_host[n_maps] = this example's first site row in each map;
+ * strides_host[n_maps*3]; base_anchors device [n_maps*A,7].  selected int64 [k] (descending score).
+ * Outputs: boxes [k,7], nms_boxes [k,7] (may be NULL), scores [k] (may be NULL).                 */
+int aabr_rpn_decode_maps(int n_maps, const void *const *coords_ptrs, const void *const *logit_ptrs,
+                         const void *const *regression_ptrs, const int32_t *seg_begin_host,
+                         const int32_t *site_begin_host, const float *strides_host,
+                         const float *base_anchors, int num_anchors, float voxel_scale,
+                         const float *weights_host, float clip, float nms_min_yx, float nms_min_z,
+                         const int64_t *selected, int64_t k, float *boxes, float *nms_boxes, float *scores,
+                         void *stream);
 
 /* Greedy rotated NMS over boxes already sorted by descending score: rotate_nms_3d_cc
  * (second/core/non_max_suppression/nms_cpu.py:32-44) with the suppression rule of

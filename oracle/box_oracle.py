@@ -60,3 +60,43 @@ def grid_anchors(site_coords, base_anchors, voxel_scale, stride):
     cen = (sc[:, :3].astype(F) / F(voxel_scale) * np.asarray(stride, F).reshape(1, 3)).astype(F)
     cen = np.concatenate([cen, np.zeros((sc.shape[0], 4), F)], 1)
     return (cen[:, None, :] + base[None]).reshape(-1, 7).astype(F)
+
+
+def rpn_proposals(site_coords, objectness, box_regression, base_anchors, strides, voxel_scale, boxes_iou_3d,
+                  nms_from_matrix, pre_nms_top_n=2000, post_nms_top_n=1000, nms_thresh=0.5,
+                  nms_aug_thickness=(0.3, 0.3), weights=(1.0,) * 7, bbox_xform_clip=10000.0):
+    """cat_scales_obj_reg (rpn_sparse3d.py:19-77) + RPNPostProcessor.forward_for_single_feature_map
+    (rpn/inference_3d.py:95-149) + boxlist_nms_3d (structures/boxlist_ops_3d.py:14-62) on numpy arrays.
+    site_coords[m] [V_m,4] (batch-contiguous), objectness[m] [V_m*A], box_regression[m] [V_m*A,7].
+    `boxes_iou_3d`, `nms_from_matrix`: the C oracle's functions (tests/oracle_lib.py).
+    Returns per example (boxes, scores, selected-local-indices)."""
+    n_maps = len(site_coords)
+    A = np.asarray(base_anchors[0]).shape[0]
+    anchors = [grid_anchors(site_coords[m], base_anchors[m], voxel_scale, strides[m]) for m in range(n_maps)]
+    nb = int(site_coords[0][:, 3].max()) + 1 if len(site_coords[0]) else 0
+    out = []
+    for bi in range(nb):
+        o, r, a = [], [], []
+        for m in range(n_maps):
+            rows = np.nonzero(np.asarray(site_coords[m])[:, 3] == bi)[0]
+            if len(rows) == 0:
+                continue
+            s, e = rows[0] * A, (rows[-1] + 1) * A
+            o.append(np.asarray(objectness[m], F).reshape(-1)[s:e])
+            r.append(np.asarray(box_regression[m], F).reshape(-1, 7)[s:e])
+            a.append(anchors[m][s:e])
+        if not o:
+            out.append((np.zeros((0, 7), F), np.zeros(0, F), np.zeros(0, np.int64)))
+            continue
+        o, r, a = np.concatenate(o), np.concatenate(r), np.concatenate(a)
+        score = (F(1) / (F(1) + np.exp(-o.astype(F)))).astype(F)
+        k = min(pre_nms_top_n, len(o))
+        idx = np.argsort(-o, kind="stable")[:k]          # sigmoid is monotone: same order as on the scores
+        dec = decode_centroid_box(r[idx], a[idx], weights, bbox_xform_clip)
+        nb7 = dec.copy()
+        nb7[:, 3:5] = np.maximum(nb7[:, 3:5], F(nms_aug_thickness[0]))
+        nb7[:, 5] = np.maximum(nb7[:, 5], F(nms_aug_thickness[1]))
+        iou = boxes_iou_3d(nb7, nb7)
+        keep = nms_from_matrix(iou, np.arange(k, dtype=np.int32), nms_thresh)[:post_nms_top_n]
+        out.append((dec[keep], score[idx][keep], idx[keep]))
+    return out

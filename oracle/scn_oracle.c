@@ -384,15 +384,24 @@ double oracle_conv_fwd(const float *in, Int nIn, float *out, Int nOut,
     const float *w = W + k * nIn * nOut;
     const Int *rk = rules + k * rule_cap * 2;
     float *tmp = (float *)malloc((size_t)nR * nOut * sizeof(float));
-#pragma omp parallel for
-    for (int64_t i = 0; i < nR; ++i) {
-      const float *s = in + (int64_t)rk[2 * i + in_col] * nIn;
-      float *t = tmp + i * nOut;
-      for (Int j = 0; j < nOut; ++j) {
-        double acc = 0; /* at::matmul: accumulation order unspecified */
-        for (Int c = 0; c < nIn; ++c) acc += (double)s[c] * w[c * nOut + j];
-        t[j] = (float)acc;
+#pragma omp parallel
+    {
+      /* acc[j] over c ascending: the same summation order per output element as the plain
+       * (j outer, c inner) loop, arranged so that the j loop vectorises */
+      double *acc = (double *)malloc((size_t)nOut * sizeof(double));
+#pragma omp for
+      for (int64_t i = 0; i < nR; ++i) {
+        const float *s = in + (int64_t)rk[2 * i + in_col] * nIn;
+        float *t = tmp + i * nOut;
+        for (Int j = 0; j < nOut; ++j) acc[j] = 0; /* at::matmul: accumulation order unspecified */
+        for (Int c = 0; c < nIn; ++c) {
+          const double sc = (double)s[c];
+          const float *wr = w + (int64_t)c * nOut;
+          for (Int j = 0; j < nOut; ++j) acc[j] += sc * wr[j];
+        }
+        for (Int j = 0; j < nOut; ++j) t[j] = (float)acc[j];
       }
+      free(acc);
     }
     /* rule_index_add_: within one offset every output row occurs once */
 #pragma omp parallel for
@@ -425,25 +434,54 @@ void oracle_conv_bwd(const float *in, float *d_in, int64_t nInRows, Int nIn,
     const float *w = W + k * nIn * nOut;
     float *dw = dW + k * nIn * nOut;
     const Int *rk = rules + k * rule_cap * 2;
-#pragma omp parallel for
-    for (Int c = 0; c < nIn; ++c)
-      for (Int j = 0; j < nOut; ++j) {
-        double acc = 0;
-        for (int64_t i = 0; i < nR; ++i)
-          acc += (double)in[(int64_t)rk[2 * i + in_col] * nIn + c] *
-                 d_out[(int64_t)rk[2 * i + 1 - in_col] * nOut + j];
-        dw[c * nOut + j] = (float)acc;
-      }
-    float *tmp = (float *)malloc((size_t)nR * nIn * sizeof(float));
-#pragma omp parallel for
-    for (int64_t i = 0; i < nR; ++i) {
-      const float *g = d_out + (int64_t)rk[2 * i + 1 - in_col] * nOut;
-      for (Int c = 0; c < nIn; ++c) {
-        double acc = 0;
-        for (Int j = 0; j < nOut; ++j) acc += (double)g[j] * w[c * nOut + j];
-        tmp[i * nIn + c] = (float)acc;
+    /* dW[c][j] = sum over rules i (ascending) of in[i][c] * d_out[i][j]; a thread owns a block of
+     * c rows and keeps their double accumulators: same order over i per element as the plain loop */
+    {
+      const Int CB = 8;
+      const Int ncb = (nIn + CB - 1) / CB;
+#pragma omp parallel
+      {
+        double *acc = (double *)malloc((size_t)CB * nOut * sizeof(double));
+#pragma omp for schedule(dynamic, 1)
+        for (Int cb = 0; cb < ncb; ++cb) {
+          const Int c0 = cb * CB, c1 = (c0 + CB < nIn) ? c0 + CB : nIn;
+          for (int64_t q = 0; q < (int64_t)(c1 - c0) * nOut; ++q) acc[q] = 0;
+          for (int64_t i = 0; i < nR; ++i) {
+            const float *a = in + (int64_t)rk[2 * i + in_col] * nIn;
+            const float *g = d_out + (int64_t)rk[2 * i + 1 - in_col] * nOut;
+            for (Int c = c0; c < c1; ++c) {
+              const double ac = (double)a[c];
+              double *ar = acc + (int64_t)(c - c0) * nOut;
+              for (Int j = 0; j < nOut; ++j) ar[j] += ac * g[j];
+            }
+          }
+          for (Int c = c0; c < c1; ++c)
+            for (Int j = 0; j < nOut; ++j) dw[c * nOut + j] = (float)acc[(int64_t)(c - c0) * nOut + j];
+        }
+        free(acc);
       }
     }
+    float *tmp = (float *)malloc((size_t)nR * nIn * sizeof(float));
+    float *wT = (float *)malloc((size_t)nIn * nOut * sizeof(float));
+    for (Int c = 0; c < nIn; ++c)
+      for (Int j = 0; j < nOut; ++j) wT[(int64_t)j * nIn + c] = w[c * nOut + j];
+#pragma omp parallel
+    {
+      double *acc = (double *)malloc((size_t)nIn * sizeof(double));
+#pragma omp for
+      for (int64_t i = 0; i < nR; ++i) {
+        const float *g = d_out + (int64_t)rk[2 * i + 1 - in_col] * nOut;
+        for (Int c = 0; c < nIn; ++c) acc[c] = 0;
+        for (Int j = 0; j < nOut; ++j) { /* j ascending per element, as in the plain loop */
+          const double gj = (double)g[j];
+          const float *wr = wT + (int64_t)j * nIn;
+          for (Int c = 0; c < nIn; ++c) acc[c] += gj * wr[c];
+        }
+        for (Int c = 0; c < nIn; ++c) tmp[i * nIn + c] = (float)acc[c];
+      }
+      free(acc);
+    }
+    free(wT);
 #pragma omp parallel for
     for (int64_t i = 0; i < nR; ++i) {
       float *t = d_in + (int64_t)rk[2 * i + in_col] * nIn;

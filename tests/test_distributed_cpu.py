@@ -5,6 +5,9 @@ import sys
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _worker(rank, world, port, q):
@@ -65,3 +68,41 @@ def test_two_rank_gloo_allreduce_and_sharding():
     # overlapped all-reduce + update: same result as the mean-gradient SGD step
     torch.testing.assert_close(v0, w0 - 0.1 * (m0 + m1) / 2)
     torch.testing.assert_close(v0, v1)
+
+
+# ---------------------------------------------------------------------------------------------- bench launcher
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("aabr_bench", os.path.join(os.path.dirname(HERE), "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_gpus_flag_spawns_n_fresh_ranks(tmp_path):
+    """`bench.py --gpus N` outside torchrun must start N rank processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set (the flag used to be parsed and ignored), wait for them and propagate failure."""
+    bench = _load_bench()
+    probe = tmp_path / "probe.py"
+    probe.write_text("import os, sys\n"
+                     "open(os.path.join(%r, 'rank%%s' %% os.environ['RANK']), 'w').write(' '.join(\n"
+                     "    os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))\n"
+                     "sys.exit(3 if os.environ['RANK'] == sys.argv[1] else 0)\n" % str(tmp_path))
+    assert bench.spawn_ranks(["-1"], 3, script=str(probe)) == 0
+    seen = [open(os.path.join(str(tmp_path), "rank%d" % r)).read().split() for r in range(3)]
+    assert [s[0] for s in seen] == ["0", "1", "2"] and all(s[2] == "3" and s[3] == "127.0.0.1" for s in seen)
+    assert len({s[4] for s in seen}) == 1
+    assert bench.spawn_ranks(["1"], 2, script=str(probe)) == 3      # a failing rank fails the launch
+
+
+def test_bench_without_gpu_fails_loudly_in_every_rank():
+    """no CPU fallback: on a GPU-less box both spawned ranks refuse to run and the parent exits non-zero
+    without printing a result line"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert r.returncode != 0 and "needs a GPU" in r.stderr and "{" not in r.stdout

@@ -433,3 +433,65 @@ def test_fused_sparse_roi_align_equals_the_dense_two_step_form():
         assert res[0][0].shape == (nroi, 160) + out_size
         assert torch.equal(res[0][0], res[1][0])
         torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5)
+
+
+def test_rpn_proposals_cross_scale_on_device():
+    """rpn_glue.rpn_proposals (one top-k + decode + NMS per example over ALL maps, the reference's shape) against
+    the numpy / C-oracle restatement; three maps with different strides and anchor sizes, one of them without
+    sites for example 1."""
+    scn = _scn()
+    import sys
+    sys.path.insert(0, O.ORACLE_DIR)
+    import box_oracle
+    import rpn_glue
+    rng = np.random.default_rng(23)
+    A = 4
+    maps, sites, objs, regs, bases, strides = [], [], [], [], [], []
+    for mi, (sp, n, st) in enumerate((((64, 64, 8), 2500, (4.0, 4.0, 4.0)), ((32, 32, 4), 900, (8.0, 8.0, 8.0)),
+                                      ((16, 16, 1), 120, (16.0, 16.0, 16.0)))):
+        b = np.sort(rng.integers(0, 2, n)) if mi < 2 else np.zeros(n, np.int64)
+        coords = np.stack([rng.integers(0, sp[0], n), rng.integers(0, sp[1], n), rng.integers(0, sp[2], n), b],
+                          1).astype(np.int64)
+        x = scn.InputLayer(3, list(sp), mode=3)([_t(coords), _t(np.zeros((n, 1), np.float32))])
+        sc = x.get_spatial_locations().numpy()
+        V = sc.shape[0]
+        base = np.zeros((A, 7), np.float32)
+        base[:, 3:6] = [0.2 * (mi + 1), 1.5 * (mi + 1), 2.6]
+        base[:, 6] = [0.0, -1.57, -0.785, 0.785]
+        maps.append(x)
+        sites.append(sc)
+        objs.append(rng.standard_normal(V * A).astype(np.float32))
+        regs.append((rng.standard_normal((V * A, 7)) * 0.3).astype(np.float32))
+        bases.append(base)
+        strides.append(st)
+    weights = (1.0, 1.0, 1.0, 2.0, 2.0, 2.0, 1.5)
+    res = rpn_glue.rpn_proposals(maps, [_t(o) for o in objs], [_t(r) for r in regs], [torch.as_tensor(b) for b in bases],
+                                 strides, 20.0, 600, 150, 0.5, (0.3, 0.3), weights, 10000.0)
+    want = box_oracle.rpn_proposals(sites, objs, regs, bases, strides, 20.0, O.boxes_iou_3d, O.nms_from_matrix, 600,
+                                    150, 0.5, (0.3, 0.3), weights, 10000.0)
+    assert len(res) == len(want) == 2
+    for (bd, sd), (bw, sw, _) in zip(res, want):
+        assert bd.shape[0] == bw.shape[0] > 10
+        np.testing.assert_allclose(bd.cpu().numpy(), bw, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(sd.cpu().numpy(), sw, rtol=1e-5, atol=1e-6)
+
+
+def test_input_layer_prepare_is_matched_by_identity_and_works_for_int32_coords():
+    """prepared geometry used to be matched by (data_ptr, n) of a temporary; int32 coordinates tripped
+    the 'already holds an input layer' assertion and a recycled address could match a stale entry."""
+    scn = _scn()
+    rng = np.random.default_rng(4)
+    coords, feats = _rand_scene(rng, 5000, (50, 40, 12), 2, 5)
+    side = torch.cuda.Stream()
+    for dt in (torch.int64, torch.int32):
+        c = _t(coords).to(dt)
+        layer = scn.InputLayer(3, [50, 40, 12], mode=4)
+        layer.prepare(c, torch.device(DEV), side)
+        other = _t(coords[:100]).to(dt)                 # an unrelated tensor never consumes the prepared entry
+        y_other = layer([other, _t(feats[:100])])
+        assert y_other.features.shape[0] <= 100 and len(layer._prepared) == 1
+        y = layer([c, _t(feats)])
+        assert len(layer._prepared) == 0
+        ref = scn.InputLayer(3, [50, 40, 12], mode=4)([_t(coords), _t(feats)])
+        assert torch.equal(y.features, ref.features)
+        assert torch.equal(y.get_spatial_locations(), ref.get_spatial_locations())
