@@ -1744,8 +1744,8 @@ using namespace aabr;
 
 // name of the kernel instance the last conv / dW entry point dispatched on this thread (bench provenance:
 // `roofline.kernel` is what actually ran, not a string typed into the bench)
-static thread_local const char *g_last_variant = "";
-extern "C" const char *aabr_conv_last_variant(void) { return g_last_variant; }
+namespace aabr { thread_local const char *g_last_variant = ""; }
+extern "C" const char *aabr_conv_last_variant(void) { return aabr::g_last_variant; }
 
 extern "C" int64_t aabr_conv_wpack_floats(int vol, int n_in, int n_out) {
   // sized for either orientation (forward uses ci=n_in, the transposed pass ci=n_out)
@@ -2150,6 +2150,18 @@ static int conv_pack_weights2_t(const float *W, int vol, int n_in, int n_out, TO
                         ((int64_t)nkc_of(n_in) * nnb_of(n_out) + (int64_t)nkc_of(n_out) * nnb_of(n_in));
   hipLaunchKernelGGL((k_pack_weights2<TO>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_,
                      W, vol, n_in, n_out, wpack_fwd, wpack_t);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+// single orientation (inference / stand-alone launches of the 256-row-tile kernel)
+extern "C" int aabr_conv_pack_weights(const float *W, int vol, int n_in, int n_out, int transpose, float *wpack,
+                                      void *stream_) {
+  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && vol > 0 && n_in <= 4096 && n_out <= 4096, "bad sizes");
+  AABR_CHECK_ARG(W && wpack && ((uintptr_t)wpack & 15) == 0, "null / misaligned pointer");
+  const int64_t total = (int64_t)vol * nkc_of(n_in) * nnb_of(n_out) * 512;
+  hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream_, W, vol,
+                     n_in, n_out, transpose, 0, wpack);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

@@ -167,11 +167,11 @@ class _Grid(object):
 
 class _Gather(object):
     """one gather table [vol, rows] + its compiled streaming forms (built lazily, cached)"""
-    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_pairs", "_host_counts", "_total")
+    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_blocks256", "_pairs", "_host_counts", "_total")
 
     def __init__(self, table, counts, vol, rows):
         self.table, self.counts, self.vol, self.rows = table, counts, vol, rows
-        self._blocks = self._pairs = self._host_counts = self._total = None
+        self._blocks = self._blocks256 = self._pairs = self._host_counts = self._total = None
 
     def total_slot(self):
         """(ring, generation, index) of this rule book's rule total on the device"""
@@ -201,6 +201,19 @@ class _Gather(object):
             check(lib.aabr_build_tile_blocks(ptr(self.table), self.rows, self.vol, ptr(w), stream()))
             self._blocks = w
         return self._blocks
+
+    def blocks_wide(self, tile_rows):
+        """128- / 256-row tile blocks for aabr_conv_forward_wide (wide layers)"""
+        if self._blocks256 is None:
+            self._blocks256 = {}
+        w = self._blocks256.get(tile_rows)
+        if w is None:
+            lib = _hip.load()
+            w = torch.empty(max(lib.aabr_wide_blocks_words(self.rows, self.vol, tile_rows), 1), dtype=torch.int32,
+                            device=self.table.device)
+            check(lib.aabr_build_wide_blocks(ptr(self.table), self.rows, self.vol, tile_rows, ptr(w), stream()))
+            self._blocks256[tile_rows] = w
+        return w
 
     def pairs(self):
         """offset-major compacted pairs for aabr_conv_backward_weight"""
@@ -562,8 +575,18 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
             del pack_t[:]
             pack_t.append(wt)
             flags |= 4
-    check(conv(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
-               ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
+    tile_rows = 0 if (bf16 or n_rows_out == 0) else lib.aabr_conv_wide_tile_rows(n_in, n_out, inp.size(0), n_rows_out,
+                                                                                  gather.vol)
+    if tile_rows:
+        # wide layer: big tiles, weights shared per offset (csrc/conv_t256.hip)
+        if not (flags & 4):
+            check(lib.aabr_conv_pack_weights(ptr(w), gather.vol, w.size(2), w.size(3), flags & 1, ptr(wpack), stream()))
+        check(lib.aabr_conv_forward_wide(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
+                                         ptr(gather.blocks_wide(tile_rows)), tile_rows, gather.vol, ptr(_opt(bias)),
+                                         flags & 3, ptr(wpack), stream()))
+    else:
+        check(conv(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
+                   ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
     if trace is not None:
         trace.append(("fwd", n_in, n_out, gather, inp.size(0), flags & 3, inp.dtype))
     return n_out

@@ -136,6 +136,10 @@ class Workload(object):
             for j, sid in enumerate(mine[b * SCENES_PER_STEP:(b + 1) * SCENES_PER_STEP]):
                 l, f = S.make_scene(N_POINTS, 9000 + sid, VOXEL_SCALE)
                 import numpy as np
+                if os.environ.get("AABR_BENCH_SORT_POINTS") == "1":   # experiment knob (tools/): coherent point order
+                    key = (l[:, 0] // 8 * 4096 + l[:, 1] // 8) * 4096 + l[:, 2] // 8
+                    o = np.argsort(key, kind="stable")
+                    l, f = l[o], f[o]
                 L.append(np.concatenate([l, np.full((l.shape[0], 1), j, np.int64)], 1))
                 F.append(f)
             import numpy as np

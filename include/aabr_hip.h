@@ -142,6 +142,26 @@ int64_t aabr_offset_pairs_words(int64_t V, int vol);  /* int32 words of `pairs` 
 int aabr_build_offset_pairs(const int32_t *table, const int32_t *block_counts, int64_t V, int vol,
                             int32_t *pairs, void *stream);
 
+/* Wide-layer forms of the same contraction (csrc/conv_t256.hip): 128- or 256-row output tiles whose blocks
+ * share one set of weights per filter offset (registers / LDS) instead of streaming 32 KiB of packed weights per
+ * 16-pair block.  Replaces the same reference loops as aabr_conv_forward (SCN/CPU/Convolution.cpp:45-185,
+ * SCN/CPU/Deconvolution.cpp:7-77; the CUDA twin it stands in for is dConvolution_KMxKN_forwardA/B,
+ * SCN/CUDA/Convolution.cu:57-203).
+ *   aabr_conv_wide_tile_rows: 0 = use aabr_conv_forward; 128 / 256 = rows per tile of the block stream that
+ *     aabr_conv_forward_wide wants for this shape (supported AND expected to beat the 64-row-tile kernels);
+ *   aabr_wide_blocks_words / aabr_build_wide_blocks: gather table [vol][V] -> per-tile per-offset blocks of 16
+ *     (partner row, local row) pairs (vol <= 63);
+ *   aabr_conv_pack_weights: W [vol][nIn][nOut] (transpose: W[k]^T) -> packed MFMA A-operand layout;
+ *   aabr_conv_forward_wide: n_in % 32 == 0, n_out % 64 == 0; `wpack` must already hold the packed weights of
+ *     this orientation; flags bit1: mirrored offsets (submanifold input-gradient through the forward table). */
+int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
+int64_t aabr_wide_blocks_words(int64_t V, int vol, int tile_rows);
+int aabr_build_wide_blocks(const int32_t *table, int64_t V, int vol, int tile_rows, int32_t *blocks, void *stream);
+int aabr_conv_pack_weights(const float *W, int vol, int n_in, int n_out, int transpose, float *wpack, void *stream);
+int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
+                           int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                           int flags, const float *wpack, void *stream);
+
 /* Name of the kernel instance (template arguments included) the last aabr_conv_forward[_bf16] /
  * aabr_conv_backward_weight[_bf16] call on this thread dispatched -- measurement provenance only.   */
 const char *aabr_conv_last_variant(void);

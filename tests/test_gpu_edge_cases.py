@@ -20,6 +20,11 @@ def _t(a):
     return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
 
 
+def _rand_scene(rng, n, size, batch, C):
+    coords = np.stack([rng.integers(0, s, n) for s in size] + [np.sort(rng.integers(0, batch, n))], 1)
+    return coords.astype(np.int64), rng.standard_normal((n, C)).astype(np.float32)
+
+
 def _unique_sites(rng, V, size=(9, 9, 9), batch=1):
     """exactly V distinct sites (dense enough that most have neighbours), batch-sorted"""
     cells = np.stack(np.meshgrid(*[np.arange(s) for s in size], indexing="ij"), -1).reshape(-1, 3)

@@ -531,9 +531,10 @@ def test_rpn_decode_kernel_vs_reference_torch_golden(golden_dir):
     n = g["dec_enc"].shape[0]
     coords = torch.zeros((1, 4), dtype=torch.int32, device=DEV)
     sel = torch.arange(n, dtype=torch.int64, device=DEV)
+    enc, anchors = _t(g["dec_enc"]), _t(g["dec_anchors"])   # named: a temporary would be freed before the launch
     for w in ("w1", "w2"):
         boxes = torch.empty((n, 7), dtype=torch.float32, device=DEV)
-        check(lib.aabr_rpn_decode(ptr(coords), 0, ptr(sel), n, ptr(_t(g["dec_enc"])), 0, ptr(_t(g["dec_anchors"])), n,
+        check(lib.aabr_rpn_decode(ptr(coords), 0, ptr(sel), n, ptr(enc), 0, ptr(anchors), n,
                                   20.0, _hip.f32xn([4.0, 4.0, 2.0]), _hip.f32xn(g["weights_" + w].tolist()), 10000.0,
                                   ptr(boxes), stream()))
         # device division / sqrt are IEEE; floorf(x/pi + .5) is exact -> tolerance only for fma contraction
