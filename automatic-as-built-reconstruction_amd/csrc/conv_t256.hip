@@ -709,8 +709,9 @@ extern "C" int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, in
     if (ov[0] == '0') return 0;
     if (ov[0] == '1') return T;
   }
-  // enough workgroups to fill the chip, and wide enough that the weight stream is what bounds the other kernels
-  return (n_in >= 64 && ((V_out + T - 1) / T) * (n_out / 64) >= 512) ? T : 0;
+  // enough workgroups to fill the chip twice over (measured, profiles/r02_conv_wide_ab.txt: wins from ~340
+  // workgroups up, loses below ~180)
+  return (((V_out + T - 1) / T) * (n_out / 64) >= 320) ? T : 0;
 }
 
 extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,

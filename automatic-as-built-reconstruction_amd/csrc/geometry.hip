@@ -205,128 +205,6 @@ __global__ __launch_bounds__(kScanThreads) void k_assign_sites(
   }
 }
 
-// ------------------------------------------------------------------ input layer
-__global__ __launch_bounds__(256) void k_insert_points(const int64_t *__restrict__ coords, int64_t n,
-                                                       int ncols, uint64_t *keys, uint64_t mask,
-                                                       uint32_t *minidx, uint32_t *slotcnt,
-                                                       int32_t *__restrict__ slot, int32_t *meta) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t *c = coords + i * ncols;
-  int64_t x = c[0], y = c[1], z = c[2], b = ncols == 4 ? c[3] : 0;
-  if (x == -1 && y == -1 && z == -1) { // dropped by aabr_quantize_points (outside FULL_SCALE): skip silently
-    slot[i] = -1;
-    return;
-  }
-  if (x < 0 || y < 0 || z < 0 || b < 0 || x > kMaxCoord || y > kMaxCoord || z > kMaxCoord ||
-      b > kMaxCoord) {
-    slot[i] = -1;
-    atomicOr(&meta[2], 1);
-    return;
-  }
-  uint32_t h = grid_insert(keys, mask, pack_key((int)b, (int)x, (int)y, (int)z));
-  atomicMin(&minidx[h], (uint32_t)i);
-  atomicAdd(&slotcnt[h], 1u);
-  slot[i] = (int32_t)h;
-}
-
-__global__ __launch_bounds__(256) void k_point_site_fill(const int32_t *__restrict__ slot, int64_t n,
-                                                         const int32_t *__restrict__ vals,
-                                                         uint32_t *slotcnt,
-                                                         const int32_t *__restrict__ site_off,
-                                                         int32_t *__restrict__ point_site,
-                                                         int32_t *__restrict__ seg) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int s = slot[i];
-  if (s < 0) { point_site[i] = -1; return; }
-  int v = vals[s];
-  point_site[i] = v;
-  // slotcnt holds count-1 after the inserts; hand out positions count-1 .. 0
-  uint32_t pos = atomicAdd(&slotcnt[s], 0xFFFFFFFFu);
-  seg[site_off[v] + (int)pos] = (int32_t)i;
-}
-
-// order every site's point list by ascending point index (rank by counting: the lists are
-// tiny -- mean N/V ~ 1.2 -- and the quadratic cost is spread over the points themselves).
-__global__ __launch_bounds__(256) void k_rank_points(const int32_t *__restrict__ point_site, int64_t n,
-                                                     const int32_t *__restrict__ site_off,
-                                                     const int32_t *__restrict__ seg,
-                                                     int32_t *__restrict__ site_pts) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int v = point_site[i];
-  if (v < 0) return;
-  int s = site_off[v], e = site_off[v + 1], r = 0;
-  for (int j = s; j < e; ++j) r += (seg[j] < (int32_t)i) ? 1 : 0;
-  site_pts[s + r] = (int32_t)i;
-}
-
-// out[v] = sum_j mult * in[pts[j]] in ascending point order, separate multiply and add
-// (no FMA contraction) so the fp32 result is bit-identical to InputLayer_ForwardPass
-// (CPU/IOLayers.cpp:18-27: `out_f[plane] += multiplier * in_f[plane]`).
-__global__ __launch_bounds__(256) void k_input_forward(const float *__restrict__ in, float *__restrict__ out,
-                                                       int64_t V, int planes,
-                                                       const int32_t *__restrict__ site_off,
-                                                       const int32_t *__restrict__ site_pts, int mode) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= V * planes) return;
-  int64_t v = idx / planes;
-  int p = (int)(idx - v * planes);
-  int s = site_off[v], e = site_off[v + 1];
-  float acc = 0.0f;
-  if (mode == 1) {
-    acc = __fadd_rn(0.0f, in[(int64_t)site_pts[s] * planes + p]);
-  } else if (mode == 2) {
-    acc = __fadd_rn(0.0f, in[(int64_t)site_pts[e - 1] * planes + p]);
-  } else {
-    float mult = (mode == 4 && e > s) ? __fdiv_rn(1.0f, (float)(e - s)) : 1.0f;
-    for (int j = s; j < e; ++j)
-      acc = __fadd_rn(acc, __fmul_rn(mult, in[(int64_t)site_pts[j] * planes + p]));
-  }
-  out[idx] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_input_backward(float *__restrict__ d_in,
-                                                        const float *__restrict__ d_out, int64_t n,
-                                                        int planes, const int32_t *__restrict__ point_site,
-                                                        const int32_t *__restrict__ site_off,
-                                                        const int32_t *__restrict__ site_pts, int mode) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n * planes) return;
-  int64_t i = idx / planes;
-  int p = (int)(idx - i * planes);
-  int v = point_site[i];
-  float g = 0.0f;
-  if (v >= 0) {
-    int s = site_off[v], e = site_off[v + 1];
-    bool take = true;
-    if (mode == 1) take = (site_pts[s] == (int32_t)i);
-    if (mode == 2) take = (site_pts[e - 1] == (int32_t)i);
-    if (take) {
-      float mult = (mode == 4) ? __fdiv_rn(1.0f, (float)(e - s)) : 1.0f;
-      g = __fadd_rn(0.0f, __fmul_rn(mult, d_out[(int64_t)v * planes + p]));
-    }
-  }
-  d_in[idx] = g;
-}
-
-__global__ __launch_bounds__(256) void k_input_rule_table(const int32_t *__restrict__ site_off,
-                                                          const int32_t *__restrict__ site_pts, int64_t V,
-                                                          int width, int mode, int32_t *__restrict__ rules) {
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
-  int s = site_off[v], e = site_off[v + 1];
-  int32_t *r = rules + v * width;
-  if (mode == 3 || mode == 4) {
-    r[0] = e - s;
-    for (int j = 1; j < width; ++j) r[j] = (s + j - 1 < e) ? site_pts[s + j - 1] : 0;
-  } else {
-    r[0] = 1;
-    r[1] = (mode == 1) ? site_pts[s] : site_pts[e - 1];
-  }
-}
-
 // ------------------------------------------------------------------ rule tables
 struct Filter3 { int size[3]; };
 
@@ -495,86 +373,6 @@ static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)ceil_div(n >
 } // namespace aabr
 
 using namespace aabr;
-
-extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys,
-                                      int32_t *vals, int64_t cap, int32_t *scratch, int32_t *point_site,
-                                      int32_t *site_coords, int32_t *site_off, int32_t *site_pts,
-                                      int32_t *meta, void *stream_) {
-  hipStream_t st = (hipStream_t)stream_;
-  AABR_CHECK_ARG(n >= 0 && (ncols == 3 || ncols == 4), "n >= 0 and ncols in {3,4} required");
-  AABR_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "cap must be a power of two >= max(64, 2n)");
-  AABR_CHECK_ARG(keys && vals && scratch && point_site && site_coords && site_off && site_pts && meta,
-                 "null pointer");
-  AABR_CHECK_ARG(n == 0 || coords, "null coords");
-  int64_t nblk = ceil_div(n > 0 ? n : 1, kScanTile);
-  uint32_t *minidx = (uint32_t *)scratch;
-  uint32_t *slotcnt = minidx + cap;
-  int32_t *slot = (int32_t *)(slotcnt + cap);
-  int32_t *seg = slot + n;
-  int32_t *blocksums = seg + n;
-  int32_t *prefix = blocksums + 2 * nblk;
-  if ((void *)(keys + cap) == (void *)minidx) { // caller laid scratch right behind keys: one fill
-    hipMemsetAsync(keys, 0xFF, cap * (sizeof(uint64_t) + 2 * sizeof(uint32_t)), st);
-  } else {
-    hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st);
-    hipMemsetAsync(minidx, 0xFF, 2 * cap * sizeof(uint32_t), st);
-  }
-  hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st);
-  ConvGeom g = {};
-  if (n > 0)
-    hipLaunchKernelGGL(k_insert_points, grid1(n, 256), dim3(256), 0, st, coords, n, ncols, keys,
-                       (uint64_t)(cap - 1), minidx, slotcnt, slot, meta);
-  hipLaunchKernelGGL(k_scan_blocksums, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx, slotcnt,
-                     n, blocksums);
-  const bool inline_prefix = nblk <= kInlinePrefixBlocks;
-  if (!inline_prefix)
-    hipLaunchKernelGGL(k_scan_blockprefix, dim3(1), dim3(1024), 0, st, blocksums, nblk, prefix, meta, site_off);
-  hipLaunchKernelGGL(k_assign_sites<0>, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx, slotcnt,
-                     n, prefix, inline_prefix ? (const int32_t *)blocksums : (const int32_t *)nullptr, vals, site_coords, site_off, meta, coords, ncols, (const int32_t *)nullptr, g);
-  if (n > 0) {
-    hipLaunchKernelGGL(k_point_site_fill, grid1(n, 256), dim3(256), 0, st, slot, n, vals, slotcnt, site_off,
-                       point_site, seg);
-    hipLaunchKernelGGL(k_rank_points, grid1(n, 256), dim3(256), 0, st, point_site, n, site_off, seg, site_pts);
-  }
-  AABR_CHECK_LAUNCH();
-  return AABR_OK;
-}
-
-extern "C" int aabr_input_layer_forward(const float *in_feats, float *out_feats, int64_t V, int planes,
-                                        const int32_t *site_off, const int32_t *site_pts, int mode,
-                                        void *stream_) {
-  AABR_CHECK_ARG(V >= 0 && planes > 0 && mode >= 1 && mode <= 4, "bad V/planes/mode");
-  if (V == 0) return AABR_OK;
-  AABR_CHECK_ARG(in_feats && out_feats && site_off && site_pts, "null pointer");
-  hipLaunchKernelGGL(k_input_forward, grid1(V * planes, 256), dim3(256), 0, (hipStream_t)stream_, in_feats,
-                     out_feats, V, planes, site_off, site_pts, mode);
-  AABR_CHECK_LAUNCH();
-  return AABR_OK;
-}
-
-extern "C" int aabr_input_layer_backward(float *d_in_feats, const float *d_out_feats, int64_t n, int planes,
-                                         const int32_t *point_site, const int32_t *site_off,
-                                         const int32_t *site_pts, int mode, void *stream_) {
-  AABR_CHECK_ARG(n >= 0 && planes > 0 && mode >= 1 && mode <= 4, "bad n/planes/mode");
-  if (n == 0) return AABR_OK;
-  AABR_CHECK_ARG(d_in_feats && d_out_feats && point_site && site_off && site_pts, "null pointer");
-  hipLaunchKernelGGL(k_input_backward, grid1(n * planes, 256), dim3(256), 0, (hipStream_t)stream_, d_in_feats,
-                     d_out_feats, n, planes, point_site, site_off, site_pts, mode);
-  AABR_CHECK_LAUNCH();
-  return AABR_OK;
-}
-
-extern "C" int aabr_input_layer_rule_table(const int32_t *site_off, const int32_t *site_pts, int64_t V,
-                                           int max_active, int mode, int32_t *rules, void *stream_) {
-  AABR_CHECK_ARG(V >= 0 && max_active >= 0 && mode >= 1 && mode <= 4, "bad V/max_active/mode");
-  if (V == 0) return AABR_OK;
-  AABR_CHECK_ARG(site_off && site_pts && rules, "null pointer");
-  int width = ((mode == 3 || mode == 4) ? max_active : 1) + 1;
-  hipLaunchKernelGGL(k_input_rule_table, grid1(V, 256), dim3(256), 0, (hipStream_t)stream_, site_off,
-                     site_pts, V, width, mode, rules);
-  AABR_CHECK_LAUNCH();
-  return AABR_OK;
-}
 
 extern "C" int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t *keys,
                                       const int32_t *vals, int64_t cap, const int32_t *fs_host,

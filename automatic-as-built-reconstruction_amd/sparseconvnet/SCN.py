@@ -280,7 +280,7 @@ class Metadata_3(object):
         self.grids = {}
         self.submanifold = {}
         self.rulebooks = {}
-        self.input = None  # dict(point_site, site_off, site_pts, n, V, mode, max_active, spatial)
+        self.input = None  # dict(point_site, first_pt, cnt_extra, head, nxt, last_pt, meta, n, V, mode, spatial)
         self.device = None
 
     # ---- reference-visible queries ----------------------------------------------------
@@ -333,31 +333,30 @@ class Metadata_3(object):
         coords = coords.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
         n, ncols = coords.shape
         cap = _hip.next_pow2(2 * n)
-        nblk = (max(n, 1) + 255) // 256
         n1 = max(n, 1)
-        # int32 words: keys(2*cap) | scratch(3*cap + 2n + 4*nblk + 16) | vals(cap) | point_site(n) |
-        #              site_coords(4*n1) | site_off(n+1) | site_pts(n1) | meta(8); 16-byte aligned pieces.
-        # scratch sits right behind keys so the library clears both with one fill.
-        order = [(0, 2 * cap), (7, 3 * cap + 2 * n + 4 * nblk + 16), (1, cap), (2, n), (3, 4 * n1), (4, n + 1),
-                 (5, n1), (6, _hip.META_WORDS)]
-        offs, tot = [0] * 8, 0
-        for idx, sz in order:
-            offs[idx] = tot
+        nst = int(lib.aabr_input_layer_status_words(n))
+        # int32 words, 16-byte aligned pieces; keys | first | vals | meta sit back to back so the library clears
+        # them with ONE fill:  keys(2*cap) first(cap) vals(cap) meta(8) | slot(n) point_site(n) nxt(n)
+        #                      site_coords(4*n1) first_pt(n1) cnt_extra(n1) head(n1) last_pt(n1) status(nst)
+        names = [("keys", 2 * cap), ("first", cap), ("vals", cap), ("meta", _hip.META_WORDS), ("slot", n),
+                 ("point_site", n), ("nxt", n), ("site_coords", 4 * n1), ("first_pt", n1), ("cnt_extra", n1),
+                 ("head", n1), ("last_pt", n1), ("status", nst)]
+        offs, tot = {}, 0
+        for name, sz in names:
+            offs[name] = tot
             tot += (sz + 3) & ~3
         buf = torch.empty(tot, dtype=torch.int32, device=device)
-        keys = buf[offs[0]:offs[0] + 2 * cap].view(torch.int64)
-        vals = buf[offs[1]:offs[1] + cap]
-        point_site = buf[offs[2]:offs[2] + n]
-        site_coords = buf[offs[3]:offs[3] + 4 * n1].view(n1, 4)
-        site_off = buf[offs[4]:offs[4] + n + 1]
-        site_pts = buf[offs[5]:offs[5] + n1]
-        meta = buf[offs[6]:offs[6] + _hip.META_WORDS]
+        piece = {name: buf[offs[name]:offs[name] + sz] for name, sz in names}
+        keys = piece["keys"].view(torch.int64)
+        vals, meta = piece["vals"], piece["meta"]
+        site_coords = piece["site_coords"].view(n1, 4)
         base = buf.data_ptr()
+        P = lambda name: base + 4 * offs[name]
         host = ev = None
         if n > 0:
-            check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, base + 4 * offs[0], base + 4 * offs[1], cap,
-                                             base + 4 * offs[7], base + 4 * offs[2], base + 4 * offs[3],
-                                             base + 4 * offs[4], base + 4 * offs[5], base + 4 * offs[6], stream()))
+            check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, P("keys"), P("first"), P("vals"), cap, P("slot"),
+                                             P("point_site"), P("site_coords"), P("first_pt"), P("cnt_extra"),
+                                             P("head"), P("nxt"), P("status"), P("meta"), stream()))
             if asynchronous:
                 # pinned read-back buffer + event from a small recycling pool (allocating pinned memory
                 # per scene costs more than the whole enqueue)
@@ -367,12 +366,12 @@ class Metadata_3(object):
                 ev.record()
         else:  # empty scene: an empty grid (all keys EMPTY), nothing to launch
             keys.fill_(-1)
-            site_off.zero_()
             meta.zero_()
         self._pending = dict(host=host, event=ev, meta=meta, site_coords=site_coords, keys=keys, vals=vals,
                              cap=cap, coords=coords, buf=buf)
-        self.input = dict(point_site=point_site, site_off=site_off, site_pts=site_pts, n=n, V=None,
-                          mode=int(mode), max_active=None, spatial=_key(spatial_size), coords_src=coords_src)
+        self.input = dict(point_site=piece["point_site"], first_pt=piece["first_pt"], cnt_extra=piece["cnt_extra"],
+                          head=piece["head"], nxt=piece["nxt"], last_pt=piece["last_pt"], meta=meta, n=n, V=None,
+                          mode=int(mode), spatial=_key(spatial_size), coords_src=coords_src)
 
     def inputLayerFinish(self):
         """wait for the read-back (the one host sync of the input layer: V sizes every later tensor)"""
@@ -391,7 +390,7 @@ class Metadata_3(object):
             V = m[0]
             key = self.input["spatial"]
             self.grids[key] = _Grid(pend["site_coords"][:V], pend["keys"], pend["vals"], pend["cap"], V)
-            self.input["V"], self.input["max_active"] = V, m[1]
+            self.input["V"] = V   # maxActive (meta[1]) is produced by the forward kernel: read lazily (max_active())
             self.input_spatial = key
         return self.input["V"]
 
@@ -456,13 +455,24 @@ class Metadata_3(object):
         return tb
 
     # ---- reference-format views (tests / API parity) ------------------------------------------
+    def max_active(self):
+        """largest number of points in one voxel (IOLayersRules.h:96-103); written by the forward kernel"""
+        il = self.input
+        if il.get("max_active") is None:
+            if not il.get("forward_done"):
+                raise _hip.AabrError("maxActive is known after InputLayer_updateOutput has run")
+            il["max_active"] = max(int(il["meta"][1].item()), 0) if il["V"] else 0
+        return il["max_active"]
+
     def inputLayerRuleBook(self):
         """[[mode, maxActive, nIn, nOut], rules V x (1+maxActive)] (IOLayersRules.h:10-15)"""
         il = self.input
-        w = (il["max_active"] if il["mode"] in (3, 4) else 1) + 1
-        rules = torch.empty((il["V"], w), dtype=torch.int32, device=il["site_off"].device)
-        check(_hip.load().aabr_input_layer_rule_table(ptr(il["site_off"]), ptr(il["site_pts"]), il["V"],
-                                                      il["max_active"], il["mode"], ptr(rules), stream()))
+        ma = self.max_active()
+        w = (ma if il["mode"] in (3, 4) else 1) + 1
+        rules = torch.empty((il["V"], w), dtype=torch.int32, device=il["first_pt"].device)
+        check(_hip.load().aabr_input_layer_rule_table(ptr(il["first_pt"]), ptr(il["last_pt"]), ptr(il["cnt_extra"]),
+                                                      ptr(il["head"]), ptr(il["nxt"]), il["V"], ma, il["mode"],
+                                                      ptr(rules), stream()))
         return [il["mode"], w - 1, il["n"], il["V"]], rules
 
     @staticmethod
@@ -522,8 +532,10 @@ def InputLayer_updateOutput(metadata, spatial_size, coords, input_features, outp
     il = metadata.input
     planes = inp.size(1)
     output_features.resize_(V, planes)
-    check(_hip.load().aabr_input_layer_forward(ptr(inp), ptr(output_features), V, planes, ptr(il["site_off"]),
-                                               ptr(il["site_pts"]), il["mode"], stream()))
+    check(_hip.load().aabr_input_layer_forward(ptr(inp), ptr(output_features), V, planes, ptr(il["first_pt"]),
+                                               ptr(il["cnt_extra"]), ptr(il["head"]), ptr(il["nxt"]),
+                                               ptr(il["last_pt"]), il["mode"], ptr(il["meta"]), stream()))
+    il["forward_done"] = True
 
 
 def InputLayer_updateGradInput(metadata, d_input_features, d_output_features):
@@ -532,8 +544,8 @@ def InputLayer_updateGradInput(metadata, d_input_features, d_output_features):
     planes = d_out.size(1)
     d_input_features.resize_(il["n"], planes)
     check(_hip.load().aabr_input_layer_backward(ptr(d_input_features), ptr(d_out), il["n"], planes,
-                                                ptr(il["point_site"]), ptr(il["site_off"]),
-                                                ptr(il["site_pts"]), il["mode"], stream()))
+                                                ptr(il["point_site"]), ptr(il["first_pt"]), ptr(il["last_pt"]),
+                                                ptr(il["cnt_extra"]), il["mode"], stream()))
 
 
 # ------------------------------------------------------------------------------------------------

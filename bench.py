@@ -231,13 +231,22 @@ def conv_kernel_table(torch, wl, dtype):
             else:
                 wpack = torch.empty(lib.aabr_conv_wpack_floats(ga.vol, w.size(2), w.size(3)), device=dev)
                 conv = lib.aabr_conv_forward
-            blocks = ga.blocks()
-            check(conv(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks), ga.vol, ptr(w), None,
-                       g["flags"], ptr(wpack), stream()))   # packs the weights once
+            tile_rows = 0 if bf else lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, ga.rows, ga.vol)
+            if tile_rows:   # the same dispatch as sparseconvnet.SCN._conv_fwd
+                blocks = ga.blocks_wide(tile_rows)
+                check(lib.aabr_conv_pack_weights(ptr(w), ga.vol, w.size(2), w.size(3), tr_, ptr(wpack), stream()))
 
-            def fn():
+                def fn():
+                    check(lib.aabr_conv_forward_wide(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks),
+                                                     tile_rows, ga.vol, None, g["flags"] & 3, ptr(wpack), stream()))
+            else:
+                blocks = ga.blocks()
                 check(conv(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks), ga.vol, ptr(w), None,
-                           g["flags"] | 4, ptr(wpack), stream()))
+                           g["flags"], ptr(wpack), stream()))   # packs the weights once
+
+                def fn():
+                    check(conv(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks), ga.vol, ptr(w), None,
+                               g["flags"] | 4, ptr(wpack), stream()))
         else:
             inp = torch.randn((rows_in, n_in), device=dev).to(fdt)
             d_out = torch.randn((ga.rows, n_out), device=dev).to(fdt)

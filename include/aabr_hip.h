@@ -56,34 +56,43 @@ int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale
  * Replaces SparseGrid / SparseGridMap (SCN/Metadata/Metadata.h:24-33).                       */
 
 /* Voxel scatter, geometry half -- replaces Metadata<3>::inputLayer -> inputLayerRules
- * (SCN/Metadata/Metadata.cpp:405-417, IOLayersRules.h:18-125), modes 1..4.
+ * (SCN/Metadata/Metadata.cpp:405-417, IOLayersRules.h:18-125), modes 1..4.  One fill + two kernels
+ * (csrc/voxel_scatter.hip): hash insert + first-point atomicMin; then ONE pass over the points that numbers the
+ * voxels in first-seen order (chunk scan + decoupled look-back) and links every further point of a voxel into
+ * the site's chain.
  *   coords       int64 [n, ncols] (ncols 3 or 4; 4th column = batch index)   (API layout)
- *   keys, vals   hash grid storage, capacity cap (contents overwritten)
- *   scratch      int32 [3*cap + 2*n + 4*nblk + 16] where nblk = ceil(n/256)
- *   point_site   int32 [n]   out: output row of every input row
+ *   keys, first, vals  hash grid storage, capacity cap each (uint64 / uint32 / int32; contents overwritten);
+ *                laid out back to back and followed by `meta` they are cleared with a single fill
+ *   slot         int32 [n]   scratch: hash slot of every point
+ *   point_site   int32 [n]   out: output row of every input row (-1: dropped)
  *   site_coords  int32 [n,4] out: first V rows valid, first-seen order
- *   site_off     int32 [n+1] out: CSR offsets of the per-site point lists (first V+1 valid)
- *   site_pts     int32 [n]   out: point indices grouped by site, ascending inside a site
- *   meta         int32 [AABR_META_WORDS] out (device): V, maxActive, error flag            */
-int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys,
-                           int32_t *vals, int64_t cap, int32_t *scratch, int32_t *point_site,
-                           int32_t *site_coords, int32_t *site_off, int32_t *site_pts,
-                           int32_t *meta, void *stream);
+ *   first_pt     int32 [n]   out: first (lowest-index) point of each site
+ *   cnt_extra    int32 [n]   out: points per site minus one
+ *   head, nxt    int32 [n]   out: chain of the site's further points (head[site] -> nxt[point] -> ... -> -1)
+ *   status       int32 [aabr_input_layer_status_words(n)] scratch (8-byte aligned)
+ *   meta         int32 [AABR_META_WORDS] out (device): V, (maxActive: written by aabr_input_layer_forward), error */
+int64_t aabr_input_layer_status_words(int64_t n);
+int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys, uint32_t *first,
+                           int32_t *vals, int64_t cap, int32_t *slot, int32_t *point_site,
+                           int32_t *site_coords, int32_t *first_pt, int32_t *cnt_extra, int32_t *head,
+                           int32_t *nxt, int32_t *status, int32_t *meta, void *stream);
 
 /* Voxel scatter, feature half -- replaces InputLayer_ForwardPass / InputLayer_fp_
  * (SCN/CPU/IOLayers.cpp:11-29, SCN/CUDA/IOLayers.cu:14-41).  mode: 1 keep-first-listed,
- * 2 keep-last-listed, 3 sum, 4 mean (exactly the reference's mode table, ioLayers.py:33-38). */
+ * 2 keep-last-listed, 3 sum, 4 mean (exactly the reference's mode table, ioLayers.py:33-38).
+ * Also writes last_pt [V] (highest-index point of each site; may be NULL) and meta[1] = maxActive. */
 int aabr_input_layer_forward(const float *in_feats, float *out_feats, int64_t V, int planes,
-                             const int32_t *site_off, const int32_t *site_pts, int mode,
-                             void *stream);
+                             const int32_t *first_pt, const int32_t *cnt_extra, const int32_t *head,
+                             const int32_t *nxt, int32_t *last_pt, int mode, int32_t *meta, void *stream);
 /* replaces InputLayer_BackwardPass / InputLayer_bp_ (CPU/IOLayers.cpp:30-47, IOLayers.cu:43-70) */
 int aabr_input_layer_backward(float *d_in_feats, const float *d_out_feats, int64_t n, int planes,
-                              const int32_t *point_site, const int32_t *site_off,
-                              const int32_t *site_pts, int mode, void *stream);
+                              const int32_t *point_site, const int32_t *first_pt, const int32_t *last_pt,
+                              const int32_t *cnt_extra, int mode, void *stream);
 
 /* Reference-format input rule table rules[1] (IOLayersRules.h:112-124): int32 [V, 1+maxActive]. */
-int aabr_input_layer_rule_table(const int32_t *site_off, const int32_t *site_pts, int64_t V,
-                                int max_active, int mode, int32_t *rules, void *stream);
+int aabr_input_layer_rule_table(const int32_t *first_pt, const int32_t *last_pt, const int32_t *cnt_extra,
+                                const int32_t *head, const int32_t *nxt, int64_t V, int max_active, int mode,
+                                int32_t *rules, void *stream);
 
 /* Submanifold rule table -- replaces Metadata<3>::getSubmanifoldRuleBook ->
  * SubmanifoldConvolution_SgToRules (Metadata.cpp:429-443, SubmanifoldConvolutionRules.h:11-45).

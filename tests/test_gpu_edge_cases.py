@@ -500,3 +500,31 @@ def test_input_layer_prepare_is_matched_by_identity_and_works_for_int32_coords()
         ref = scn.InputLayer(3, [50, 40, 12], mode=4)([_t(coords), _t(feats)])
         assert torch.equal(y.features, ref.features)
         assert torch.equal(y.get_spatial_locations(), ref.get_spatial_locations())
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_input_layer_long_chains_and_chunk_boundaries(mode):
+    """voxel scatter (csrc/voxel_scatter.hip): voxels with far more points than the in-register chain sort holds
+    (300 points in one voxel), first points spread over many look-back chunks, duplicates that straddle chunk
+    boundaries -- sites, rule table and features bit-exact against the oracle"""
+    scn = _scn()
+    rng = np.random.default_rng(40 + mode)
+    n = 9000                                             # 9 chunks of 1024
+    coords = np.stack([rng.integers(0, 30, n), rng.integers(0, 30, n), rng.integers(0, 4, n),
+                       np.sort(rng.integers(0, 2, n))], 1).astype(np.int64)
+    hot = rng.choice(n, 300, replace=False)
+    coords[hot, :3] = (7, 7, 1)                          # one voxel (per batch index) with ~150 points each
+    feats = rng.standard_normal((n, 5)).astype(np.float32)
+    layer = scn.InputLayer(3, [32, 32, 4], mode=mode)
+    f = _t(feats).requires_grad_(True)
+    x = layer([_t(coords), f])
+    ref = O.input_layer(coords, feats, mode)
+    assert x.metadata.input["V"] == ref["V"] and ref["max_active"] > 100 or mode in (1, 2)
+    np.testing.assert_array_equal(x.get_spatial_locations().numpy(), ref["coords"])
+    np.testing.assert_array_equal(x.metadata.input["point_site"].cpu().numpy(), ref["point_voxel"])
+    hdr, rules = x.metadata.inputLayerRuleBook()
+    np.testing.assert_array_equal(rules.cpu().numpy(), ref["rules"])
+    np.testing.assert_array_equal(x.features.detach().cpu().numpy(), ref["out"])
+    g = rng.standard_normal(ref["out"].shape).astype(np.float32)
+    x.features.backward(_t(g))
+    np.testing.assert_array_equal(f.grad.cpu().numpy(), O.input_layer_bwd(ref, g))
