@@ -1,0 +1,402 @@
+// conv_wide.hip -- the wide-layer form of the sparse convolution (gfx950): 128-row output tiles, output columns
+// split across the waves of a workgroup, gathered rows shared through LDS, weights held in registers per offset.
+//
+// Why: in the 64-row-tile kernels of conv.hip every 16-pair block streams its own 2 KiB x NBW of packed weights
+// per 32-channel chunk through the vector-memory path; on the layers that dominate the FPN_Net step (64..256
+// planes, 3x3x3) that is ~5x the bytes of the gathered rows, and the L2->CU feed, not the MFMA pipe, bounds the
+// kernel (34 % of the fp32 MFMA peak at 128->128).  Two other forms were built and measured on the way
+// (profiles/r02_conv_wide_ab.txt): weights staged through LDS per (offset, chunk) with the
+// waves in lockstep (slower: a barrier per ~1.5 blocks of work and 75 % balance), and columns split across waves
+// with every wave gathering every row itself (slower: 4x the gather traffic misses the vector L1).  What is kept:
+//
+//   k_conv_cs  -- a workgroup (4 waves) owns 128 consecutive output rows x 64 output columns in LDS (32 KiB, XOR-
+//   swizzled 16-byte granules so the read-add-write of a block's 16 rows is bank-conflict free); wave w owns column
+//   block w.  Per filter offset a wave loads its 16-column weight slice ONCE into registers (8 KiB per 128 input
+//   channels = 32 VGPRs) and reuses it for every block of that offset in the tile; per pair of 16-pair blocks the
+//   workgroup gathers the 32 rows once into a double-buffered LDS stage (each wave a quarter; loads in flight
+//   during the previous pair's MFMAs) and every wave reads its MFMA B-operands from there.  Waves never touch each
+//   other's tile columns, every wave issues the same MFMAs (perfect balance), accumulation order is fixed (offset,
+//   block) => bit-reproducible, no atomics.  One barrier per block pair; 64 KiB LDS => two workgroups per CU.
+//
+// Same contraction as conv.hip (reference: SCN/CPU/Convolution.cpp:45-185, SCN/CPU/Deconvolution.cpp:7-77):
+//     out[o] = bias + sum_k in[table[k][o]] @ Wl[k]
+// Requires n_in % 32 == 0 (above 128: % 128), n_out % 64 == 0, vol <= 63, rows_in < 2^23, buffers < 2 GiB.
+#include "common.h"
+#include <stdlib.h>
+
+namespace aabr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+extern thread_local const char *g_last_variant; // conv.hip
+
+constexpr int kWS = 64;    // tile row stride in floats = slab width
+constexpr int kNB = 4;     // 16-column blocks per slab
+constexpr int kMaxVol = 63;  // vol + 1 prefix entries live in the lanes of one VGPR
+
+// ------------------------------------------------------------------ compiled rule book, big-tile form
+//   words: [ntiles][vol+1] block prefix per offset | [ntiles][(T/16)*vol][16] entries   (T rows per tile)
+//   entry = (partner_row << 8) | local_row; padding entries repeat the block's first pair with bit 31 set.
+// Pairs of one offset are in ascending local-row order (deterministic).
+template <int T> // rows per tile = threads per workgroup (128 or 256)
+__global__ __launch_bounds__(T) void k_build_tileT(const int32_t *__restrict__ table, int64_t V, int vol,
+                                                    int32_t *__restrict__ words) {
+  constexpr int kT = T;
+  constexpr int NWV = T / 64;
+  __shared__ int s_cnt[4][kMaxVol];
+  __shared__ int s_base[kMaxVol + 1];
+  __shared__ int s_tot[kMaxVol];
+  __shared__ int s_first[kMaxVol];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t ntiles = (V + T - 1) / T, tile = blockIdx.x;
+  const int maxb = (T / 16) * vol;
+  int32_t *pre = words + tile * (vol + 1);
+  int32_t *ent = words + ntiles * (vol + 1) + tile * (int64_t)maxb * 16;
+  const int64_t row = tile * kT + threadIdx.x;
+  const bool valid = row < V;
+  for (int k = 0; k < vol; ++k) {
+    const int t = valid ? table[(int64_t)k * V + row] : -1;
+    const unsigned long long m = __ballot(t >= 0);
+    if (lane == 0) s_cnt[wave][k] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int b = 0;
+    for (int k = 0; k < vol; ++k) {
+      int tot = 0;
+      for (int w = 0; w < NWV; ++w) tot += s_cnt[w][k];
+      s_tot[k] = tot;
+      s_base[k] = b;
+      b += (tot + 15) >> 4;
+    }
+    s_base[vol] = b;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x <= vol) pre[threadIdx.x] = s_base[threadIdx.x];
+  for (int k = 0; k < vol; ++k) {
+    const int t = valid ? table[(int64_t)k * V + row] : -1;
+    const unsigned long long m = __ballot(t >= 0);
+    if (t >= 0) {
+      int rank = __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) rank += s_cnt[w][k];
+      const int e = (t << 8) | (int)threadIdx.x;
+      ent[s_base[k] * 16 + rank] = e;
+      if (rank == 0) s_first[k] = e;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < vol; ++k) {
+    const int tot = s_tot[k];
+    if (tot == 0) continue;
+    const int pad = ((tot + 15) & ~15) - tot;
+    if ((int)threadIdx.x < pad) ent[s_base[k] * 16 + tot + threadIdx.x] = s_first[k] | (int)0x80000000;
+  }
+}
+
+__device__ inline float bcf_(unsigned int v) { return __builtin_bit_cast(float, v); }
+
+// ------------------------------------------------------------------ the kernel
+// Per pair of blocks the workgroup gathers the 32 rows once (each wave a quarter, 4 x 16-byte loads per lane, in
+// flight during the previous pair's MFMAs), stores them in a double-buffered, granule-swizzled stage (2 x 16 KiB)
+// and every wave reads its MFMA B-operands from there with conflict-free ds_read_b128.  So per 16-pair block the
+// vector-memory path carries the 8 KiB of gathered rows ONCE (64-row-tile kernels: 8 KiB + 32 KiB of weights), the
+// weights cost 8 KiB per wave per OFFSET (registers), and every wave issues the same MFMAs.
+// One barrier per block pair (~2 x 1024 MFMA cycles per wave); 64 KiB LDS => two workgroups per CU.
+constexpr int kT2 = 128;
+
+template <int KG, int DBG>
+__global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
+                                                    float *__restrict__ out, int co, int64_t V_out,
+                                                    const int32_t *__restrict__ words, int64_t words_bytes, int vol,
+                                                    int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
+                                                    const float *__restrict__ bias) {
+  constexpr int RG = KG * 8;               // 16-byte granules per staged row
+  constexpr int RF = KG * 32;              // floats per staged row
+  constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
+  constexpr int STAGE = 2 * 16 * RF;       // floats per stage buffer (two blocks)
+  extern __shared__ __align__(16) float smem[];
+  float *Ct = smem;                        // [128 + 1][64] floats, granule-swizzled; row 128 swallows padding entries
+  float *St = smem + (kT2 + 1) * kWS;      // [2][2][16][RF]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int pr = wave * 8 + (lane >> 3), seg = lane & 7; // gather role: pair row 0..31, 16-byte segment
+  const int nkc = ci >> 5, nnb = co >> 4;
+  const int nb0 = blockIdx.y * kNB;
+  const int64_t tile = blockIdx.x, row0 = tile * kT2;
+  const int64_t ntiles = (V_out + kT2 - 1) / kT2;
+  const int maxb = (kT2 / 16) * vol;
+  const int vpre = lane <= vol ? words[tile * (vol + 1) + lane] : 0;
+  {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 *c4 = reinterpret_cast<f32x4 *>(Ct);
+#pragma unroll
+    for (int i = 0; i < (kT2 * kWS / 4) / 256; ++i) c4[i * 256 + threadIdx.x] = z;
+  }
+  const __amdgpu_buffer_rsrc_t rin =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwords =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(words), 0, (int)words_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, (int)wp_bytes, 0x00020000);
+  const unsigned ebase = (unsigned)((ntiles * (vol + 1) + tile * (int64_t)maxb * 16) * 4);
+  const unsigned rowbytes = (unsigned)ci * 4u;
+  const unsigned lane32 = (unsigned)lane * 32u;
+  auto pre_of = [&](int k) { return __builtin_amdgcn_readlane(vpre, k); };
+  auto next_offset = [&](int k) {
+    ++k;
+    while (k < vol && pre_of(k + 1) == pre_of(k)) ++k;
+    return k;
+  };
+  struct WReg { u32x4 w0[KG], w1[KG]; };
+  struct GReg { u32x4 v[KG]; };
+  struct Ent { int eg, ea, eb; };          // gather-role entry of this lane's pair row; compute-role entries (A, B)
+  const int ngroups = (nkc + KG - 1) / KG;
+  const int nblk_all = pre_of(vol);
+  auto load_w = [&](WReg &w, int k, int kg) {
+    const int kW = wflip ? vol - 1 - k : k;
+#pragma unroll
+    for (int c = 0; c < KG; ++c) { // nkc % KG == 0 (dispatch): every load is unconditional, so the compiler's
+      const int kc = kg * KG + c;  // vmcnt bookkeeping stays exact and nothing waits for a prefetch it does not use
+      const unsigned so = (unsigned)((((int64_t)kW * nkc + kc) * nnb + nb0 + wave) * 2048);
+      w.w0[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, so, 0);
+      w.w1[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16u, so, 0);
+    }
+  };
+  // entries of the pair (bb, bb+1) of offset kk; the second block only if it belongs to the same offset,
+  // otherwise block A again with the discard bit
+  auto load_ent = [&](int bb, int kk) {
+    Ent e;
+    const bool hasB = bb + 1 < pre_of(kk + 1);
+    const unsigned bA = (unsigned)bb * 64u, bB = (unsigned)(hasB ? bb + 1 : bb) * 64u;
+    e.ea = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, (unsigned)c16 * 4u, ebase + bA, 0);
+    e.eb = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, (unsigned)c16 * 4u, ebase + bB, 0);
+    e.eg = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, (unsigned)(pr & 15) * 4u, ebase + (pr < 16 ? bA : bB), 0);
+    if (!hasB) e.eb |= (int)0x80000000;
+    return e;
+  };
+  auto gather = [&](GReg &q, int eg, int kg) {
+    const unsigned va = (((unsigned)eg & 0x7fffffffu) >> 8) * rowbytes + (unsigned)seg * 16u;
+#pragma unroll
+    for (int i = 0; i < KG; ++i) { // granule seg + 8 i of the row's current channel group
+      const unsigned so = (unsigned)(kg * KG + i) * 128u;
+      if (DBG & 2) q.v[i] = (u32x4){(unsigned)eg, 0u, 0u, 0u}; // timing experiments: no global gathers
+      else q.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
+    }
+  };
+  auto stage_store = [&](const GReg &q, int buf) {
+    float *rowp = St + buf * STAGE + pr * RF;
+#pragma unroll
+    for (int i = 0; i < KG; ++i)
+      *reinterpret_cast<u32x4 *>(rowp + (((seg + 8 * i) ^ (pr & SWZ)) << 2)) = q.v[i];
+  };
+  // branch-free: a padding entry (bit 31) lands in the dummy row; the two blocks of a pair never share a real row,
+  // so both reads go out before either write
+  auto accumulate2 = [&](int ea, const f32x4 &accA, int eb, const f32x4 &accB) {
+    const int ra = ea >= 0 ? (ea & 255) : kT2, rb = eb >= 0 ? (eb & 255) : kT2;
+    f32x4 *da = reinterpret_cast<f32x4 *>(Ct + ra * kWS + (((wave * 4 + g) ^ (ra & 15)) << 2));
+    f32x4 *db = reinterpret_cast<f32x4 *>(Ct + rb * kWS + (((wave * 4 + g) ^ (rb & 15)) << 2));
+    const f32x4 va = *da, vb = *db;
+    *da = va + accA;
+    *db = vb + accB;
+  };
+  // Software pipeline over the tile's block pairs (pairs never straddle an offset):
+  //   entries two pairs ahead (registers), gathered rows one pair ahead (registers -> LDS stage after this pair's
+  //   MFMAs), weights one offset ahead.  A gather never waits for an entry load issued in the same iteration.
+  struct Pos { int b, k; };                // k >= vol: past the end
+  auto adv = [&](Pos q) {
+    if (q.k >= vol) return q;
+    const int kend = pre_of(q.k + 1);
+    q.b += 2;
+    if (q.b >= kend) { q.b = kend; q.k = next_offset(q.k); }
+    return q;
+  };
+  auto wg_barrier = [&]() {                // LDS traffic of this wave retired, then the workgroup barrier; unlike
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // __syncthreads() it does not drain the prefetches
+  };
+  int par = 0;
+  for (int kg = 0; kg < ngroups; ++kg) {
+    Pos p0;
+    p0.k = next_offset(-1);
+    if (p0.k >= vol) break;
+    p0.b = pre_of(p0.k);
+    Pos p1 = adv(p0), p2 = adv(p1);
+    Ent e0 = load_ent(p0.b, p0.k), e2 = e0;
+    Ent e1 = load_ent(p1.k < vol ? p1.b : p0.b, p1.k < vol ? p1.k : p0.k);
+    GReg gq;
+    gather(gq, e0.eg, kg);
+    __syncthreads();                       // zero fill done / previous group's stage reads done
+    stage_store(gq, par);
+    __syncthreads();
+    // one pipeline step: pair p0 with the weight registers `w` (passed by reference: the two weight sets are
+    // used from fixed registers by two copies of this body -- no register shuffling at an offset change)
+    auto step = [&](const WReg &w) __attribute__((always_inline)) {
+      // unconditional: past the tile's last pair the loads repeat a valid pair and their results are dropped
+      gather(gq, e1.eg, kg);                                 // entry loaded an iteration ago: no wait
+      {
+        const bool v2 = p2.k < vol;
+        e2 = load_ent(v2 ? p2.b : p0.b, v2 ? p2.k : p0.k);
+      }
+      __builtin_amdgcn_sched_barrier(0);                     // the prefetches are issued HERE, ahead of the MFMAs
+
+      {
+        const float *sa = St + par * STAGE + c16 * RF;
+        const float *sb = sa + 16 * RF;
+        // all of the pair's B operands leave LDS before the first MFMA (counted lgkmcnt waits follow)
+        u32x4 a0[KG], a1[KG], b0[KG], b1[KG];
+#pragma unroll
+        for (int c = 0; c < KG; ++c) {
+          const int q0 = ((c * 8 + g * 2) ^ (c16 & SWZ)) << 2, q1 = ((c * 8 + g * 2 + 1) ^ (c16 & SWZ)) << 2;
+          a0[c] = *reinterpret_cast<const u32x4 *>(sa + q0);
+          b0[c] = *reinterpret_cast<const u32x4 *>(sb + q0);
+          a1[c] = *reinterpret_cast<const u32x4 *>(sa + q1);
+          b1[c] = *reinterpret_cast<const u32x4 *>(sb + q1);
+        }
+        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
+#pragma unroll
+        for (int c = 0; c < KG; ++c) {
+          {
+            if (DBG & 1) { // timing experiments: operands consumed, no MFMAs
+              accA[0] += bcf_(a0[c][0]) + bcf_(a1[c][0]) + bcf_(w.w0[c][0]) + bcf_(w.w1[c][0]);
+              accB[0] += bcf_(b0[c][0]) + bcf_(b1[c][0]);
+            } else {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[c][t]), bcf_(a0[c][t]), accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[c][t]), bcf_(b0[c][t]), accB, 0, 0, 0);
+              }
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[c][t]), bcf_(a1[c][t]), accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[c][t]), bcf_(b1[c][t]), accB, 0, 0, 0);
+              }
+            }
+          }
+        }
+        accumulate2(e0.ea, accA, e0.eb, accB);
+      }
+      if (p1.k < vol) stage_store(gq, par ^ 1);
+      wg_barrier();
+      par ^= 1;
+      p0 = p1; p1 = p2; p2 = adv(p2);
+      e0 = e1; e1 = e2;
+    };
+    WReg wA, wB;
+    int k = p0.k;
+    load_w(wA, k, kg);
+    for (;;) {
+      int kn = next_offset(k);
+      if (kn < vol) load_w(wB, kn, kg);                      // next offset's weights in flight during this offset
+      while (p0.k == k) step(wA);
+      if (kn >= vol) break;
+      k = kn;
+      kn = next_offset(k);
+      if (kn < vol) load_w(wA, kn, kg);
+      while (p0.k == k) step(wB);
+      if (kn >= vol) break;
+      k = kn;
+    }
+  }
+  __syncthreads();
+  const int nrows = (int)((V_out - row0) < kT2 ? (V_out - row0) : kT2);
+#pragma unroll 4
+  for (int i = threadIdx.x; i < nrows * 16; i += 256) {
+    const int r = i >> 4, q = i & 15;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + r * kWS + ((q ^ (r & 15)) << 2));
+    if (bias) {
+      const float *bb = bias + nb0 * 16 + q * 4;
+      v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
+    }
+    *reinterpret_cast<f32x4 *>(out + (row0 + r) * co + nb0 * 16 + q * 4) = v;
+  }
+}
+
+} // namespace aabr
+using namespace aabr;
+
+static int64_t wide_words(int64_t V, int vol, int T) {
+  const int64_t nt = (V + T - 1) / T;
+  return nt * (vol + 1) + nt * (int64_t)(T / 16) * vol * 16;
+}
+
+extern "C" int64_t aabr_wide_blocks_words(int64_t V, int vol, int tile_rows) { return wide_words(V, vol, tile_rows); }
+
+extern "C" int aabr_build_wide_blocks(const int32_t *table, int64_t V, int vol, int tile_rows, int32_t *blocks,
+                                      void *stream_) {
+  AABR_CHECK_ARG(V >= 0 && vol > 0 && vol <= kMaxVol, "bad sizes (vol <= 63)");
+  AABR_CHECK_ARG(tile_rows == 128, "tile_rows must be 128");
+  if (V == 0) return AABR_OK;
+  AABR_CHECK_ARG(table && blocks, "null pointer");
+  const unsigned nt = (unsigned)((V + tile_rows - 1) / tile_rows);
+  hipLaunchKernelGGL(k_build_tileT<128>, dim3(nt), dim3(128), 0, (hipStream_t)stream_, table, V, vol, blocks);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+// 0: use the 64-row-tile kernels of conv.hip; 128 / 256: rows per tile of the block stream aabr_conv_forward_wide wants
+extern "C" int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
+  if (n_in <= 0 || n_out <= 0 || (n_in & 31) || (n_out & 63) || vol <= 0 || vol > kMaxVol) return 0;
+  if (rows_in >= (1ll << 23) || rows_in * n_in * 4 >= (1ll << 31)) return 0;
+  const int T = 128;
+  if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
+  if ((int64_t)vol * n_in * n_out * 4 >= (1ll << 31)) return 0;
+  if (n_in > 128 && (n_in & 127)) return 0; // channel groups of 128: every load of the inner loop unconditional
+  if (const char *ov = getenv("AABR_CONV_WIDE")) { // tuning experiments only: 0 = never, 1 = whenever supported
+    if (ov[0] == '0') return 0;
+    if (ov[0] == '1') return T;
+  }
+  // enough workgroups to fill the chip twice over (measured, profiles/r02_conv_wide_ab.txt: wins from ~340
+  // workgroups up, loses below ~180)
+  return (((V_out + T - 1) / T) * (n_out / 64) >= 320) ? T : 0;
+}
+
+extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
+                                      int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                                      int flags, const float *wpack, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 31) == 0 && (n_out & 63) == 0, "plane counts: n_in % 32, n_out % 64");
+  AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
+  AABR_CHECK_ARG(tile_rows == 128, "tile_rows must be 128");
+  if (V_out == 0) return AABR_OK;
+  AABR_CHECK_ARG(in_feats && out_feats && blocks && wpack && rows_in > 0, "null pointer / empty input");
+  AABR_CHECK_ARG(rows_in < (1ll << 23), "too many input rows for the wide block format");
+  const int64_t in_bytes = rows_in * n_in * 4, words_bytes = wide_words(V_out, vol, tile_rows) * 4;
+  AABR_CHECK_ARG(in_bytes < (1ll << 31) && words_bytes < (1ll << 31), "buffers must be < 2 GiB");
+  AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 15) == 0 && ((uintptr_t)wpack & 15) == 0,
+                 "feature / weight pointers must be 16-byte aligned");
+  const int dbg = flags >> 8;
+  const int nkc = n_in / 32;
+  const int64_t wp_bytes = (int64_t)vol * nkc * (n_out / 16) * 2048;
+  AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
+  AABR_CHECK_ARG(n_in <= 128 || (n_in & 127) == 0, "n_in above 128 must be a multiple of 128");
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / 64));
+  const int flip = (flags >> 1) & 1;
+  const int kg = nkc >= 4 ? 4 : nkc;
+#define AABR_LAUNCH_WIDE(KERNEL, NAME, LDS, ...)                                                          \
+  do {                                                                                                    \
+    static bool attr = false;                                                                             \
+    if (!attr) {                                                                                          \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS))); \
+      attr = true;                                                                                        \
+    }                                                                                                     \
+    g_last_variant = NAME;                                                                                \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(256), (LDS), st, __VA_ARGS__);                                  \
+  } while (0)
+  {
+#define AABR_WIDE_CS(KG, D)                                                                               \
+  AABR_LAUNCH_WIDE((k_conv_cs<KG, D>), "k_conv_cs<" #KG "," #D ">",                                       \
+                   (size_t)((kT2 + 1) * kWS + 2 * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes, out_feats, \
+                   n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias)
+    if (dbg & 3) { // timing experiments (tools/): only the 128-channel-group instance carries the debug variants
+      AABR_CHECK_ARG(kg == 4, "debug variants exist for n_in >= 128 only");
+      if ((dbg & 3) == 1) AABR_WIDE_CS(4, 1); else if ((dbg & 3) == 2) AABR_WIDE_CS(4, 2); else AABR_WIDE_CS(4, 3);
+    } else {
+      if (kg == 1) AABR_WIDE_CS(1, 0); else if (kg == 2) AABR_WIDE_CS(2, 0); else if (kg == 3) AABR_WIDE_CS(3, 0);
+      else AABR_WIDE_CS(4, 0);
+    }
+#undef AABR_WIDE_CS
+  }
+#undef AABR_LAUNCH_WIDE
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}

@@ -590,7 +590,7 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
     tile_rows = 0 if (bf16 or n_rows_out == 0) else lib.aabr_conv_wide_tile_rows(n_in, n_out, inp.size(0), n_rows_out,
                                                                                   gather.vol)
     if tile_rows:
-        # wide layer: big tiles, weights shared per offset (csrc/conv_t256.hip)
+        # wide layer: big tiles, weights shared per offset (csrc/conv_wide.hip)
         if not (flags & 4):
             check(lib.aabr_conv_pack_weights(ptr(w), gather.vol, w.size(2), w.size(3), flags & 1, ptr(wpack), stream()))
         check(lib.aabr_conv_forward_wide(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,

@@ -24,6 +24,7 @@ class FPN_Net(torch.nn.Module):
         nn.Module.__init__(self)
         assert feature_dtype in (torch.float32, torch.bfloat16)
         self.feature_dtype = feature_dtype
+        self.prebuild_geometry = True   # extension: see _prebuild_geometry
         self.bn_momentum = bn_momentum
         self.track_running_stats = track_running_stats
         self.dimension = dimension
@@ -128,8 +129,39 @@ class FPN_Net(torch.nn.Module):
         out.features = net.features.to(dtype)
         return out
 
+    def _prebuild_geometry(self, net):
+        """Extension (not in the reference): build every grid and rule table of the pass NOW, before the first
+        convolution is enqueued.  The geometry depends on the coordinates only; each strided level costs one small
+        device->host read (its site count sizes the next tensors), and a read drains the stream -- so the reads are
+        taken here, back to back on a nearly empty queue, instead of one in front of every down-sampling layer where
+        each would wait for all the convolutions queued before it and leave the GPU idle while the host catches up.
+        Same rule books, same cache keys (Metadata caches by (spatial, filter[, stride])): the layers find them."""
+        md = net.metadata
+        if getattr(md, "_fpn_prebuilt", False):
+            return
+        sz = net.spatial_size
+        sizes = [sz]
+        three, one = torch.LongTensor([3, 3, 3]), torch.LongTensor([1, 1, 1])
+        nscale = len(self.m_downs)
+        for k in range(nscale):
+            md.getSubmanifoldRuleBook(sz, three)
+            md.getSubmanifoldRuleBook(sz, one)
+            if k + 1 < nscale:
+                ks, st = torch.LongTensor(self.down_kernels[k]), torch.LongTensor(self.down_strides[k])
+                out = (sz - ks) // st + 1
+                md.getRuleBook(sz, out, ks, st)
+                sz = out
+                sizes.append(sz)
+        for i, scale_from_top in enumerate(self.fpn_scales_from_top):
+            msz = sizes[nscale - 1 - scale_from_top]
+            ks = torch.LongTensor([1, 1, int(self.rpn_map_sizes[i][2])])
+            md.getRuleBook(msz, (msz - ks) // one + 1, ks, one)
+        md._fpn_prebuilt = True
+
     def forward(self, net0):
         net1 = self.layers_in(net0)
+        if self.prebuild_geometry:
+            self._prebuild_geometry(net1)
         if self.feature_dtype == torch.float32:
             return self.forward_fpn(net1)
         rpn_maps, roi_maps = self.forward_fpn(self._cast(net1, self.feature_dtype))

@@ -151,12 +151,12 @@ int64_t aabr_offset_pairs_words(int64_t V, int vol);  /* int32 words of `pairs` 
 int aabr_build_offset_pairs(const int32_t *table, const int32_t *block_counts, int64_t V, int vol,
                             int32_t *pairs, void *stream);
 
-/* Wide-layer forms of the same contraction (csrc/conv_t256.hip): 128- or 256-row output tiles whose blocks
+/* Wide-layer forms of the same contraction (csrc/conv_wide.hip): 128-row output tiles whose blocks
  * share one set of weights per filter offset (registers / LDS) instead of streaming 32 KiB of packed weights per
  * 16-pair block.  Replaces the same reference loops as aabr_conv_forward (SCN/CPU/Convolution.cpp:45-185,
  * SCN/CPU/Deconvolution.cpp:7-77; the CUDA twin it stands in for is dConvolution_KMxKN_forwardA/B,
  * SCN/CUDA/Convolution.cu:57-203).
- *   aabr_conv_wide_tile_rows: 0 = use aabr_conv_forward; 128 / 256 = rows per tile of the block stream that
+ *   aabr_conv_wide_tile_rows: 0 = use aabr_conv_forward; 128 = rows per tile of the block stream that
  *     aabr_conv_forward_wide wants for this shape (supported AND expected to beat the 64-row-tile kernels);
  *   aabr_wide_blocks_words / aabr_build_wide_blocks: gather table [vol][V] -> per-tile per-offset blocks of 16
  *     (partner row, local row) pairs (vol <= 63);
