@@ -39,12 +39,12 @@ constexpr int kMaxVol = 63;  // vol + 1 prefix entries live in the lanes of one 
 //   words: [ntiles][vol+1] block prefix per offset | [ntiles][(T/16)*vol][16] entries   (T rows per tile)
 //   entry = (partner_row << 8) | local_row; padding entries repeat the block's first pair with bit 31 set.
 // Pairs of one offset are in ascending local-row order (deterministic).
-template <int T> // rows per tile = threads per workgroup (128 or 256)
-__global__ __launch_bounds__(T) void k_build_tileT(const int32_t *__restrict__ table, int64_t V, int vol,
-                                                    int32_t *__restrict__ words) {
-  constexpr int kT = T;
-  constexpr int NWV = T / 64;
-  __shared__ int s_cnt[4][kMaxVol];
+// T = rows per tile (a multiple of 16, <= 128); the workgroup has ceil(T/64) waves
+__global__ __launch_bounds__(128) void k_build_tileT(const int32_t *__restrict__ table, int64_t V, int vol, int T,
+                                                      int32_t *__restrict__ words) {
+  const int kT = T;
+  const int NWV = (T + 63) / 64;
+  __shared__ int s_cnt[2][kMaxVol];
   __shared__ int s_base[kMaxVol + 1];
   __shared__ int s_tot[kMaxVol];
   __shared__ int s_first[kMaxVol];
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(T) void k_build_tileT(const int32_t *__restrict__ t
   int32_t *pre = words + tile * (vol + 1);
   int32_t *ent = words + ntiles * (vol + 1) + tile * (int64_t)maxb * 16;
   const int64_t row = tile * kT + threadIdx.x;
-  const bool valid = row < V;
+  const bool valid = (int)threadIdx.x < T && row < V;
   for (int k = 0; k < vol; ++k) {
     const int t = valid ? table[(int64_t)k * V + row] : -1;
     const unsigned long long m = __ballot(t >= 0);
@@ -103,20 +103,20 @@ __device__ inline float bcf_(unsigned int v) { return __builtin_bit_cast(float, 
 // vector-memory path carries the 8 KiB of gathered rows ONCE (64-row-tile kernels: 8 KiB + 32 KiB of weights), the
 // weights cost 8 KiB per wave per OFFSET (registers), and every wave issues the same MFMAs.
 // One barrier per block pair (~2 x 1024 MFMA cycles per wave); 64 KiB LDS => two workgroups per CU.
-constexpr int kT2 = 128;
+constexpr int kMaxTileRows = 128;
 
 template <int KG, int DBG>
 __global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
-                                                    const float *__restrict__ bias) {
+                                                    const float *__restrict__ bias, int kT2) {
   constexpr int RG = KG * 8;               // 16-byte granules per staged row
   constexpr int RF = KG * 32;              // floats per staged row
   constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
   constexpr int STAGE = 2 * 16 * RF;       // floats per stage buffer (two blocks)
   extern __shared__ __align__(16) float smem[];
-  float *Ct = smem;                        // [128 + 1][64] floats, granule-swizzled; row 128 swallows padding entries
+  float *Ct = smem;                        // [kT2 + 1][64] floats, granule-swizzled; the last row swallows padding entries
   float *St = smem + (kT2 + 1) * kWS;      // [2][2][16][RF]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
@@ -130,8 +130,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in
   {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 *c4 = reinterpret_cast<f32x4 *>(Ct);
-#pragma unroll
-    for (int i = 0; i < (kT2 * kWS / 4) / 256; ++i) c4[i * 256 + threadIdx.x] = z;
+    for (int i = threadIdx.x; i < (kT2 + 1) * kWS / 4; i += 256) c4[i] = z;
   }
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
@@ -324,11 +323,12 @@ extern "C" int64_t aabr_wide_blocks_words(int64_t V, int vol, int tile_rows) { r
 extern "C" int aabr_build_wide_blocks(const int32_t *table, int64_t V, int vol, int tile_rows, int32_t *blocks,
                                       void *stream_) {
   AABR_CHECK_ARG(V >= 0 && vol > 0 && vol <= kMaxVol, "bad sizes (vol <= 63)");
-  AABR_CHECK_ARG(tile_rows == 128, "tile_rows must be 128");
+  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 128");
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(table && blocks, "null pointer");
   const unsigned nt = (unsigned)((V + tile_rows - 1) / tile_rows);
-  hipLaunchKernelGGL(k_build_tileT<128>, dim3(nt), dim3(128), 0, (hipStream_t)stream_, table, V, vol, blocks);
+  hipLaunchKernelGGL(k_build_tileT, dim3(nt), dim3(64 * ((tile_rows + 63) / 64)), 0, (hipStream_t)stream_, table, V, vol,
+                     tile_rows, blocks);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -337,7 +337,21 @@ extern "C" int aabr_build_wide_blocks(const int32_t *table, int64_t V, int vol, 
 extern "C" int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
   if (n_in <= 0 || n_out <= 0 || (n_in & 31) || (n_out & 63) || vol <= 0 || vol > kMaxVol) return 0;
   if (rows_in >= (1ll << 23) || rows_in * n_in * 4 >= (1ll << 31)) return 0;
-  const int T = 128;
+  // rows per tile: 128, except when the whole launch fits the chip in ONE round (512 resident workgroups, 2 per
+  // CU): then its time is the longest workgroup, so take the smallest tile (>= 64 rows) that still fits one round
+  // (measured, profiles/r02_conv_wide_ab.txt: 22k rows x 2 slabs, 128 -> 96 rows: 184 -> 133 us; with several rounds
+  // smaller tiles only lower the block fill: 84k rows 385 -> 400 us)
+  int T = 128;
+  {
+    const int64_t slabs = n_out / 64;
+    if (((V_out + 127) / 128) * slabs <= 512)
+      for (int t = 64; t < 128; t += 16)
+        if (((V_out + t - 1) / t) * slabs <= 512) { T = t; break; }
+  }
+  if (const char *ov = getenv("AABR_WIDE_ROWS")) { // tuning experiments only
+    const int v = atoi(ov);
+    if (v >= 16 && v <= 128 && (v & 15) == 0) T = v;
+  }
   if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
   if ((int64_t)vol * n_in * n_out * 4 >= (1ll << 31)) return 0;
   if (n_in > 128 && (n_in & 127)) return 0; // channel groups of 128: every load of the inner loop unconditional
@@ -356,7 +370,7 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 31) == 0 && (n_out & 63) == 0, "plane counts: n_in % 32, n_out % 64");
   AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
-  AABR_CHECK_ARG(tile_rows == 128, "tile_rows must be 128");
+  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 128");
   if (V_out == 0) return AABR_OK;
   AABR_CHECK_ARG(in_feats && out_feats && blocks && wpack && rows_in > 0, "null pointer / empty input");
   AABR_CHECK_ARG(rows_in < (1ll << 23), "too many input rows for the wide block format");
@@ -376,7 +390,7 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
   do {                                                                                                    \
     static bool attr = false;                                                                             \
     if (!attr) {                                                                                          \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS))); \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
       attr = true;                                                                                        \
     }                                                                                                     \
     g_last_variant = NAME;                                                                                \
@@ -385,8 +399,8 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
   {
 #define AABR_WIDE_CS(KG, D)                                                                               \
   AABR_LAUNCH_WIDE((k_conv_cs<KG, D>), "k_conv_cs<" #KG "," #D ">",                                       \
-                   (size_t)((kT2 + 1) * kWS + 2 * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes, out_feats, \
-                   n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias)
+                   (size_t)((tile_rows + 1) * kWS + 2 * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes,    \
+                   out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows)
     if (dbg & 3) { // timing experiments (tools/): only the 128-channel-group instance carries the debug variants
       AABR_CHECK_ARG(kg == 4, "debug variants exist for n_in >= 128 only");
       if ((dbg & 3) == 1) AABR_WIDE_CS(4, 1); else if ((dbg & 3) == 2) AABR_WIDE_CS(4, 2); else AABR_WIDE_CS(4, 3);

@@ -233,6 +233,7 @@ def conv_kernel_table(torch, wl, dtype):
                 conv = lib.aabr_conv_forward
             tile_rows = 0 if bf else lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, ga.rows, ga.vol)
             if tile_rows:   # the same dispatch as sparseconvnet.SCN._conv_fwd
+                g["grid_threads"] = ((ga.rows + tile_rows - 1) // tile_rows) * (n_out // 64) * 256
                 blocks = ga.blocks_wide(tile_rows)
                 check(lib.aabr_conv_pack_weights(ptr(w), ga.vol, w.size(2), w.size(3), tr_, ptr(wpack), stream()))
 
@@ -266,27 +267,27 @@ def conv_kernel_table(torch, wl, dtype):
         rows.append(dict(kind=g["kind"], kernel=variant, n_in=n_in, n_out=n_out, vol=ga.vol, rows_out=int(ga.rows),
                          rules=int(R), calls_per_step=g["calls"], launch_us=round(sec * 1e6, 2),
                          step_us=round(sec * 1e6 * g["calls"], 1), tflops=round(flops / sec / 1e12, 2),
-                         flops_per_launch=flops))
+                         flops_per_launch=flops, grid_threads=g.get("grid_threads", 0)))
         del inp
     rows.sort(key=lambda r: -r["step_us"])
     return rows
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes of THIS command (profiles/, separate
-    --pmc runs; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note of MI355X_MICROARCH.md).  Returns (bytes, source)
-    or (None, reason) -- never a number for a different kernel."""
+def pmc_traffic(kernel_name, grid_threads):
+    """HBM bytes per launch of the (kernel, grid size) instance from the committed PMC passes of THIS command
+    (profiles/, separate --pmc runs, tools/tools_pmc.sh; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note of
+    MI355X_MICROARCH.md).  Returns (bytes, source) or (None, reason) -- never a number for a different kernel."""
     path = os.path.join(REPO, "profiles", "r02_pmc_fetch_write_per_kernel.json")
     try:
         pm = json.load(open(path))["kernels"]
     except Exception:
         return None, "no committed PMC profile for this round"
-    base = kernel_name.replace(" ", "")
-    for kname, v in pm.items():
-        if kname.replace(" ", "").startswith(base.split("(")[0]):
-            return int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024), \
-                "committed profile profiles/r02_pmc_fetch_write_per_kernel.json (average over that kernel's launches)"
-    return None, "kernel not in the committed PMC profile (dispatch changed since it was taken)"
+    key = "%s|grid=%d" % (kernel_name.replace(" ", ""), grid_threads)
+    v = pm.get(key)
+    if v is None:
+        return None, "instance %s not in the committed PMC profile (dispatch or workload changed since it was taken)" % key
+    return int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024), \
+        "committed profile profiles/r02_pmc_fetch_write_per_kernel.json, entry %s (%d launches)" % (key, v["launches"])
 
 
 def cpu_baseline(wl, torch, budget_s=25.0):
@@ -471,7 +472,7 @@ def main():
             table = conv_kernel_table(torch, wl, head_dtype)
             top = table[0]
             peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" and "bf16" in top["kernel"] else PEAK_FP32_MFMA_TFLOPS
-            traffic, src = pmc_traffic(top["kernel"])
+            traffic, src = pmc_traffic(top["kernel"], top["grid_threads"])
             line["roofline"] = dict(
                 kernel="%s (%s %d->%d, vol %d, %d output rows, %d rules; %d launches per step = %.0f us of the %.0f us step)"
                        % (top["kernel"], top["kind"], top["n_in"], top["n_out"], top["vol"], top["rows_out"], top["rules"],
@@ -480,7 +481,8 @@ def main():
                 traffic=traffic, traffic_source=src, launch_us=top["launch_us"],
                 algorithmic_flops_per_launch=top["flops_per_launch"],
                 kernel_source="aabr_conv_last_variant() of the timed launch")
-            line["conv_kernels"] = [{k: v for k, v in r.items() if k != "flops_per_launch"} for r in table[:8]]
+            line["conv_kernels"] = [{k: v for k, v in r.items() if k not in ("flops_per_launch", "grid_threads")}
+                                    for r in table[:8]]
             line["conv_step_us_total"] = round(sum(r["step_us"] for r in table), 1)
             # voxel scatter (A1+A2): N*(32 + 4*C_in) + V*(4*C_in + 16) algorithmic bytes
             locs, feats = wl.batches[0]
