@@ -214,29 +214,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // __syncthreads() it does not drain the prefetches
   };
   int par = 0;
+  long long dbg_t[5] = {0, 0, 0, 0, 0};
   for (int kg = 0; kg < ngroups; ++kg) {
     Pos p0;
     p0.k = next_offset(-1);
     if (p0.k >= vol) break;
     p0.b = pre_of(p0.k);
-    Pos p1 = adv(p0), p2 = adv(p1);
-    Ent e0 = load_ent(p0.b, p0.k), e2 = e0;
-    Ent e1 = load_ent(p1.k < vol ? p1.b : p0.b, p1.k < vol ? p1.k : p0.k);
-    GReg gq;
-    gather(gq, e0.eg, kg);
+    Pos p1 = adv(p0), p2 = adv(p1), p3 = adv(p2);
+    auto ent_of = [&](const Pos &q) { const bool v = q.k < vol; return load_ent(v ? q.b : p0.b, v ? q.k : p0.k); };
+    Ent e0 = ent_of(p0), e1 = ent_of(p1), e2 = ent_of(p2), e3 = e0;
+    // gathered rows travel TWO pairs ahead of the MFMAs (a random-row gather takes ~2 us, one pair's MFMAs ~1 us):
+    // two register sets, used alternately by the two copies (PAR) of the step body
+    GReg gqA, gqB;
+    gather(gqA, e0.eg, kg);
     __syncthreads();                       // zero fill done / previous group's stage reads done
-    stage_store(gq, par);
+    par = 0;                               // (the register-set roles below are tied to the stage parity)
+    stage_store(gqA, par);
+    gather(gqB, e1.eg, kg);                // pair p1: stored at the end of the first step
     __syncthreads();
     // one pipeline step: pair p0 with the weight registers `w` (passed by reference: the two weight sets are
-    // used from fixed registers by two copies of this body -- no register shuffling at an offset change)
-    auto step = [&](const WReg &w) __attribute__((always_inline)) {
+    // used from fixed registers by separate copies of this body -- no register shuffling at an offset change)
+    auto step = [&](const WReg &w, GReg &g_issue, GReg &g_store) __attribute__((always_inline)) {
+      long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+      if (DBG & 4) t0 = __builtin_amdgcn_s_memtime();
       // unconditional: past the tile's last pair the loads repeat a valid pair and their results are dropped
-      gather(gq, e1.eg, kg);                                 // entry loaded an iteration ago: no wait
-      {
-        const bool v2 = p2.k < vol;
-        e2 = load_ent(v2 ? p2.b : p0.b, v2 ? p2.k : p0.k);
-      }
+      gather(g_issue, e2.eg, kg);                            // pair p2; its entry was loaded an iteration ago
+      e3 = ent_of(p3);
       __builtin_amdgcn_sched_barrier(0);                     // the prefetches are issued HERE, ahead of the MFMAs
+      if (DBG & 4) { t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 
       {
         const float *sa = St + par * STAGE + c16 * RF;
@@ -272,13 +277,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in
             }
           }
         }
+        if (DBG & 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(accA), "v"(accB)); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         accumulate2(e0.ea, accA, e0.eb, accB);
       }
-      if (p1.k < vol) stage_store(gq, par ^ 1);
+      if (p1.k < vol) stage_store(g_store, par ^ 1);         // pair p1, gathered during the previous step
+      if (DBG & 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); }
       wg_barrier();
+      if (DBG & 4) {
+        t4 = __builtin_amdgcn_s_memtime();
+        dbg_t[0] += t1 - t0; dbg_t[1] += t2 - t1; dbg_t[2] += t3 - t2; dbg_t[3] += t4 - t3; dbg_t[4] += 1;
+      }
       par ^= 1;
-      p0 = p1; p1 = p2; p2 = adv(p2);
-      e0 = e1; e1 = e2;
+      p0 = p1; p1 = p2; p2 = p3; p3 = adv(p3);
+      e0 = e1; e1 = e2; e2 = e3;
+    };
+    // stage parity 0: issue into gqA, store gqB; parity 1: the other way round
+    auto step2 = [&](const WReg &w) __attribute__((always_inline)) {
+      if (par == 0) step(w, gqA, gqB);
+      else step(w, gqB, gqA);
     };
     WReg wA, wB;
     int k = p0.k;
@@ -286,15 +302,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in
     for (;;) {
       int kn = next_offset(k);
       if (kn < vol) load_w(wB, kn, kg);                      // next offset's weights in flight during this offset
-      while (p0.k == k) step(wA);
+      while (p0.k == k) step2(wA);
       if (kn >= vol) break;
       k = kn;
       kn = next_offset(k);
       if (kn < vol) load_w(wA, kn, kg);
-      while (p0.k == k) step(wB);
+      while (p0.k == k) step2(wB);
       if (kn >= vol) break;
       k = kn;
     }
+  }
+  if (DBG & 4) { // timing experiments: per-wave phase clocks -> the buffer passed as `bias` (which is then not added)
+    if (lane == 0) {
+      long long *d = reinterpret_cast<long long *>(const_cast<float *>(bias)) +
+                     (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 5;
+      for (int q = 0; q < 5; ++q) d[q] = dbg_t[q];
+    }
+    bias = nullptr;
   }
   __syncthreads();
   const int nrows = (int)((V_out - row0) < kT2 ? (V_out - row0) : kT2);
@@ -394,6 +418,11 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
       attr = true;                                                                                        \
     }                                                                                                     \
     g_last_variant = NAME;                                                                                \
+    if (getenv("AABR_WIDE_OCC")) { /* tuning experiments only */                                          \
+      int nb_ = 0;                                                                                        \
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (const void *)KERNEL, 256, (LDS));               \
+      fprintf(stderr, "%s: %d workgroups per CU at %zu B LDS\n", NAME, nb_, (size_t)(LDS));               \
+    }                                                                                                     \
     hipLaunchKernelGGL(KERNEL, grid, dim3(256), (LDS), st, __VA_ARGS__);                                  \
   } while (0)
   {
@@ -401,9 +430,10 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
   AABR_LAUNCH_WIDE((k_conv_cs<KG, D>), "k_conv_cs<" #KG "," #D ">",                                       \
                    (size_t)((tile_rows + 1) * kWS + 2 * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes,    \
                    out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows)
-    if (dbg & 3) { // timing experiments (tools/): only the 128-channel-group instance carries the debug variants
+    if (dbg & 7) { // timing experiments (tools/): only the 128-channel-group instance carries the debug variants
       AABR_CHECK_ARG(kg == 4, "debug variants exist for n_in >= 128 only");
-      if ((dbg & 3) == 1) AABR_WIDE_CS(4, 1); else if ((dbg & 3) == 2) AABR_WIDE_CS(4, 2); else AABR_WIDE_CS(4, 3);
+      if (dbg & 4) AABR_WIDE_CS(4, 4);
+      else if ((dbg & 3) == 1) AABR_WIDE_CS(4, 1); else if ((dbg & 3) == 2) AABR_WIDE_CS(4, 2); else AABR_WIDE_CS(4, 3);
     } else {
       if (kg == 1) AABR_WIDE_CS(1, 0); else if (kg == 2) AABR_WIDE_CS(2, 0); else if (kg == 3) AABR_WIDE_CS(3, 0);
       else AABR_WIDE_CS(4, 0);
