@@ -7,7 +7,7 @@
 //
 //   fill      keys | first | vals | meta  <- 0xFF                            (one memset; meta counts up from -1)
 //   K1 k_voxel_insert : point i -> hash slot (one 64-bit CAS) ; first[slot] = min point index (one atomicMin)
-//   K2 k_voxel_number : ONE pass over the points in chunks of 4096: flag "I am my voxel's first point",
+//   K2 k_voxel_number : ONE pass over the points in chunks of 1024: flag "I am my voxel's first point",
 //                       chunk scan in LDS, decoupled look-back across chunks (wave-parallel, 64 predecessors per
 //                       probe) => first-seen site number, exactly the reference's order, with no serial pass and
 //                       no second launch; first points write vals[slot], the site's coordinates and first_pt;
@@ -25,14 +25,15 @@
 // (histogram + scan + stable scatter of 44-byte records) costs more passes over the points than the whole of the
 // above.  LDS is used where it pays: the chunk scan / look-back of K2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace aabr {
 
 constexpr int kVsThreads = 256;
-// points per K2 workgroup = 256 x ITEMS.  All chunks are resident at once on this chip, so a chunk walks back to
-// chunk 0 (chunk/64 probes): few chunks => short look-back (ITEMS = 16 above 256k points), but small scenes want
-// many workgroups (ITEMS = 4: 79 workgroups for 80k points instead of 20).
-static inline int vs_items(int64_t n) { return n > (1 << 18) ? 16 : 4; }
+// points per K2 workgroup = 256 x 4.  All chunks are resident at once on this chip, so a chunk walks back to chunk 0
+// (chunk/64 probes of relaxed polls); measured 80k .. 1.5 M points, 1024-point chunks beat 4096-point ones at every
+// size (more workgroups for the dependent first[slot] reads; the look-back is not the cost).
+static inline int vs_items(int64_t) { return 4; }
 constexpr int kMetaTicket = 4;                  // meta word used as the chunk ticket counter
 
 __global__ __launch_bounds__(256) void k_voxel_insert(const int64_t *__restrict__ coords, int64_t n, int ncols,
@@ -426,14 +427,9 @@ extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncol
   // K1 also clears the chunk status words and the per-site chain heads / counts (consumed by K2 only)
   hipLaunchKernelGGL(k_voxel_insert, grid1(n > nchunks ? n : nchunks, 256), dim3(256), 0, st, coords, n, ncols, keys,
                      (uint64_t)(cap - 1), first, slot, cnt_extra, head, (unsigned long long *)status, nchunks, meta);
-  if (items == 4)
-    hipLaunchKernelGGL(k_voxel_number<4>, dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
-                       first, vals, site_coords, first_pt, point_site, cnt_extra, head, nxt,
-                       (unsigned long long *)status, meta);
-  else
-    hipLaunchKernelGGL(k_voxel_number<16>, dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
-                       first, vals, site_coords, first_pt, point_site, cnt_extra, head, nxt,
-                       (unsigned long long *)status, meta);
+  hipLaunchKernelGGL(k_voxel_number<4>, dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
+                     first, vals, site_coords, first_pt, point_site, cnt_extra, head, nxt,
+                     (unsigned long long *)status, meta);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

@@ -7,7 +7,7 @@ import torch
 import sparseconvnet as scn
 import synth_scenes as S
 dev = "cuda:0"
-for npts, vs, ext in ((80000, 20, (16.0, 12.0, 2.7)), (1500000, 50, (16.0, 12.0, 2.7)), (1500000, 50, (40.0, 30.0, 2.7))):
+for npts, vs, ext in ((80000, 20, (16.0, 12.0, 2.7)), (320000, 50, (32.0, 24.0, 2.7)), (600000, 50, (32.0, 24.0, 2.7)), (1000000, 50, (40.0, 30.0, 2.7)), (1500000, 50, (16.0, 12.0, 2.7)), (1500000, 50, (40.0, 30.0, 2.7))):
     locs, feats = S.make_batch(1, npts, 0, vs, ext)
     l, f = torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)
     layer = scn.InputLayer(3, list(S.FULL_SCALE), mode=4)
