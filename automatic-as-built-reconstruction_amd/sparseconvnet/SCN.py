@@ -289,6 +289,8 @@ class Metadata_3(object):
         return self.getSpatialLocationsDevice(spatial_size).cpu()
 
     def getSpatialLocationsDevice(self, spatial_size):
+        if getattr(self, "_inb", None) is not None:
+            self._materialise_input(torch.device("cuda", torch.cuda.current_device()))
         g = self.grids[_key(spatial_size)]
         loc = torch.empty((g.V, 4), dtype=torch.int64, device=g.coords.device)
         check(_hip.load().aabr_spatial_locations(ptr(g.coords), g.V, ptr(loc), stream()))
@@ -307,10 +309,77 @@ class Metadata_3(object):
         return ts
 
     def getNActive(self, spatial_size):
+        if getattr(self, "_inb", None) is not None and _key(spatial_size) == self.input_spatial:
+            return len(self._inb["locs"])
         return self.grids[_key(spatial_size)].V
 
     def setInputSpatialSize(self, spatial_size):
+        """Metadata::setInputSpatialSize (Metadata.cpp:76-80)"""
         self.input_spatial = _key(spatial_size)
+
+    # ---- incremental input construction (pybind.cpp:15-19; Metadata.cpp:81-145, 30-44) --------------------------
+    # The reference fills the caller's `features` tensor on the HOST, one location at a time: a location not seen
+    # before in the sample appends a row (first-seen numbering across all calls), a repeated one overwrites its row
+    # or is ignored.  Same here, in Python (this is host bookkeeping in the reference too); the DEVICE grid of the
+    # collected sites is built at the first geometry query (`_materialise_input`) through the voxel-scatter kernels.
+    def batchAddSample(self):
+        assert getattr(self, "input_spatial", None) is not None, "Call setInputSpatialSize first, please!"
+        b = self.__dict__.setdefault("_inb", dict(rows={}, locs=[], nsamples=0))
+        b["nsamples"] += 1
+
+    def _add_point(self, features, key, vec, overwrite, rows_out):
+        b = self._inb
+        r = b["rows"].get(key)
+        if r is None:
+            b["rows"][key] = len(b["locs"])
+            b["locs"].append(key)
+            rows_out.append((len(b["locs"]) - 1, vec))
+        elif overwrite:
+            rows_out.append((r, vec))
+
+    def _flush_rows(self, features, planes, rows):
+        n = len(self._inb["locs"])
+        old = features.clone() if features.numel() else None
+        features.resize_(n, planes)
+        if old is not None:
+            features[: old.shape[0]] = old
+        for r, vec in rows:
+            features[r] = vec
+
+    def setInputSpatialLocation(self, features, location, vec, overwrite):
+        assert getattr(self, "_inb", None) and self._inb["nsamples"] > 0, "call batchAddSample first"
+        rows = []
+        key = (self._inb["nsamples"] - 1,) + tuple(int(v) for v in location.tolist())
+        self._add_point(features, key, vec, overwrite, rows)
+        self._flush_rows(features, int(vec.shape[0]), rows)
+
+    def setInputSpatialLocations(self, features, locations, vecs, overwrite):
+        assert getattr(self, "input_spatial", None) is not None, "Call setInputSpatialSize first, please!"
+        b = self.__dict__.setdefault("_inb", dict(rows={}, locs=[], nsamples=0))
+        L = locations.tolist()
+        rows = []
+        for i, loc in enumerate(L):
+            if len(loc) == self.dimension:
+                assert b["nsamples"] > 0, "call batchAddSample first"
+                key = (b["nsamples"] - 1,) + tuple(int(v) for v in loc)
+            else:                                       # 4th column = sample index; grows the batch as needed
+                key = (int(loc[-1]),) + tuple(int(v) for v in loc[:-1])
+                b["nsamples"] = max(b["nsamples"], key[0] + 1)
+            self._add_point(features, key, vecs[i], overwrite, rows)
+        self._flush_rows(features, int(vecs.shape[1]), rows)
+
+    def _materialise_input(self, device):
+        """device grid of the incrementally collected sites (unique by construction, sample-major like the
+        reference's per-sample grids with their `ctr` offsets)"""
+        b = self.__dict__.pop("_inb", None)
+        if b is None or self.input is not None:
+            return
+        order = sorted(range(len(b["locs"])), key=lambda i: (b["locs"][i][0], i))   # samples contiguous, first-seen inside
+        if order != list(range(len(order))):
+            raise _hip.AabrError("incremental input: add the samples one after the other (rows of a sample must be "
+                                 "contiguous, as Metadata::getSpatialLocations' ctr offsets assume)")
+        coords = torch.tensor([list(k[1:]) + [k[0]] for k in b["locs"]], dtype=torch.int64).reshape(-1, 4)
+        self.inputLayer(torch.LongTensor(list(self.input_spatial)), coords, b["nsamples"], 3, device)
 
     # ---- builders ---------------------------------------------------------------------------
     def inputLayer(self, spatial_size, coords, batch_size, mode, device):
@@ -399,6 +468,8 @@ class Metadata_3(object):
         k = _key(spatial_size) + _key(filter_size)
         tb = self.submanifold.get(k)
         if tb is None:
+            if getattr(self, "_inb", None) is not None:
+                self._materialise_input(torch.device("cuda", torch.cuda.current_device()))
             g = self.grids[_key(spatial_size)]
             fs = _key(filter_size)
             vol = fs[0] * fs[1] * fs[2]
@@ -422,6 +493,8 @@ class Metadata_3(object):
         tb = self.rulebooks.get(k)
         if tb is None:
             lib = _hip.load()
+            if getattr(self, "_inb", None) is not None:
+                self._materialise_input(torch.device("cuda", torch.cuda.current_device()))
             gi = self.grids[_key(in_spatial)]
             fs, st, osz = _key(filter_size), _key(filter_stride), _key(out_spatial)
             dev = gi.keys.device
@@ -546,6 +619,31 @@ def InputLayer_updateGradInput(metadata, d_input_features, d_output_features):
     check(_hip.load().aabr_input_layer_backward(ptr(d_input_features), ptr(d_out), il["n"], planes,
                                                 ptr(il["point_site"]), ptr(il["first_pt"]), ptr(il["last_pt"]),
                                                 ptr(il["cnt_extra"]), il["mode"], stream()))
+
+
+# OutputLayer (pybind.cpp:163-170; SCN/CPU/IOLayers.cpp:95-134): the InputLayer run backwards without averaging --
+# every point listed in the input rule table receives its site's row (cpu_OutputLayer_updateOutput calls
+# InputLayer_BackwardPass(..., average=false)); its gradient is InputLayer_ForwardPass(..., average=false).
+def OutputLayer_updateOutput(metadata, input_features, output_features):
+    inp = _f32c(input_features, "input_features")
+    il = metadata.input
+    planes = inp.size(1)
+    mode = 3 if il["mode"] == 4 else il["mode"]
+    output_features.resize_(il["n"], planes)
+    check(_hip.load().aabr_input_layer_backward(ptr(output_features), ptr(inp), il["n"], planes,
+                                                ptr(il["point_site"]), ptr(il["first_pt"]), ptr(il["last_pt"]),
+                                                ptr(il["cnt_extra"]), mode, stream()))
+
+
+def OutputLayer_updateGradInput(metadata, d_input_features, d_output_features):
+    d_out = _f32c(d_output_features, "d_output_features")
+    il = metadata.input
+    planes = d_out.size(1)
+    mode = 3 if il["mode"] == 4 else il["mode"]
+    d_input_features.resize_(il["V"], planes)
+    check(_hip.load().aabr_input_layer_forward(ptr(d_out), ptr(d_input_features), il["V"], planes, ptr(il["first_pt"]),
+                                               ptr(il["cnt_extra"]), ptr(il["head"]), ptr(il["nxt"]), None, mode,
+                                               ptr(il["meta"]), stream()))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ from .batchNormalization import BatchNormalization, BatchNormReLU, BatchNormLeak
 from .convolution import Convolution  # noqa: E402
 from .deconvolution import Deconvolution  # noqa: E402
 from .identity import Identity  # noqa: E402
-from .ioLayers import InputLayer  # noqa: E402
+from .ioLayers import InputLayer, OutputLayer  # noqa: E402
 from .metadata import Metadata  # noqa: E402
 from .networkInNetwork import NetworkInNetwork  # noqa: E402
 from .sequential import Sequential  # noqa: E402

@@ -47,8 +47,8 @@ class FPN_Net(torch.nn.Module):
             scn.InputLayer(dimension, full_scale, mode=4),
             scn.SubmanifoldConvolution(dimension, in_channels, nPlanesF[0], 3, False))
         # the reference also owns layers_out (BatchNormReLU + OutputLayer) and a 20-way linear
-        # head it never calls in forward (fpn_net.py:46-50); kept by name, minus OutputLayer
-        self.layers_out = scn.Sequential(scn.BatchNormReLU(nPlanesF[0], **bn))
+        # head it never calls in forward (fpn_net.py:46-50); kept by name
+        self.layers_out = scn.Sequential(scn.BatchNormReLU(nPlanesF[0], **bn), scn.OutputLayer(dimension))
         self.linear = nn.Linear(nPlanesF[0], 20)
         self.voxel_scale = voxel_scale
         self.rpn_map_sizes = np.array(rpn_map_sizes)

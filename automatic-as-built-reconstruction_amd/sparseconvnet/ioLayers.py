@@ -70,6 +70,34 @@ class InputLayer(Module):
         return output
 
 
+class OutputLayer(Module):
+    """Used with an InputLayer for 'autoencoder' style networks: SparseConvNetTensor -> float tensor [N, planes],
+    N defined by the InputLayer (reference: ioLayers.py:66-87)."""
+
+    def __init__(self, dimension):
+        Module.__init__(self)
+        self.dimension = dimension
+
+    def forward(self, input):
+        return OutputLayerFunction.apply(self.dimension, input.metadata, input.features)
+
+
+class OutputLayerFunction(Function):
+    @staticmethod
+    def forward(ctx, dimension, metadata, input_features):
+        output_features = input_features.new()
+        ctx.metadata_ = metadata
+        ctx.dimension = dimension
+        SCN.OutputLayer_updateOutput(metadata, input_features.contiguous(), output_features)
+        return output_features
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        grad_input = grad_output.new()
+        SCN.OutputLayer_updateGradInput(ctx.metadata_, grad_input, grad_output.contiguous())
+        return None, None, grad_input
+
+
 class InputLayerFunction(Function):
     @staticmethod
     def forward(ctx, dimension, metadata, spatial_size, coords, input_features, batch_size, mode):

@@ -194,3 +194,27 @@ def test_cat_scales_obj_reg_regroups_example_major():
             want_o.append(obj[s].reshape(-1, 1)[a:e])
             want_r.append(reg[s].reshape(-1, 7)[a:e])
     assert torch.equal(o, torch.cat(want_o)) and torch.equal(r, torch.cat(want_r))
+
+
+def test_metadata_incremental_input_is_host_bookkeeping_like_the_reference():
+    """Metadata.batchAddSample / setInputSpatialLocation(s) (pybind.cpp:15-19; Metadata.cpp:30-44,81-145): a new
+    location appends a feature row (first-seen numbering), a repeated one overwrites or is ignored; nothing touches
+    the GPU until a geometry query."""
+    import sparseconvnet as scn
+    md = scn.Metadata(3)
+    md.setInputSpatialSize(torch.LongTensor([8, 8, 8]))
+    feats = torch.FloatTensor()
+    md.batchAddSample()
+    md.setInputSpatialLocation(feats, torch.LongTensor([1, 2, 3]), torch.FloatTensor([1, 10]), False)
+    md.setInputSpatialLocation(feats, torch.LongTensor([4, 4, 4]), torch.FloatTensor([2, 20]), False)
+    md.setInputSpatialLocation(feats, torch.LongTensor([1, 2, 3]), torch.FloatTensor([3, 30]), False)   # ignored
+    assert feats.tolist() == [[1, 10], [2, 20]]
+    md.setInputSpatialLocation(feats, torch.LongTensor([1, 2, 3]), torch.FloatTensor([4, 40]), True)    # overwritten
+    assert feats.tolist() == [[4, 40], [2, 20]]
+    md.batchAddSample()
+    md.setInputSpatialLocations(feats, torch.LongTensor([[1, 2, 3], [0, 0, 0], [1, 2, 3]]),
+                                torch.FloatTensor([[5, 50], [6, 60], [7, 70]]), True)
+    assert feats.tolist() == [[4, 40], [2, 20], [7, 70], [6, 60]]       # same location, other sample: new row
+    assert md.getNActive(torch.LongTensor([8, 8, 8])) == 4
+    md.setInputSpatialLocations(feats, torch.LongTensor([[7, 7, 7, 2]]), torch.FloatTensor([[8, 80]]), False)
+    assert feats.shape == (5, 2) and md._inb["nsamples"] == 3

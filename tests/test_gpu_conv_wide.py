@@ -1,0 +1,133 @@
+"""The wide-layer convolution kernel (csrc/conv_wide.hip, k_conv_cs) against the oracle.  The library's own
+dispatch only picks it for launches of >= 320 workgroups; here AABR_CONV_WIDE=1 (a tuning knob the library reads
+on every call) forces it for every supported shape, so tile edges, single-tile rule books, odd pair counts, bias,
+strided / transposed tables and several channel groups are all exercised at sizes the oracle finishes in seconds.
+One case runs at a size where the default dispatch takes the wide path by itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scn():
+    import sparseconvnet as scn
+    return scn
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture
+def force_wide():
+    old = os.environ.get("AABR_CONV_WIDE")
+    os.environ["AABR_CONV_WIDE"] = "1"
+    yield
+    if old is None:
+        del os.environ["AABR_CONV_WIDE"]
+    else:
+        os.environ["AABR_CONV_WIDE"] = old
+
+
+def _scene(rng, n, size, batch, C):
+    coords = np.stack([rng.integers(0, s, n) for s in size] + [np.sort(rng.integers(0, batch, n))], 1)
+    return coords.astype(np.int64), rng.standard_normal((n, C)).astype(np.float32)
+
+
+def _variant():
+    import _hip
+    return _hip.load().aabr_conv_last_variant().decode()
+
+
+@pytest.mark.parametrize("nIn,nOut,npts,bias", [(32, 64, 700, False), (64, 64, 3000, True), (96, 128, 2500, False),
+                                                (128, 128, 127, False), (128, 64, 129, True), (256, 192, 2000, False),
+                                                (384, 64, 900, False)])
+def test_wide_submanifold_forward_backward(force_wide, nIn, nOut, npts, bias):
+    scn = _scn()
+    rng = np.random.default_rng(nIn * 7 + nOut + npts)
+    coords, feats = _scene(rng, npts, (12, 11, 5), 2, nIn)
+    f = _t(feats).requires_grad_(True)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), f])
+    conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, bias).to(DEV)
+    if bias:
+        conv.bias.data.normal_()
+    y = conv(x)
+    assert _variant().startswith("k_conv_cs<"), _variant()
+    il = O.input_layer(coords, feats, 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    W = conv.weight.detach().cpu().numpy().reshape(27, nIn, nOut)
+    b = conv.bias.detach().cpu().numpy() if bias else None
+    ref, _ = O.conv_fwd(il["out"], W, rb, il["V"], b)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=2e-6 * np.abs(ref).max() * nIn)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(_t(g))
+    d_in, dW, db = O.conv_bwd(il["out"], g, W, rb, want_bias=bias)
+    d_feats = O.input_layer_bwd(il, d_in)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), d_feats, rtol=1e-4, atol=2e-6 * np.abs(d_feats).max() * nOut)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(27, nIn, nOut), dW, rtol=1e-4,
+                               atol=1e-5 * np.abs(dW).max())
+    # bit-reproducible: same launch, same bits
+    with torch.no_grad():
+        assert torch.equal(conv(x).features, conv(x).features)
+
+
+@pytest.mark.parametrize("fs,st,nIn,nOut", [([2, 2, 2], [2, 2, 2], 64, 128), ([1, 1, 8], [1, 1, 1], 128, 128),
+                                            ([3, 3, 3], [2, 2, 2], 32, 64)])
+def test_wide_strided_conv_and_deconv(force_wide, fs, st, nIn, nOut):
+    scn = _scn()
+    rng = np.random.default_rng(90 + nIn)
+    size = np.array([16, 16, 8]) if fs != [3, 3, 3] else np.array([17, 17, 9])
+    coords, feats = _scene(rng, 2500, tuple(size), 2, nIn)
+    f = _t(feats).requires_grad_(True)
+    x = scn.InputLayer(3, list(size), mode=4)([_t(coords), f])
+    conv = scn.Convolution(3, nIn, nOut, fs, st, False).to(DEV)
+    dec = scn.Deconvolution(3, nOut, nIn - nIn % 64 if nIn % 64 == 0 else 64, fs, st, False).to(DEV)
+    nBack = dec.weight.shape[3]
+    y = conv(x)
+    assert _variant().startswith("k_conv_cs<"), _variant()
+    z = dec(y)
+    assert _variant().startswith("k_conv_cs<"), _variant()
+    il = O.input_layer(coords, feats, 4)
+    osz = (size - np.array(fs)) // np.array(st) + 1
+    rb, oc = O.convolution_rules(il["coords"], fs, st, osz)
+    Wc = conv.weight.detach().cpu().numpy().reshape(rb.vol, nIn, nOut)
+    Wd = dec.weight.detach().cpu().numpy().reshape(rb.vol, nOut, nBack)
+    yr, _ = O.conv_fwd(il["out"], Wc, rb, oc.shape[0])
+    zr, _ = O.conv_fwd(yr, Wd, rb, il["V"], in_col=1)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), yr, rtol=1e-4, atol=1e-5 * np.abs(yr).max())
+    np.testing.assert_allclose(z.features.detach().cpu().numpy(), zr, rtol=1e-4, atol=1e-5 * np.abs(zr).max())
+    g = rng.standard_normal(zr.shape).astype(np.float32)
+    z.features.backward(_t(g))
+    d_y, dWd, _ = O.conv_bwd(yr, g, Wd, rb, in_col=1)
+    d_x, dWc, _ = O.conv_bwd(il["out"], d_y, Wc, rb)
+    np.testing.assert_allclose(dec.weight.grad.cpu().numpy().reshape(Wd.shape), dWd, rtol=1e-4,
+                               atol=1e-5 * np.abs(dWd).max())
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(Wc.shape), dWc, rtol=1e-4,
+                               atol=1e-5 * np.abs(dWc).max())
+    d_feats = O.input_layer_bwd(il, d_x)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), d_feats, rtol=1e-4, atol=1e-5 * np.abs(d_feats).max())
+
+
+def test_default_dispatch_takes_the_wide_kernel_on_a_large_layer():
+    """no env knob: 60k sites x 128 output planes = 940 workgroups -> the library picks k_conv_cs by itself"""
+    scn = _scn()
+    import synth_scenes as S
+    assert "AABR_CONV_WIDE" not in os.environ
+    locs, feats = S.make_batch(1, 80000, 3, 20)
+    rng = np.random.default_rng(1)
+    feats = rng.standard_normal((locs.shape[0], 64)).astype(np.float32)
+    x = scn.InputLayer(3, list(S.FULL_SCALE), mode=4)([_t(locs), _t(feats)])
+    conv = scn.SubmanifoldConvolution(3, 64, 128, 3, False).to(DEV)
+    with torch.no_grad():
+        y = conv(x)
+    assert _variant().startswith("k_conv_cs<2"), _variant()
+    il = O.input_layer(locs, feats, 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    ref, _ = O.conv_fwd(il["out"], conv.weight.detach().cpu().numpy().reshape(27, 64, 128), rb, il["V"])
+    np.testing.assert_allclose(y.features.cpu().numpy(), ref, rtol=1e-4, atol=2e-6 * np.abs(ref).max() * 64)

@@ -528,3 +528,38 @@ def test_input_layer_long_chains_and_chunk_boundaries(mode):
     g = rng.standard_normal(ref["out"].shape).astype(np.float32)
     x.features.backward(_t(g))
     np.testing.assert_array_equal(f.grad.cpu().numpy(), O.input_layer_bwd(ref, g))
+
+
+def test_output_layer_and_incremental_input_match_oracle():
+    """OutputLayer (pybind.cpp:163-170) = InputLayer backwards without averaging; Metadata.setInputSpatialLocations
+    builds the same grid as an InputLayer over the unique locations"""
+    scn = _scn()
+    rng = np.random.default_rng(77)
+    coords, feats = _rand_scene(rng, 4000, (12, 10, 6), 2, 6)
+    for mode in (1, 2, 3, 4):
+        f = _t(feats).requires_grad_(True)
+        x = scn.InputLayer(3, [16, 16, 8], mode=mode)([_t(coords), f])
+        out = scn.OutputLayer(3)(x)
+        il = O.input_layer(coords, feats, mode)
+        il_noavg = dict(il, mode=3 if mode == 4 else mode)
+        want = O.input_layer_bwd(il_noavg, il["out"])            # InputLayer_BackwardPass(average=false)
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), want)
+        g = rng.standard_normal(want.shape).astype(np.float32)
+        out.backward(_t(g))
+        # d features = InputLayer backward of (OutputLayer backward of g) = bwd(fwd_noavg(g))
+        d_sites = np.zeros_like(il["out"])
+        O.lib().oracle_input_layer_fwd(g, d_sites, il["V"], il["max_active"], g.shape[1], il["rules"], 0)
+        np.testing.assert_array_equal(f.grad.cpu().numpy(), O.input_layer_bwd(il, d_sites))
+    # incremental construction
+    md = scn.Metadata(3)
+    md.setInputSpatialSize(torch.LongTensor([16, 16, 8]))
+    hf = torch.FloatTensor()
+    md.setInputSpatialLocations(hf, torch.as_tensor(coords), torch.as_tensor(feats), False)   # keep first
+    il1 = O.input_layer(coords, feats, 1)
+    np.testing.assert_array_equal(hf.numpy(), il1["out"])
+    xin = scn.SparseConvNetTensor(hf.to(DEV), md, torch.LongTensor([16, 16, 8]))
+    conv = scn.SubmanifoldConvolution(3, 6, 8, 3, False).to(DEV)
+    y = conv(xin)
+    ref = scn.InputLayer(3, [16, 16, 8], mode=1)([_t(coords), _t(feats)])
+    torch.testing.assert_close(y.features, conv(ref).features, rtol=0, atol=0)
+    np.testing.assert_array_equal(xin.get_spatial_locations().numpy(), il1["coords"])
