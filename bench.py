@@ -146,8 +146,9 @@ class Workload(object):
             self.batches.append((torch.as_tensor(np.concatenate(L, 0)).to(dev),
                                  torch.as_tensor(np.concatenate(F, 0)).to(dev).requires_grad_(True)))
         self.last = None
+        self.side = torch.cuda.Stream(device=dev)
 
-    def forward_backward(self, i, proposals=True):
+    def forward_backward(self, i, proposals=True, after_backward=None):
         import rpn_glue
         torch = self.torch
         locs, feats = self.batches[i % len(self.batches)]
@@ -158,21 +159,37 @@ class Workload(object):
             objs.append(o)
             regs.append(r)
             loss = loss + o.square().mean() + r.square().mean()
+        # The proposal stage reads only forward results.  It is a chain of small launches (one-workgroup NMS scan,
+        # top-k, decode) with a few host reads of counts; enqueued on a side stream AFTER the backward pass has been
+        # enqueued on the main one, it runs on otherwise idle CUs underneath the backward kernels and its host
+        # reads wait for the side stream only.
+        ev_fwd = torch.cuda.Event()
+        ev_fwd.record()
         loss.backward()
         feats.grad = None
+        if after_backward is not None:
+            after_backward()      # N > 1: the gradient all-reduce starts here and runs under the proposal stage
         props = None
         if proposals:
-            with torch.no_grad():
+            main = torch.cuda.current_stream()
+            with torch.no_grad(), torch.cuda.stream(self.side):
+                self.side.wait_event(ev_fwd)
                 props = rpn_glue.rpn_proposals(rpn_maps, [o.detach() for o in objs], [r.detach() for r in regs],
                                                self.base, self.strides, float(VOXEL_SCALE), 2000, 1000, 0.5, (0.3, 0.3))
+            main.wait_stream(self.side)
         self.last = (rpn_maps, props)
         return loss
 
     def step(self, i):
         self.flat.zero_grad()
-        self.forward_backward(i)
-        self.flat.allreduce_mean(self.world)
-        self.flat.sgd_step(1e-5, self.world)
+        if self.world > 1:
+            # one flat all-reduce (RCCL over xGMI), launched asynchronously right after backward; the proposal stage
+            # (top-k, decode, NMS: no dependence on the gradients) runs while it is in flight; the update waits for it
+            self.forward_backward(i, after_backward=self.flat.start_allreduce)
+            self.flat.finish_update(1e-5, self.world)
+        else:
+            self.forward_backward(i)
+            self.flat.sgd_step(1e-5, 1)
 
 
 # ------------------------------------------------------------------------------------------------ measurement
