@@ -297,7 +297,7 @@ class Metadata_3(object):
         return loc
 
     def device_tensors(self):
-        """tensors owned by the input-layer state (for cross-stream hand-over)"""
+        """every device tensor this object owns (for cross-stream hand-over of geometry prepared ahead of time)"""
         ts = []
         pend = getattr(self, "_pending", None)
         if pend is not None:
@@ -306,6 +306,13 @@ class Metadata_3(object):
             ts += [g.coords, g.keys, g.vals]
         if self.input is not None:
             ts += [self.input["point_site"]]
+        for tb in list(self.submanifold.values()) + list(self.rulebooks.values()):
+            for ga in (tb.out, tb.inn):
+                if ga is None:
+                    continue
+                ts += [t for t in (ga.table, ga.counts, ga._blocks, ga._pairs) if t is not None]
+                if ga._blocks256:
+                    ts += list(ga._blocks256.values())
         return ts
 
     def getNActive(self, spatial_size):
@@ -716,6 +723,22 @@ def _conv_dw(inp, d_out, gather, d_weight, d_bias):
              ptr(d_weight), ptr(_opt(d_bias)), ptr(scratch), stream()))
     if trace is not None:
         trace.append(("dw", n_in, n_out, gather, inp.size(0), 0, inp.dtype))
+
+
+def compile_streams(gather, rows_in, n_in, n_out, dtype, weight_grad=False):
+    """Build, ahead of their first use, the block stream the forward-form launch (n_in -> n_out over `gather`) will
+    read -- the same choice `_conv_fwd` makes -- and, with `weight_grad`, the offset-pair lists of the dW kernel."""
+    if gather is None or gather.rows == 0:
+        return
+    tile_rows = 0
+    if dtype == torch.float32:
+        tile_rows = _hip.load().aabr_conv_wide_tile_rows(n_in, n_out, rows_in, gather.rows, gather.vol)
+    if tile_rows:
+        gather.blocks_wide(tile_rows)
+    else:
+        gather.blocks()
+    if weight_grad:
+        gather.pairs()
 
 
 def _macs(tb, weight):

@@ -137,8 +137,8 @@ class FPN_Net(torch.nn.Module):
         each would wait for all the convolutions queued before it and leave the GPU idle while the host catches up.
         Same rule books, same cache keys (Metadata caches by (spatial, filter[, stride])): the layers find them."""
         md = net.metadata
-        if getattr(md, "_fpn_prebuilt", False):
-            return
+        if getattr(md, "_fpn_prebuilt", None) is not None:
+            return md._fpn_prebuilt
         sz = net.spatial_size
         sizes = [sz]
         three, one = torch.LongTensor([3, 3, 3]), torch.LongTensor([1, 1, 1])
@@ -156,7 +156,68 @@ class FPN_Net(torch.nn.Module):
             msz = sizes[nscale - 1 - scale_from_top]
             ks = torch.LongTensor([1, 1, int(self.rpn_map_sizes[i][2])])
             md.getRuleBook(msz, (msz - ks) // one + 1, ks, one)
-        md._fpn_prebuilt = True
+        md._fpn_prebuilt = sizes
+        return sizes
+
+    def _compile_streams(self, md, sizes, in_channels):
+        """block streams / offset-pair lists of every convolution of the pass (forward, input-gradient and weight-
+        gradient launches), built now instead of at each layer's first use"""
+        from . import SCN
+        dt = self.feature_dtype
+        f32 = torch.float32
+        three, one = (3, 3, 3), (1, 1, 1)
+        nscale = len(self.m_downs)
+        key = lambda sz: tuple(int(v) for v in sz.tolist())
+
+        def subm(k, fs, ci, co, dtype):
+            tb = md.submanifold[key(sizes[k]) + fs]
+            SCN.compile_streams(tb.out, tb.V_in, ci, co, dtype, weight_grad=True)    # forward + dW
+            SCN.compile_streams(tb.out, tb.V_out, co, ci, dtype)                      # input gradient (mirrored)
+
+        def strided(tb, ci, co, dtype, transposed):
+            if not transposed:     # Convolution: fine -> coarse
+                SCN.compile_streams(tb.out, tb.V_in, ci, co, dtype, weight_grad=True)
+                SCN.compile_streams(tb.inn, tb.V_out, co, ci, dtype)
+            else:                  # Deconvolution over the same book: coarse -> fine
+                SCN.compile_streams(tb.inn, tb.V_out, ci, co, dtype, weight_grad=True)
+                SCN.compile_streams(tb.out, tb.V_in, co, ci, dtype)
+
+        planes = [self.m_shortcuts[k].nIn for k in range(nscale)]
+        nM = self.m_shortcuts[0].nOut
+        subm(0, three, in_channels, planes[0], f32)               # layers_in convolution runs in fp32
+        for k in range(nscale):
+            subm(k, three, planes[k], planes[k], dt)              # residual blocks
+            subm(k, one, planes[k], nM, dt)                       # lateral 1x1x1
+            if k + 1 < nscale:
+                ks, st = tuple(self.down_kernels[k]), tuple(self.down_strides[k])
+                tb = md.rulebooks[key(sizes[k]) + ks + st]
+                strided(tb, planes[k], planes[k + 1], dt, False)  # down-sampling convolution
+                strided(tb, nM, nM, dt, True)                     # up-sampling deconvolution of the same book
+            if k < nscale - 1:
+                subm(k, three, nM, nM, dt)                        # merged 3x3x3 on the up path
+        for i, scale_from_top in enumerate(self.fpn_scales_from_top):
+            msz = sizes[nscale - 1 - scale_from_top]
+            ks = (1, 1, int(self.rpn_map_sizes[i][2]))
+            strided(md.rulebooks[key(msz) + ks + one], nM, nM, dt, False)
+
+    def prepare(self, input, stream):
+        """Extension (not in the reference): build the NEXT batch's whole geometry -- voxel grid, every strided grid,
+        rule tables, compiled block streams -- on `stream` while the current batch still trains on the main stream.
+        The geometry depends on the coordinates only, so this is the device-side analogue of a data-loader prefetch;
+        its host reads (one site count per grid) wait for `stream` alone.  `forward` picks the prepared Metadata up
+        when it is called with the same coordinate tensor (InputLayer._prepared)."""
+        coords = input[0]
+        inp_layer = self.layers_in[0]
+        dev = coords.device if coords.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        inp_layer.prepare(coords, dev, stream)
+        src, ver, c64, md = inp_layer._prepared[-1]
+        with torch.cuda.stream(stream):
+            md.inputLayerFinish()
+            stub = scn.SparseConvNetTensor(None, md, inp_layer.spatial_size)
+            sizes = self._prebuild_geometry(stub)
+            in_channels = self.layers_in[1].nIn
+            self._compile_streams(md, sizes, in_channels)
+        md.prepared_on = stream
 
     def forward(self, net0):
         net1 = self.layers_in(net0)

@@ -147,6 +147,7 @@ class Workload(object):
                                  torch.as_tensor(np.concatenate(F, 0)).to(dev).requires_grad_(True)))
         self.last = None
         self.side = torch.cuda.Stream(device=dev)
+        self.prefetch_geometry = os.environ.get("AABR_BENCH_PREFETCH", "1") != "0"
 
     def forward_backward(self, i, proposals=True, after_backward=None):
         import rpn_glue
@@ -172,6 +173,12 @@ class Workload(object):
         props = None
         if proposals:
             main = torch.cuda.current_stream()
+            if self.prefetch_geometry:
+                # the NEXT batch's geometry (voxel grid, strided grids, rule tables, block streams: coordinates only)
+                # is built on the side stream while this batch's backward runs -- a data-loader-style prefetch; every
+                # step still builds its geometry from scratch, one step ahead
+                with torch.no_grad():
+                    self.net.prepare(self.batches[(i + 1) % len(self.batches)], self.side)
             with torch.no_grad(), torch.cuda.stream(self.side):
                 self.side.wait_event(ev_fwd)
                 props = rpn_glue.rpn_proposals(rpn_maps, [o.detach() for o in objs], [r.detach() for r in regs],

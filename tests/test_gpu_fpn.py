@@ -219,3 +219,36 @@ def test_bench_gpus2_rehearsal_on_one_gpu():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+
+
+def test_fpn_prepare_on_side_stream_is_bit_identical():
+    """FPN_Net.prepare builds the next batch's geometry (voxel grid, strided grids, rule tables, block streams) on
+    a side stream; the forward that picks it up must give the same bits as the plain path (fp32 and bf16)."""
+    for fdt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(2)
+        net = _fpn(feature_dtype=fdt).to(DEV)
+        locs, feats = S.make_batch(2, 20000, 31, 20)
+        l = _t(locs)
+
+        def run(prepared):
+            f = _t(feats).requires_grad_(True)
+            net.zero_grad()
+            if prepared:
+                side = torch.cuda.Stream()
+                net.prepare([l, f], side)
+                assert len(net.layers_in[0]._prepared) == 1
+            rpn, roi = net([l, f])
+            if prepared:
+                assert len(net.layers_in[0]._prepared) == 0 and rpn[0].metadata._fpn_prebuilt is not None
+            sum(m.features.square().mean() for m in rpn).backward()
+            torch.cuda.synchronize()
+            return [m.features.detach().clone() for m in rpn], f.grad.clone(), \
+                [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+        a, b = run(False), run(True)
+        # BN running statistics moved between the two runs, but training-mode BN uses batch statistics: same bits
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(a[1], b[1])
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y)
