@@ -11,7 +11,15 @@ maskrcnn_benchmark/config/defaults.py:48-57, SparseConvNet/sparseconvnet/fpn_net
   -> backward through head and backbone (all weight gradients + the input-feature gradient)
   -> gradient all-reduce (N > 1: ONE flat RCCL all-reduce) -> SGD update.
 The headline runs in fp32, the reference's arithmetic; the same step with bf16 feature storage is reported
-beside it (`extras.bf16`).  Inputs are resident in HBM before the timed region.  One process per GPU
+beside it (`extras.bf16`).  Inputs are resident in HBM before the timed region.
+Pipelining inside a step, all of it real work of that step or the next (nothing cached, nothing skipped):
+  * the proposal stage (top-k, decode, NMS: reads forward results only) is enqueued on a side stream after the
+    backward pass has been enqueued, so its small launches and host reads run underneath the backward kernels;
+  * the NEXT batch's geometry (voxel grid, strided grids, rule tables, block streams -- coordinates only) is built
+    on that side stream during this batch's backward (`FPN_Net.prepare`, the device-side analogue of a data-loader
+    prefetch; AABR_BENCH_PREFETCH=0 builds it inline instead); every step's geometry is built from scratch, one
+    step ahead; the first step builds its own;
+  * N > 1: the gradient all-reduce is started right after backward and waited for before the SGD update.  One process per GPU
 (`--gpus N` spawns the ranks itself when not already under torchrun); ranks take different scenes of one global
 scene list (weak scaling: per-GPU work fixed); the only collective is the gradient all-reduce.
 
