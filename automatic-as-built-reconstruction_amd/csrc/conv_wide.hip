@@ -102,11 +102,13 @@ __device__ inline float bcf_(unsigned int v) { return __builtin_bit_cast(float, 
 // and every wave reads its MFMA B-operands from there with conflict-free ds_read_b128.  So per 16-pair block the
 // vector-memory path carries the 8 KiB of gathered rows ONCE (64-row-tile kernels: 8 KiB + 32 KiB of weights), the
 // weights cost 8 KiB per wave per OFFSET (registers), and every wave issues the same MFMAs.
-// One barrier per block pair (~2 x 1024 MFMA cycles per wave); 64 KiB LDS => two workgroups per CU.
+// One barrier per block pair (~2 x 1024 MFMA cycles per wave) with the double-buffered stage (NBUF = 2), two with a
+// single stage buffer (NBUF = 1: 49 KiB of LDS at 128-channel groups => three workgroups per CU instead of two).
 constexpr int kMaxTileRows = 128;
 
-template <int KG, int DBG>
-__global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
+// NBUF = LDS stage buffers: 2 (one barrier per pair, 2 workgroups per CU) or 1 (two barriers per pair, 3 per CU)
+template <int KG, int DBG, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in
     }
   };
   auto stage_store = [&](const GReg &q, int buf) {
-    float *rowp = St + buf * STAGE + pr * RF;
+    float *rowp = St + (NBUF == 2 ? buf : 0) * STAGE + pr * RF;
 #pragma unroll
     for (int i = 0; i < KG; ++i)
       *reinterpret_cast<u32x4 *>(rowp + (((seg + 8 * i) ^ (pr & SWZ)) << 2)) = q.v[i];
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in
       if (DBG & 4) { t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 
       {
-        const float *sa = St + par * STAGE + c16 * RF;
+        const float *sa = St + (NBUF == 2 ? par : 0) * STAGE + c16 * RF;
         const float *sb = sa + 16 * RF;
         // all of the pair's B operands leave LDS before the first MFMA (counted lgkmcnt waits follow)
         u32x4 a0[KG], a1[KG], b0[KG], b1[KG];
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_cs(const float *__restrict__ in
         if (DBG & 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(accA), "v"(accB)); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         accumulate2(e0.ea, accA, e0.eb, accB);
       }
+      if (NBUF == 1) wg_barrier();                           // single stage: every wave is done reading it
       if (p1.k < vol) stage_store(g_store, par ^ 1);         // pair p1, gathered during the previous step
       if (DBG & 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); }
       wg_barrier();
@@ -410,6 +413,14 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
   dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / 64));
   const int flip = (flags >> 1) & 1;
   const int kg = nkc >= 4 ? 4 : nkc;
+  // LDS stage buffers: with 128-channel groups the double-buffered stage (32 KiB) allows two workgroups per CU, a
+  // single buffer three (49 KiB each) at the price of a second barrier per pair: measured +4...+10 % (128->128 at 84k
+  // rows 380 -> 367 us, 256->256 1366 -> 1272 us); narrower groups fit three workgroups with the double buffer
+  int nbuf = kg == 4 ? 1 : 2;
+  if (const char *ov = getenv("AABR_WIDE_NBUF")) { // tuning experiments only
+    if (ov[0] == '1') nbuf = 1;
+    if (ov[0] == '2') nbuf = 2;
+  }
 #define AABR_LAUNCH_WIDE(KERNEL, NAME, LDS, ...)                                                          \
   do {                                                                                                    \
     static bool attr = false;                                                                             \
@@ -426,12 +437,17 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
     hipLaunchKernelGGL(KERNEL, grid, dim3(256), (LDS), st, __VA_ARGS__);                                  \
   } while (0)
   {
-#define AABR_WIDE_CS(KG, D)                                                                               \
-  AABR_LAUNCH_WIDE((k_conv_cs<KG, D>), "k_conv_cs<" #KG "," #D ">",                                       \
-                   (size_t)((tile_rows + 1) * kWS + 2 * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes,    \
+#define AABR_WIDE_CS_N(KG, D, NB)                                                                         \
+  AABR_LAUNCH_WIDE((k_conv_cs<KG, D, NB>), "k_conv_cs<" #KG "," #D "," #NB ">",                           \
+                   (size_t)((tile_rows + 1) * kWS + NB * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes,   \
                    out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows)
+#define AABR_WIDE_CS(KG, D)                                                                               \
+  do {                                                                                                    \
+    if (nbuf == 1) AABR_WIDE_CS_N(KG, D, 1); else AABR_WIDE_CS_N(KG, D, 2);                               \
+  } while (0)
     if (dbg & 7) { // timing experiments (tools/): only the 128-channel-group instance carries the debug variants
       AABR_CHECK_ARG(kg == 4, "debug variants exist for n_in >= 128 only");
+      nbuf = 2;
       if (dbg & 4) AABR_WIDE_CS(4, 4);
       else if ((dbg & 3) == 1) AABR_WIDE_CS(4, 1); else if ((dbg & 3) == 2) AABR_WIDE_CS(4, 2); else AABR_WIDE_CS(4, 3);
     } else {
@@ -439,6 +455,7 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
       else AABR_WIDE_CS(4, 0);
     }
 #undef AABR_WIDE_CS
+#undef AABR_WIDE_CS_N
   }
 #undef AABR_LAUNCH_WIDE
   AABR_CHECK_LAUNCH();

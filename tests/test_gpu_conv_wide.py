@@ -126,7 +126,7 @@ def test_default_dispatch_takes_the_wide_kernel_on_a_large_layer():
     conv = scn.SubmanifoldConvolution(3, 64, 128, 3, False).to(DEV)
     with torch.no_grad():
         y = conv(x)
-    assert _variant().startswith("k_conv_cs<2"), _variant()
+    assert _variant().startswith("k_conv_cs<2,0,"), _variant()
     il = O.input_layer(locs, feats, 4)
     rb = O.submanifold_rules(il["coords"], [3, 3, 3])
     ref, _ = O.conv_fwd(il["out"], conv.weight.detach().cpu().numpy().reshape(27, 64, 128), rb, il["V"])
