@@ -1463,35 +1463,72 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in,
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int q64 = p0; q64 < p1; q64 += 64) {
-    const int q = q64 + lane;
-    int2 pr = (q < p1) ? pairs[q] : make_int2(-1, -1);
-    const int nhere = (p1 - q64) < 64 ? (p1 - q64) : 64;
-    for (int q0 = 0; q0 < nhere; q0 += 16) {
-      float av[4][CB], bv[4][NB];
+  // Software pipeline: the rows of the NEXT group of 16 pairs are in flight while the current group's
+  // MFMAs issue (two register sets, static alternation: a block of 64 pairs is four groups).  All loads
+  // are unconditional from clamped addresses and masked at use, so the waits stay counted.
+  const int cA = ci - 1, nA = co - 1;
+  int ca[CB], na[NB];
 #pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const int src = q0 + st * 4 + g;
-        const int tq = __shfl(pr.x, src), oq = __shfl(pr.y, src);
-        const bool on = tq >= 0;
+  for (int a = 0; a < CB; ++a) { int c = (cb0 + a) * 16 + c16; ca[a] = c < ci ? c : cA; }
 #pragma unroll
-        for (int a = 0; a < CB; ++a) {
-          int c = (cb0 + a) * 16 + c16;
-          av[st][a] = (on && c < ci) ? ldf(in, (int64_t)tq * ci + c) : 0.0f;
-        }
+  for (int b = 0; b < NB; ++b) { int n = (nb0 + b) * 16 + c16; na[b] = n < co ? n : nA; }
+  auto gather = [&](T (&av)[4][CB], T (&bv)[4][NB], int2 pr, int q0) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          int n = (nb0 + b) * 16 + c16;
-          bv[st][b] = (on && n < co) ? ldf(d_out, (int64_t)oq * co + n) : 0.0f;
-        }
-      }
+    for (int st = 0; st < 4; ++st) {
+      const int src = q0 + st * 4 + g;
+      int tq = __shfl(pr.x, src), oq = __shfl(pr.y, src);
+      tq = tq < 0 ? 0 : tq; oq = oq < 0 ? 0 : oq;
 #pragma unroll
-      for (int st = 0; st < 4; ++st)
+      for (int a = 0; a < CB; ++a) av[st][a] = in[(int64_t)tq * ci + ca[a]];
 #pragma unroll
-        for (int a = 0; a < CB; ++a)
+      for (int b = 0; b < NB; ++b) bv[st][b] = d_out[(int64_t)oq * co + na[b]];
+    }
+  };
+  auto mfmas = [&](T (&av)[4][CB], T (&bv)[4][NB], int qbase) {
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][a], bv[st][b], acc[a][b], 0, 0, 0);
+    for (int st = 0; st < 4; ++st) {
+      const bool on = qbase + st * 4 + g < p1;
+      float fa[CB], fb[NB];
+#pragma unroll
+      for (int a = 0; a < CB; ++a) fa[a] = (on && (cb0 + a) * 16 + c16 < ci) ? (float)av[st][a] : 0.0f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) fb[b] = (on && (nb0 + b) * 16 + c16 < co) ? (float)bv[st][b] : 0.0f;
+#pragma unroll
+      for (int a = 0; a < CB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+  };
+  if (p0 < p1) {
+    T avA[4][CB], bvA[4][NB], avB[4][CB], bvB[4][NB];
+    const int last = rk - 1;                                 // rk >= 1 here
+    auto load_pr = [&](int q64) {
+      int q = q64 + lane;
+      int2 v = pairs[q < rk ? q : last];
+      return (q < p1) ? v : make_int2(-1, -1);
+    };
+    int2 pr = load_pr(p0);
+    gather(avA, bvA, pr, 0);
+    for (int q64 = p0; q64 < p1; q64 += 64) {
+      int2 prn = load_pr(q64 + 64);
+      __builtin_amdgcn_sched_barrier(0);
+      gather(avB, bvB, pr, 16);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(avA, bvA, q64);
+      __builtin_amdgcn_sched_barrier(0);
+      gather(avA, bvA, pr, 32);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(avB, bvB, q64 + 16);
+      __builtin_amdgcn_sched_barrier(0);
+      gather(avB, bvB, pr, 48);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(avA, bvA, q64 + 32);
+      __builtin_amdgcn_sched_barrier(0);
+      gather(avA, bvA, prn, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(avB, bvB, q64 + 48);
+      pr = prn;
     }
   }
   // sum the four waves' accumulators in wave order: w0 + w1 + w2 + w3
