@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   };
   struct WReg { u32x4 w0[KG], w1[KG]; };
   struct GReg { u32x4 v[KG]; };
-  struct Ent { int eg, ea, eb; };          // gather-role entry of this lane's pair row; compute-role entries (A, B)
+  struct Ent { int eg, ea, eb, hb; };      // gather-role entry of this lane's pair row; compute-role entries (A, B);
+                                           // hb (wave-uniform): the pair has a second block
   const int ngroups = (nkc + KG - 1) / KG;
   const int nblk_all = pre_of(vol);
   auto load_w = [&](WReg &w, int k, int kg) {
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
     e.eb = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, (unsigned)c16 * 4u, ebase + bB, 0);
     e.eg = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, (unsigned)(pr & 15) * 4u, ebase + (pr < 16 ? bA : bB), 0);
     if (!hasB) e.eb |= (int)0x80000000;
+    e.hb = hasB ? 1 : 0;
     return e;
   };
   auto gather = [&](GReg &q, int eg, int kg) {
@@ -259,23 +261,33 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
           b1[c] = *reinterpret_cast<const u32x4 *>(sb + q1);
         }
         f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
+        if (DBG & 1) { // timing experiments: operands consumed, no MFMAs
 #pragma unroll
-        for (int c = 0; c < KG; ++c) {
-          {
-            if (DBG & 1) { // timing experiments: operands consumed, no MFMAs
-              accA[0] += bcf_(a0[c][0]) + bcf_(a1[c][0]) + bcf_(w.w0[c][0]) + bcf_(w.w1[c][0]);
-              accB[0] += bcf_(b0[c][0]) + bcf_(b1[c][0]);
-            } else {
+          for (int c = 0; c < KG; ++c) {
+            accA[0] += bcf_(a0[c][0]) + bcf_(a1[c][0]) + bcf_(w.w0[c][0]) + bcf_(w.w1[c][0]);
+            accB[0] += bcf_(b0[c][0]) + bcf_(b1[c][0]);
+          }
+        } else {
+          // block A, then block B only if the pair has one (sparse rule books: most offsets of a tile hold a single
+          // block; the branch is wave-uniform and covers nothing but MFMAs, so no load waits move)
 #pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[c][t]), bcf_(a0[c][t]), accA, 0, 0, 0);
+          for (int c = 0; c < KG; ++c) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              accA = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[c][t]), bcf_(a0[c][t]), accA, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              accA = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[c][t]), bcf_(a1[c][t]), accA, 0, 0, 0);
+          }
+          if (e0.hb) {
+#pragma unroll
+            for (int c = 0; c < KG; ++c) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
                 accB = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[c][t]), bcf_(b0[c][t]), accB, 0, 0, 0);
-              }
 #pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[c][t]), bcf_(a1[c][t]), accA, 0, 0, 0);
+              for (int t = 0; t < 4; ++t)
                 accB = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[c][t]), bcf_(b1[c][t]), accB, 0, 0, 0);
-              }
             }
           }
         }
