@@ -86,6 +86,54 @@ __global__ __launch_bounds__(256) void k_pack_weights2(const float *__restrict__
   (tr ? Wt : Wf)[idx] = pack_cvt<TO>(v);
 }
 
+// every convolution of a network in ONE launch (a training step packs each weight once per version; 40-odd
+// launches of a few microseconds each otherwise).  jobs (device, 48 bytes each):
+//   { W, Wf, Wt : pointers; vol, n_in, n_out, bf16 : int32; first_block : int64 } -- job j owns the
+// thread blocks [first_block[j], first_block[j+1]) of the grid; a block never straddles two jobs.
+struct PackJob {
+  const float *W;
+  void *Wf, *Wt;
+  int32_t vol, n_in, n_out, bf16;
+  int64_t first_block;
+};
+static_assert(sizeof(PackJob) == 48, "PackJob layout is part of the C ABI");
+
+__global__ __launch_bounds__(256) void k_pack_weights_jobs(const PackJob *__restrict__ jobs, int n_jobs) {
+  __shared__ int sj;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n_jobs - 1; // last job whose first_block <= blockIdx.x
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    sj = lo;
+  }
+  __syncthreads();
+  const PackJob jb = jobs[sj];
+  const int vol = jb.vol, n_in = jb.n_in, n_out = jb.n_out;
+  const int64_t total_f = (int64_t)vol * nkc_of(n_in) * nnb_of(n_out) * 512;
+  const int64_t total_t = (int64_t)vol * nkc_of(n_out) * nnb_of(n_in) * 512;
+  int64_t idx = ((int64_t)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+  const bool tr = idx >= total_f;
+  if (tr) idx -= total_f;
+  if (idx >= (tr ? total_t : total_f)) return;
+  const int ci = tr ? n_out : n_in, co = tr ? n_in : n_out;
+  const int nkc = nkc_of(ci), nnb = nnb_of(co);
+  int s = idx & 7;
+  int lane = (idx >> 3) & 63;
+  int64_t r = idx >> 9;
+  int nb = (int)(r % nnb); r /= nnb;
+  int kc = (int)(r % nkc); r /= nkc;
+  int k = (int)r;
+  int c = kc * kKC + (lane >> 4) * 8 + s;
+  int n = nb * 16 + (lane & 15);
+  float v = 0.0f;
+  if (c < ci && n < co) v = tr ? jb.W[((int64_t)k * co + n) * ci + c] : jb.W[((int64_t)k * ci + c) * co + n];
+  void *dst = tr ? jb.Wt : jb.Wf;
+  if (jb.bf16) reinterpret_cast<__bf16 *>(dst)[idx] = (__bf16)v;
+  else reinterpret_cast<float *>(dst)[idx] = v;
+}
+
 // ------------------------------------------------------------------ compiled rule book, part 1
 // Tile-major MFMA block lists.  For every tile of 64 consecutive output rows the gather table
 // is compiled ONCE per rule book into blocks of 16 (partner row, local row) pairs that share a
@@ -2212,6 +2260,23 @@ extern "C" int aabr_conv_pack_weights2_bf16(const float *W, int vol, int n_in, i
                                             uint16_t *wpack_t, void *stream_) {
   return conv_pack_weights2_t<__bf16>(W, vol, n_in, n_out, reinterpret_cast<__bf16 *>(wpack_fwd),
                                       reinterpret_cast<__bf16 *>(wpack_t), stream_);
+}
+
+// thread blocks of one job of aabr_conv_pack_weights_jobs (both orientations)
+extern "C" int64_t aabr_conv_pack_job_blocks(int vol, int n_in, int n_out) {
+  const int64_t total = (int64_t)vol * 512 *
+                        ((int64_t)nkc_of(n_in) * nnb_of(n_out) + (int64_t)nkc_of(n_out) * nnb_of(n_in));
+  return ceil_div(total, (int64_t)256);
+}
+
+extern "C" int aabr_conv_pack_weights_jobs(const void *jobs_dev, int n_jobs, int64_t total_blocks, void *stream_) {
+  AABR_CHECK_ARG(n_jobs >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31), "bad sizes");
+  if (n_jobs == 0 || total_blocks == 0) return AABR_OK;
+  AABR_CHECK_ARG(jobs_dev && ((uintptr_t)jobs_dev & 7) == 0, "null / misaligned job table");
+  hipLaunchKernelGGL(k_pack_weights_jobs, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream_,
+                     reinterpret_cast<const PackJob *>(jobs_dev), n_jobs);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
 }
 
 extern "C" int aabr_conv_dw_chunk_pairs(int64_t V_out, int vol, int n_in, int n_out) {

@@ -682,7 +682,15 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
     else:
         elems, name, dt = lib.aabr_conv_wpack_floats(gather.vol, w.size(2), w.size(3)), "wpack", torch.float32
         conv, pack2 = lib.aabr_conv_forward, lib.aabr_conv_pack_weights2
-    if pack_t is not None and (flags & 1) and len(pack_t) == 1 and pack_t[0].dtype == dt:
+    pre = getattr(weight, "_aabr_pack", None)            # WeightPackPlan: packed once per weight version
+    if pre is not None and pre[0] == weight._version and pre[1] == dt and n_rows_out > 0:
+        wpack = pre[3 if (flags & 1) else 2]
+        if pack_t is not None and not (flags & 1):           # the node's backward pass finds its layout here
+            del pack_t[:]
+            pack_t.append(pre[3])
+        flags |= 4
+        pack_stats["plan"] += 1
+    elif pack_t is not None and (flags & 1) and len(pack_t) == 1 and pack_t[0].dtype == dt:
         wpack, flags = pack_t[0], flags | 4
     else:
         wpack = _hip.workspace(name, elems, dt, inp.device)
@@ -692,6 +700,8 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
             del pack_t[:]
             pack_t.append(wt)
             flags |= 4
+    if not (flags & 4) and n_rows_out > 0:
+        pack_stats["own"] += 1                               # this call packs its weights itself
     tile_rows = 0 if (bf16 or n_rows_out == 0) else lib.aabr_conv_wide_tile_rows(n_in, n_out, inp.size(0), n_rows_out,
                                                                                   gather.vol)
     if tile_rows:
@@ -707,6 +717,64 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
     if trace is not None:
         trace.append(("fwd", n_in, n_out, gather, inp.size(0), flags & 3, inp.dtype))
     return n_out
+
+
+pack_stats = {"plan": 0, "own": 0}   # convolution launches served by a WeightPackPlan / packing on their own
+
+
+class WeightPackPlan:
+    """Extension (the reference's GEMMs read W[k] in place): the packed copies of EVERY convolution weight of a
+    network -- forward layout and input-gradient layout -- produced by ONE launch per forward pass
+    (`aabr_conv_pack_weights_jobs`) instead of one pack launch per layer call.  `refresh()` packs and leaves each
+    weight's packs on the parameter (`_aabr_pack`) for `_conv_fwd` to pick up; `release()` takes them away again
+    when the forward pass is over (the autograd nodes keep the input-gradient packs they need), so a layer called
+    on its own later -- possibly after an optimizer changed the weights through `.data`, which no version counter
+    sees -- never meets a stale pack."""
+
+    def __init__(self, weights, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.weights = [w for w in weights if w.is_cuda]
+        self.dtype = dtype
+        self._ptrs = None
+
+    def _build(self):
+        import struct
+        lib = _hip.load()
+        dev = self.weights[0].device
+        es = 4 if self.dtype == torch.float32 else 2
+        offs, total, blocks = [], 0, [0]
+        for w in self.weights:
+            assert w.dim() == 4 and w.size(1) == 1 and w.dtype == torch.float32 and w.is_contiguous()
+            e = int(lib.aabr_conv_wpack_floats(w.size(0), w.size(2), w.size(3)))
+            e = (e + 63) // 64 * 64                              # every pack 16-byte aligned in the arena
+            offs.append((total, total + e, e))
+            total += 2 * e
+            blocks.append(blocks[-1] + int(lib.aabr_conv_pack_job_blocks(w.size(0), w.size(2), w.size(3))))
+        self.arena = torch.empty(total, dtype=self.dtype, device=dev)
+        base = self.arena.data_ptr()
+        rec = b""
+        self.packs = []
+        for w, (f, t, e), b in zip(self.weights, offs, blocks):
+            rec += struct.pack("<QQQiiiiq", w.data_ptr(), base + f * es, base + t * es, w.size(0), w.size(2), w.size(3),
+                               0 if self.dtype == torch.float32 else 1, b)
+            self.packs.append((self.arena[f:f + e], self.arena[t:t + e]))
+        self.jobs = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
+        self.total_blocks = blocks[-1]
+        self._ptrs = [w.data_ptr() for w in self.weights]
+
+    def refresh(self):
+        if not self.weights:
+            return
+        if [w.data_ptr() for w in self.weights] != self._ptrs:
+            self._build()
+        check(_hip.load().aabr_conv_pack_weights_jobs(ptr(self.jobs), len(self.weights), self.total_blocks, stream()))
+        for w, (pf, pt) in zip(self.weights, self.packs):
+            w._aabr_pack = (w._version, self.dtype, pf, pt)
+
+    def release(self):
+        for w in self.weights:
+            if hasattr(w, "_aabr_pack"):
+                del w._aabr_pack
 
 
 def _conv_dw(inp, d_out, gather, d_weight, d_bias):

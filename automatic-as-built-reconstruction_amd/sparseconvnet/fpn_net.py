@@ -25,6 +25,7 @@ class FPN_Net(torch.nn.Module):
         assert feature_dtype in (torch.float32, torch.bfloat16)
         self.feature_dtype = feature_dtype
         self.prebuild_geometry = True   # extension: see _prebuild_geometry
+        self.prepack_weights = True     # extension: see _refresh_weight_packs
         self.bn_momentum = bn_momentum
         self.track_running_stats = track_running_stats
         self.dimension = dimension
@@ -219,7 +220,26 @@ class FPN_Net(torch.nn.Module):
             self._compile_streams(md, sizes, in_channels)
         md.prepared_on = stream
 
+    def _refresh_weight_packs(self):
+        """Extension: all convolution weights packed (both orientations) by one launch per weight version"""
+        from . import SCN
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or plan.dtype != self.feature_dtype:
+            ws = [m.weight for m in self.modules()
+                  if isinstance(m, (scn.SubmanifoldConvolution, scn.Convolution, scn.Deconvolution))]
+            plan = self._pack_plan = SCN.WeightPackPlan(ws, self.feature_dtype)
+        plan.refresh()
+        return plan
+
     def forward(self, net0):
+        plan = self._refresh_weight_packs() if self.prepack_weights else None
+        try:
+            return self._forward(net0)
+        finally:
+            if plan is not None:
+                plan.release()
+
+    def _forward(self, net0):
         net1 = self.layers_in(net0)
         if self.prebuild_geometry:
             self._prebuild_geometry(net1)

@@ -201,6 +201,13 @@ int aabr_conv_pack_weights2(const float *W, int vol, int n_in, int n_out, float 
                             float *wpack_t, void *stream);
 int aabr_conv_pack_weights2_bf16(const float *W, int vol, int n_in, int n_out, uint16_t *wpack_fwd,
                                  uint16_t *wpack_t, void *stream);
+/* All convolutions of a network in one launch.  jobs_dev: device array of n_jobs records of 48 bytes
+ *   { const float *W; void *wpack_fwd; void *wpack_t; int32 vol, n_in, n_out, bf16; int64 first_block; }
+ * first_block[j] = sum of aabr_conv_pack_job_blocks(...) of the jobs before j; total_blocks = that sum over
+ * all jobs.  Same layouts as aabr_conv_pack_weights2[_bf16] (bf16 != 0: bf16 bit patterns).  The reference
+ * has no counterpart: its GEMMs read W[k] in place (CPU/Convolution.cpp:60-66).                       */
+int64_t aabr_conv_pack_job_blocks(int vol, int n_in, int n_out);
+int aabr_conv_pack_weights_jobs(const void *jobs_dev, int n_jobs, int64_t total_blocks, void *stream);
 /* dW[k] = sum over offset k's pairs (t, o) of in[t]^T (x) d_out[o]; d_bias (optional) = column
  * sums of d_out.  max_chunks bounds the number of chunks of c = aabr_conv_dw_chunk_pairs(V, vol, nIn, nOut) pairs:
  * sum_k ceil(R_k/c) when the rule counts are known on the host, else ceil(vol*V/c) + vol; scratch float32

@@ -252,3 +252,56 @@ def test_fpn_prepare_on_side_stream_is_bit_identical():
         assert torch.equal(a[1], b[1])
         for x, y in zip(a[2], b[2]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_fpn_weights_packed_once_per_version_is_bit_identical():
+    """FPN_Net packs every convolution weight (both orientations) with one launch per weight version
+    (SCN.WeightPackPlan) instead of one launch per layer call: same bits as the per-call packing, the packs are
+    really used, and an in-place weight update is picked up (version check), fp32 and bf16."""
+    import sparseconvnet as scn
+    from sparseconvnet import SCN
+    for fdt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(4)
+        net = _fpn(feature_dtype=fdt).to(DEV)
+        locs, feats = S.make_batch(2, 20000, 37, 20)
+        l = _t(locs)
+
+        def run(prepack):
+            net.prepack_weights = prepack
+            if not prepack:
+                for p in net.parameters():
+                    if hasattr(p, "_aabr_pack"):
+                        del p._aabr_pack
+            f = _t(feats).requires_grad_(True)
+            net.zero_grad()
+            rpn, roi = net([l, f])
+            sum(m.features.square().mean() for m in rpn).backward()
+            torch.cuda.synchronize()
+            return [m.features.detach().clone() for m in rpn], f.grad.clone(), \
+                [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+        a = run(False)
+        SCN.pack_stats.update(plan=0, own=0)
+        b = run(True)
+        assert SCN.pack_stats["own"] == 0 and SCN.pack_stats["plan"] >= 40, SCN.pack_stats
+        convs = [m for m in net.modules() if isinstance(m, (scn.SubmanifoldConvolution, scn.Convolution,
+                                                             scn.Deconvolution))]
+        # the plan covers every convolution, no pack launch of a layer's own ran, nothing is left on the parameters
+        assert len(net._pack_plan.weights) == len(convs) and not any(hasattr(m.weight, "_aabr_pack") for m in convs)
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(a[1], b[1])
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y)
+        # an update through .data (no version counter moves -- dp.FlatParams does this): the next forward must
+        # see the new weights
+        for m in convs:
+            m.weight.data.mul_(0.5)
+        c = run(True)
+        d = run(False)
+        assert not torch.equal(b[0][0], c[0][0])
+        for x, y in zip(c[0], d[0]):
+            assert torch.equal(x, y)
+        for x, y in zip(c[2], d[2]):
+            assert torch.equal(x, y)
