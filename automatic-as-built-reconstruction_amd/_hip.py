@@ -46,6 +46,9 @@ _SIGS = {
     "aabr_conv_dw_chunk_pairs": (C.c_int, [_i64, _i32, _i32, _i32]),
     "aabr_conv_pack_weights2": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "aabr_conv_pack_weights2_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "aabr_plan_run": (C.c_int, [_vp, _i32, _vp]),
+    "aabr_add": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "aabr_cast_storage": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "aabr_conv_pack_job_blocks": (C.c_int64, [_i32, _i32, _i32]),
     "aabr_conv_pack_weights_jobs": (C.c_int, [_vp, _i32, _i64, _vp]),
     "aabr_conv_wpack_bf16_elems": (C.c_int64, [_i32, _i32, _i32]),

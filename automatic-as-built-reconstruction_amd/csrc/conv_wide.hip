@@ -40,11 +40,11 @@ constexpr int kMaxVol = 63;  // vol + 1 prefix entries live in the lanes of one 
 //   entry = (partner_row << 8) | local_row; padding entries repeat the block's first pair with bit 31 set.
 // Pairs of one offset are in ascending local-row order (deterministic).
 // T = rows per tile (a multiple of 16, <= 128); the workgroup has ceil(T/64) waves
-__global__ __launch_bounds__(128) void k_build_tileT(const int32_t *__restrict__ table, int64_t V, int vol, int T,
+__global__ __launch_bounds__(256) void k_build_tileT(const int32_t *__restrict__ table, int64_t V, int vol, int T,
                                                       int32_t *__restrict__ words) {
   const int kT = T;
   const int NWV = (T + 63) / 64;
-  __shared__ int s_cnt[2][kMaxVol];
+  __shared__ int s_cnt[4][kMaxVol];
   __shared__ int s_base[kMaxVol + 1];
   __shared__ int s_tot[kMaxVol];
   __shared__ int s_first[kMaxVol];
@@ -104,7 +104,7 @@ __device__ inline float bcf_(unsigned int v) { return __builtin_bit_cast(float, 
 // weights cost 8 KiB per wave per OFFSET (registers), and every wave issues the same MFMAs.
 // One barrier per block pair (~2 x 1024 MFMA cycles per wave) with the double-buffered stage (NBUF = 2), two with a
 // single stage buffer (NBUF = 1: 49 KiB of LDS at 128-channel groups => three workgroups per CU instead of two).
-constexpr int kMaxTileRows = 128;
+constexpr int kMaxTileRows = 240; // (240 + 1) rows x 256 B + 16 KiB stage = 76 KiB: two workgroups per CU
 
 // NBUF = LDS stage buffers: 2 (one barrier per pair, 2 workgroups per CU) or 1 (two barriers per pair, 3 per CU)
 template <int KG, int DBG, int NBUF>
@@ -362,7 +362,7 @@ extern "C" int64_t aabr_wide_blocks_words(int64_t V, int vol, int tile_rows) { r
 extern "C" int aabr_build_wide_blocks(const int32_t *table, int64_t V, int vol, int tile_rows, int32_t *blocks,
                                       void *stream_) {
   AABR_CHECK_ARG(V >= 0 && vol > 0 && vol <= kMaxVol, "bad sizes (vol <= 63)");
-  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 128");
+  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(table && blocks, "null pointer");
   const unsigned nt = (unsigned)((V + tile_rows - 1) / tile_rows);
@@ -389,7 +389,7 @@ extern "C" int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, in
   }
   if (const char *ov = getenv("AABR_WIDE_ROWS")) { // tuning experiments only
     const int v = atoi(ov);
-    if (v >= 16 && v <= 128 && (v & 15) == 0) T = v;
+    if (v >= 16 && v <= kMaxTileRows && (v & 15) == 0) T = v;
   }
   if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
   if ((int64_t)vol * n_in * n_out * 4 >= (1ll << 31)) return 0;
@@ -409,7 +409,7 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 31) == 0 && (n_out & 63) == 0, "plane counts: n_in % 32, n_out % 64");
   AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
-  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 128");
+  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
   if (V_out == 0) return AABR_OK;
   AABR_CHECK_ARG(in_feats && out_feats && blocks && wpack && rows_in > 0, "null pointer / empty input");
   AABR_CHECK_ARG(rows_in < (1ll << 23), "too many input rows for the wide block format");

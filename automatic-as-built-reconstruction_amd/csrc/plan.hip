@@ -1,0 +1,151 @@
+// plan.hip -- run a compiled list of hot-path launches with ONE call across the C ABI (gfx950).
+//
+// The reference drives its layers from Python, one pybind call per layer and direction
+// (sparseconvnet/{submanifoldConvolution,convolution,deconvolution,batchNormalization}.py ->
+// SCN/pybind.cpp:134-221).  Behind the same operator API the host side here can compile the static part of a
+// network (sparseconvnet/planExecutor.py: every BatchNorm / convolution / residual add between the input layer
+// and the returned feature maps) into a flat array of PlanOp records and hand it over once per pass: the
+// per-layer interpreter overhead (tens of microseconds per layer and direction) leaves the critical path and the
+// launches go out back to back.  Every record names one of the library's own entry points; nothing here computes
+// differently from calling them one by one.
+//
+// Also the two elementwise launches such a plan needs that the layer API gets from torch: residual add and the
+// fp32 <-> bf16 storage casts (round-to-nearest-even, as torch's `.to(torch.bfloat16)`).
+#include "common.h"
+
+namespace aabr {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_add2(const T *__restrict__ a, const T *__restrict__ b, T *__restrict__ o,
+                                              int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    if constexpr (sizeof(T) == 4) {
+      const float4 x = *reinterpret_cast<const float4 *>(a + i), y = *reinterpret_cast<const float4 *>(b + i);
+      *reinterpret_cast<float4 *>(o + i) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    } else {
+      const bf16x4 x = *reinterpret_cast<const bf16x4 *>(a + i), y = *reinterpret_cast<const bf16x4 *>(b + i);
+      bf16x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = (__bf16)((float)x[j] + (float)y[j]);
+      *reinterpret_cast<bf16x4 *>(o + i) = r;
+    }
+  } else {
+    for (int64_t j = i; j < n; ++j) o[j] = (T)((float)a[j] + (float)b[j]);
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_cast(const TI *__restrict__ in, TO *__restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[i + j] = (TO)(float)in[i + j];
+  } else {
+    for (int64_t j = i; j < n; ++j) out[j] = (TO)(float)in[j];
+  }
+}
+
+} // namespace aabr
+using namespace aabr;
+
+extern "C" int aabr_add(const void *a, const void *b, void *out, int64_t n, int bf16, void *stream_) {
+  AABR_CHECK_ARG(n >= 0, "bad size");
+  if (n == 0) return AABR_OK;
+  AABR_CHECK_ARG(a && b && out, "null pointer");
+  const int es = bf16 ? 2 : 4;
+  AABR_CHECK_ARG((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & (uintptr_t)(4 * es - 1)) == 0,
+                 "operands must be aligned to four elements");
+  const dim3 grid((unsigned)((n + 1023) / 1024));
+  AABR_CHECK_ARG((n + 1023) / 1024 < (1ll << 31), "too many elements");
+  if (bf16)
+    hipLaunchKernelGGL((k_add2<__bf16>), grid, dim3(256), 0, (hipStream_t)stream_, (const __bf16 *)a, (const __bf16 *)b,
+                       (__bf16 *)out, n);
+  else
+    hipLaunchKernelGGL((k_add2<float>), grid, dim3(256), 0, (hipStream_t)stream_, (const float *)a, (const float *)b,
+                       (float *)out, n);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_cast_storage(const void *in, void *out, int64_t n, int to_bf16, void *stream_) {
+  AABR_CHECK_ARG(n >= 0, "bad size");
+  if (n == 0) return AABR_OK;
+  AABR_CHECK_ARG(in && out, "null pointer");
+  AABR_CHECK_ARG((n + 1023) / 1024 < (1ll << 31), "too many elements");
+  const dim3 grid((unsigned)((n + 1023) / 1024));
+  if (to_bf16)
+    hipLaunchKernelGGL((k_cast<float, __bf16>), grid, dim3(256), 0, (hipStream_t)stream_, (const float *)in,
+                       (__bf16 *)out, n);
+  else
+    hipLaunchKernelGGL((k_cast<__bf16, float>), grid, dim3(256), 0, (hipStream_t)stream_, (const __bf16 *)in,
+                       (float *)out, n);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+// One record = one library call; the field use per kind is listed in include/aabr_hip.h (AabrPlanOp).
+static_assert(sizeof(AabrPlanOp) == 176, "AabrPlanOp layout is part of the C ABI");
+
+extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st) {
+  AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
+  for (int j = 0; j < n_ops; ++j) {
+    const AabrPlanOp &o = ops[j];
+    const bool bf = (o.flags & AABR_PLAN_BF16) != 0;
+    void *const *p = o.p;
+    int rc = AABR_OK;
+    switch (o.kind) {
+    case AABR_PLAN_CONV:
+      rc = bf ? aabr_conv_forward_bf16((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1], o.i64[1],
+                                       (const int32_t *)p[2], o.i32[2], (const float *)p[3], (const float *)p[4],
+                                       o.i32[3], (uint16_t *)p[5], st)
+              : aabr_conv_forward((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
+                                  (const int32_t *)p[2], o.i32[2], (const float *)p[3], (const float *)p[4], o.i32[3],
+                                  (float *)p[5], st);
+      break;
+    case AABR_PLAN_CONV_WIDE:
+      rc = aabr_conv_forward_wide((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
+                                  (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
+                                  (const float *)p[5], st);
+      break;
+    case AABR_PLAN_CONV_DW:
+      rc = bf ? aabr_conv_backward_weight_bf16((const uint16_t *)p[0], o.i32[0], (const uint16_t *)p[1], o.i32[1],
+                                               o.i64[0], (const int32_t *)p[2], o.i32[2], o.i64[1], (float *)p[3],
+                                               (float *)p[4], (float *)p[5], st)
+              : aabr_conv_backward_weight((const float *)p[0], o.i32[0], (const float *)p[1], o.i32[1], o.i64[0],
+                                          (const int32_t *)p[2], o.i32[2], o.i64[1], (float *)p[3], (float *)p[4],
+                                          (float *)p[5], st);
+      break;
+    case AABR_PLAN_BN_FWD:
+      rc = bf ? aabr_bn_forward_bf16((const uint16_t *)p[0], (uint16_t *)p[1], o.i64[0], o.i32[0], (float *)p[2],
+                                     (float *)p[3], (float *)p[4], (float *)p[5], (const float *)p[6],
+                                     (const float *)p[7], o.f32[0], o.f32[1], o.i32[1], o.f32[2], (float *)p[8], st)
+              : aabr_bn_forward((const float *)p[0], (float *)p[1], o.i64[0], o.i32[0], (float *)p[2], (float *)p[3],
+                                (float *)p[4], (float *)p[5], (const float *)p[6], (const float *)p[7], o.f32[0],
+                                o.f32[1], o.i32[1], o.f32[2], (float *)p[8], st);
+      break;
+    case AABR_PLAN_BN_BWD:
+      rc = bf ? aabr_bn_backward_bf16((const uint16_t *)p[0], (uint16_t *)p[1], (const uint16_t *)p[2],
+                                      (const uint16_t *)p[3], o.i64[0], o.i32[0], (const float *)p[4],
+                                      (const float *)p[5], (const float *)p[6], (float *)p[7], (float *)p[8], o.f32[2],
+                                      (float *)p[9], st)
+              : aabr_bn_backward((const float *)p[0], (float *)p[1], (const float *)p[2], (const float *)p[3], o.i64[0],
+                                 o.i32[0], (const float *)p[4], (const float *)p[5], (const float *)p[6], (float *)p[7],
+                                 (float *)p[8], o.f32[2], (float *)p[9], st);
+      break;
+    case AABR_PLAN_ADD:
+      rc = aabr_add(p[0], p[1], p[2], o.i64[0], bf ? 1 : 0, st);
+      break;
+    case AABR_PLAN_CAST:
+      rc = aabr_cast_storage(p[0], p[1], o.i64[0], (o.flags & AABR_PLAN_TO_BF16) ? 1 : 0, st);
+      break;
+    default:
+      aabr::set_error("aabr_plan_run: op %d has unknown kind %d", j, o.kind);
+      return AABR_EINVAL;
+    }
+    if (rc != AABR_OK) return rc;   // the failing entry point has set the error text
+  }
+  return AABR_OK;
+}

@@ -26,6 +26,7 @@ class FPN_Net(torch.nn.Module):
         self.feature_dtype = feature_dtype
         self.prebuild_geometry = True   # extension: see _prebuild_geometry
         self.prepack_weights = True     # extension: see _refresh_weight_packs
+        self.compiled_graph = False     # extension: planExecutor.run_fpn (one launch list per pass)
         self.bn_momentum = bn_momentum
         self.track_running_stats = track_running_stats
         self.dimension = dimension
@@ -243,6 +244,11 @@ class FPN_Net(torch.nn.Module):
         net1 = self.layers_in(net0)
         if self.prebuild_geometry:
             self._prebuild_geometry(net1)
+        if self.compiled_graph and self.prepack_weights:
+            from . import planExecutor
+            out = planExecutor.run_fpn(self, net1)
+            if out is not None:
+                return out
         if self.feature_dtype == torch.float32:
             return self.forward_fpn(net1)
         rpn_maps, roi_maps = self.forward_fpn(self._cast(net1, self.feature_dtype))

@@ -96,6 +96,9 @@ def build_net(scn, torch, dev, dtype):
                       [[[2, 2, 2]] * 8, [[2, 2, 2]] * 8],
                       [[256, 256, 32], [128, 128, 16], [64, 64, 8], [32, 32, 4]], [1, 2, 3, 4, 5, 6],
                       leakiness=0, voxel_scale=VOXEL_SCALE, bn_momentum=0.95, feature_dtype=dtype).to(dev)
+    # every layer between the input layer and the returned maps as one launch list per pass (planExecutor.py):
+    # same kernels, arguments and order as the module path, without its per-layer interpreter time
+    net.compiled_graph = os.environ.get("AABR_BENCH_COMPILED_GRAPH", "1") != "0"
 
     class RpnHead(torch.nn.Module):
         """SingleConvRPNHead_Sparse3D (rpn_sparse3d.py:81-131): 1x1 conv + ReLU, objectness and box heads --
@@ -235,7 +238,9 @@ def conv_kernel_table(torch, wl, dtype):
     lib = _hip.load()
     SCN.trace = []
     wl.flat.zero_grad()
+    compiled, wl.net.compiled_graph = wl.net.compiled_graph, False   # the module path reports its launches
     wl.forward_backward(0, proposals=False)
+    wl.net.compiled_graph = compiled
     torch.cuda.synchronize()
     tr, SCN.trace = SCN.trace, None
     groups = {}

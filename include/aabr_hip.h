@@ -259,6 +259,50 @@ int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *ou
                           const float *save_invstd, const float *weight, float *d_weight,
                           float *d_bias, float leakiness, float *scratch, void *stream);
 
+/* ---- compiled launch plans (extension) --------------------------------------------------------
+ * The reference enters its library once per layer and direction from Python (SCN/pybind.cpp:134-221 behind
+ * sparseconvnet/ layer modules).  A host that has compiled the static part of a network into a list of launches hands
+ * the whole list over with ONE call: every record stands for one of the entry points above, called with the
+ * record's fields in the order given here -- nothing is computed differently.
+ *   kind AABR_PLAN_CONV       aabr_conv_forward[_bf16](p0 in, i32[0] n_in, i64[0] rows_in, p1 out, i32[1] n_out,
+ *                             i64[1] V_out, p2 blocks, i32[2] vol, p3 W, p4 bias, i32[3] flags, p5 wpack)
+ *        AABR_PLAN_CONV_WIDE  aabr_conv_forward_wide(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
+ *                             i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack)
+ *        AABR_PLAN_CONV_DW    aabr_conv_backward_weight[_bf16](p0 in, i32[0] n_in, p1 d_out, i32[1] n_out,
+ *                             i64[0] V_out, p2 pairs, i32[2] vol, i64[1] max_chunks, p3 dW, p4 d_bias, p5 scratch)
+ *        AABR_PLAN_BN_FWD     aabr_bn_forward[_bf16](p0 in, p1 out, i64[0] rows, i32[0] planes, p2 save_mean,
+ *                             p3 save_invstd, p4 running_mean, p5 running_var, p6 weight, p7 bias, f32[0] eps,
+ *                             f32[1] momentum, i32[1] train, f32[2] leakiness, p8 scratch)
+ *        AABR_PLAN_BN_BWD     aabr_bn_backward[_bf16](p0 in, p1 d_in, p2 out, p3 d_out, i64[0] rows, i32[0] planes,
+ *                             p4 save_mean, p5 save_invstd, p6 weight, p7 d_weight, p8 d_bias, f32[2] leakiness,
+ *                             p9 scratch)
+ *        AABR_PLAN_ADD        aabr_add(p0 a, p1 b, p2 out, i64[0] n)
+ *        AABR_PLAN_CAST       aabr_cast_storage(p0 in, p1 out, i64[0] n, flags & AABR_PLAN_TO_BF16)
+ *   flags & AABR_PLAN_BF16 selects the bf16-storage entry point.  Stops at the first failing record and returns
+ *   its code (aabr_last_error() holds that entry point's message).                                    */
+#define AABR_PLAN_CONV 1
+#define AABR_PLAN_CONV_WIDE 2
+#define AABR_PLAN_CONV_DW 3
+#define AABR_PLAN_BN_FWD 4
+#define AABR_PLAN_BN_BWD 5
+#define AABR_PLAN_ADD 6
+#define AABR_PLAN_CAST 7
+#define AABR_PLAN_BF16 1
+#define AABR_PLAN_TO_BF16 2
+typedef struct AabrPlanOp {
+  int32_t kind, flags;
+  int32_t i32[6];
+  float f32[4];
+  int64_t i64[4];
+  void *p[12];
+} AabrPlanOp; /* 176 bytes, no padding */
+int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *stream);
+/* out = a + b elementwise over n elements (fp32, or bf16 storage with the sum formed in fp32 and rounded to
+ * nearest even); fp32 <-> bf16 storage cast.  What the layer API gets from torch (`a + b`, `.to(dtype)`; the
+ * reference: AddTable, tables.py:27-41) as plan records.                                           */
+int aabr_add(const void *a, const void *b, void *out, int64_t n, int bf16, void *stream);
+int aabr_cast_storage(const void *in, void *out, int64_t n, int to_bf16, void *stream);
+
 /* ---- rotated IoU / NMS ---------------------------------------------------------------------
  * iou[n,k] = devRotateIoUEval(query k, box n, criterion), then forced to 1 where the five
  * parameters differ by < 1e-6 -- rotate_iou_gpu_eval + check_same_boxes

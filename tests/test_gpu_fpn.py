@@ -305,3 +305,73 @@ def test_fpn_weights_packed_once_per_version_is_bit_identical():
             assert torch.equal(x, y)
         for x, y in zip(c[2], d[2]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_fpn_compiled_graph_matches_module_path():
+    """FPN_Net.compiled_graph (sparseconvnet/planExecutor.py: every layer between the input layer and the returned
+    maps as one launch list per pass, one autograd node) against the module path on the same net and input:
+    feature maps, input gradient and BatchNorm running statistics bit-equal; parameter gradients bit-equal where
+    at most two gradient contributions meet and within 1e-6 relative otherwise; MAC counter equal; fp32 and bf16;
+    evaluation mode; fallback when a hook is registered."""
+    import sparseconvnet as scn
+    from sparseconvnet import planExecutor
+    for fdt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(6)
+        net = _fpn(feature_dtype=fdt).to(DEV)
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        locs, feats = S.make_batch(2, 20000, 41, 20)
+        l = _t(locs)
+
+        def run(compiled, train=True):
+            net.load_state_dict(state)
+            net.train(train)
+            net.compiled_graph = compiled
+            f = _t(feats).requires_grad_(train)
+            net.zero_grad()
+            scn.forward_pass_multiplyAdd_count = 0
+            before = planExecutor.stats["passes"]
+            with torch.set_grad_enabled(train):
+                rpn, roi = net([l, f])
+            assert (planExecutor.stats["passes"] - before) == (1 if compiled else 0)
+            macs = float(scn.forward_pass_multiplyAdd_count)
+            outs = [m.features.detach().clone() for m in rpn + roi]
+            sizes = [tuple(m.spatial_size.tolist()) for m in rpn + roi]
+            if not train:
+                return outs, sizes, macs
+            w = [torch.linspace(0.5, 1.5, m.features.numel(), device=DEV).view_as(m.features) for m in rpn + roi]
+            sum((m.features * wi).square().mean() for m, wi in zip(rpn + roi, w)).backward()
+            torch.cuda.synchronize()
+            bn = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+            return outs, sizes, macs, f.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters()
+                                                       if p.grad is not None}, bn
+
+        a, b = run(False), run(True)
+        assert a[1] == b[1] and a[2] == b[2] and len(a[0]) == len(b[0])
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(a[3], b[3])
+        assert a[4].keys() == b[4].keys()
+        exact = 0
+        for n in a[4]:
+            ga, gb = a[4][n], b[4][n]
+            if torch.equal(ga, gb):
+                exact += 1
+            else:
+                tol = 1e-6 if fdt == torch.float32 else 1e-2
+                assert float((ga - gb).abs().max()) <= tol * float(ga.abs().max()), n
+        assert exact >= len(a[4]) * 3 // 4, (exact, len(a[4]))
+        for k in a[5]:
+            assert torch.equal(a[5][k], b[5][k]), k
+        # evaluation mode (running statistics), no autograd
+        ea, eb = run(False, train=False), run(True, train=False)
+        for x, y in zip(ea[0], eb[0]):
+            assert torch.equal(x, y)
+        # a hook anywhere: the modules run
+        h = net.m_mergeds[0].register_forward_hook(lambda mod, i, o: None)
+        before = planExecutor.stats["passes"]
+        net.compiled_graph = True
+        with torch.no_grad():
+            net([l, _t(feats)])
+        assert planExecutor.stats["passes"] == before
+        h.remove()

@@ -16,6 +16,8 @@ dtype = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else tor
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 dev = torch.device("cuda", 0)
 wl = B.Workload(scn, torch, dp, dev, dtype, 0, 1, 2)
+if len(sys.argv) > 3:
+    wl.net.compiled_graph = sys.argv[3] != "0"
 for i in range(6):
     wl.step(i)
 torch.cuda.synchronize()
