@@ -6,7 +6,8 @@ maskrcnn_benchmark/config/defaults.py:48-57, SparseConvNet/sparseconvnet/fpn_net
   4 synthetic SUNCG-shaped scenes (~80k points each) at 2 cm voxels, C_in = 9
   -> HIP voxel scatter (InputLayer mode 4; hash grid, site numbering and every rule book rebuilt each step)
   -> FPN_Net: 9 scales, 36 SubmanifoldConvolution + 12 Convolution + 8 Deconvolution + 35 BatchNorm(+ReLU)
-  -> RPN head (three dense 1x1 layers, torch plumbing as in the reference, rpn_sparse3d.py:81-131)
+  -> RPN head (three dense 1x1 layers, torch plumbing as in the reference, rpn_sparse3d.py:81-131; the shared head
+     runs once over the rows of all six maps) and a synthetic loss over all anchors
   -> per scene: cross-scale top-k(2000) -> fused anchor + BoxCoder3D decode -> rotated-3D NMS (1000)
   -> backward through head and backbone (all weight gradients + the input-feature gradient)
   -> gradient all-reduce (N > 1: ONE flat RCCL all-reduce) -> SGD update.
@@ -19,6 +20,9 @@ Pipelining inside a step, all of it real work of that step or the next (nothing 
     on that side stream during this batch's backward (`FPN_Net.prepare`, the device-side analogue of a data-loader
     prefetch; AABR_BENCH_PREFETCH=0 builds it inline instead); every step's geometry is built from scratch, one
     step ahead; the first step builds its own;
+  * the layers between the input layer and the returned maps run through the compiled graph executor
+    (sparseconvnet/planExecutor.py: same kernels, arguments and order as the per-layer modules, one launch list
+    per pass; AABR_BENCH_COMPILED_GRAPH=0 runs the modules);
   * N > 1: the gradient all-reduce is started right after backward and waited for before the SGD update.  One process per GPU
 (`--gpus N` spawns the ranks itself when not already under torchrun); ranks take different scenes of one global
 scene list (weak scaling: per-GPU work fixed); the only collective is the gradient all-reduce.
@@ -160,17 +164,24 @@ class Workload(object):
         self.side = torch.cuda.Stream(device=dev)
         self.prefetch_geometry = os.environ.get("AABR_BENCH_PREFETCH", "1") != "0"
 
+    def head_loss(self, rpn_maps):
+        """The shared RPN head over the rows of all six maps in one call (the reference applies the same head map
+        by map, rpn_sparse3d.py:118-131, and concatenates the scales before its loss, :19-77; row-wise layers give
+        the same rows either way) and a synthetic loss over all anchors.  Returns the per-map slices the proposal
+        stage wants."""
+        torch = self.torch
+        rows = [m.features.shape[0] for m in rpn_maps]
+        o, r = self.head(torch.cat([m.features for m in rpn_maps], 0))
+        loss = o.square().mean() + r.square().mean()
+        A = o.shape[0] // max(sum(rows), 1)
+        return loss, list(o.split([v * A for v in rows])), list(r.split([v * A for v in rows]))
+
     def forward_backward(self, i, proposals=True, after_backward=None):
         import rpn_glue
         torch = self.torch
         locs, feats = self.batches[i % len(self.batches)]
         rpn_maps, _ = self.net([locs, feats])
-        loss, objs, regs = 0, [], []
-        for m in rpn_maps:
-            o, r = self.head(m.features)
-            objs.append(o)
-            regs.append(r)
-            loss = loss + o.square().mean() + r.square().mean()
+        loss, objs, regs = self.head_loss(rpn_maps)
         # The proposal stage reads only forward results.  It is a chain of small launches (one-workgroup NMS scan,
         # top-k, decode) with a few host reads of counts; enqueued on a side stream AFTER the backward pass has been
         # enqueued on the main one, it runs on otherwise idle CUs underneath the backward kernels and its host
@@ -469,6 +480,10 @@ def main():
     backend = os.environ.get("AABR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # one device per process: run Function.backward on the calling thread instead of handing every node to the
+    # autograd engine's device thread (a torch setting; saves the per-step thread hand-offs, ~1 ms of host time)
+    if os.environ.get("AABR_BENCH_AUTOGRAD_THREAD", "0") != "1":
+        torch.autograd.set_multithreading_enabled(False)
     if os.environ.get("AABR_BENCH_PIN", "1") != "0":
         pin_host_threads(torch, local)
     if world > 1:

@@ -15,6 +15,7 @@ fdt = torch.bfloat16 if (len(sys.argv) > 4 and sys.argv[4] == "bf16") else torch
 dev = "cuda:0"
 torch.manual_seed(0)
 net = default_fpn(feature_dtype=fdt).to(dev)
+net.compiled_graph = os.environ.get("AABR_COMPILED_GRAPH", "1") != "0"   # planExecutor (one launch list per pass)
 locs, feats = S.make_batch(bs, npts, 0, vs)
 l, f = torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev)
 

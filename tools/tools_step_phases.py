@@ -40,12 +40,7 @@ for i in range(steps):
     locs, feats = wl.batches[i % len(wl.batches)]
     rpn_maps, _ = wl.net([locs, feats])
     mark()
-    loss, objs, regs = 0, [], []
-    for m in rpn_maps:
-        o, r = wl.head(m.features)
-        objs.append(o)
-        regs.append(r)
-        loss = loss + o.square().mean() + r.square().mean()
+    loss, objs, regs = wl.head_loss(rpn_maps)
     ev_fwd = torch.cuda.Event()
     ev_fwd.record()
     mark()
