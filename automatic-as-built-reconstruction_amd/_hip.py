@@ -49,6 +49,7 @@ _SIGS = {
     "aabr_plan_run": (C.c_int, [_vp, _i32, _vp]),
     "aabr_add": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "aabr_cast_storage": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "aabr_sum_counts": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "aabr_conv_pack_job_blocks": (C.c_int64, [_i32, _i32, _i32]),
     "aabr_conv_pack_weights_jobs": (C.c_int, [_vp, _i32, _i64, _vp]),
     "aabr_conv_wpack_bf16_elems": (C.c_int64, [_i32, _i32, _i32]),

@@ -48,8 +48,49 @@ __global__ __launch_bounds__(256) void k_cast(const TI *__restrict__ in, TO *__r
   }
 }
 
+// rule totals of many rule books in one launch: job j sums n[j] int32 counts into the float64 slot out[j]
+struct SumJobs {
+  const int32_t *c[64];
+  int64_t n[64];
+  double *o[64];
+};
+
+__global__ __launch_bounds__(256) void k_sum_counts(SumJobs jobs) {
+  __shared__ long long red[256];
+  const int j = blockIdx.x;
+  const int32_t *c = jobs.c[j];
+  long long s = 0;
+  for (int64_t i = threadIdx.x; i < jobs.n[j]; i += 256) s += c[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *jobs.o[j] = (double)red[0];   // integer sum: exact and order-independent
+}
+
 } // namespace aabr
 using namespace aabr;
+
+extern "C" int aabr_sum_counts(const int32_t *const *counts_host, const int64_t *n_host, double *const *out_host,
+                               int n_jobs, void *stream_) {
+  AABR_CHECK_ARG(n_jobs >= 0 && (n_jobs == 0 || (counts_host && n_host && out_host)), "bad arguments");
+  for (int j0 = 0; j0 < n_jobs; j0 += 64) {
+    SumJobs jobs;
+    const int m = n_jobs - j0 < 64 ? n_jobs - j0 : 64;
+    for (int j = 0; j < m; ++j) {
+      AABR_CHECK_ARG(n_host[j0 + j] >= 0 && out_host[j0 + j] && (counts_host[j0 + j] || n_host[j0 + j] == 0),
+                     "bad job");
+      jobs.c[j] = counts_host[j0 + j];
+      jobs.n[j] = n_host[j0 + j];
+      jobs.o[j] = out_host[j0 + j];
+    }
+    hipLaunchKernelGGL(k_sum_counts, dim3((unsigned)m), dim3(256), 0, (hipStream_t)stream_, jobs);
+  }
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
 
 extern "C" int aabr_add(const void *a, const void *b, void *out, int64_t n, int bf16, void *stream_) {
   AABR_CHECK_ARG(n >= 0, "bad size");

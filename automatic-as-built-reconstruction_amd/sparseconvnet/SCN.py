@@ -9,6 +9,8 @@ pre-zeroed.  What differs by design: all grid state (hash tables, site lists, ru
 lives in HBM inside `Metadata_3`, nothing is rebuilt or copied per layer, and every kernel
 runs on the current PyTorch HIP stream.
 """
+import ctypes as C
+
 import torch
 
 import os
@@ -244,6 +246,26 @@ class _Gather(object):
         if self._host_counts is not None:
             return sum((c + cp - 1) // cp for c in self._host_counts)
         return bound
+
+
+def prefetch_totals(gathers):
+    """rule totals of many rule books with ONE launch (LazyMacs slots; `total_slot` otherwise costs one reduction
+    launch per rule book at its first use)"""
+    todo = [g for g in gathers if g is not None and g._total is None and g.counts is not None and g.rows > 0]
+    if not todo:
+        return
+    ring = _ring(todo[0].table.device)
+    es = ring.buf.element_size()
+    cs, ns, os_ = [], [], []
+    for g in todo:
+        gen, idx = ring.alloc()
+        g._total = (ring, gen, idx)
+        cs.append(g.counts.data_ptr())
+        ns.append(g.counts.numel())
+        os_.append(ring.buf.data_ptr() + idx * es)
+    n = len(todo)
+    check(_hip.load().aabr_sum_counts((C.c_void_p * n)(*cs), (C.c_int64 * n)(*ns), (C.c_void_p * n)(*os_), n,
+                                      stream()))
 
 
 class _Table(object):

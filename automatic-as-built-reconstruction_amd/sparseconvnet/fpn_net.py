@@ -138,6 +138,7 @@ class FPN_Net(torch.nn.Module):
         taken here, back to back on a nearly empty queue, instead of one in front of every down-sampling layer where
         each would wait for all the convolutions queued before it and leave the GPU idle while the host catches up.
         Same rule books, same cache keys (Metadata caches by (spatial, filter[, stride])): the layers find them."""
+        from . import SCN
         md = net.metadata
         if getattr(md, "_fpn_prebuilt", None) is not None:
             return md._fpn_prebuilt
@@ -158,6 +159,8 @@ class FPN_Net(torch.nn.Module):
             msz = sizes[nscale - 1 - scale_from_top]
             ks = torch.LongTensor([1, 1, int(self.rpn_map_sizes[i][2])])
             md.getRuleBook(msz, (msz - ks) // one + 1, ks, one)
+        if SCN.count_macs:      # rule totals of all books of the pass (the MAC counter's terms): one launch
+            SCN.prefetch_totals([tb.out for tb in list(md.submanifold.values()) + list(md.rulebooks.values())])
         md._fpn_prebuilt = sizes
         return sizes
 

@@ -4,25 +4,29 @@ convolution.py:29-90, deconvolution.py:16-87, batchNormalization.py:29-108, tabl
 
 Between the input layer and the returned feature maps FPN_Net (fpn_net.py:168-203) is a fixed dataflow graph of
 BatchNorm+LeakyReLU, submanifold / strided / transposed convolutions and residual adds over geometry that is
-known before the first feature row is computed.  `run_fpn` walks the SAME module objects once per pass with
-symbolic tensors (sizes, no data), turns every layer into one `AabrPlanOp` record of the library's own entry
-point -- the launch `SCN.py` would have made, same kernel, same arguments, same order -- and hands the list to
-`aabr_plan_run` in one call.  Activations live in one arena; the backward pass is generated the same way in
-reverse (input gradients, weight gradients, BatchNorm backward, gradient sums for tensors with several
-consumers in the order autograd would add them) and runs as a second list.  One autograd node stands for the
-whole graph; parameters, running statistics and state_dict are the modules' own.
+known before the first feature row is computed.  `run_fpn` turns every layer into one `AabrPlanOp` record of the
+library's own entry point -- the launch `SCN.py` would have made, same kernel, same arguments, same order -- and
+hands the list to `aabr_plan_run` in one call.  Activations live in one arena; the backward pass is a second list
+generated in reverse (input gradients, weight gradients, BatchNorm backward, gradient sums for tensors with
+several consumers in the order autograd would add them).  One autograd node stands for the whole graph;
+parameters, running statistics and state_dict are the modules' own.
 
-What it buys: the ~25 us of interpreter + autograd work per layer and direction leave the critical path (the
-4-scene training step of bench.py is host-bound without it in bf16).  What it does not do: change any number --
-`tests/test_gpu_fpn.py` holds it bit-equal to the module path.  Falls back (returns None) when a module of the
-graph carries hooks or is of a type it does not know."""
+Two stages, so that a pass costs little Python:
+  * `_Template` (once per network / input size / dtype / mode): walks the SAME module objects with symbolic
+    tensors and records the structure -- which buffer feeds which launch, plane counts, rule-book keys, parameter
+    and weight-pack addresses, the backward list and its gradient buffers;
+  * a pass fills in what the scene decides: rows per scale, rule-book streams, arena addresses.
+
+What it buys: the ~25 us of interpreter + autograd work per layer and direction leave the critical path.  What it
+does not do: change any number -- `tests/test_gpu_fpn.py` holds it bit-equal to the module path.  Falls back
+(returns None) when a module of the graph carries hooks or is of a type it does not know."""
 import struct
 
 import torch
 from torch.autograd import Function
 
 import _hip
-from _hip import ptr, stream, check
+from _hip import stream, check
 from . import SCN
 from .sparseConvNetTensor import SparseConvNetTensor
 from .sequential import Sequential
@@ -38,87 +42,84 @@ assert _OP.size == 176
 K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST = 1, 2, 3, 4, 5, 6, 7
 F_BF16, F_TO_BF16 = 1, 2
 _ALIGN = 256
-_Z6, _Z4, _Z12 = (0,) * 6, (0,) * 4, ((0, 0),) * 12
-ABS, FWD, GRAD, STAT, PGRAD = 0, 1, 2, 3, 4   # pointer spaces: absolute / arenas (resolved when the arena exists)
+BF16 = torch.bfloat16
 
-stats = {"passes": 0, "fallbacks": 0}
+stats = {"passes": 0, "fallbacks": 0, "templates": 0}
 
 
 class Unsupported(Exception):
     pass
 
 
-def _rec(kind, flags, i32=(), f32=(), i64=(), ps=()):
-    return (kind, flags, tuple(i32) + _Z6[len(i32):], tuple(f32) + _Z4[len(f32):], tuple(i64) + _Z4[len(i64):],
-            tuple(ps) + _Z12[len(ps):])
+def _es(dt):
+    return 2 if dt == BF16 else 4
 
 
-def _run(recs, bases):
-    if not recs:
-        return
-    buf = bytearray(len(recs) * 176)
-    off = 0
-    pack = _OP.pack_into
-    for kind, flags, i32, f32, i64, ps in recs:
-        pack(buf, off, kind, flags, *i32, *f32, *i64, *[bases[s] + o for s, o in ps])
-        off += 176
-    check(_hip.load().aabr_plan_run(bytes(buf), len(recs), stream()))
+def _dp(t):
+    return t.data_ptr() if t is not None else 0
 
 
-class _Bufs(object):
-    """bump allocation of [rows, planes] matrices in one arena (offsets first, memory when the total is known)"""
-
-    def __init__(self, space):
-        self.space, self.meta, self.total = space, [], 0
-
-    def new(self, rows, planes, dtype):
-        nbytes = rows * planes * (2 if dtype == torch.bfloat16 else 4)
-        self.meta.append((rows, planes, dtype, (self.space, self.total)))
-        self.total += (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
-        return len(self.meta) - 1
+# buffer references inside a backward list: (space, index); spaces resolved to address lists per pass
+F, G, E = 0, 1, 2      # forward arena (index 0 = the graph input) / gradient arena / external output gradients
 
 
-def _p(t):
-    """absolute pointer of a live tensor (None -> NULL)"""
-    return (ABS, ptr(t) or 0) if t is not None else (ABS, 0)
+class _Template(object):
+    """the structure of the graph, independent of the scene"""
 
-
-class _Pass(object):
-    """one forward pass through the graph (and the state its backward pass needs)"""
-
-    def __init__(self, net, metadata, dtype, x, x_spatial, train):
-        self.net, self.md, self.dtype, self.train = net, metadata, dtype, train
-        self.lib = _hip.load()
-        self.dev = x.device
-        self.bf = F_BF16 if dtype == torch.bfloat16 else 0
-        self.a = _Bufs(FWD)
-        self.ext = {}                      # forward buffer id -> external tensor (the graph input)
-        self.fops = []                     # symbolic forward ops, in the order the module path creates them
-        self.frecs = []
-        self.params = []                   # parameters in first-use order
-        self.pidx = {}
+    def __init__(self, net, x_spatial, x_planes, dtype, plan):
+        self.dtype = dtype
+        self.levels, self.lvl = [], {}
+        self.fbufs = []                      # (level, planes, dtype)
+        self.books, self.bidx = [], {}       # rule books: (kind, dict key, builder args)
+        self.fops = []
+        self.params, self.pidx = [], {}
         self.stat_floats = 0
-        self.dw_floats = 0
         self.bn_floats = 0
-        self.macs, self.hidden = [], 0
-        self.x = x
-        b = self.a.new(x.size(0), x.size(1), x.dtype)
-        self.a.meta[b] = self.a.meta[b][:3] + (_p(x),)
-        self.a.total = 0                   # the input is not in the arena
-        self.ext[b] = x
-        self.x_sym = (b, x_spatial)
+        self.hidden = []                     # (level, planes) of every convolution output (hidden-state counter)
+        self.macs = []                       # (book, weight) per convolution, in order
+        self.bns = []
+        self.packs = {id(w): (pf.data_ptr(), pt.data_ptr()) for w, (pf, pt) in zip(plan.weights, plan.packs)}
+        self.lib = _hip.load()
+        x = (self._new(self._level(x_spatial), x_planes, torch.float32), x_spatial)
+        xs = self.cast(x, dtype)
+        rpn, roi = _fpn_graph(net, self, xs)
+        self.n_rpn = len(rpn)
+        self.outs = [self.cast(t, torch.float32) for t in rpn] + [self.cast(t, torch.float32) for t in roi]
+        self._bwd = {}
+        stats["templates"] += 1
 
-    # ---- parameters --------------------------------------------------------------------------------------------
-    def param(self, p):
+    # ---- bookkeeping -------------------------------------------------------------------------------------------
+    def signature(self, plan):
+        return (plan.arena.data_ptr(), tuple(p.data_ptr() for p in self.params),
+                tuple(m.running_mean.data_ptr() for m in self.bns), tuple(m.running_var.data_ptr() for m in self.bns))
+
+    def _level(self, sp):
+        i = self.lvl.get(sp)
+        if i is None:
+            i = self.lvl[sp] = len(self.levels)
+            self.levels.append(sp)
+        return i
+
+    def _new(self, lvl, planes, dt):
+        self.fbufs.append((lvl, planes, dt))
+        return len(self.fbufs) - 1
+
+    def _param(self, p):
         i = self.pidx.get(id(p))
         if i is None:
             i = self.pidx[id(p)] = len(self.params)
             self.params.append(p)
         return i
 
+    def _book(self, kind, key, args):
+        i = self.bidx.get((kind, key))
+        if i is None:
+            i = self.bidx[(kind, key)] = len(self.books)
+            self.books.append((kind, key, args))
+        return i
+
     # ---- symbolic forward: one handler per module type ----------------------------------------------------------
     def run(self, m, x):
-        t = type(m)
         if isinstance(m, ConcatTable):
             return [self.run(c, x) for c in m._modules.values()]
         if isinstance(m, AddTable):
@@ -137,161 +138,98 @@ class _Pass(object):
             return self.conv(m, x)
         if isinstance(m, Deconvolution):
             return self.deconv(m, x)
-        raise Unsupported(t.__name__)
+        raise Unsupported(type(m).__name__)
 
     def add(self, xs):
         """left-to-right sum (utils._sum_features)"""
         acc = xs[0]
         for t in xs[1:]:
-            rows, planes, dt, _ = self.a.meta[acc[0]]
-            assert self.a.meta[t[0]][:3] == (rows, planes, dt) and t[1] == acc[1]
-            y = self.a.new(rows, planes, dt)
-            self.fops.append(("add", acc[0], t[0], y))
-            a_, b_, y_ = self.a.meta[acc[0]][3], self.a.meta[t[0]][3], self.a.meta[y][3]
-            self.frecs.append(_rec(K_ADD, self.bf if dt == torch.bfloat16 else 0, i64=(rows * planes,),
-                                   ps=(a_, b_, y_)))
+            lvl, planes, dt = self.fbufs[acc[0]]
+            assert self.fbufs[t[0]] == (lvl, planes, dt) and t[1] == acc[1]
+            y = self._new(lvl, planes, dt)
+            self.fops.append(("add", acc[0], t[0], y, lvl, planes, F_BF16 if dt == BF16 else 0))
             acc = (y, acc[1])
         return acc
 
     def cast(self, x, dtype):
-        rows, planes, dt, px = self.a.meta[x[0]]
+        lvl, planes, dt = self.fbufs[x[0]]
         if dt == dtype:
             return x
-        y = self.a.new(rows, planes, dtype)
-        self.fops.append(("cast", x[0], y))
-        self.frecs.append(_rec(K_CAST, F_TO_BF16 if dtype == torch.bfloat16 else 0, i64=(rows * planes,),
-                               ps=(px, self.a.meta[y][3])))
+        y = self._new(lvl, planes, dtype)
+        self.fops.append(("cast", x[0], y, lvl, planes, F_TO_BF16 if dtype == BF16 else 0))
         return (y, x[1])
 
     def bn(self, m, x):
-        if (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or
-                not (m.training or m.track_running_stats)):
-            raise Unsupported("BatchNormalization with hooks / batch statistics in evaluation mode")
-        rows, planes, dt, px = self.a.meta[x[0]]
+        if not (m.training or m.track_running_stats):
+            raise Unsupported("BatchNormalization on batch statistics in evaluation mode")
+        lvl, planes, dt = self.fbufs[x[0]]
         assert planes == m.nPlanes, (planes, m.nPlanes)
-        y = self.a.new(rows, planes, dt)
+        y = self._new(lvl, planes, dt)
         st = self.stat_floats
         self.stat_floats += 2 * planes
         w = m.weight if m.affine else None
         b = m.bias if m.affine else None
         if m.affine:
-            self.param(w)
-            self.param(b)
+            self._param(w)
+            self._param(b)
+        self.bns.append(m)
         self.bn_floats = max(self.bn_floats, int(self.lib.aabr_bn_scratch_floats(planes)))
-        self.fops.append(("bn", x[0], y, m, st))
-        if rows:
-            self.frecs.append(_rec(K_BNF, self.bf if dt == torch.bfloat16 else 0,
-                                   i32=(planes, 1 if m.training else 0), f32=(m.eps, m.momentum, m.leakiness),
-                                   i64=(rows,),
-                                   ps=(px, self.a.meta[y][3], (STAT, st * 4), (STAT, (st + planes) * 4),
-                                       _p(m.running_mean), _p(m.running_var), _p(w), _p(b), ("bn", 0))))
+        self.fops.append(("bn", x[0], y, lvl, planes, F_BF16 if dt == BF16 else 0, 1 if m.training else 0,
+                          float(m.eps), float(m.momentum), float(m.leakiness), st, _dp(m.running_mean),
+                          _dp(m.running_var), _dp(w), _dp(b), m))
         return (y, x[1])
 
-    def _conv_rec(self, src, rows_in, n_in, dst, rows_out, n_out, gather, weight, wpack, flags, dt):
-        """the launch SCN._conv_fwd makes for a prepacked weight"""
-        if rows_out == 0:
-            return None
-        bf = dt == torch.bfloat16
-        T = 0 if bf else self.lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, gather.vol)
-        if T:
-            return _rec(K_WIDE, 0, i32=(n_in, n_out, gather.vol, flags & 3, T), i64=(rows_in, rows_out),
-                        ps=(src, dst, _p(gather.blocks_wide(T)), (ABS, 0), (ABS, 0), _p(wpack)))
-        return _rec(K_CONV, F_BF16 if bf else 0, i32=(n_in, n_out, gather.vol, flags | 4), i64=(rows_in, rows_out),
-                    ps=(src, dst, _p(gather.blocks()), _p(weight), (ABS, 0), _p(wpack)))
-
-    def _conv_common(self, m, x, out_spatial, tb, g_fwd, rows_out, g_din, din_flags, g_dw):
-        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks:
-            raise Unsupported("convolution with hooks")
+    def _conv_common(self, m, x, out_spatial, book, side_fwd, side_din, din_flags, side_dw):
         if hasattr(m, "bias") or getattr(m, "groups", 1) != 1:
             raise Unsupported("convolution with bias / groups")
-        rows, planes, dt, px = self.a.meta[x[0]]
+        lvl, planes, dt = self.fbufs[x[0]]
         assert planes == m.nIn, (planes, m.nIn)
         w = m.weight
-        pk = getattr(w, "_aabr_pack", None)
-        if pk is None or pk[1] != dt or pk[0] != w._version:
+        if id(w) not in self.packs or not w.is_contiguous():
             raise Unsupported("weight packs missing (FPN_Net.prepack_weights)")
-        y = self.a.new(rows_out, m.nOut, dt)
-        self.param(w)
-        self.macs.append((tb, w))
-        self.hidden += rows_out * m.nOut
-        self.fops.append(("conv", x[0], y, m, g_din, din_flags, g_dw, pk[3]))
-        r = self._conv_rec(px, rows, m.nIn, self.a.meta[y][3], rows_out, m.nOut, g_fwd, w, pk[2], 0, dt)
-        if r is not None:
-            self.frecs.append(r)
+        lo = self._level(out_spatial)
+        y = self._new(lo, m.nOut, dt)
+        self._param(w)
+        self.macs.append((book, w))
+        self.hidden.append((lo, m.nOut))
+        pf, pt = self.packs[id(w)]
+        self.fops.append(("conv", x[0], y, lvl, lo, m.nIn, m.nOut, book, side_fwd, w.data_ptr(), pf,
+                          side_din, din_flags, side_dw, pt, m))
         return (y, out_spatial)
 
     def subm(self, m, x):
-        tb = self.md.getSubmanifoldRuleBook(x[1], m.filter_size)
-        return self._conv_common(m, x, x[1], tb, tb.out, tb.V_out, tb.out, 1 | 2, tb.out)
+        fs = SCN._key(m.filter_size)
+        book = self._book("s", x[1] + fs, (x[1], m.filter_size))
+        return self._conv_common(m, x, x[1], book, 0, 0, 1 | 2, 0)
 
     def conv(self, m, x):
         fs, st = SCN._key(m.filter_size), SCN._key(m.filter_stride)
         osz = tuple((i - f) // s + 1 for i, f, s in zip(x[1], fs, st))
         assert all((o - 1) * s + f == i for o, s, f, i in zip(osz, st, fs, x[1])), (x[1], osz, fs, st)
-        tb = self.md.getRuleBook(x[1], osz, m.filter_size, m.filter_stride)
-        return self._conv_common(m, x, osz, tb, tb.out, tb.V_out, tb.inn, 1, tb.out)
+        book = self._book("c", x[1] + fs + st, (x[1], osz, m.filter_size, m.filter_stride))
+        return self._conv_common(m, x, osz, book, 0, 1, 1, 0)
 
     def deconv(self, m, x):
         fs, st = SCN._key(m.filter_size), SCN._key(m.filter_stride)
         osz = tuple((i - 1) * s + f for i, f, s in zip(x[1], fs, st))
-        tb = self.md.getRuleBook(osz, x[1], m.filter_size, m.filter_stride)
-        return self._conv_common(m, x, osz, tb, tb.inn, tb.V_in, tb.out, 1, tb.inn)
+        book = self._book("c", osz + fs + st, (osz, x[1], m.filter_size, m.filter_stride))
+        return self._conv_common(m, x, osz, book, 1, 0, 1, 1)
 
-    # ---- execution ---------------------------------------------------------------------------------------------
-    def _workspaces(self):
-        ws = {}
-        if self.bn_floats:
-            ws["bn"] = ptr(_hip.workspace("bn", self.bn_floats, torch.float32, self.dev))
-        if self.dw_floats:
-            ws["dw"] = ptr(_hip.workspace("dw", self.dw_floats, torch.float32, self.dev))
-        return ws
+    # ---- the backward list for one pattern of incoming gradients -------------------------------------------------
+    def backward(self, pattern, need_dx):
+        key = (pattern, need_dx, tuple(p.requires_grad for p in self.params))
+        b = self._bwd.get(key)
+        if b is None:
+            b = self._bwd[key] = self._make_backward(pattern, need_dx)
+        return b
 
-    @staticmethod
-    def _resolve(recs, ws):
-        """workspace placeholders ("bn", 0) -> absolute pointers"""
-        out = []
-        for kind, flags, i32, f32, i64, ps in recs:
-            if kind in (K_BNF, K_BNB, K_DW):
-                ps = tuple((ABS, ws[s]) if isinstance(s, str) else (s, o) for s, o in ps)
-            out.append((kind, flags, i32, f32, i64, ps))
-        return out
+    def _make_backward(self, pattern, need_dx):
+        gbufs, ops, contrib = [], [], {}
+        poff, ptotal = {}, 0
 
-    def forward(self, outs):
-        """run the recorded forward launches; returns one tensor (an arena view) per entry of `outs`"""
-        self.arena = torch.empty(max(self.a.total, 1), dtype=torch.uint8, device=self.dev)
-        self.stat = torch.empty(max(self.stat_floats, 1), dtype=torch.float32, device=self.dev)
-        self.bases = {ABS: 0, FWD: self.arena.data_ptr(), STAT: self.stat.data_ptr()}
-        _run(self._resolve(self.frecs, self._workspaces()), self.bases)
-        self.frecs = None
-        res = []
-        for b, _ in outs:
-            rows, planes, dt, (space, off) = self.a.meta[b]
-            if b in self.ext:
-                res.append(self.ext[b].view(rows, planes))
-                continue
-            es = 2 if dt == torch.bfloat16 else 4
-            res.append(self.arena[off:off + rows * planes * es].view(dt).view(rows, planes))
-        self.outs = [b for b, _ in outs]
-        return res
-
-    def backward(self, gouts, need_dx):
-        """generate and run the backward launches; returns (d_x or None, [parameter gradient or None])"""
-        g = _Bufs(GRAD)
-        recs = []
-        contrib = {}
-        keep = []
-        for b, go in zip(self.outs, gouts):
-            if go is None:
-                continue
-            go = go.contiguous()
-            keep.append(go)
-            rows, planes, dt, _ = self.a.meta[b]
-            assert go.dtype == dt and go.numel() == rows * planes
-            k = g.new(rows, planes, dt)
-            g.meta[k] = g.meta[k][:3] + (_p(go),)
-            contrib.setdefault(b, []).append(k)
-        g.total = 0                        # external gradients are not in the arena
-        poff, ptotal, pgrad = {}, 0, [None] * len(self.params)
+        def gnew(lvl, planes, dt):
+            gbufs.append((lvl, planes, dt))
+            return (G, len(gbufs) - 1)
 
         def pslot(p):
             nonlocal ptotal
@@ -299,103 +237,240 @@ class _Pass(object):
             if i not in poff:
                 poff[i] = ptotal
                 ptotal += (p.numel() + 63) // 64 * 64
-            return (PGRAD, poff[i] * 4)
+            return poff[i] * 4
+
+        for k, ((b, _), has) in enumerate(zip(self.outs, pattern)):
+            if has:
+                contrib.setdefault(b, []).append((E, k))
 
         def total(b):
-            """sum of the gradient contributions of forward buffer b, in arrival order (autograd's order: the
+            """sum of the gradient contributions of forward buffer b in arrival order (autograd's order: the
             consumer created last delivers first); None when nothing flows back"""
             c = contrib.get(b)
             if not c:
                 return None
+            lvl, planes, dt = self.fbufs[b]
             acc = c[0]
             for nxt in c[1:]:
-                rows, planes, dt, _ = g.meta[acc]
-                s = g.new(rows, planes, dt)
-                recs.append(_rec(K_ADD, F_BF16 if dt == torch.bfloat16 else 0, i64=(rows * planes,),
-                                 ps=(g.meta[acc][3], g.meta[nxt][3], g.meta[s][3])))
+                s = gnew(lvl, planes, dt)
+                ops.append(("add", acc, nxt, s, lvl, planes, F_BF16 if dt == BF16 else 0))
                 acc = s
             return acc
 
-        dx = None
-        x0 = self.x_sym[0]
         for op in reversed(self.fops):
             kind = op[0]
             if kind == "add":
-                _, a_, b_, y = op
+                _, a_, b_, y, lvl, planes, flg = op
                 gy = total(y)
                 if gy is not None:       # same order as autograd's AddBackward: first operand, then second
                     contrib.setdefault(a_, []).append(gy)
                     contrib.setdefault(b_, []).append(gy)
             elif kind == "cast":
-                _, x, y = op
+                _, x, y, lvl, planes, flg = op
                 gy = total(y)
                 if gy is None:
                     continue
-                rows, planes, dt, px = self.a.meta[x]
-                gx = g.new(rows, planes, dt)
-                recs.append(_rec(K_CAST, F_TO_BF16 if dt == torch.bfloat16 else 0, i64=(rows * planes,),
-                                 ps=(g.meta[gy][3], g.meta[gx][3])))
+                dtx = self.fbufs[x][2]
+                gx = gnew(lvl, planes, dtx)
+                ops.append(("cast", gy, gx, lvl, planes, F_TO_BF16 if dtx == BF16 else 0))
                 contrib.setdefault(x, []).append(gx)
             elif kind == "bn":
-                _, x, y, m, st = op
+                _, x, y, lvl, planes, flg, train, eps, mom, leak, st, p_rm, p_rv, p_w, p_b, m = op
                 gy = total(y)
                 if gy is None:
                     continue
-                rows, planes, dt, px = self.a.meta[x]
-                gx = g.new(rows, planes, dt)
-                w = m.weight if m.affine else None
-                pw = pslot(m.weight) if m.affine and m.weight.requires_grad else (ABS, 0)
-                pb = pslot(m.bias) if m.affine and m.bias.requires_grad else (ABS, 0)
-                if rows:
-                    recs.append(_rec(K_BNB, F_BF16 if dt == torch.bfloat16 else 0, i32=(planes,),
-                                     f32=(0.0, 0.0, m.leakiness), i64=(rows,),
-                                     ps=(px, g.meta[gx][3], self.a.meta[y][3], g.meta[gy][3], (STAT, st * 4),
-                                         (STAT, (st + planes) * 4), _p(w), pw, pb, ("bn", 0))))
+                gx = gnew(lvl, planes, self.fbufs[x][2])
+                pw = pslot(m.weight) if m.affine and m.weight.requires_grad else -1
+                pb = pslot(m.bias) if m.affine and m.bias.requires_grad else -1
+                ops.append(("bn", x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb))
                 contrib.setdefault(x, []).append(gx)
             else:
-                _, x, y, m, g_din, din_flags, g_dw, wpack_t = op
+                _, x, y, lvl, lo, n_in, n_out, book, side_fwd, p_w, pf, side_din, din_flags, side_dw, pt, m = op
                 gy = total(y)
                 if gy is None:
                     continue
-                rows, planes, dt, px = self.a.meta[x]
-                rows_y = self.a.meta[y][0]
-                if x != x0 or need_dx:
-                    gx = g.new(rows, planes, dt)
-                    r = self._conv_rec(g.meta[gy][3], rows_y, m.nOut, g.meta[gx][3], rows, m.nIn, g_din, m.weight,
-                                       wpack_t, din_flags, dt)
-                    if r is not None:
-                        recs.append(r)
+                dt = self.fbufs[x][2]
+                flg = F_BF16 if dt == BF16 else 0
+                if x != 0 or need_dx:
+                    gx = gnew(lvl, n_in, dt)
+                    # the launch reads d_out (n_out planes) and writes d_in (n_in planes)
+                    ops.append(("din", gy, gx, lo, lvl, n_out, n_in, book, side_din, din_flags, p_w, pt, flg))
                     contrib.setdefault(x, []).append(gx)
                 if m.weight.requires_grad:
-                    mc = g_dw.max_chunks(m.nIn, m.nOut)
-                    self.dw_floats = max(self.dw_floats, int(self.lib.aabr_conv_dw_scratch_floats(mc, m.nIn, m.nOut)))
-                    recs.append(_rec(K_DW, F_BF16 if dt == torch.bfloat16 else 0, i32=(m.nIn, m.nOut, g_dw.vol),
-                                     i64=(rows_y, mc),
-                                     ps=(px, g.meta[gy][3], _p(g_dw.pairs()), pslot(m.weight), (ABS, 0), ("dw", 0))))
-        gx0 = total(x0) if need_dx else None
-        garena = torch.empty(max(g.total, 1), dtype=torch.uint8, device=self.dev)
-        gparams = torch.empty(max(ptotal, 1), dtype=torch.float32, device=self.dev)
-        bases = dict(self.bases)
-        bases[GRAD] = garena.data_ptr()
-        bases[PGRAD] = gparams.data_ptr()
-        _run(self._resolve(recs, self._workspaces()), bases)
-        for i, o in poff.items():
-            p = self.params[i]
+                    ops.append(("dw", x, gy, lo, n_in, n_out, book, side_dw, pslot(m.weight), flg))
+        gx0 = total(0) if need_dx else None
+        return {"gbufs": gbufs, "ops": ops, "poff": poff, "ptotal": ptotal, "gx0": gx0}
+
+
+def _offsets(bufs, V, first=0):
+    """arena offsets of [rows(level), planes] matrices; bufs[:first] are not in the arena"""
+    offs, total = [0] * len(bufs), 0
+    for i in range(first, len(bufs)):
+        lvl, planes, dt = bufs[i]
+        offs[i] = total
+        total += (V[lvl] * planes * (2 if dt == BF16 else 4) + _ALIGN - 1) // _ALIGN * _ALIGN
+    return offs, total
+
+
+class _Pass(object):
+    """one pass through the graph: the template bound to a scene"""
+
+    def __init__(self, tpl, md, x):
+        self.t, self.md, self.x = tpl, md, x
+        self.dev = x.device
+        self.lib = tpl.lib
+        self.V = V = [md.grids[sp].V for sp in tpl.levels]
+        assert V[tpl.fbufs[0][0]] == x.size(0)
+        # rule books of the pass (built by FPN_Net._prebuild_geometry; looked up by their cache keys)
+        bk = []
+        for kind, key, args in tpl.books:
+            tb = (md.submanifold if kind == "s" else md.rulebooks).get(key)
+            if tb is None:
+                tb = md.getSubmanifoldRuleBook(*args) if kind == "s" else md.getRuleBook(*args)
+            bk.append((tb.out, tb.inn if tb.inn is not None else tb.out, tb))
+        self.books = bk
+        self._wide = {}
+
+    def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf):
+        """the record of the launch SCN._conv_fwd makes for a prepacked weight; returns the new write offset"""
+        if rows_out == 0:
+            return off
+        T = 0
+        if not bf:
+            key = (n_in, n_out, rows_in, rows_out, gather.vol)
+            T = self._wide.get(key)
+            if T is None:
+                T = self._wide[key] = self.lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, gather.vol)
+        if T:
+            pack(buf, off, K_WIDE, 0, n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
+                 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), 0, 0, p_pack, 0, 0, 0, 0, 0, 0)
+        else:
+            pack(buf, off, K_CONV, F_BF16 if bf else 0, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,
+                 rows_in, rows_out, 0, 0, src, dst, gather.blocks().data_ptr(), p_w, 0, p_pack, 0, 0, 0, 0, 0, 0)
+        return off + 176
+
+    def forward(self):
+        t, V = self.t, self.V
+        offs, total = _offsets(t.fbufs, V, 1)
+        self.arena = torch.empty(max(total, 1), dtype=torch.uint8, device=self.dev)
+        self.stat = torch.empty(max(t.stat_floats, 1), dtype=torch.float32, device=self.dev)
+        base, sbase = self.arena.data_ptr(), self.stat.data_ptr()
+        A = self.A = [base + o for o in offs]
+        A[0] = self.x.data_ptr()
+        bnws = _hip.workspace("bn", t.bn_floats, torch.float32, self.dev).data_ptr() if t.bn_floats else 0
+        buf = bytearray(len(t.fops) * 176)
+        pack, off = _OP.pack_into, 0
+        books = self.books
+        fbufs = t.fbufs
+        for op in t.fops:
+            kind = op[0]
+            if kind == "conv":
+                x, y, lvl, lo, n_in, n_out, book, side, p_w, pf = op[1:11]
+                off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[y], V[lo], n_out, books[book][side], p_w,
+                                       pf, 0, fbufs[x][2] == BF16)
+            elif kind == "bn":
+                _, x, y, lvl, planes, flg, train, eps, mom, leak, st, p_rm, p_rv, p_w, p_b, m = op
+                if V[lvl]:
+                    pack(buf, off, K_BNF, flg, planes, train, 0, 0, 0, 0, eps, mom, leak, 0.0, V[lvl], 0, 0, 0,
+                         A[x], A[y], sbase + st * 4, sbase + (st + planes) * 4, p_rm, p_rv, p_w, p_b, bnws, 0, 0, 0)
+                    off += 176
+            elif kind == "add":
+                _, a_, b_, y, lvl, planes, flg = op
+                pack(buf, off, K_ADD, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
+                     A[a_], A[b_], A[y], 0, 0, 0, 0, 0, 0, 0, 0, 0)
+                off += 176
+            else:
+                _, x, y, lvl, planes, flg = op
+                pack(buf, off, K_CAST, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
+                     A[x], A[y], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+                off += 176
+        if off:
+            check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, stream()))
+        res = []
+        for b, _ in t.outs:
+            lvl, planes, dt = fbufs[b]
+            n = V[lvl] * planes * _es(dt)
+            res.append(self.arena[offs[b]:offs[b] + n].view(dt).view(V[lvl], planes))
+        return res
+
+    def backward(self, gouts, need_dx):
+        t, V, A = self.t, self.V, self.A
+        gouts = [g.contiguous() if g is not None else None for g in gouts]
+        bw = t.backward(tuple(g is not None for g in gouts), need_dx)
+        gbufs, bops = bw["gbufs"], bw["ops"]
+        offs, total = _offsets(gbufs, V)
+        garena = torch.empty(max(total, 1), dtype=torch.uint8, device=self.dev)
+        gparams = torch.empty(max(bw["ptotal"], 1), dtype=torch.float32, device=self.dev)
+        gbase, pbase, sbase = garena.data_ptr(), gparams.data_ptr(), self.stat.data_ptr()
+        AD = (A, [gbase + o for o in offs], [_dp(g) for g in gouts])
+        for (b, _), g in zip(t.outs, gouts):
+            if g is not None:
+                lvl, planes, dt = t.fbufs[b]
+                assert g.dtype == dt and g.numel() == V[lvl] * planes
+        books = self.books
+        # weight-gradient scratch: the largest of the pass
+        dws, dwmc = 0, []
+        for op in bops:
+            if op[0] == "dw":
+                mc = books[op[6]][op[7]].max_chunks(op[4], op[5])
+                dwmc.append(mc)
+                dws = max(dws, mc * op[4] * op[5])
+        dwmc.reverse()
+        dwws = _hip.workspace("dw", dws, torch.float32, self.dev).data_ptr() if dws else 0
+        bnws = _hip.workspace("bn", t.bn_floats, torch.float32, self.dev).data_ptr() if t.bn_floats else 0
+        buf = bytearray(len(bops) * 176)
+        pack, off = _OP.pack_into, 0
+        for op in bops:
+            kind = op[0]
+            if kind == "din":
+                _, gy, gx, lo, lvl, n_in, n_out, book, side, flags, p_w, pt, flg = op
+                off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl], n_out,
+                                       books[book][side], p_w, pt, flags, flg == F_BF16)
+            elif kind == "dw":
+                _, x, gy, lo, n_in, n_out, book, side, pg, flg = op
+                g = books[book][side]
+                pack(buf, off, K_DW, flg, n_in, n_out, g.vol, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lo], dwmc.pop(), 0, 0,
+                     A[x], AD[gy[0]][gy[1]], g.pairs().data_ptr(), pbase + pg, 0, dwws, 0, 0, 0, 0, 0, 0)
+                off += 176
+            elif kind == "bn":
+                _, x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb = op
+                if V[lvl]:
+                    pack(buf, off, K_BNB, flg, planes, 0, 0, 0, 0, 0, 0.0, 0.0, leak, 0.0, V[lvl], 0, 0, 0,
+                         A[x], AD[gx[0]][gx[1]], A[y], AD[gy[0]][gy[1]], sbase + st * 4, sbase + (st + planes) * 4,
+                         p_w, pbase + pw if pw >= 0 else 0, pbase + pb if pb >= 0 else 0, bnws, 0, 0)
+                    off += 176
+            elif kind == "add":
+                _, a_, b_, s, lvl, planes, flg = op
+                pack(buf, off, K_ADD, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
+                     AD[a_[0]][a_[1]], AD[b_[0]][b_[1]], AD[s[0]][s[1]], 0, 0, 0, 0, 0, 0, 0, 0, 0)
+                off += 176
+            else:
+                _, gy, gx, lvl, planes, flg = op
+                pack(buf, off, K_CAST, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
+                     AD[gy[0]][gy[1]], AD[gx[0]][gx[1]], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+                off += 176
+        if off:
+            check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, stream()))
+        pgrad = [None] * len(t.params)
+        for i, o in bw["poff"].items():
+            p = t.params[i]
             pgrad[i] = gparams[o:o + p.numel()].view_as(p)
+        dx = None
+        gx0 = bw["gx0"]
         if gx0 is not None:
-            rows, planes, dt, (space, off) = g.meta[gx0]
-            es = 2 if dt == torch.bfloat16 else 4
-            if space == GRAD:
-                dx = garena[off:off + rows * planes * es].view(dt).view(rows, planes)
+            lvl, planes, dt = t.fbufs[0]
+            if gx0[0] == G:
+                o = offs[gx0[1]]
+                dx = garena[o:o + V[lvl] * planes * _es(dt)].view(dt).view(V[lvl], planes)
             else:   # the graph input reached an output untouched: its gradient is the incoming one
-                dx = [t for t in keep if t.data_ptr() == off][0]
+                dx = gouts[gx0[1]]
         return dx, pgrad
 
 
 class _GraphFunction(Function):
     @staticmethod
-    def forward(ctx, ps, outs, x, *params):
-        res = ps.forward(outs)
+    def forward(ctx, ps, x, *params):
+        res = ps.forward()
         ctx.ps = ps
         ctx.need_dx = x.requires_grad
         return tuple(res)
@@ -404,7 +479,7 @@ class _GraphFunction(Function):
     def backward(ctx, *gouts):
         ps, ctx.ps = ctx.ps, None
         dx, pgrad = ps.backward(gouts, ctx.need_dx)
-        return (None, None, dx) + tuple(pgrad)
+        return (None, dx) + tuple(pgrad)
 
 
 def _fpn_graph(net, ps, x):
@@ -432,43 +507,60 @@ def _fpn_graph(net, ps, x):
     return rpn, roi
 
 
+def _template(net, x_spatial, x_planes, plan):
+    """the cached template of this network state (rebuilt when a mode flag, a parameter address, the weight-pack
+    arena or the set of hooks changes)"""
+    mods = net.__dict__.get("_graph_modules")
+    if mods is None:
+        mods = net.__dict__["_graph_modules"] = list(net.modules())
+    mode = 0
+    for m in mods:                 # any hook anywhere in the graph: the modules themselves must run
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+            raise Unsupported("hooks")
+        mode = mode * 2 + (1 if m.training else 0)
+    cache = net.__dict__.setdefault("_graph_templates", {})
+    key = (x_spatial, x_planes, net.feature_dtype, mode)
+    tpl = cache.get(key)
+    if tpl is not None and tpl.sig == tpl.signature(plan):
+        return tpl
+    tpl = _Template(net, x_spatial, x_planes, net.feature_dtype, plan)
+    tpl.sig = tpl.signature(plan)
+    if len(cache) > 8:
+        cache.clear()
+    cache[key] = tpl
+    return tpl
+
+
 def run_fpn(net, net1):
     """FPN_Net.forward after layers_in: (rpn_maps, roi_maps) as SparseConvNetTensors, or None when the graph
     holds something the executor does not handle (the caller then runs the modules)."""
+    import sparseconvnet
     x = net1.features
-    if x.dim() != 2 or x.size(0) == 0 or x.dtype != torch.float32:
+    plan = net.__dict__.get("_pack_plan")
+    if x.dim() != 2 or x.size(0) == 0 or x.dtype != torch.float32 or not x.is_contiguous() or plan is None or \
+            plan.dtype != net.feature_dtype or plan._ptrs is None:
         return None
-    for m in net.modules():        # any hook anywhere in the graph: the modules themselves must run
-        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
-            stats["fallbacks"] += 1
-            return None
-    train = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in net.parameters()))
     try:
-        ps = _Pass(net, net1.metadata, net.feature_dtype, x, SCN._key(net1.spatial_size), train)
-        xs = ps.cast(ps.x_sym, net.feature_dtype)
-        rpn, roi = _fpn_graph(net, ps, xs)
-        rpn = [ps.cast(t, torch.float32) for t in rpn]
-        roi = [ps.cast(t, torch.float32) for t in roi]
+        tpl = _template(net, SCN._key(net1.spatial_size), x.size(1), plan)
     except Unsupported:
         stats["fallbacks"] += 1
         return None
-    outs = rpn + roi
-    import sparseconvnet
-    for tb, w in ps.macs:
-        sparseconvnet.forward_pass_multiplyAdd_count += SCN._macs(tb, w)
-    sparseconvnet.forward_pass_hidden_states += ps.hidden
-    ps.macs = None
+    train = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in tpl.params))
+    ps = _Pass(tpl, net1.metadata, x)
+    if SCN.count_macs:
+        for book, w in tpl.macs:
+            sparseconvnet.forward_pass_multiplyAdd_count += SCN._macs(ps.books[book][2], w)
+    sparseconvnet.forward_pass_hidden_states += sum(ps.V[lvl] * planes for lvl, planes in tpl.hidden)
     if train:
-        feats = _GraphFunction.apply(ps, outs, x, *ps.params)
+        feats = _GraphFunction.apply(ps, x, *tpl.params)
     else:
-        feats = ps.forward(outs)
-        ps.fops = None
+        feats = ps.forward()
     stats["passes"] += 1
     res = []
-    for (b, sp), f in zip(outs, feats):
+    for (b, sp), f in zip(tpl.outs, feats):
         t = SparseConvNetTensor()
         t.metadata = net1.metadata
         t.spatial_size = torch.LongTensor(list(sp))
         t.features = f
         res.append(t)
-    return res[:len(rpn)], res[len(rpn):]
+    return res[:tpl.n_rpn], res[tpl.n_rpn:]

@@ -302,6 +302,12 @@ int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *stream);
  * reference: AddTable, tables.py:27-41) as plan records.                                           */
 int aabr_add(const void *a, const void *b, void *out, int64_t n, int bf16, void *stream);
 int aabr_cast_storage(const void *in, void *out, int64_t n, int to_bf16, void *stream);
+/* out_host[j][0] = sum of the n_host[j] int32 values at counts_host[j], for n_jobs rule books in one launch (the
+ * host arrays hold DEVICE pointers).  The reference returns the rule total of a layer from host memory
+ * (`forward_pass_multiplyAdd_count`, submanifoldConvolution.py:85-94); here the per-block rule counts live on the
+ * device and the totals are kept there until somebody reads the counter.                             */
+int aabr_sum_counts(const int32_t *const *counts_host, const int64_t *n_host, double *const *out_host, int n_jobs,
+                    void *stream);
 
 /* ---- rotated IoU / NMS ---------------------------------------------------------------------
  * iou[n,k] = devRotateIoUEval(query k, box n, criterion), then forced to 1 where the five
