@@ -12,6 +12,7 @@
 // Also the two elementwise launches such a plan needs that the layer API gets from torch: residual add and the
 // fp32 <-> bf16 storage casts (round-to-nearest-even, as torch's `.to(torch.bfloat16)`).
 #include "common.h"
+#include <vector>
 
 namespace aabr {
 
@@ -130,13 +131,46 @@ extern "C" int aabr_cast_storage(const void *in, void *out, int64_t n, int to_bf
 // One record = one library call; the field use per kind is listed in include/aabr_hip.h (AabrPlanOp).
 static_assert(sizeof(AabrPlanOp) == 176, "AabrPlanOp layout is part of the C ABI");
 
-extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st) {
+// Records flagged AABR_PLAN_SIDE run on a second stream of the library's own: they start once everything recorded
+// before them on the caller's stream is done (one event each) and the caller's stream waits for all of them before
+// aabr_plan_run returns control of it.  Meant for launches whose results nothing later in the list reads (the
+// weight gradients of a backward pass): they fill the CUs that the tails and the small launches of the main chain
+// leave idle.  Same kernels on the same operands: the results do not depend on the interleaving.
+namespace {
+struct SideStream {
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;
+  hipEvent_t get(size_t k) {
+    while (events.size() <= k) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      events.push_back(e);
+    }
+    return events[k];
+  }
+};
+thread_local SideStream g_side;
+} // namespace
+
+extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
   AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
+  hipStream_t main_stream = (hipStream_t)st_;
+  size_t n_side = 0;
   for (int j = 0; j < n_ops; ++j) {
     const AabrPlanOp &o = ops[j];
     const bool bf = (o.flags & AABR_PLAN_BF16) != 0;
     void *const *p = o.p;
     int rc = AABR_OK;
+    void *st = st_;
+    if (o.flags & AABR_PLAN_SIDE) {
+      if (!g_side.stream) AABR_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+      hipEvent_t e = g_side.get(n_side + 1);            // slot 0 is the join event
+      AABR_CHECK_ARG(e != nullptr, "event creation failed");
+      AABR_CHECK_HIP(hipEventRecord(e, main_stream));
+      AABR_CHECK_HIP(hipStreamWaitEvent(g_side.stream, e, 0));
+      ++n_side;
+      st = (void *)g_side.stream;
+    }
     switch (o.kind) {
     case AABR_PLAN_CONV:
       rc = bf ? aabr_conv_forward_bf16((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1], o.i64[1],
@@ -186,7 +220,16 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st) {
       aabr::set_error("aabr_plan_run: op %d has unknown kind %d", j, o.kind);
       return AABR_EINVAL;
     }
-    if (rc != AABR_OK) return rc;   // the failing entry point has set the error text
+    if (rc != AABR_OK) {            // the failing entry point has set the error text; never leave the side stream unjoined
+      if (n_side) hipStreamSynchronize(g_side.stream);
+      return rc;
+    }
+  }
+  if (n_side) {
+    hipEvent_t e = g_side.get(0);
+    AABR_CHECK_ARG(e != nullptr, "event creation failed");
+    AABR_CHECK_HIP(hipEventRecord(e, g_side.stream));
+    AABR_CHECK_HIP(hipStreamWaitEvent(main_stream, e, 0));
   }
   return AABR_OK;
 }

@@ -40,11 +40,15 @@ from .deconvolution import Deconvolution
 _OP = struct.Struct("<ii6i4f4q12Q")          # AabrPlanOp (include/aabr_hip.h)
 assert _OP.size == 176
 K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST = 1, 2, 3, 4, 5, 6, 7
-F_BF16, F_TO_BF16 = 1, 2
+F_BF16, F_TO_BF16, F_SIDE = 1, 2, 4
 _ALIGN = 256
 BF16 = torch.bfloat16
 
 stats = {"passes": 0, "fallbacks": 0, "templates": 0}
+# weight gradients on the library's second stream (nothing later in a backward list reads them): they fill the CUs
+# the tails and small launches of the input-gradient chain leave idle
+import os  # noqa: E402
+dw_side_stream = os.environ.get("AABR_PLAN_DW_SIDE", "1") != "0"
 
 
 class Unsupported(Exception):
@@ -420,6 +424,7 @@ class _Pass(object):
         bnws = _hip.workspace("bn", t.bn_floats, torch.float32, self.dev).data_ptr() if t.bn_floats else 0
         buf = bytearray(len(bops) * 176)
         pack, off = _OP.pack_into, 0
+        dw_side = F_SIDE if dw_side_stream else 0
         for op in bops:
             kind = op[0]
             if kind == "din":
@@ -429,7 +434,7 @@ class _Pass(object):
             elif kind == "dw":
                 _, x, gy, lo, n_in, n_out, book, side, pg, flg = op
                 g = books[book][side]
-                pack(buf, off, K_DW, flg, n_in, n_out, g.vol, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lo], dwmc.pop(), 0, 0,
+                pack(buf, off, K_DW, flg | dw_side, n_in, n_out, g.vol, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lo], dwmc.pop(), 0, 0,
                      A[x], AD[gy[0]][gy[1]], g.pairs().data_ptr(), pbase + pg, 0, dwws, 0, 0, 0, 0, 0, 0)
                 off += 176
             elif kind == "bn":
