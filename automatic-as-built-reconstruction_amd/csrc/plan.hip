@@ -133,9 +133,10 @@ static_assert(sizeof(AabrPlanOp) == 176, "AabrPlanOp layout is part of the C ABI
 
 // Records flagged AABR_PLAN_SIDE run on a second stream of the library's own: they start once everything recorded
 // before them on the caller's stream is done (one event each) and the caller's stream waits for all of them before
-// aabr_plan_run returns control of it.  Meant for launches whose results nothing later in the list reads (the
-// weight gradients of a backward pass): they fill the CUs that the tails and the small launches of the main chain
-// leave idle.  Same kernels on the same operands: the results do not depend on the interleaving.
+// aabr_plan_run returns control of it -- or earlier, in front of a record flagged AABR_PLAN_JOIN (the first reader
+// of what they produce).  Meant for launches nothing (or nothing soon) in the list reads: the weight gradients of a
+// backward pass, the lateral branches of a forward pass.  They fill the CUs that the tails and the small launches
+// of the main chain leave idle.  Same kernels on the same operands: the results do not depend on the interleaving.
 namespace {
 struct SideStream {
   hipStream_t stream = nullptr;
@@ -155,20 +156,27 @@ thread_local SideStream g_side;
 extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
   AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
   hipStream_t main_stream = (hipStream_t)st_;
-  size_t n_side = 0;
+  size_t n_events = 0, n_pending = 0;   // events used by this call / side launches not yet joined
   for (int j = 0; j < n_ops; ++j) {
     const AabrPlanOp &o = ops[j];
     const bool bf = (o.flags & AABR_PLAN_BF16) != 0;
     void *const *p = o.p;
     int rc = AABR_OK;
     void *st = st_;
+    if ((o.flags & AABR_PLAN_JOIN) && n_pending) {      // this record reads what the side stream produced
+      hipEvent_t e = g_side.get(n_events++);
+      AABR_CHECK_ARG(e != nullptr, "event creation failed");
+      AABR_CHECK_HIP(hipEventRecord(e, g_side.stream));
+      AABR_CHECK_HIP(hipStreamWaitEvent(main_stream, e, 0));
+      n_pending = 0;
+    }
     if (o.flags & AABR_PLAN_SIDE) {
       if (!g_side.stream) AABR_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
-      hipEvent_t e = g_side.get(n_side + 1);            // slot 0 is the join event
+      hipEvent_t e = g_side.get(n_events++);
       AABR_CHECK_ARG(e != nullptr, "event creation failed");
       AABR_CHECK_HIP(hipEventRecord(e, main_stream));
       AABR_CHECK_HIP(hipStreamWaitEvent(g_side.stream, e, 0));
-      ++n_side;
+      ++n_pending;
       st = (void *)g_side.stream;
     }
     switch (o.kind) {
@@ -221,12 +229,12 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
       return AABR_EINVAL;
     }
     if (rc != AABR_OK) {            // the failing entry point has set the error text; never leave the side stream unjoined
-      if (n_side) hipStreamSynchronize(g_side.stream);
+      if (n_pending) hipStreamSynchronize(g_side.stream);
       return rc;
     }
   }
-  if (n_side) {
-    hipEvent_t e = g_side.get(0);
+  if (n_pending) {
+    hipEvent_t e = g_side.get(n_events++);
     AABR_CHECK_ARG(e != nullptr, "event creation failed");
     AABR_CHECK_HIP(hipEventRecord(e, g_side.stream));
     AABR_CHECK_HIP(hipStreamWaitEvent(main_stream, e, 0));

@@ -40,7 +40,7 @@ from .deconvolution import Deconvolution
 _OP = struct.Struct("<ii6i4f4q12Q")          # AabrPlanOp (include/aabr_hip.h)
 assert _OP.size == 176
 K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST = 1, 2, 3, 4, 5, 6, 7
-F_BF16, F_TO_BF16, F_SIDE = 1, 2, 4
+F_BF16, F_TO_BF16, F_SIDE, F_JOIN = 1, 2, 4, 8
 _ALIGN = 256
 BF16 = torch.bfloat16
 
@@ -49,6 +49,10 @@ stats = {"passes": 0, "fallbacks": 0, "templates": 0}
 # the tails and small launches of the input-gradient chain leave idle
 import os  # noqa: E402
 dw_side_stream = os.environ.get("AABR_PLAN_DW_SIDE", "1") != "0"
+# the lateral 1x1x1 convolutions of the FPN (they read a down-path map long before the up path needs them) can go
+# there too (AABR_PLAN_JOIN in front of their reader); measured on the bench step: 14.65 -> 14.60 ms, inside the
+# noise, so off by default
+lateral_side_stream = os.environ.get("AABR_PLAN_LATERAL_SIDE", "0") != "0"
 
 
 class Unsupported(Exception):
@@ -82,6 +86,7 @@ class _Template(object):
         self.hidden = []                     # (level, planes) of every convolution output (hidden-state counter)
         self.macs = []                       # (book, weight) per convolution, in order
         self.bns = []
+        self.branches = []
         self.packs = {id(w): (pf.data_ptr(), pt.data_ptr()) for w, (pf, pt) in zip(plan.weights, plan.packs)}
         self.lib = _hip.load()
         x = (self._new(self._level(x_spatial), x_planes, torch.float32), x_spatial)
@@ -90,7 +95,35 @@ class _Template(object):
         self.n_rpn = len(rpn)
         self.outs = [self.cast(t, torch.float32) for t in rpn] + [self.cast(t, torch.float32) for t in roi]
         self._bwd = {}
+        # forward emission order: a lateral branch (ops that depend on one earlier buffer only) is issued right after
+        # that buffer's producer, on the second stream; its first reader joins
+        self.emit = self._emission()
         stats["templates"] += 1
+
+    def branch(self, start, after_buf):
+        """ops fops[start:] so far form a branch that reads only `after_buf`; the NEXT op traced is its reader"""
+        self.branches.append((start, len(self.fops), after_buf))
+
+    def _emission(self):
+        order = [(i, 0) for i in range(len(self.fops))]
+        if not (lateral_side_stream and self.branches):
+            return [(self.fops[i], f) for i, f in order]
+        moved, joins, after = set(), set(), {}
+        for start, end, buf in self.branches:
+            prod = [i for i, op in enumerate(self.fops) if _out_of(op) == buf]
+            if len(prod) != 1 or prod[0] >= start or end >= len(self.fops):
+                continue
+            moved.update(range(start, end))
+            joins.add(end)
+            after.setdefault(prod[0], []).extend(range(start, end))
+        out = []
+        for i in range(len(self.fops)):
+            if i in moved:
+                continue
+            out.append((self.fops[i], F_JOIN if i in joins else 0))
+            for j in after.get(i, ()):
+                out.append((self.fops[j], F_SIDE))
+        return out
 
     # ---- bookkeeping -------------------------------------------------------------------------------------------
     def signature(self, plan):
@@ -306,6 +339,10 @@ class _Template(object):
         return {"gbufs": gbufs, "ops": ops, "poff": poff, "ptotal": ptotal, "gx0": gx0}
 
 
+def _out_of(op):
+    return op[3] if op[0] == "add" else op[2]
+
+
 def _offsets(bufs, V, first=0):
     """arena offsets of [rows(level), planes] matrices; bufs[:first] are not in the arena"""
     offs, total = [0] * len(bufs), 0
@@ -335,7 +372,8 @@ class _Pass(object):
         self.books = bk
         self._wide = {}
 
-    def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf):
+    def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf,
+                    xf=0):
         """the record of the launch SCN._conv_fwd makes for a prepacked weight; returns the new write offset"""
         if rows_out == 0:
             return off
@@ -346,10 +384,10 @@ class _Pass(object):
             if T is None:
                 T = self._wide[key] = self.lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, gather.vol)
         if T:
-            pack(buf, off, K_WIDE, 0, n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
+            pack(buf, off, K_WIDE, xf, n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
                  0, 0, src, dst, gather.blocks_wide(T).data_ptr(), 0, 0, p_pack, 0, 0, 0, 0, 0, 0)
         else:
-            pack(buf, off, K_CONV, F_BF16 if bf else 0, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,
+            pack(buf, off, K_CONV, (F_BF16 if bf else 0) | xf, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,
                  rows_in, rows_out, 0, 0, src, dst, gather.blocks().data_ptr(), p_w, 0, p_pack, 0, 0, 0, 0, 0, 0)
         return off + 176
 
@@ -366,26 +404,26 @@ class _Pass(object):
         pack, off = _OP.pack_into, 0
         books = self.books
         fbufs = t.fbufs
-        for op in t.fops:
+        for op, xf in t.emit:
             kind = op[0]
             if kind == "conv":
                 x, y, lvl, lo, n_in, n_out, book, side, p_w, pf = op[1:11]
                 off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[y], V[lo], n_out, books[book][side], p_w,
-                                       pf, 0, fbufs[x][2] == BF16)
+                                       pf, 0, fbufs[x][2] == BF16, xf)
             elif kind == "bn":
                 _, x, y, lvl, planes, flg, train, eps, mom, leak, st, p_rm, p_rv, p_w, p_b, m = op
                 if V[lvl]:
-                    pack(buf, off, K_BNF, flg, planes, train, 0, 0, 0, 0, eps, mom, leak, 0.0, V[lvl], 0, 0, 0,
+                    pack(buf, off, K_BNF, flg | xf, planes, train, 0, 0, 0, 0, eps, mom, leak, 0.0, V[lvl], 0, 0, 0,
                          A[x], A[y], sbase + st * 4, sbase + (st + planes) * 4, p_rm, p_rv, p_w, p_b, bnws, 0, 0, 0)
                     off += 176
             elif kind == "add":
                 _, a_, b_, y, lvl, planes, flg = op
-                pack(buf, off, K_ADD, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
+                pack(buf, off, K_ADD, flg | xf, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
                      A[a_], A[b_], A[y], 0, 0, 0, 0, 0, 0, 0, 0, 0)
                 off += 176
             else:
                 _, x, y, lvl, planes, flg = op
-                pack(buf, off, K_CAST, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
+                pack(buf, off, K_CAST, flg | xf, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
                      A[x], A[y], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
                 off += 176
         if off:
@@ -499,7 +537,9 @@ def _fpn_graph(net, ps, x):
     for k in range(n - 1):
         j = n - 1 - k - 1
         x = ps.run(net.m_ups[k], x)
+        mark = len(ps.fops)
         sc = ps.run(net.m_shortcuts[j], downs[j])
+        ps.branch(mark, downs[j][0])
         x = ps.add([x, sc])
         ups.append(ps.run(net.m_mergeds[k], x))
     rpn3d = [ups[i] for i in net.fpn_scales_from_top]

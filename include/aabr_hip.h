@@ -289,6 +289,7 @@ int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *ou
 #define AABR_PLAN_CAST 7
 #define AABR_PLAN_BF16 1
 #define AABR_PLAN_TO_BF16 2
+#define AABR_PLAN_JOIN 8 /* the caller's stream waits for the second stream in front of this record */
 #define AABR_PLAN_SIDE 4 /* run this record on the library's second stream: it starts after everything recorded
                             before it, and the caller's stream waits for it before aabr_plan_run returns it */
 typedef struct AabrPlanOp {
