@@ -63,10 +63,10 @@ _SIGS = {
     "aabr_bn_scratch_floats": (C.c_int64, [_i32]),
     "aabr_bn_forward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32,
                                   _vp, _vp]),
-    "aabr_bn_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
+    "aabr_bn_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
     "aabr_bn_forward_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32,
                                        _vp, _vp]),
-    "aabr_bn_backward_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp,
+    "aabr_bn_backward_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp,
                                         _vp]),
     "aabr_rotate_iou_eval": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp]),
     "aabr_boxes_iou_3d": (C.c_int, [_vp, _i64, _vp, _i64, _f32p, _i32, _i32, _vp, _vp]),

@@ -42,7 +42,10 @@ template <int MODE, int VEC, typename T>
 __global__ __launch_bounds__(256) void k_bn_partials(const T *__restrict__ x, const T *__restrict__ out,
                                                      const T *__restrict__ d_out,
                                                      const float *__restrict__ mean, float leak, int64_t rows,
-                                                     int planes, double *__restrict__ part) {
+                                                     int planes, double *__restrict__ part,
+                                                     const float *__restrict__ invstd = nullptr,
+                                                     const float *__restrict__ weight = nullptr,
+                                                     const float *__restrict__ bias = nullptr, int recompute = 0) {
   __shared__ double ra[256][VEC], rb[256][VEC];
   const int pv = planes / VEC;                 // vector columns
   const int tpr = pv < 256 ? pv : 256;         // threads per row
@@ -54,9 +57,17 @@ __global__ __launch_bounds__(256) void k_bn_partials(const T *__restrict__ x, co
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { a[j] = 0.0; b[j] = 0.0; }
     if (cv < pv && ty < rpi) {
-      float mu[VEC];
+      float mu[VEC], wc[VEC], bc[VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) mu[j] = (MODE == 1) ? mean[cv * VEC + j] : 0.0f;
+      for (int j = 0; j < VEC; ++j) {
+        mu[j] = (MODE == 1) ? mean[cv * VEC + j] : 0.0f;
+        wc[j] = bc[j] = 0.0f;
+        if (MODE == 1 && recompute) { // the forward pass's affine coefficients, from the same floats by the same operations
+          const int p = cv * VEC + j;
+          wc[j] = invstd[p] * (weight ? weight[p] : 1.0f);
+          bc[j] = -mu[j] * wc[j] + (bias ? bias[p] : 0.0f);
+        }
+      }
       for (int64_t r = (int64_t)blockIdx.x * rpi + ty; r < rows; r += (int64_t)gridDim.x * rpi) {
         const int64_t i = r * planes + (int64_t)cv * VEC;
         float xv[VEC], ov[VEC], dv[VEC];
@@ -64,14 +75,22 @@ __global__ __launch_bounds__(256) void k_bn_partials(const T *__restrict__ x, co
           float4 t = ld4(x, i);
           xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
           if (MODE == 1) {
-            float4 o = ld4(out, i);
             float4 d = ld4(d_out, i);
-            ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
             dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+            if (recompute) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ov[j] = xv[j] * wc[j] + bc[j];
+            } else {
+              float4 o = ld4(out, i);
+              ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
+            }
           }
         } else {
           xv[0] = ld1(x, i);
-          if (MODE == 1) { ov[0] = ld1(out, i); dv[0] = ld1(d_out, i); }
+          if (MODE == 1) {
+            dv[0] = ld1(d_out, i);
+            ov[0] = recompute ? xv[0] * wc[0] + bc[0] : ld1(out, i);
+          }
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -204,12 +223,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, T
                                                       const T *__restrict__ out,
                                                       const T *__restrict__ d_out, int64_t total,
                                                       int planes, const float *__restrict__ mean,
-                                                      const float *__restrict__ coef, float leak) {
+                                                      const float *__restrict__ coef, float leak,
+                                                      const float *__restrict__ bias, int recompute) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int p = (int)(i % planes);
   float d = ld1(d_out, i);
-  d = (ld1(out, i) > 0.0f) ? d : d * leak;
+  // recompute: the activation's sign from x with the forward pass's coefficients (coef[2P+p] = invstd * weight)
+  const float o = recompute ? ld1(x, i) * coef[2 * planes + p] + (-mean[p] * coef[2 * planes + p] + (bias ? bias[p] : 0.0f))
+                            : ld1(out, i);
+  d = (o > 0.0f) ? d : d * leak;
   st1(d_in, i, (d - coef[p] - (ld1(x, i) - mean[p]) * coef[planes + p]) * coef[2 * planes + p]);
 }
 
@@ -218,14 +241,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const T *__restrict__ x, 
                                                        const T *__restrict__ out,
                                                        const T *__restrict__ d_out, int64_t total,
                                                        int planes, const float *__restrict__ mean,
-                                                       const float *__restrict__ coef, float leak) {
+                                                       const float *__restrict__ coef, float leak,
+                                                       const float *__restrict__ bias, int recompute) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   int p = (int)(i % planes);
-  float4 xv = ld4(x, i), ov = ld4(out, i);
+  float4 xv = ld4(x, i), ov;
   float4 dv = ld4(d_out, i), mu = *reinterpret_cast<const float4 *>(mean + p);
   float4 gm = *reinterpret_cast<const float4 *>(coef + p), kk = *reinterpret_cast<const float4 *>(coef + planes + p);
   float4 sw = *reinterpret_cast<const float4 *>(coef + 2 * planes + p), r;
+  if (recompute) { // sign of the forward activation from x: y = x*w + b with w = invstd*weight (= sw), b = -mean*w + bias
+    float4 bb = bias ? *reinterpret_cast<const float4 *>(bias + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ov.x = xv.x * sw.x + (-mu.x * sw.x + bb.x); ov.y = xv.y * sw.y + (-mu.y * sw.y + bb.y);
+    ov.z = xv.z * sw.z + (-mu.z * sw.z + bb.z); ov.w = xv.w * sw.w + (-mu.w * sw.w + bb.w);
+  } else {
+    ov = ld4(out, i);
+  }
   float d;
   d = ov.x > 0.0f ? dv.x : dv.x * leak; r.x = (d - gm.x - (xv.x - mu.x) * kk.x) * sw.x;
   d = ov.y > 0.0f ? dv.y : dv.y * leak; r.y = (d - gm.y - (xv.y - mu.y) * kk.y) * sw.y;
@@ -288,7 +319,7 @@ static int bn_forward_t(const T *in, T *out, int64_t rows, int planes, float *sa
 
 template <typename T>
 static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int64_t rows, int planes,
-                         const float *save_mean, const float *save_invstd, const float *weight,
+                         const float *save_mean, const float *save_invstd, const float *weight, const float *bias,
                          float *d_weight, float *d_bias, float leakiness, float *scratch, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(rows >= 0 && planes > 0, "bad sizes");
@@ -298,26 +329,32 @@ static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int
     if (d_bias) hipMemsetAsync(d_bias, 0, planes * sizeof(float), st);
     return AABR_OK;
   }
-  AABR_CHECK_ARG(in && d_in && out && d_out, "null pointer");
+  // fp32 storage: the sign of the forward activation is recomputed from x with the forward pass's own coefficients
+  // (same floats, same operations => the same bits as reading `out`; for leakiness >= 0 out > 0 <=> x*w+b > 0), which
+  // saves both passes over `out` -- 2 of the 7 matrix passes of the backward.  bf16 storage keeps reading the
+  // rounded `out` (half the bytes, and the rounding could flip a sign at the very bottom of the range).
+  const int recompute = (sizeof(T) == 4 && leakiness >= 0.0f) ? 1 : 0;
+  AABR_CHECK_ARG(in && d_in && d_out && (out || recompute), "null pointer");
   double *part = reinterpret_cast<double *>(scratch);
   float *coef = scratch + (int64_t)kMaxParts * 2 * planes * 2;
-  const bool v4 = (planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)d_out) & 15) == 0;
+  const bool v4 = (planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)(recompute ? nullptr : out) | (uintptr_t)d_out) & 15) == 0;
   int nparts = bn_parts(rows, planes, v4 ? 4 : 1);
   if (v4)
     hipLaunchKernelGGL((k_bn_partials<1, 4, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
-                       leakiness, rows, planes, part);
+                       leakiness, rows, planes, part, save_invstd, weight, bias, recompute);
   else
     hipLaunchKernelGGL((k_bn_partials<1, 1, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
-                       leakiness, rows, planes, part);
+                       leakiness, rows, planes, part, save_invstd, weight, bias, recompute);
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
                      rows, planes, save_invstd, weight, d_weight, d_bias, coef);
   int64_t total = rows * planes;
   if (v4 && (((uintptr_t)d_in | (uintptr_t)save_mean) & 15) == 0)
     hipLaunchKernelGGL((k_bn_bwd_apply4<T>), dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, d_in, out,
-                       d_out, total, planes, save_mean, coef, leakiness);
+                       d_out, total, planes, save_mean, coef, leakiness, bias,
+                       (recompute && (!bias || ((uintptr_t)bias & 15) == 0)) ? 1 : 0);
   else
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, d_in, out,
-                       d_out, total, planes, save_mean, coef, leakiness);
+                       d_out, total, planes, save_mean, coef, leakiness, bias, recompute);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -332,9 +369,9 @@ extern "C" int aabr_bn_forward(const float *in, float *out, int64_t rows, int pl
 
 extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, const float *d_out,
                                 int64_t rows, int planes, const float *save_mean, const float *save_invstd,
-                                const float *weight, float *d_weight, float *d_bias, float leakiness,
-                                float *scratch, void *stream_) {
-  return bn_backward_t<float>(in, d_in, out, d_out, rows, planes, save_mean, save_invstd, weight, d_weight,
+                                const float *weight, const float *bias, float *d_weight, float *d_bias,
+                                float leakiness, float *scratch, void *stream_) {
+  return bn_backward_t<float>(in, d_in, out, d_out, rows, planes, save_mean, save_invstd, weight, bias, d_weight,
                               d_bias, leakiness, scratch, stream_);
 }
 
@@ -350,10 +387,11 @@ extern "C" int aabr_bn_forward_bf16(const uint16_t *in, uint16_t *out, int64_t r
 
 extern "C" int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out,
                                      const uint16_t *d_out, int64_t rows, int planes, const float *save_mean,
-                                     const float *save_invstd, const float *weight, float *d_weight,
-                                     float *d_bias, float leakiness, float *scratch, void *stream_) {
+                                     const float *save_invstd, const float *weight, const float *bias,
+                                     float *d_weight, float *d_bias, float leakiness, float *scratch,
+                                     void *stream_) {
   return bn_backward_t<__bf16>(reinterpret_cast<const __bf16 *>(in), reinterpret_cast<__bf16 *>(d_in),
                                reinterpret_cast<const __bf16 *>(out), reinterpret_cast<const __bf16 *>(d_out),
-                               rows, planes, save_mean, save_invstd, weight, d_weight, d_bias, leakiness,
+                               rows, planes, save_mean, save_invstd, weight, bias, d_weight, d_bias, leakiness,
                                scratch, stream_);
 }

@@ -212,11 +212,11 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
     case AABR_PLAN_BN_BWD:
       rc = bf ? aabr_bn_backward_bf16((const uint16_t *)p[0], (uint16_t *)p[1], (const uint16_t *)p[2],
                                       (const uint16_t *)p[3], o.i64[0], o.i32[0], (const float *)p[4],
-                                      (const float *)p[5], (const float *)p[6], (float *)p[7], (float *)p[8], o.f32[2],
-                                      (float *)p[9], st)
+                                      (const float *)p[5], (const float *)p[6], (const float *)p[10], (float *)p[7],
+                                      (float *)p[8], o.f32[2], (float *)p[9], st)
               : aabr_bn_backward((const float *)p[0], (float *)p[1], (const float *)p[2], (const float *)p[3], o.i64[0],
-                                 o.i32[0], (const float *)p[4], (const float *)p[5], (const float *)p[6], (float *)p[7],
-                                 (float *)p[8], o.f32[2], (float *)p[9], st);
+                                 o.i32[0], (const float *)p[4], (const float *)p[5], (const float *)p[6],
+                                 (const float *)p[10], (float *)p[7], (float *)p[8], o.f32[2], (float *)p[9], st);
       break;
     case AABR_PLAN_ADD:
       rc = aabr_add(p[0], p[1], p[2], o.i64[0], bf ? 1 : 0, st);

@@ -936,7 +936,7 @@ def BatchNormalization_backward(input_features, d_input_features, output_feature
     _same_dtype(inp, output_features, "BatchNormalization backward")
     fn = lib.aabr_bn_backward_bf16 if inp.dtype == torch.bfloat16 else lib.aabr_bn_backward
     check(fn(ptr(inp), ptr(d_input_features), ptr(output_features.contiguous()), ptr(d_out),
-                               rows, planes, ptr(saveMean), ptr(saveInvStd), ptr(_opt(weight)),
+                               rows, planes, ptr(saveMean), ptr(saveInvStd), ptr(_opt(weight)), ptr(_opt(bias)),
                                ptr(_opt(d_weight)), ptr(_opt(d_bias)), float(leakiness), ptr(scratch), stream()))
 
 

@@ -319,7 +319,7 @@ class _Template(object):
                 gx = gnew(lvl, planes, self.fbufs[x][2])
                 pw = pslot(m.weight) if m.affine and m.weight.requires_grad else -1
                 pb = pslot(m.bias) if m.affine and m.bias.requires_grad else -1
-                ops.append(("bn", x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb))
+                ops.append(("bn", x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b))
                 contrib.setdefault(x, []).append(gx)
             else:
                 _, x, y, lvl, lo, n_in, n_out, book, side_fwd, p_w, pf, side_din, din_flags, side_dw, pt, m = op
@@ -476,11 +476,11 @@ class _Pass(object):
                      A[x], AD[gy[0]][gy[1]], g.pairs().data_ptr(), pbase + pg, 0, dwws, 0, 0, 0, 0, 0, 0)
                 off += 176
             elif kind == "bn":
-                _, x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb = op
+                _, x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b = op
                 if V[lvl]:
                     pack(buf, off, K_BNB, flg, planes, 0, 0, 0, 0, 0, 0.0, 0.0, leak, 0.0, V[lvl], 0, 0, 0,
                          A[x], AD[gx[0]][gx[1]], A[y], AD[gy[0]][gy[1]], sbase + st * 4, sbase + (st + planes) * 4,
-                         p_w, pbase + pw if pw >= 0 else 0, pbase + pb if pb >= 0 else 0, bnws, 0, 0)
+                         p_w, pbase + pw if pw >= 0 else 0, pbase + pb if pb >= 0 else 0, bnws, p_b, 0)
                     off += 176
             elif kind == "add":
                 _, a_, b_, s, lvl, planes, flg = op

@@ -229,9 +229,12 @@ int aabr_bn_forward(const float *in, float *out, int64_t rows, int planes, float
                     float *save_invstd, float *running_mean, float *running_var,
                     const float *weight, const float *bias, float eps, float momentum,
                     int train, float leakiness, float *scratch, void *stream);
+/* backward: `bias` is the forward pass's bias (as the reference's BatchNormalization_backward receives it,
+ * pybind.cpp:219-221).  fp32 storage with leakiness >= 0 derives the activation mask from in, save_mean,
+ * save_invstd, weight and bias (bit-identical to reading it from `out`, which may then be NULL).       */
 int aabr_bn_backward(const float *in, float *d_in, const float *out, const float *d_out,
                      int64_t rows, int planes, const float *save_mean, const float *save_invstd,
-                     const float *weight, float *d_weight, float *d_bias, float leakiness,
+                     const float *weight, const float *bias, float *d_weight, float *d_bias, float leakiness,
                      float *scratch, void *stream);
 
 /* ---- bf16 feature storage (extension; BASELINE.json configs 3-5) ------------------------------
@@ -256,7 +259,7 @@ int aabr_bn_forward_bf16(const uint16_t *in, uint16_t *out, int64_t rows, int pl
                          float momentum, int train, float leakiness, float *scratch, void *stream);
 int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out,
                           const uint16_t *d_out, int64_t rows, int planes, const float *save_mean,
-                          const float *save_invstd, const float *weight, float *d_weight,
+                          const float *save_invstd, const float *weight, const float *bias, float *d_weight,
                           float *d_bias, float leakiness, float *scratch, void *stream);
 
 /* ---- compiled launch plans (extension) --------------------------------------------------------
@@ -274,8 +277,8 @@ int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *ou
  *                             p3 save_invstd, p4 running_mean, p5 running_var, p6 weight, p7 bias, f32[0] eps,
  *                             f32[1] momentum, i32[1] train, f32[2] leakiness, p8 scratch)
  *        AABR_PLAN_BN_BWD     aabr_bn_backward[_bf16](p0 in, p1 d_in, p2 out, p3 d_out, i64[0] rows, i32[0] planes,
- *                             p4 save_mean, p5 save_invstd, p6 weight, p7 d_weight, p8 d_bias, f32[2] leakiness,
- *                             p9 scratch)
+ *                             p4 save_mean, p5 save_invstd, p6 weight, p10 bias, p7 d_weight, p8 d_bias,
+ *                             f32[2] leakiness, p9 scratch)
  *        AABR_PLAN_ADD        aabr_add(p0 a, p1 b, p2 out, i64[0] n)
  *        AABR_PLAN_CAST       aabr_cast_storage(p0 in, p1 out, i64[0] n, flags & AABR_PLAN_TO_BF16)
  *   flags & AABR_PLAN_BF16 selects the bf16-storage entry point.  Stops at the first failing record and returns
