@@ -395,10 +395,15 @@ extern "C" int aabr_submanifold_table(const int32_t *site_coords, int64_t V, con
   return AABR_OK;
 }
 
-static int make_geom(const int32_t *size, const int32_t *stride, const int32_t *out_sp, ConvGeom &g) {
+// sites_only: output-grid construction alone also accepts the composition of several non-overlapping levels
+// (size == stride up to 65536: exactly one output site per input site), see aabr_convolution_sites
+static int make_geom(const int32_t *size, const int32_t *stride, const int32_t *out_sp, ConvGeom &g,
+                     bool sites_only = false) {
   g.maxout = 1;
   for (int i = 0; i < 3; ++i) {
-    if (size[i] < 1 || size[i] > 64 || stride[i] < 1 || stride[i] > 64 || out_sp[i] < 1) return -1;
+    const bool composed = sites_only && size[i] == stride[i] && size[i] >= 1 && size[i] <= 65536;
+    if (!composed && (size[i] < 1 || size[i] > 64 || stride[i] < 1 || stride[i] > 64)) return -1;
+    if (out_sp[i] < 1) return -1;
     g.size[i] = size[i]; g.stride[i] = stride[i]; g.out_sp[i] = out_sp[i];
     g.maxout *= (size[i] + stride[i] - 1) / stride[i];
   }
@@ -413,7 +418,7 @@ extern "C" int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, co
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(V_in >= 0 && size_host && stride_host && out_spatial_host, "bad arguments");
   ConvGeom g;
-  AABR_CHECK_ARG(make_geom(size_host, stride_host, out_spatial_host, g) == 0, "bad filter geometry");
+  AABR_CHECK_ARG(make_geom(size_host, stride_host, out_spatial_host, g, true) == 0, "bad filter geometry");
   int64_t E = V_in * g.maxout;
   AABR_CHECK_ARG(E < (int64_t)0x7fffffff, "too many encounters");
   AABR_CHECK_ARG(is_pow2(out_cap) && out_cap >= 2 * E && out_cap >= 64,

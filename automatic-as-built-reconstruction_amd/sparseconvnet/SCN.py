@@ -304,6 +304,7 @@ class Metadata_3(object):
         self.rulebooks = {}
         self.input = None  # dict(point_site, first_pt, cnt_extra, head, nxt, last_pt, meta, n, V, mode, spatial)
         self.device = None
+        self._pregrids = set()
 
     # ---- reference-visible queries ----------------------------------------------------
     def getSpatialLocations(self, spatial_size):
@@ -516,6 +517,40 @@ class Metadata_3(object):
             self.submanifold[k] = tb
         return tb
 
+    def buildGridsFromInput(self, in_spatial, specs):
+        """Extension: the output grids of a chain of NON-OVERLAPPING strided levels (filter size == stride at every
+        level) built straight from the chain's first grid -- `specs` = [(out_spatial, composed)], composed = the
+        per-axis product of the strides down to that level -- all enqueued back to back and sized by ONE read of
+        their site counts (level by level every grid costs its own blocking read: 12 per FPN_Net pass).  A site of
+        level k is (x >> ..) of its level-0 sites and is numbered at its first level-0 site, which is also where the
+        level-by-level construction numbers it: same site lists, same order (tests compare them with the oracle's).
+        `getRuleBook` picks the grids up by their spatial size."""
+        lib = _hip.load()
+        gi = self.grids[_key(in_spatial)]
+        dev = gi.keys.device
+        E = gi.V
+        cap = _hip.next_pow2(2 * E)
+        nblk = (max(E, 1) + 255) // 256
+        metas = torch.empty((max(len(specs), 1), _hip.META_WORDS), dtype=torch.int32, device=dev)
+        pend = []
+        for i, (osz, comp) in enumerate(specs):
+            osz, comp = _key(osz), _key(comp)
+            keys = torch.empty(cap, dtype=torch.int64, device=dev)
+            vals = torch.empty(cap, dtype=torch.int32, device=dev)
+            scratch = torch.empty(3 * cap + 2 * E + 4 * nblk + 16, dtype=torch.int32, device=dev)
+            out_coords = torch.empty((max(E, 1), 4), dtype=torch.int32, device=dev)
+            check(lib.aabr_convolution_sites(ptr(gi.coords), gi.V, _hip.i32x3(comp), _hip.i32x3(comp),
+                                             _hip.i32x3(osz), ptr(keys), ptr(vals), cap, ptr(scratch),
+                                             ptr(out_coords), metas[i].data_ptr(), stream()))
+            pend.append((osz, out_coords, keys, vals))
+        if not pend:
+            return
+        counts = metas[:len(pend), 0].tolist()  # the one host sync
+        pre = self.__dict__.setdefault("_pregrids", set())
+        for (osz, out_coords, keys, vals), V_out in zip(pend, counts):
+            self.grids[osz] = _Grid(out_coords[:V_out], keys, vals, cap, V_out)
+            pre.add(osz)
+
     def getRuleBook(self, in_spatial, out_spatial, filter_size, filter_stride):
         """Metadata::getRuleBook (Metadata.cpp:484-510): builds the output grid on first use."""
         k = _key(in_spatial) + _key(filter_size) + _key(filter_stride)
@@ -528,6 +563,20 @@ class Metadata_3(object):
             fs, st, osz = _key(filter_size), _key(filter_stride), _key(out_spatial)
             dev = gi.keys.device
             vol = fs[0] * fs[1] * fs[2]
+            go = self.grids.get(osz) if osz in self.__dict__.get("_pregrids", ()) else None
+            if go is not None:         # built ahead by buildGridsFromInput
+                self._pregrids.discard(osz)
+                V_out = go.V
+                t_out = torch.empty((vol, V_out), dtype=torch.int32, device=dev)
+                t_in = torch.empty((vol, gi.V), dtype=torch.int32, device=dev)
+                counts = torch.empty(vol * ((V_out + 255) // 256), dtype=torch.int32, device=dev)
+                check(lib.aabr_convolution_tables(ptr(gi.coords), gi.V, ptr(gi.keys), ptr(gi.vals), gi.cap,
+                                                  ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
+                                                  _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),
+                                                  ptr(t_in), ptr(counts), stream()))
+                tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, None, vol, gi.V), vol, V_out, gi.V)
+                self.rulebooks[k] = tb
+                return tb
             maxout = 1
             for a, b in zip(fs, st):
                 maxout *= (a + b - 1) // b

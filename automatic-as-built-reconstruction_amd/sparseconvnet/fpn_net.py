@@ -26,6 +26,7 @@ class FPN_Net(torch.nn.Module):
         self.feature_dtype = feature_dtype
         self.prebuild_geometry = True   # extension: see _prebuild_geometry
         self.prepack_weights = True     # extension: see _refresh_weight_packs
+        self.grids_from_input = True    # extension: see _grids_from_input
         self.compiled_graph = False     # extension: planExecutor.run_fpn (one launch list per pass)
         self.bn_momentum = bn_momentum
         self.track_running_stats = track_running_stats
@@ -146,6 +147,8 @@ class FPN_Net(torch.nn.Module):
         sizes = [sz]
         three, one = torch.LongTensor([3, 3, 3]), torch.LongTensor([1, 1, 1])
         nscale = len(self.m_downs)
+        if self.grids_from_input:
+            self._grids_from_input(md, sz)
         for k in range(nscale):
             md.getSubmanifoldRuleBook(sz, three)
             md.getSubmanifoldRuleBook(sz, one)
@@ -163,6 +166,44 @@ class FPN_Net(torch.nn.Module):
             SCN.prefetch_totals([tb.out for tb in list(md.submanifold.values()) + list(md.rulebooks.values())])
         md._fpn_prebuilt = sizes
         return sizes
+
+    def _grids_from_input(self, md, sz0):
+        """the strided grids of the pass in rounds of four levels when the down-sampling levels do not overlap
+        (filter == stride, the reference's default [[2,2,2]]*8): every grid of a round is built straight from the
+        round's base grid (Metadata.buildGridsFromInput) and the round costs ONE host read -- 3 reads per pass
+        instead of 13.  Not all from level 0: a 49-site level built from 310 k sites is 310 k atomics on 49 words
+        (measured: +2 ms); four levels deep the contention stays below ~20 per word on scene data."""
+        nscale = len(self.m_downs)
+        cum = torch.LongTensor([1, 1, 1])
+        sz, lvl = sz0, [(sz0, cum)]
+        for k in range(nscale - 1):
+            ks, st = torch.LongTensor(self.down_kernels[k]), torch.LongTensor(self.down_strides[k])
+            if not torch.equal(ks, st):
+                return
+            sz = (sz - ks) // st + 1
+            cum = cum * st
+            lvl.append((sz, cum))
+        zmaps = {}                                   # level -> z-collapse filter that spans the whole z extent
+        for i, scale_from_top in enumerate(self.fpn_scales_from_top):
+            k = nscale - 1 - scale_from_top
+            z = int(self.rpn_map_sizes[i][2])
+            if z == int(lvl[k][0][2]) and z > 1:
+                zmaps[k] = z
+        step = 4
+        for base in range(0, nscale, step):
+            bsz, bcum = lvl[base]
+            if tuple(bsz.tolist()) not in md.grids:
+                return
+            specs = []
+            for k in range(base + 1, min(base + step, nscale - 1) + 1):
+                specs.append((lvl[k][0], lvl[k][1] // bcum))
+            for k, z in zmaps.items():
+                if base <= k < base + step and (base > 0 or k == 0 or True):
+                    # a z-collapse grid needs its level's sites only through their (x, y): from the base as well
+                    specs.append((torch.LongTensor([int(lvl[k][0][0]), int(lvl[k][0][1]), 1]),
+                                  (lvl[k][1] // bcum) * torch.LongTensor([1, 1, z])))
+            specs = [(o, c) for o, c in specs if tuple(o.tolist()) not in md.grids and int(c.max()) <= 65536]
+            md.buildGridsFromInput(bsz, specs)
 
     def _compile_streams(self, md, sizes, in_channels):
         """block streams / offset-pair lists of every convolution of the pass (forward, input-gradient and weight-

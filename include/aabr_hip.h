@@ -109,7 +109,10 @@ int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t
  * RectangularRegions.h:95-119).  Creates the output grid (sites numbered in first-seen order
  * over input rows ascending, then output-region order) and reports V_out in meta[0].
  *   scratch int32 [3*out_cap + 2*E + 4*ceil(E/256) + 16], E = V_in * max_out_per_in,
- *   max_out_per_in = prod(ceil(size/stride)); out_site_coords int32 [E,4].                  */
+ *   max_out_per_in = prod(ceil(size/stride)); out_site_coords int32 [E,4].
+ * size, stride <= 64 per axis; for size == stride (one output site per input site) up to 65536, so that a chain of
+ * non-overlapping levels can be built from its FIRST grid in one step each (size = stride = product of the chain's
+ * strides): the site set and its first-seen order are those of the level-by-level construction.          */
 int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, const int32_t *size_host,
                            const int32_t *stride_host, const int32_t *out_spatial_host,
                            uint64_t *out_keys, int32_t *out_vals, int64_t out_cap,
