@@ -17,8 +17,8 @@ Pipelining inside a step, all of it real work of that step or the next (nothing 
   * the proposal stage (top-k, decode, NMS: reads forward results only) is enqueued on a side stream after the
     backward pass has been enqueued, so its small launches and host reads run underneath the backward kernels;
   * the NEXT batch's geometry (voxel grid, strided grids, rule tables, block streams -- coordinates only) is built
-    on that side stream during this batch's backward (`FPN_Net.prepare`, the device-side analogue of a data-loader
-    prefetch; AABR_BENCH_PREFETCH=0 builds it inline instead); every step's geometry is built from scratch, one
+    on that side stream from the end of this batch's forward pass on (`FPN_Net.prepare`, the device-side analogue
+    of a data-loader prefetch; AABR_BENCH_PREFETCH=0 builds it inline instead); every step's geometry is built from scratch, one
     step ahead; the first step builds its own;
   * the layers between the input layer and the returned maps run through the compiled graph executor
     (sparseconvnet/planExecutor.py: same kernels, arguments and order as the per-layer modules, one launch list
@@ -188,6 +188,10 @@ class Workload(object):
         # reads wait for the side stream only.
         ev_fwd = torch.cuda.Event()
         ev_fwd.record()
+        early = proposals and self.prefetch_geometry and os.environ.get("AABR_BENCH_PREFETCH_EARLY", "1") == "1"
+        if early:
+            with torch.no_grad():
+                self.net.prepare(self.batches[(i + 1) % len(self.batches)], self.side)
         loss.backward()
         feats.grad = None
         if after_backward is not None:
@@ -195,7 +199,7 @@ class Workload(object):
         props = None
         if proposals:
             main = torch.cuda.current_stream()
-            if self.prefetch_geometry:
+            if self.prefetch_geometry and not early:
                 # the NEXT batch's geometry (voxel grid, strided grids, rule tables, block streams: coordinates only)
                 # is built on the side stream while this batch's backward runs -- a data-loader-style prefetch; every
                 # step still builds its geometry from scratch, one step ahead
