@@ -1,0 +1,111 @@
+"""aabr_plan_run and its helpers through the C ABI: elementwise add / storage cast against torch (bit-equal),
+rule totals of many rule books in one launch, a two-record plan with a side-stream record and a join, the error
+path (unknown record kind), and the strided grids built in rounds from a base grid against the level-by-level
+construction."""
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+import synth_scenes as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OP = struct.Struct("<ii6i4f4q12Q")
+
+
+def _lib():
+    import _hip
+    return _hip, _hip.load()
+
+
+def _rec(kind, flags, i32=(), f32=(), i64=(), ps=()):
+    return OP.pack(kind, flags, *(tuple(i32) + (0,) * (6 - len(i32))), *(tuple(f32) + (0.0,) * (4 - len(f32))),
+                   *(tuple(i64) + (0,) * (4 - len(i64))), *(tuple(ps) + (0,) * (12 - len(ps))))
+
+
+def test_add_and_cast_match_torch_bitwise():
+    _hip, lib = _lib()
+    torch.manual_seed(0)
+    for n in (1, 3, 4, 1023, 1024, 100003):
+        a, b = torch.randn(n, device=DEV), torch.randn(n, device=DEV) * 1e3
+        out = torch.empty_like(a)
+        _hip.check(lib.aabr_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, 0, _hip.stream()))
+        assert torch.equal(out, a + b)
+        a16, b16 = a.bfloat16(), b.bfloat16()
+        o16 = torch.empty_like(a16)
+        _hip.check(lib.aabr_add(a16.data_ptr(), b16.data_ptr(), o16.data_ptr(), n, 1, _hip.stream()))
+        assert torch.equal(o16, a16 + b16)
+        c16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        _hip.check(lib.aabr_cast_storage(a.data_ptr(), c16.data_ptr(), n, 1, _hip.stream()))
+        assert torch.equal(c16, a.to(torch.bfloat16))
+        c32 = torch.empty(n, dtype=torch.float32, device=DEV)
+        _hip.check(lib.aabr_cast_storage(c16.data_ptr(), c32.data_ptr(), n, 0, _hip.stream()))
+        assert torch.equal(c32, c16.float())
+
+
+def test_sum_counts_many_jobs():
+    import ctypes as C
+    _hip, lib = _lib()
+    rng = np.random.default_rng(1)
+    sizes = [0, 1, 255, 256, 257, 40000] + [int(v) for v in rng.integers(1, 5000, 70)]   # > 64 jobs: two launches
+    cs = [torch.as_tensor(rng.integers(0, 2000, n).astype(np.int32)).to(DEV) for n in sizes]
+    out = torch.full((len(sizes),), -1.0, dtype=torch.float64, device=DEV)
+    n = len(sizes)
+    _hip.check(lib.aabr_sum_counts((C.c_void_p * n)(*[c.data_ptr() if c.numel() else None for c in cs]),
+                                   (C.c_int64 * n)(*sizes),
+                                   (C.c_void_p * n)(*[out.data_ptr() + 8 * i for i in range(n)]), n, _hip.stream()))
+    assert out.tolist() == [float(c.long().sum().item()) for c in cs]
+
+
+def test_plan_run_records_side_stream_join_and_error_path():
+    _hip, lib = _lib()
+    n = 1 << 20
+    a, b = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+    s1, s2, s3 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    plan = b"".join([
+        _rec(6, 4, i64=(n,), ps=(a.data_ptr(), b.data_ptr(), s1.data_ptr())),        # s1 = a + b on the second stream
+        _rec(6, 0, i64=(n,), ps=(a.data_ptr(), a.data_ptr(), s2.data_ptr())),        # s2 = a + a meanwhile
+        _rec(6, 8, i64=(n,), ps=(s1.data_ptr(), s2.data_ptr(), s3.data_ptr())),      # s3 = s1 + s2: joins first
+    ])
+    for _ in range(3):
+        _hip.check(lib.aabr_plan_run(plan, 3, _hip.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(s3, (a + b) + (a + a))
+    bad = _rec(99, 0)
+    assert lib.aabr_plan_run(bad, 1, _hip.stream()) != 0
+    assert b"unknown kind" in lib.aabr_last_error()
+    # a failing record reports its entry point's message (misaligned operands of aabr_add)
+    bad = _rec(6, 0, i64=(8,), ps=(a.data_ptr() + 4, b.data_ptr(), s1.data_ptr()))
+    assert lib.aabr_plan_run(bad, 1, _hip.stream()) != 0
+    assert b"aligned" in lib.aabr_last_error()
+
+
+def test_strided_grids_in_rounds_equal_level_by_level():
+    """FPN_Net.grids_from_input (Metadata.buildGridsFromInput: every grid of a round of four levels straight from
+    the round's base grid, one host read per round) against the level-by-level construction: every grid's site
+    list in the same order, every rule table equal, outputs bit-equal."""
+    from test_cabi_and_host import default_fpn
+    torch.manual_seed(3)
+    net = default_fpn().to(DEV)
+    locs, feats = S.make_batch(2, 30000, 77, 20)
+    l, f = torch.as_tensor(locs).to(DEV), torch.as_tensor(feats).to(DEV)
+    res = []
+    for flag in (False, True):
+        net.grids_from_input = flag
+        with torch.no_grad():
+            rpn, roi = net([l, f])
+        md = rpn[0].metadata
+        grids = {k: g.coords.clone() for k, g in md.grids.items()}
+        tabs = {k: (tb.out.table.clone(), tb.inn.table.clone()) for k, tb in md.rulebooks.items()}
+        res.append((grids, tabs, [m.features.clone() for m in rpn]))
+    (g0, t0, o0), (g1, t1, o1) = res
+    assert g0.keys() == g1.keys() and len(g0) >= 13
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    assert t0.keys() == t1.keys() and len(t0) >= 12
+    for k in t0:
+        assert torch.equal(t0[k][0], t1[k][0]) and torch.equal(t0[k][1], t1[k][1]), k
+    for x, y in zip(o0, o1):
+        assert torch.equal(x, y)
