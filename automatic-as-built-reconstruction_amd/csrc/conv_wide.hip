@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
-                                                    const float *__restrict__ bias, int kT2) {
+                                                    const float *__restrict__ bias, int kT2,
+                                                    const float *__restrict__ res) {
   constexpr int RG = KG * 8;               // 16-byte granules per staged row
   constexpr int RF = KG * 32;              // floats per staged row
   constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
@@ -345,6 +346,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
       const float *bb = bias + nb0 * 16 + q * 4;
       v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
     }
+    if (res) { // out = conv + res: the residual / lateral add of the consumer folded into the write-out
+      const f32x4 rr = *reinterpret_cast<const f32x4 *>(res + (row0 + r) * co + nb0 * 16 + q * 4);
+      v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+    }
     *reinterpret_cast<f32x4 *>(out + (row0 + r) * co + nb0 * 16 + q * 4) = v;
   }
 }
@@ -403,10 +408,24 @@ extern "C" int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, in
   return (((V_out + T - 1) / T) * (n_out / 64) >= 320) ? T : 0;
 }
 
+extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64_t rows_in, float *out_feats,
+                                          int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                          const float *bias, int flags, const float *wpack, const float *residual,
+                                          void *stream_);
+
 extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
                                       int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
                                       int flags, const float *wpack, void *stream_) {
+  return aabr_conv_forward_wide_res(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias,
+                                    flags, wpack, nullptr, stream_);
+}
+
+extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64_t rows_in, float *out_feats,
+                                          int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                          const float *bias, int flags, const float *wpack, const float *residual,
+                                          void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(((uintptr_t)residual & 15) == 0, "residual must be 16-byte aligned");
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 31) == 0 && (n_out & 63) == 0, "plane counts: n_in % 32, n_out % 64");
   AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
   AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
@@ -452,7 +471,7 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
 #define AABR_WIDE_CS_N(KG, D, NB)                                                                         \
   AABR_LAUNCH_WIDE((k_conv_cs<KG, D, NB>), "k_conv_cs<" #KG "," #D "," #NB ">",                           \
                    (size_t)((tile_rows + 1) * kWS + NB * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes,   \
-                   out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows)
+                   out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows, residual)
 #define AABR_WIDE_CS(KG, D)                                                                               \
   do {                                                                                                    \
     if (nbuf == 1) AABR_WIDE_CS_N(KG, D, 1); else AABR_WIDE_CS_N(KG, D, 2);                               \

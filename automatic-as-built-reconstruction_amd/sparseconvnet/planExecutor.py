@@ -53,6 +53,9 @@ dw_side_stream = os.environ.get("AABR_PLAN_DW_SIDE", "1") != "0"
 # there too (AABR_PLAN_JOIN in front of their reader); measured on the bench step: 14.65 -> 14.60 ms, inside the
 # noise, so off by default
 lateral_side_stream = os.environ.get("AABR_PLAN_LATERAL_SIDE", "0") != "0"
+# a residual / lateral add whose second operand comes straight from a wide-kernel convolution rides in that
+# convolution's write-out (forward only; the backward list is unchanged)
+fuse_adds = os.environ.get("AABR_PLAN_FUSE_ADDS", "1") != "0"
 
 
 class Unsupported(Exception):
@@ -98,7 +101,32 @@ class _Template(object):
         # forward emission order: a lateral branch (ops that depend on one earlier buffer only) is issued right after
         # that buffer's producer, on the second stream; its first reader joins
         self.emit = self._emission()
+        self.fuse = self._fusable_adds() if (fuse_adds and not lateral_side_stream) else {}
         stats["templates"] += 1
+
+    def _fusable_adds(self):
+        """{id(conv op): (add op, other operand)}: an fp32 convolution whose only reader is an add with an operand
+        that exists before the convolution runs -- the add can ride in the convolution's write-out when the pass
+        dispatches it to the wide kernel (`aabr_conv_forward_wide_res`; a + b == b + a bit for bit)"""
+        uses, prod = {}, {0: -1}
+        for i, op in enumerate(self.fops):
+            ins = (op[1], op[2]) if op[0] == "add" else (op[1],)
+            for b in ins:
+                uses[b] = uses.get(b, 0) + 1
+            prod[_out_of(op)] = i
+        for b, _ in self.outs:
+            uses[b] = uses.get(b, 0) + 1
+        out = {}
+        for i, op in enumerate(self.fops):
+            if op[0] != "add" or op[6]:
+                continue
+            for conv_b, other in ((op[2], op[1]), (op[1], op[2])):
+                j = prod.get(conv_b, -1)
+                if j >= 0 and self.fops[j][0] == "conv" and uses.get(conv_b) == 1 and prod.get(other, 1 << 30) < j \
+                        and id(self.fops[j]) not in out:
+                    out[id(self.fops[j])] = (op, other)
+                    break
+        return out
 
     def branch(self, start, after_buf):
         """ops fops[start:] so far form a branch that reads only `after_buf`; the NEXT op traced is its reader"""
@@ -372,20 +400,23 @@ class _Pass(object):
         self.books = bk
         self._wide = {}
 
+    def wide_rows(self, n_in, n_out, rows_in, rows_out, vol):
+        key = (n_in, n_out, rows_in, rows_out, vol)
+        T = self._wide.get(key)
+        if T is None:
+            T = self._wide[key] = self.lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, vol)
+        return T
+
     def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf,
-                    xf=0):
+                    xf=0, res=0):
         """the record of the launch SCN._conv_fwd makes for a prepacked weight; returns the new write offset"""
         if rows_out == 0:
             return off
-        T = 0
-        if not bf:
-            key = (n_in, n_out, rows_in, rows_out, gather.vol)
-            T = self._wide.get(key)
-            if T is None:
-                T = self._wide[key] = self.lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, gather.vol)
+        T = 0 if bf else self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol)
+        assert T or not res
         if T:
             pack(buf, off, K_WIDE, xf, n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
-                 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), 0, 0, p_pack, 0, 0, 0, 0, 0, 0)
+                 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), res, 0, p_pack, 0, 0, 0, 0, 0, 0)
         else:
             pack(buf, off, K_CONV, (F_BF16 if bf else 0) | xf, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,
                  rows_in, rows_out, 0, 0, src, dst, gather.blocks().data_ptr(), p_w, 0, p_pack, 0, 0, 0, 0, 0, 0)
@@ -404,12 +435,20 @@ class _Pass(object):
         pack, off = _OP.pack_into, 0
         books = self.books
         fbufs = t.fbufs
+        fuse, skip = t.fuse, set()
         for op, xf in t.emit:
             kind = op[0]
             if kind == "conv":
                 x, y, lvl, lo, n_in, n_out, book, side, p_w, pf = op[1:11]
-                off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[y], V[lo], n_out, books[book][side], p_w,
-                                       pf, 0, fbufs[x][2] == BF16, xf)
+                fz = fuse.get(id(op))
+                if fz is not None and V[lo] and self.wide_rows(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
+                    add_op, other = fz           # out = conv + other, written where the add would have written
+                    skip.add(id(add_op))
+                    off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[add_op[3]], V[lo], n_out,
+                                           books[book][side], p_w, pf, 0, False, xf, A[other])
+                else:
+                    off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[y], V[lo], n_out, books[book][side],
+                                           p_w, pf, 0, fbufs[x][2] == BF16, xf)
             elif kind == "bn":
                 _, x, y, lvl, planes, flg, train, eps, mom, leak, st, p_rm, p_rv, p_w, p_b, m = op
                 if V[lvl]:
@@ -417,6 +456,8 @@ class _Pass(object):
                          A[x], A[y], sbase + st * 4, sbase + (st + planes) * 4, p_rm, p_rv, p_w, p_b, bnws, 0, 0, 0)
                     off += 176
             elif kind == "add":
+                if id(op) in skip:
+                    continue
                 _, a_, b_, y, lvl, planes, flg = op
                 pack(buf, off, K_ADD, flg | xf, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
                      A[a_], A[b_], A[y], 0, 0, 0, 0, 0, 0, 0, 0, 0)

@@ -173,6 +173,12 @@ int aabr_conv_pack_weights(const float *W, int vol, int n_in, int n_out, int tra
 int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
                            int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
                            int flags, const float *wpack, void *stream);
+/* the same with out = conv + residual ([V_out, n_out] fp32, may be NULL): the residual / lateral add that follows
+ * the convolution in the reference's graph (AddTable, tables.py:27-41; add_feature_planes, utils.py:38-44) folded
+ * into the write-out; a + b is commutative bit for bit, so the result equals the separate add's.           */
+int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
+                               int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                               int flags, const float *wpack, const float *residual, void *stream);
 
 /* Name of the kernel instance (template arguments included) the last aabr_conv_forward[_bf16] /
  * aabr_conv_backward_weight[_bf16] call on this thread dispatched -- measurement provenance only.   */
@@ -272,8 +278,8 @@ int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *ou
  * record's fields in the order given here -- nothing is computed differently.
  *   kind AABR_PLAN_CONV       aabr_conv_forward[_bf16](p0 in, i32[0] n_in, i64[0] rows_in, p1 out, i32[1] n_out,
  *                             i64[1] V_out, p2 blocks, i32[2] vol, p3 W, p4 bias, i32[3] flags, p5 wpack)
- *        AABR_PLAN_CONV_WIDE  aabr_conv_forward_wide(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
- *                             i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack)
+ *        AABR_PLAN_CONV_WIDE  aabr_conv_forward_wide_res(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
+ *                             i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual)
  *        AABR_PLAN_CONV_DW    aabr_conv_backward_weight[_bf16](p0 in, i32[0] n_in, p1 d_out, i32[1] n_out,
  *                             i64[0] V_out, p2 pairs, i32[2] vol, i64[1] max_chunks, p3 dW, p4 d_bias, p5 scratch)
  *        AABR_PLAN_BN_FWD     aabr_bn_forward[_bf16](p0 in, p1 out, i64[0] rows, i32[0] planes, p2 save_mean,
