@@ -66,6 +66,8 @@ _SIGS = {
     "aabr_bn_forward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32,
                                   _vp, _vp]),
     "aabr_bn_backward": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp]),
+    "aabr_bn_backward_add": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp,
+                                       _vp]),
     "aabr_bn_forward_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _f32,
                                        _vp, _vp]),
     "aabr_bn_backward_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp,

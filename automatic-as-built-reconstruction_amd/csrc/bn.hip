@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, T
                                                       const T *__restrict__ d_out, int64_t total,
                                                       int planes, const float *__restrict__ mean,
                                                       const float *__restrict__ coef, float leak,
-                                                      const float *__restrict__ bias, int recompute) {
+                                                      const float *__restrict__ bias, int recompute,
+                                                      const T *__restrict__ res) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int p = (int)(i % planes);
@@ -233,7 +234,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, T
   const float o = recompute ? ld1(x, i) * coef[2 * planes + p] + (-mean[p] * coef[2 * planes + p] + (bias ? bias[p] : 0.0f))
                             : ld1(out, i);
   d = (o > 0.0f) ? d : d * leak;
-  st1(d_in, i, (d - coef[p] - (ld1(x, i) - mean[p]) * coef[planes + p]) * coef[2 * planes + p]);
+  float r = (d - coef[p] - (ld1(x, i) - mean[p]) * coef[planes + p]) * coef[2 * planes + p];
+  if (res) r += ld1(res, i);
+  st1(d_in, i, r);
 }
 
 template <typename T>
@@ -242,7 +245,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const T *__restrict__ x, 
                                                        const T *__restrict__ d_out, int64_t total,
                                                        int planes, const float *__restrict__ mean,
                                                        const float *__restrict__ coef, float leak,
-                                                       const float *__restrict__ bias, int recompute) {
+                                                       const float *__restrict__ bias, int recompute,
+                                                       const T *__restrict__ res) {
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= total) return;
   int p = (int)(i % planes);
@@ -262,6 +266,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const T *__restrict__ x, 
   d = ov.y > 0.0f ? dv.y : dv.y * leak; r.y = (d - gm.y - (xv.y - mu.y) * kk.y) * sw.y;
   d = ov.z > 0.0f ? dv.z : dv.z * leak; r.z = (d - gm.z - (xv.z - mu.z) * kk.z) * sw.z;
   d = ov.w > 0.0f ? dv.w : dv.w * leak; r.w = (d - gm.w - (xv.w - mu.w) * kk.w) * sw.w;
+  if (res) { // d_in = BatchNorm gradient + another contribution to the same tensor's gradient
+    const float4 q = ld4(res, i);
+    r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+  }
   st4(d_in, i, r);
 }
 
@@ -320,7 +328,8 @@ static int bn_forward_t(const T *in, T *out, int64_t rows, int planes, float *sa
 template <typename T>
 static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int64_t rows, int planes,
                          const float *save_mean, const float *save_invstd, const float *weight, const float *bias,
-                         float *d_weight, float *d_bias, float leakiness, float *scratch, void *stream_) {
+                         float *d_weight, float *d_bias, float leakiness, float *scratch, void *stream_,
+                         const T *d_in_add = nullptr) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(rows >= 0 && planes > 0, "bad sizes");
   AABR_CHECK_ARG(save_mean && save_invstd && scratch, "null pointer");
@@ -348,13 +357,13 @@ static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
                      rows, planes, save_invstd, weight, d_weight, d_bias, coef);
   int64_t total = rows * planes;
-  if (v4 && (((uintptr_t)d_in | (uintptr_t)save_mean) & 15) == 0)
+  if (v4 && (((uintptr_t)d_in | (uintptr_t)save_mean | (uintptr_t)d_in_add) & 15) == 0)
     hipLaunchKernelGGL((k_bn_bwd_apply4<T>), dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, d_in, out,
                        d_out, total, planes, save_mean, coef, leakiness, bias,
-                       (recompute && (!bias || ((uintptr_t)bias & 15) == 0)) ? 1 : 0);
+                       (recompute && (!bias || ((uintptr_t)bias & 15) == 0)) ? 1 : 0, d_in_add);
   else
     hipLaunchKernelGGL((k_bn_bwd_apply<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, in, d_in, out,
-                       d_out, total, planes, save_mean, coef, leakiness, bias, recompute);
+                       d_out, total, planes, save_mean, coef, leakiness, bias, recompute, d_in_add);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -373,6 +382,17 @@ extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, 
                                 float leakiness, float *scratch, void *stream_) {
   return bn_backward_t<float>(in, d_in, out, d_out, rows, planes, save_mean, save_invstd, weight, bias, d_weight,
                               d_bias, leakiness, scratch, stream_);
+}
+
+// d_in = BatchNorm gradient + d_in_add: the gradient sum of a tensor with a second consumer (the identity branch of
+// a residual block, a lateral connection) folded into the apply pass; fp32 only (a + b is commutative bit for bit,
+// in bf16 storage the separate add would round twice)
+extern "C" int aabr_bn_backward_add(const float *in, float *d_in, const float *out, const float *d_out,
+                                    int64_t rows, int planes, const float *save_mean, const float *save_invstd,
+                                    const float *weight, const float *bias, float *d_weight, float *d_bias,
+                                    float leakiness, float *scratch, const float *d_in_add, void *stream_) {
+  return bn_backward_t<float>(in, d_in, out, d_out, rows, planes, save_mean, save_invstd, weight, bias, d_weight,
+                              d_bias, leakiness, scratch, stream_, d_in_add);
 }
 
 // bf16 feature storage (extension; statistics in fp64, affine maths in fp32, parameters fp32)

@@ -214,9 +214,10 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
                                       (const uint16_t *)p[3], o.i64[0], o.i32[0], (const float *)p[4],
                                       (const float *)p[5], (const float *)p[6], (const float *)p[10], (float *)p[7],
                                       (float *)p[8], o.f32[2], (float *)p[9], st)
-              : aabr_bn_backward((const float *)p[0], (float *)p[1], (const float *)p[2], (const float *)p[3], o.i64[0],
-                                 o.i32[0], (const float *)p[4], (const float *)p[5], (const float *)p[6],
-                                 (const float *)p[10], (float *)p[7], (float *)p[8], o.f32[2], (float *)p[9], st);
+              : aabr_bn_backward_add((const float *)p[0], (float *)p[1], (const float *)p[2], (const float *)p[3],
+                                     o.i64[0], o.i32[0], (const float *)p[4], (const float *)p[5], (const float *)p[6],
+                                     (const float *)p[10], (float *)p[7], (float *)p[8], o.f32[2], (float *)p[9],
+                                     (const float *)p[11], st);
       break;
     case AABR_PLAN_ADD:
       rc = aabr_add(p[0], p[1], p[2], o.i64[0], bf ? 1 : 0, st);

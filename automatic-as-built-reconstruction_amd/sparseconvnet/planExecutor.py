@@ -289,7 +289,7 @@ class _Template(object):
         return b
 
     def _make_backward(self, pattern, need_dx):
-        gbufs, ops, contrib = [], [], {}
+        gbufs, ops = [], []
         poff, ptotal = {}, 0
 
         def gnew(lvl, planes, dt):
@@ -304,23 +304,25 @@ class _Template(object):
                 ptotal += (p.numel() + 63) // 64 * 64
             return poff[i] * 4
 
+        acc = {}           # forward buffer -> the gradient accumulated so far (contributions in arrival order:
+                           # autograd's order, the consumer created last delivers first; ((c0 + c1) + c2) ...)
+
+        def arrive(b, ref):
+            """an existing gradient buffer contributes to forward buffer b"""
+            cur = acc.get(b)
+            if cur is None:
+                acc[b] = ref
+                return
+            lvl, planes, dt = self.fbufs[b]
+            s = gnew(lvl, planes, dt)
+            ops.append(("add", cur, ref, s, lvl, planes, F_BF16 if dt == BF16 else 0))
+            acc[b] = s
+
         for k, ((b, _), has) in enumerate(zip(self.outs, pattern)):
             if has:
-                contrib.setdefault(b, []).append((E, k))
-
-        def total(b):
-            """sum of the gradient contributions of forward buffer b in arrival order (autograd's order: the
-            consumer created last delivers first); None when nothing flows back"""
-            c = contrib.get(b)
-            if not c:
-                return None
-            lvl, planes, dt = self.fbufs[b]
-            acc = c[0]
-            for nxt in c[1:]:
-                s = gnew(lvl, planes, dt)
-                ops.append(("add", acc, nxt, s, lvl, planes, F_BF16 if dt == BF16 else 0))
-                acc = s
-            return acc
+                arrive(b, (E, k))
+        total = acc.get
+        fuse = fuse_adds
 
         for op in reversed(self.fops):
             kind = op[0]
@@ -328,8 +330,8 @@ class _Template(object):
                 _, a_, b_, y, lvl, planes, flg = op
                 gy = total(y)
                 if gy is not None:       # same order as autograd's AddBackward: first operand, then second
-                    contrib.setdefault(a_, []).append(gy)
-                    contrib.setdefault(b_, []).append(gy)
+                    arrive(a_, gy)
+                    arrive(b_, gy)
             elif kind == "cast":
                 _, x, y, lvl, planes, flg = op
                 gy = total(y)
@@ -338,7 +340,7 @@ class _Template(object):
                 dtx = self.fbufs[x][2]
                 gx = gnew(lvl, planes, dtx)
                 ops.append(("cast", gy, gx, lvl, planes, F_TO_BF16 if dtx == BF16 else 0))
-                contrib.setdefault(x, []).append(gx)
+                arrive(x, gx)
             elif kind == "bn":
                 _, x, y, lvl, planes, flg, train, eps, mom, leak, st, p_rm, p_rv, p_w, p_b, m = op
                 gy = total(y)
@@ -347,8 +349,12 @@ class _Template(object):
                 gx = gnew(lvl, planes, self.fbufs[x][2])
                 pw = pslot(m.weight) if m.affine and m.weight.requires_grad else -1
                 pb = pslot(m.bias) if m.affine and m.bias.requires_grad else -1
-                ops.append(("bn", x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b))
-                contrib.setdefault(x, []).append(gx)
+                res = acc.get(x) if (fuse and not flg) else None
+                ops.append(("bn", x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b, res))
+                if res is not None:      # fp32: the sum with what has arrived so far rides in the apply pass
+                    acc[x] = gx
+                else:
+                    arrive(x, gx)
             else:
                 _, x, y, lvl, lo, n_in, n_out, book, side_fwd, p_w, pf, side_din, din_flags, side_dw, pt, m = op
                 gy = total(y)
@@ -358,9 +364,15 @@ class _Template(object):
                 flg = F_BF16 if dt == BF16 else 0
                 if x != 0 or need_dx:
                     gx = gnew(lvl, n_in, dt)
+                    res = acc.get(x) if (fuse and not flg) else None
+                    tmp = gnew(lvl, n_in, dt) if res is not None else None   # used when the launch is not a wide one
                     # the launch reads d_out (n_out planes) and writes d_in (n_in planes)
-                    ops.append(("din", gy, gx, lo, lvl, n_out, n_in, book, side_din, din_flags, p_w, pt, flg))
-                    contrib.setdefault(x, []).append(gx)
+                    ops.append(("din", gy, gx, lo, lvl, n_out, n_in, book, side_din, din_flags, p_w, pt, flg, res,
+                                tmp))
+                    if res is not None:
+                        acc[x] = gx
+                    else:
+                        arrive(x, gx)
                 if m.weight.requires_grad:
                     ops.append(("dw", x, gy, lo, n_in, n_out, book, side_dw, pslot(m.weight), flg))
         gx0 = total(0) if need_dx else None
@@ -501,15 +513,26 @@ class _Pass(object):
         dwmc.reverse()
         dwws = _hip.workspace("dw", dws, torch.float32, self.dev).data_ptr() if dws else 0
         bnws = _hip.workspace("bn", t.bn_floats, torch.float32, self.dev).data_ptr() if t.bn_floats else 0
-        buf = bytearray(len(bops) * 176)
+        buf = bytearray(len(bops) * 2 * 176)
         pack, off = _OP.pack_into, 0
         dw_side = F_SIDE if dw_side_stream else 0
         for op in bops:
             kind = op[0]
             if kind == "din":
-                _, gy, gx, lo, lvl, n_in, n_out, book, side, flags, p_w, pt, flg = op
-                off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl], n_out,
-                                       books[book][side], p_w, pt, flags, flg == F_BF16)
+                _, gy, gx, lo, lvl, n_in, n_out, book, side, flags, p_w, pt, flg, res, tmp = op
+                g = books[book][side]
+                if res is None:
+                    off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
+                                           n_out, g, p_w, pt, flags, flg == F_BF16)
+                elif V[lvl] and self.wide_rows(n_in, n_out, V[lo], V[lvl], g.vol):
+                    off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
+                                           n_out, g, p_w, pt, flags, False, 0, AD[res[0]][res[1]])
+                else:                    # not a wide launch: d_in into the spare buffer, then the sum
+                    off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[tmp[0]][tmp[1]], V[lvl],
+                                           n_out, g, p_w, pt, flags, False)
+                    pack(buf, off, K_ADD, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * n_out, 0, 0, 0,
+                         AD[res[0]][res[1]], AD[tmp[0]][tmp[1]], AD[gx[0]][gx[1]], 0, 0, 0, 0, 0, 0, 0, 0, 0)
+                    off += 176
             elif kind == "dw":
                 _, x, gy, lo, n_in, n_out, book, side, pg, flg = op
                 g = books[book][side]
@@ -517,11 +540,12 @@ class _Pass(object):
                      A[x], AD[gy[0]][gy[1]], g.pairs().data_ptr(), pbase + pg, 0, dwws, 0, 0, 0, 0, 0, 0)
                 off += 176
             elif kind == "bn":
-                _, x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b = op
+                _, x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b, res = op
                 if V[lvl]:
                     pack(buf, off, K_BNB, flg, planes, 0, 0, 0, 0, 0, 0.0, 0.0, leak, 0.0, V[lvl], 0, 0, 0,
                          A[x], AD[gx[0]][gx[1]], A[y], AD[gy[0]][gy[1]], sbase + st * 4, sbase + (st + planes) * 4,
-                         p_w, pbase + pw if pw >= 0 else 0, pbase + pb if pb >= 0 else 0, bnws, p_b, 0)
+                         p_w, pbase + pw if pw >= 0 else 0, pbase + pb if pb >= 0 else 0, bnws, p_b,
+                         AD[res[0]][res[1]] if res is not None else 0)
                     off += 176
             elif kind == "add":
                 _, a_, b_, s, lvl, planes, flg = op

@@ -246,6 +246,14 @@ int aabr_bn_backward(const float *in, float *d_in, const float *out, const float
                      const float *weight, const float *bias, float *d_weight, float *d_bias, float leakiness,
                      float *scratch, void *stream);
 
+/* the same with d_in = BatchNorm gradient + d_in_add ([rows, planes] fp32, may be NULL): the gradient sum autograd
+ * forms for a tensor with a second consumer (identity branch of a residual block, lateral connection) folded into
+ * the apply pass.                                                                                       */
+int aabr_bn_backward_add(const float *in, float *d_in, const float *out, const float *d_out, int64_t rows,
+                         int planes, const float *save_mean, const float *save_invstd, const float *weight,
+                         const float *bias, float *d_weight, float *d_bias, float leakiness, float *scratch,
+                         const float *d_in_add, void *stream);
+
 /* ---- bf16 feature storage (extension; BASELINE.json configs 3-5) ------------------------------
  * The reference instantiates its operators for float only (SCN/sparseconvnet_cuda.cpp:281-310).
  * These variants keep the SAME rule-book formats, fp32 parameters (W, bias, batch-norm affine and
@@ -287,7 +295,7 @@ int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *ou
  *                             f32[1] momentum, i32[1] train, f32[2] leakiness, p8 scratch)
  *        AABR_PLAN_BN_BWD     aabr_bn_backward[_bf16](p0 in, p1 d_in, p2 out, p3 d_out, i64[0] rows, i32[0] planes,
  *                             p4 save_mean, p5 save_invstd, p6 weight, p10 bias, p7 d_weight, p8 d_bias,
- *                             f32[2] leakiness, p9 scratch)
+ *                             f32[2] leakiness, p9 scratch); fp32 with p11 != NULL: aabr_bn_backward_add(..., p11)
  *        AABR_PLAN_ADD        aabr_add(p0 a, p1 b, p2 out, i64[0] n)
  *        AABR_PLAN_CAST       aabr_cast_storage(p0 in, p1 out, i64[0] n, flags & AABR_PLAN_TO_BF16)
  *   flags & AABR_PLAN_BF16 selects the bf16-storage entry point.  Stops at the first failing record and returns
