@@ -38,12 +38,15 @@ def boxes_iou_3d(targets, anchors, aug=(0.0, 0.0, 0.0, 0.0), criterion=-1, only_
     return iou
 
 
-def rotate_nms_sorted(boxes7_sorted, thresh, post_max=-1, only_xy=True):
-    """boxes already in descending-score order -> LongTensor of kept positions (device)."""
+def rotate_nms_sorted(boxes7_sorted, thresh, post_max=-1, only_xy=True, lazy=False):
+    """boxes already in descending-score order -> LongTensor of kept positions (device).
+    `lazy`: no host read here -- returns (keep [n], meta) with the number kept in meta[0] on the device, so that a
+    caller with several lists to suppress can enqueue them all and read the counts once."""
     b = _dev(boxes7_sorted)
     n = b.size(0)
     if n == 0:
-        return torch.zeros(0, dtype=torch.int64, device=b.device)
+        z = torch.zeros(0, dtype=torch.int64, device=b.device)
+        return (z, None) if lazy else z
     cb = (n + 63) // 64
     mask = torch.empty(n * cb, dtype=torch.int64, device=b.device)
     keep = torch.empty(n, dtype=torch.int64, device=b.device)
@@ -51,6 +54,8 @@ def rotate_nms_sorted(boxes7_sorted, thresh, post_max=-1, only_xy=True):
     check(_hip.load().aabr_rotate_nms_sorted(ptr(b), n, float(thresh), int(bool(only_xy)),
                                              int(post_max if post_max is not None else -1), ptr(mask), ptr(keep),
                                              ptr(meta), stream()))
+    if lazy:
+        return keep, meta
     nk = int(meta[0].item())
     return keep[:nk]
 

@@ -91,7 +91,7 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
     strides_h = _hip.f32xn([v for st in strides for v in st])
     weights_h = _hip.f32xn(weights)
     site0 = [0] * n_maps
-    out = []
+    out, pending = [], []
     for bi in range(nb):
         seg = [0]
         for m in range(n_maps):
@@ -110,10 +110,18 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
                                        ptr(ba), A, float(voxel_scale), weights_h, float(bbox_xform_clip),
                                        float(nms_aug_thickness[0]), float(nms_aug_thickness[1]), ptr(sel), k,
                                        ptr(boxes), ptr(nms_boxes), ptr(scores), stream()))
-        keep = _nms.rotate_nms_sorted(nms_boxes, nms_thresh, post_nms_top_n, _nms.REFERENCE_DEBUG_ONLY_XY)
-        out.append((boxes[keep], scores[keep]))
+        # every example's launches go out first; the numbers kept are read once, after the last one
+        keep, meta = _nms.rotate_nms_sorted(nms_boxes, nms_thresh, post_nms_top_n, _nms.REFERENCE_DEBUG_ONLY_XY,
+                                            lazy=True)
+        pending.append((len(out), boxes, scores, keep, meta))
+        out.append(None)
         for m in range(n_maps):
             site0[m] += counts[m][bi]
+    if pending:
+        kept = torch.stack([p[4][0] for p in pending]).tolist()      # the one read of the NMS stage
+        for (i, boxes, scores, keep, meta), nk in zip(pending, kept):
+            k = keep[:nk]
+            out[i] = (boxes[k], scores[k])
     return out
 
 
