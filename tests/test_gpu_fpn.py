@@ -375,3 +375,34 @@ def test_fpn_compiled_graph_matches_module_path():
             net([l, _t(feats)])
         assert planExecutor.stats["passes"] == before
         h.remove()
+
+
+@pytest.mark.gpu
+def test_fpn_compiled_graph_is_bit_reproducible():
+    """the compiled graph runs its weight gradients on a second stream and folds adds into their producers: the same
+    step twice (fresh geometry each time) must give the same bits -- maps, input gradient, every parameter gradient"""
+    torch.manual_seed(8)
+    net = _fpn().to(DEV)
+    net.compiled_graph = True
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    locs, feats = S.make_batch(2, 25000, 43, 20)
+    l = _t(locs)
+
+    def run():
+        net.load_state_dict(state)
+        f = _t(feats).requires_grad_(True)
+        net.zero_grad()
+        rpn, roi = net([l, f])
+        sum(m.features.square().mean() for m in rpn + roi).backward()
+        torch.cuda.synchronize()
+        return [m.features.detach().clone() for m in rpn], f.grad.clone(), \
+            [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+    a, b, c = run(), run(), run()
+    for other in (b, c):
+        for x, y in zip(a[0], other[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(a[1], other[1])
+        assert len(a[2]) == len(other[2]) > 100
+        for x, y in zip(a[2], other[2]):
+            assert torch.equal(x, y)
