@@ -198,7 +198,7 @@ class FPN_Net(torch.nn.Module):
             for k in range(base + 1, min(base + step, nscale - 1) + 1):
                 specs.append((lvl[k][0], lvl[k][1] // bcum))
             for k, z in zmaps.items():
-                if base <= k < base + step and (base > 0 or k == 0 or True):
+                if base <= k < base + step:
                     # a z-collapse grid needs its level's sites only through their (x, y): from the base as well
                     specs.append((torch.LongTensor([int(lvl[k][0][0]), int(lvl[k][0][1]), 1]),
                                   (lvl[k][1] // bcum) * torch.LongTensor([1, 1, z])))
