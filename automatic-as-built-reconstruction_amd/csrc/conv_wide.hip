@@ -107,7 +107,12 @@ __device__ inline float bcf_(unsigned int v) { return __builtin_bit_cast(float, 
 constexpr int kMaxTileRows = 240; // (240 + 1) rows x 256 B + 16 KiB stage = 76 KiB: two workgroups per CU
 
 // NBUF = LDS stage buffers: 2 (one barrier per pair, 2 workgroups per CU) or 1 (two barriers per pair, 3 per CU)
-template <int KG, int DBG, int NBUF>
+// BF: bf16 feature storage (extension): rows, stage and weight packs hold bf16, one v_mfma_f32_16x16x32_bf16 per 32
+// channels; KG then counts 128-BYTE row chunks (64 channels), so the gather / stage code is the same byte for byte
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+
+template <int KG, int DBG, int NBUF, bool BF = false>
 __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
   const int pr = wave * 8 + (lane >> 3), seg = lane & 7; // gather role: pair row 0..31, 16-byte segment
-  const int nkc = ci >> 5, nnb = co >> 4;
+  const int nkc = BF ? ci >> 6 : ci >> 5, nnb = co >> 4;   // 128-byte chunks per row
   const int nb0 = blockIdx.y * kNB;
   const int64_t tile = blockIdx.x, row0 = tile * kT2;
   const int64_t ntiles = (V_out + kT2 - 1) / kT2;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   const __amdgpu_buffer_rsrc_t rw =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, (int)wp_bytes, 0x00020000);
   const unsigned ebase = (unsigned)((ntiles * (vol + 1) + tile * (int64_t)maxb * 16) * 4);
-  const unsigned rowbytes = (unsigned)ci * 4u;
+  const unsigned rowbytes = (unsigned)ci * (BF ? 2u : 4u);
   const unsigned lane32 = (unsigned)lane * 32u;
   auto pre_of = [&](int k) { return __builtin_amdgcn_readlane(vpre, k); };
   auto next_offset = [&](int k) {
@@ -161,9 +166,15 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
 #pragma unroll
     for (int c = 0; c < KG; ++c) { // nkc % KG == 0 (dispatch): every load is unconditional, so the compiler's
       const int kc = kg * KG + c;  // vmcnt bookkeeping stays exact and nothing waits for a prefetch it does not use
-      const unsigned so = (unsigned)((((int64_t)kW * nkc + kc) * nnb + nb0 + wave) * 2048);
-      w.w0[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, so, 0);
-      w.w1[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16u, so, 0);
+      if (BF) { // two 32-channel MFMA chunks per 128-byte row chunk, 1 KiB of packed weights each
+        const unsigned so = (unsigned)((((int64_t)kW * (2 * nkc) + 2 * kc) * nnb + nb0 + wave) * 1024);
+        w.w0[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, so, 0);
+        w.w1[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, so + (unsigned)nnb * 1024u, 0);
+      } else {
+        const unsigned so = (unsigned)((((int64_t)kW * nkc + kc) * nnb + nb0 + wave) * 2048);
+        w.w0[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, so, 0);
+        w.w1[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16u, so, 0);
+      }
     }
   };
   // entries of the pair (bb, bb+1) of offset kk; the second block only if it belongs to the same offset,
@@ -255,7 +266,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
         u32x4 a0[KG], a1[KG], b0[KG], b1[KG];
 #pragma unroll
         for (int c = 0; c < KG; ++c) {
-          const int q0 = ((c * 8 + g * 2) ^ (c16 & SWZ)) << 2, q1 = ((c * 8 + g * 2 + 1) ^ (c16 & SWZ)) << 2;
+          // fp32: the lane's 8 consecutive channels of a 32-channel chunk = granules 2g, 2g+1; bf16: its 8 channels
+          // of each of the chunk's two 32-channel halves = granules g and 4+g
+          const int q0 = ((c * 8 + (BF ? g : g * 2)) ^ (c16 & SWZ)) << 2,
+                    q1 = ((c * 8 + (BF ? 4 + g : g * 2 + 1)) ^ (c16 & SWZ)) << 2;
           a0[c] = *reinterpret_cast<const u32x4 *>(sa + q0);
           b0[c] = *reinterpret_cast<const u32x4 *>(sb + q0);
           a1[c] = *reinterpret_cast<const u32x4 *>(sa + q1);
@@ -267,6 +281,23 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
           for (int c = 0; c < KG; ++c) {
             accA[0] += bcf_(a0[c][0]) + bcf_(a1[c][0]) + bcf_(w.w0[c][0]) + bcf_(w.w1[c][0]);
             accB[0] += bcf_(b0[c][0]) + bcf_(b1[c][0]);
+          }
+        } else if (BF) {
+#pragma unroll
+          for (int c = 0; c < KG; ++c) {
+            accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[c]),
+                                                           __builtin_bit_cast(bf16x8w, a0[c]), accA, 0, 0, 0);
+            accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[c]),
+                                                           __builtin_bit_cast(bf16x8w, a1[c]), accA, 0, 0, 0);
+          }
+          if (e0.hb) {
+#pragma unroll
+            for (int c = 0; c < KG; ++c) {
+              accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[c]),
+                                                             __builtin_bit_cast(bf16x8w, b0[c]), accB, 0, 0, 0);
+              accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[c]),
+                                                             __builtin_bit_cast(bf16x8w, b1[c]), accB, 0, 0, 0);
+            }
           }
         } else {
           // block A, then block B only if the pair has one (sparse rule books: most offsets of a tile hold a single
@@ -350,7 +381,12 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
       const f32x4 rr = *reinterpret_cast<const f32x4 *>(res + (row0 + r) * co + nb0 * 16 + q * 4);
       v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
     }
-    *reinterpret_cast<f32x4 *>(out + (row0 + r) * co + nb0 * 16 + q * 4) = v;
+    if (BF) {
+      bf16x4w o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      *reinterpret_cast<bf16x4w *>(reinterpret_cast<__bf16 *>(out) + (row0 + r) * co + nb0 * 16 + q * 4) = o;
+    } else {
+      *reinterpret_cast<f32x4 *>(out + (row0 + r) * co + nb0 * 16 + q * 4) = v;
+    }
   }
 }
 
@@ -489,6 +525,86 @@ extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64
 #undef AABR_WIDE_CS_N
   }
 #undef AABR_LAUNCH_WIDE
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+// ---- bf16 feature storage (extension): the same kernel on 128-byte row chunks of 64 bf16 channels ------------------
+// 0: use aabr_conv_forward_bf16 (64-row tiles); otherwise rows per tile for aabr_conv_forward_wide_bf16
+extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
+  if (n_in <= 0 || n_out <= 0 || (n_in & 63) || (n_out & 63) || vol <= 0 || vol > kMaxVol) return 0;
+  if (rows_in >= (1ll << 23) || rows_in * n_in * 2 >= (1ll << 31)) return 0;
+  if (n_in > 256 && (n_in & 255)) return 0; // channel groups of 256: every load of the inner loop unconditional
+  int T = 128;
+  {
+    const int64_t slabs = n_out / 64;
+    if (((V_out + 127) / 128) * slabs <= 512)
+      for (int t = 64; t < 128; t += 16)
+        if (((V_out + t - 1) / t) * slabs <= 512) { T = t; break; }
+  }
+  if (const char *ov = getenv("AABR_WIDE_ROWS")) { // tuning experiments only
+    const int v = atoi(ov);
+    if (v >= 16 && v <= kMaxTileRows && (v & 15) == 0) T = v;
+  }
+  if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
+  if ((int64_t)vol * n_in * n_out * 2 >= (1ll << 31)) return 0;
+  if (const char *ov = getenv("AABR_CONV_WIDE_BF16")) { // tuning experiments only: 0 = never, 1 = whenever supported
+    if (ov[0] == '0') return 0;
+    if (ov[0] == '1') return T;
+  }
+  return (((V_out + T - 1) / T) * (n_out / 64) >= 320) ? T : 0;
+}
+
+extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
+                                           int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                           const float *bias, int flags, const uint16_t *wpack, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 63) == 0 && (n_out & 63) == 0, "plane counts: n_in % 64, n_out % 64");
+  AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
+  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
+  if (V_out == 0) return AABR_OK;
+  AABR_CHECK_ARG(in_feats && out_feats && blocks && wpack && rows_in > 0, "null pointer / empty input");
+  AABR_CHECK_ARG(rows_in < (1ll << 23), "too many input rows for the wide block format");
+  const int64_t in_bytes = rows_in * n_in * 2, words_bytes = wide_words(V_out, vol, tile_rows) * 4;
+  AABR_CHECK_ARG(in_bytes < (1ll << 31) && words_bytes < (1ll << 31), "buffers must be < 2 GiB");
+  AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 15) == 0 && ((uintptr_t)wpack & 15) == 0,
+                 "feature / weight pointers must be 16-byte aligned");
+  const int nkc = n_in / 64; // 128-byte chunks per row
+  const int64_t wp_bytes = (int64_t)vol * (n_in / 32) * (n_out / 16) * 1024;
+  AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
+  AABR_CHECK_ARG(n_in <= 256 || (n_in & 255) == 0, "n_in above 256 must be a multiple of 256");
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / 64));
+  const int flip = (flags >> 1) & 1;
+  const int kg = nkc >= 4 ? 4 : nkc;
+  int nbuf = kg == 4 ? 1 : 2;
+  if (const char *ov = getenv("AABR_WIDE_NBUF")) { // tuning experiments only
+    if (ov[0] == '1') nbuf = 1;
+    if (ov[0] == '2') nbuf = 2;
+  }
+  const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
+  float *out_f = reinterpret_cast<float *>(out_feats);
+#define AABR_WIDE_BF(KG, NB)                                                                                       \
+  do {                                                                                                             \
+    static bool attr = false;                                                                                      \
+    if (!attr) {                                                                                                   \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB, true>),                               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                  \
+      attr = true;                                                                                                 \
+    }                                                                                                              \
+    g_last_variant = "k_conv_cs<" #KG ",0," #NB ",bf16>";                                                          \
+    hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true>), grid, dim3(256),                                              \
+                       (size_t)((tile_rows + 1) * kWS + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f, n_in,    \
+                       in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,        \
+                       tile_rows, (const float *)nullptr);                                                         \
+  } while (0)
+#define AABR_WIDE_BF_K(KG)                                                                                         \
+  do {                                                                                                             \
+    if (nbuf == 1) AABR_WIDE_BF(KG, 1); else AABR_WIDE_BF(KG, 2);                                                  \
+  } while (0)
+  if (kg == 1) AABR_WIDE_BF_K(1); else if (kg == 2) AABR_WIDE_BF_K(2); else if (kg == 3) AABR_WIDE_BF_K(3);
+  else AABR_WIDE_BF_K(4);
+#undef AABR_WIDE_BF_K
+#undef AABR_WIDE_BF
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

@@ -773,9 +773,12 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
             flags |= 4
     if not (flags & 4) and n_rows_out > 0:
         pack_stats["own"] += 1                               # this call packs its weights itself
-    tile_rows = 0 if (bf16 or n_rows_out == 0) else lib.aabr_conv_wide_tile_rows(n_in, n_out, inp.size(0), n_rows_out,
-                                                                                  gather.vol)
-    if tile_rows:
+    tile_rows = wide_tile_rows(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16, bool(flags & 4))
+    if tile_rows and bf16:
+        check(lib.aabr_conv_forward_wide_bf16(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
+                                              ptr(gather.blocks_wide(tile_rows)), tile_rows, gather.vol,
+                                              ptr(_opt(bias)), flags & 3, ptr(wpack), stream()))
+    elif tile_rows:
         # wide layer: big tiles, weights shared per offset (csrc/conv_wide.hip)
         if not (flags & 4):
             check(lib.aabr_conv_pack_weights(ptr(w), gather.vol, w.size(2), w.size(3), flags & 1, ptr(wpack), stream()))
@@ -848,6 +851,18 @@ class WeightPackPlan:
                 del w._aabr_pack
 
 
+def wide_tile_rows(n_in, n_out, rows_in, rows_out, vol, bf16=False, prepacked=True):
+    """rows per tile when this launch goes to the wide-layer kernel (csrc/conv_wide.hip), else 0 -- the one place the
+    layer code, the stream pre-builder and the graph executor take that decision from.  bf16 storage: only with a
+    prepacked weight (the training path always has one; a stand-alone call packs inside the 64-row-tile entry)."""
+    if rows_out == 0:
+        return 0
+    lib = _hip.load()
+    if bf16:
+        return lib.aabr_conv_wide_tile_rows_bf16(n_in, n_out, rows_in, rows_out, vol) if prepacked else 0
+    return lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, vol)
+
+
 def _conv_dw(inp, d_out, gather, d_weight, d_bias):
     lib = _hip.load()
     n_in, n_out, V_out = inp.size(1), d_out.size(1), d_out.size(0)
@@ -869,9 +884,7 @@ def compile_streams(gather, rows_in, n_in, n_out, dtype, weight_grad=False):
     read -- the same choice `_conv_fwd` makes -- and, with `weight_grad`, the offset-pair lists of the dW kernel."""
     if gather is None or gather.rows == 0:
         return
-    tile_rows = 0
-    if dtype == torch.float32:
-        tile_rows = _hip.load().aabr_conv_wide_tile_rows(n_in, n_out, rows_in, gather.rows, gather.vol)
+    tile_rows = wide_tile_rows(n_in, n_out, rows_in, gather.rows, gather.vol, dtype == torch.bfloat16)
     if tile_rows:
         gather.blocks_wide(tile_rows)
     else:

@@ -412,11 +412,11 @@ class _Pass(object):
         self.books = bk
         self._wide = {}
 
-    def wide_rows(self, n_in, n_out, rows_in, rows_out, vol):
-        key = (n_in, n_out, rows_in, rows_out, vol)
+    def wide_rows(self, n_in, n_out, rows_in, rows_out, vol, bf=False):
+        key = (n_in, n_out, rows_in, rows_out, vol, bf)
         T = self._wide.get(key)
         if T is None:
-            T = self._wide[key] = self.lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, vol)
+            T = self._wide[key] = SCN.wide_tile_rows(n_in, n_out, rows_in, rows_out, vol, bf)
         return T
 
     def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf,
@@ -424,11 +424,12 @@ class _Pass(object):
         """the record of the launch SCN._conv_fwd makes for a prepacked weight; returns the new write offset"""
         if rows_out == 0:
             return off
-        T = 0 if bf else self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol)
+        T = self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf)
         assert T or not res
         if T:
-            pack(buf, off, K_WIDE, xf, n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
-                 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), res, 0, p_pack, 0, 0, 0, 0, 0, 0)
+            pack(buf, off, K_WIDE, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0,
+                 0.0, rows_in, rows_out, 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), res, 0, p_pack, 0, 0, 0, 0,
+                 0, 0)
         else:
             pack(buf, off, K_CONV, (F_BF16 if bf else 0) | xf, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,
                  rows_in, rows_out, 0, 0, src, dst, gather.blocks().data_ptr(), p_w, 0, p_pack, 0, 0, 0, 0, 0, 0)

@@ -266,6 +266,13 @@ int64_t aabr_conv_wpack_bf16_elems(int vol, int n_in, int n_out);
 int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
                            int n_out, int64_t V_out, const int32_t *blocks, int vol, const float *W,
                            const float *bias, int flags, uint16_t *wpack, void *stream);
+/* bf16 storage through the wide-layer kernel (128-row tiles, columns split over the waves, gathered rows shared
+ * through LDS): n_in % 64 == 0 (above 256: % 256), n_out % 64 == 0; the block stream is the fp32 wide kernel's
+ * (aabr_build_wide_blocks), the weight pack aabr_conv_pack_weights2_bf16's.                              */
+int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
+int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
+                                int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                                int flags, const uint16_t *wpack, void *stream);
 int aabr_conv_backward_weight_bf16(const uint16_t *in_feats, int n_in, const uint16_t *d_out,
                                    int n_out, int64_t V_out, const int32_t *pairs, int vol,
                                    int64_t max_chunks, float *dW, float *d_bias, float *scratch,
