@@ -131,3 +131,68 @@ def test_default_dispatch_takes_the_wide_kernel_on_a_large_layer():
     rb = O.submanifold_rules(il["coords"], [3, 3, 3])
     ref, _ = O.conv_fwd(il["out"], conv.weight.detach().cpu().numpy().reshape(27, 64, 128), rb, il["V"])
     np.testing.assert_allclose(y.features.cpu().numpy(), ref, rtol=1e-4, atol=2e-6 * np.abs(ref).max() * 64)
+
+
+@pytest.mark.parametrize("nIn,nOut,npts,vol3", [(64, 64, 3000, True), (128, 128, 2500, True), (128, 64, 129, True),
+                                                (192, 128, 1500, True), (256, 192, 2000, True), (512, 64, 700, True),
+                                                (128, 128, 900, False)])
+def test_wide_bf16_storage_matches_oracle_on_rounded_operands(nIn, nOut, npts, vol3):
+    """k_conv_cs<.., bf16> through the C ABI (forced for every supported shape) against the oracle fed with the SAME
+    bf16-rounded features and weights: the products are exact in fp32 either way, so the only differences are the
+    fp32 accumulation order and the final rounding to bf16 (<= 1 bf16 ulp of the largest term); forward form and
+    input-gradient form (transposed pack, mirrored offsets), 1..4 chunks per row and two channel groups (512)."""
+    import _hip
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(nIn + 3 * nOut + npts)
+    coords, _ = _scene(rng, npts, (12, 11, 5), 2, 1)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
+    fsz = [3, 3, 3] if vol3 else [1, 1, 1]
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor(fsz))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    il = O.input_layer(coords, np.zeros((npts, 1), np.float32), 4)
+    rb = O.submanifold_rules(il["coords"], fsz)
+    T = lib.aabr_conv_wide_tile_rows_bf16(nIn, nOut, V, V, vol) or 128
+    os.environ["AABR_CONV_WIDE_BF16"] = "1"
+    try:
+        T = lib.aabr_conv_wide_tile_rows_bf16(nIn, nOut, V, V, vol)
+    finally:
+        del os.environ["AABR_CONV_WIDE_BF16"]
+    assert T in (64, 80, 96, 112, 128)
+    W = (rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32)
+    Wd = _t(W)
+    n = int(lib.aabr_conv_wpack_bf16_elems(vol, nIn, nOut))
+    pf = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    pt = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    check(lib.aabr_conv_pack_weights2_bf16(ptr(Wd), vol, nIn, nOut, ptr(pf), ptr(pt), stream()))
+    Wr = Wd.bfloat16().float().cpu().numpy().reshape(vol, nIn, nOut)
+    blocks = ga.blocks_wide(T)
+    # forward form
+    f = torch.as_tensor(rng.standard_normal((V, nIn)).astype(np.float32)).to(DEV).bfloat16()
+    out = torch.empty((V, nOut), dtype=torch.bfloat16, device=DEV)
+    check(lib.aabr_conv_forward_wide_bf16(ptr(f), nIn, V, ptr(out), nOut, V, ptr(blocks), T, vol, None, 0, ptr(pf),
+                                          stream()))
+    assert _variant().endswith(",bf16>"), _variant()
+    ref, _ = O.conv_fwd(f.float().cpu().numpy(), Wr, rb, V, None)
+    got = out.float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=2 ** -7 * np.abs(ref).max())
+    # input-gradient form: d_in = sum_k d_out[partner] @ W[k]^T over the mirrored offsets
+    g = torch.as_tensor(rng.standard_normal((V, nOut)).astype(np.float32)).to(DEV).bfloat16()
+    d_in = torch.empty((V, nIn), dtype=torch.bfloat16, device=DEV)
+    Tb = T
+    os.environ["AABR_CONV_WIDE_BF16"] = "1"
+    try:
+        Tb = lib.aabr_conv_wide_tile_rows_bf16(nOut, nIn, V, V, vol)
+    finally:
+        del os.environ["AABR_CONV_WIDE_BF16"]
+    if Tb:
+        check(lib.aabr_conv_forward_wide_bf16(ptr(g), nOut, V, ptr(d_in), nIn, V, ptr(ga.blocks_wide(Tb)), Tb, vol,
+                                              None, 1 | 2, ptr(pt), stream()))
+        dref, _, _ = O.conv_bwd(np.zeros((V, nIn), np.float32), g.float().cpu().numpy(), Wr, rb, want_bias=False)
+        np.testing.assert_allclose(d_in.float().cpu().numpy(), dref, rtol=2 ** -7, atol=2 ** -7 * np.abs(dref).max())
+    # same launch, same bits
+    out2 = torch.empty_like(out)
+    check(lib.aabr_conv_forward_wide_bf16(ptr(f), nIn, V, ptr(out2), nOut, V, ptr(blocks), T, vol, None, 0, ptr(pf),
+                                          stream()))
+    assert torch.equal(out, out2)
