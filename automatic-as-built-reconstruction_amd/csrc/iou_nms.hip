@@ -425,3 +425,81 @@ extern "C" int aabr_nms_sorted(const float *dets4, int64_t n, float thresh, uint
                                int32_t *meta, void *stream_) {
   return nms_sorted_impl<1>(dets4, n, thresh, 1, -1, mask, keep, meta, (hipStream_t)stream_, "aabr_nms_sorted");
 }
+
+// ---- the proposal stage of a whole batch (extension) ---------------------------------------------------------------
+// The reference's RPNPostProcessor loops over the examples in Python (rpn/inference_3d.py:95-149).  These two
+// entries let a host do the same work with one top-k over a padded matrix and one call here:
+//   aabr_rpn_gather_logits: logits[b][j] = the j-th logit of example b's cross-scale anchor list (maps in order),
+//                           -inf past its end, so ONE torch.topk(dim=1) selects for every example;
+//   aabr_rpn_proposals_batch: per example the decode of the selected anchors (aabr_rpn_decode_maps) and the rotated
+//                           NMS of the decoded list (aabr_rotate_nms_sorted), looped HERE; the numbers kept stay on
+//                           the device (meta[b][0]) for the caller to read once.
+constexpr int kMaxRpnBatch = 16;
+struct RpnGatherParams {
+  const float *logits[kMaxRpnMaps];
+  int32_t seg_begin[kMaxRpnBatch][kMaxRpnMaps + 1]; // in anchors, per example
+  int32_t src_begin[kMaxRpnBatch][kMaxRpnMaps];     // first anchor of example b in map m's logit vector
+  int n_maps, nb;
+};
+
+__global__ __launch_bounds__(256) void k_rpn_gather_logits(RpnGatherParams p, int64_t lmax, float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= lmax) return;
+  float v = -__builtin_inff();
+  if (j < p.seg_begin[b][p.n_maps]) {
+    int m = 0;
+    while (m + 1 < p.n_maps && j >= p.seg_begin[b][m + 1]) ++m;
+    v = p.logits[m][(int64_t)p.src_begin[b][m] + (j - p.seg_begin[b][m])];
+  }
+  out[(int64_t)b * lmax + j] = v;
+}
+
+extern "C" int aabr_rpn_gather_logits(int n_maps, const void *const *logit_ptrs, int nb, const int32_t *seg_begin_host,
+                                      const int32_t *site_begin_host, int num_anchors, int64_t lmax, float *out,
+                                      void *stream_) {
+  AABR_CHECK_ARG(n_maps >= 1 && n_maps <= kMaxRpnMaps && nb >= 1 && nb <= kMaxRpnBatch && num_anchors > 0 && lmax > 0,
+                 "bad arguments (at most 8 maps, 16 examples)");
+  AABR_CHECK_ARG(logit_ptrs && seg_begin_host && site_begin_host && out, "null pointer");
+  RpnGatherParams p;
+  p.n_maps = n_maps; p.nb = nb;
+  for (int m = 0; m < kMaxRpnMaps; ++m) p.logits[m] = m < n_maps ? (const float *)logit_ptrs[m] : nullptr;
+  for (int b = 0; b < nb; ++b) {
+    for (int m = 0; m <= n_maps; ++m) p.seg_begin[b][m] = seg_begin_host[b * (n_maps + 1) + m];
+    for (int m = 0; m < n_maps; ++m) {
+      p.src_begin[b][m] = site_begin_host[b * n_maps + m] * num_anchors;
+      AABR_CHECK_ARG(p.seg_begin[b][m + 1] >= p.seg_begin[b][m], "segment table must be non-decreasing");
+      AABR_CHECK_ARG(p.seg_begin[b][m + 1] == p.seg_begin[b][m] || p.logits[m], "null map pointer");
+    }
+    AABR_CHECK_ARG(p.seg_begin[b][n_maps] <= lmax, "lmax smaller than an example's list");
+  }
+  hipLaunchKernelGGL(k_rpn_gather_logits, dim3((unsigned)ceil_div(lmax, 256), (unsigned)nb), dim3(256), 0,
+                     (hipStream_t)stream_, p, lmax, out);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_ptrs, const void *const *logit_ptrs,
+                                        const void *const *regression_ptrs, int nb, const int32_t *seg_begin_host,
+                                        const int32_t *site_begin_host, const float *strides_host,
+                                        const float *base_anchors, int num_anchors, float voxel_scale,
+                                        const float *weights_host, float clip, float nms_min_yx, float nms_min_z,
+                                        const int64_t *selected, int64_t k, float *boxes, float *nms_boxes,
+                                        float *scores, float nms_thresh, int only_xy, int64_t post_max, uint64_t *mask,
+                                        int64_t *keep, int32_t *meta, void *stream_) {
+  AABR_CHECK_ARG(nb >= 1 && nb <= kMaxRpnBatch && k >= 0 && seg_begin_host && site_begin_host, "bad arguments");
+  AABR_CHECK_ARG(selected && boxes && nms_boxes && scores && mask && keep && meta, "null pointer");
+  const int64_t cb = ceil_div(k > 0 ? k : 1, (int64_t)64);
+  for (int b = 0; b < nb; ++b) {
+    int rc = aabr_rpn_decode_maps(n_maps, coords_ptrs, logit_ptrs, regression_ptrs, seg_begin_host + b * (n_maps + 1),
+                                  site_begin_host + b * n_maps, strides_host, base_anchors, num_anchors, voxel_scale,
+                                  weights_host, clip, nms_min_yx, nms_min_z, selected + (int64_t)b * k, k,
+                                  boxes + (int64_t)b * k * 7, nms_boxes + (int64_t)b * k * 7, scores + (int64_t)b * k,
+                                  stream_);
+    if (rc != AABR_OK) return rc;
+    rc = aabr_rotate_nms_sorted(nms_boxes + (int64_t)b * k * 7, k, nms_thresh, only_xy, post_max,
+                                mask + (int64_t)b * k * cb, keep + (int64_t)b * k, meta + b * AABR_META_WORDS, stream_);
+    if (rc != AABR_OK) return rc;
+  }
+  return AABR_OK;
+}

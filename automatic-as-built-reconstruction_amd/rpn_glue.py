@@ -63,7 +63,7 @@ def rpn_proposals_single_map(tensor, objectness, box_regression, base_anchors, v
 
 def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel_scale, pre_nms_top_n=2000,
                   post_nms_top_n=1000, nms_thresh=0.5, nms_aug_thickness=(0.3, 0.3), weights=(1.0,) * 7,
-                  bbox_xform_clip=10000.0):
+                  bbox_xform_clip=10000.0, batch_size=None, batched=False):
     """Cross-scale proposals, the shape the reference runs in (RPNModule.forward, rpn_sparse3d.py:184-209):
     `cat_scales_obj_reg` regroups the scales example-major and RPNPostProcessor then does, per example, ONE
     sigmoid -> top-k(2000) -> decode -> boxlist_nms_3d(1000) over the anchors of all maps
@@ -84,9 +84,53 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
     ba = torch.cat([b.reshape(A, 7) for b in base_anchors], 0).to(device=dev, dtype=torch.float32).contiguous()
     obj = [o.reshape(-1).contiguous().float() for o in objectness]
     reg = [r.reshape(-1, 7).contiguous().float() for r in box_regression]
-    nb = max((int(g.coords[-1, 3].item()) + 1 if g.V else 0) for g in grids[:1])
+    # `batch_size` (extension): the number of examples when the caller knows it -- saves the read of the last site's
+    # batch index.  `batched` (extension): one top-k over a padded [examples, anchors] matrix and one library call for
+    # every example's decode + NMS (aabr_rpn_gather_logits / aabr_rpn_proposals_batch) when every example has at
+    # least pre_nms_top_n anchors; same selections unless logits tie exactly at the cut
+    if batch_size is not None:
+        nb = int(batch_size)
+    else:
+        nb = max((int(g.coords[-1, 3].item()) + 1 if g.V else 0) for g in grids[:1])
     counts = torch.stack([torch.bincount(g.coords[:, 3].long(), minlength=nb)[:nb] if g.V else
                           torch.zeros(nb, dtype=torch.int64, device=dev) for g in grids]).tolist()   # [map][example]
+    if batched and 1 <= nb <= 16 and n_maps <= 8:
+        segs, sites, site0 = [], [], [0] * n_maps
+        for bi in range(nb):
+            seg = [0]
+            for m in range(n_maps):
+                seg.append(seg[-1] + counts[m][bi] * A)
+            segs.append(seg)
+            sites.append(list(site0))
+            for m in range(n_maps):
+                site0[m] += counts[m][bi]
+        if min(s[-1] for s in segs) >= pre_nms_top_n:
+            k = int(pre_nms_top_n)
+            lmax = max(s[-1] for s in segs)
+            seg_h = _hip.i32xn([v for s_ in segs for v in s_])
+            site_h = _hip.i32xn([v for s_ in sites for v in s_])
+            padded = torch.empty((nb, lmax), dtype=torch.float32, device=dev)
+            check(lib.aabr_rpn_gather_logits(n_maps, _hip.ptrs(obj), nb, seg_h, site_h, A, lmax, ptr(padded), stream()))
+            _, sel = padded.topk(k, dim=1, sorted=True)
+            boxes = torch.empty((nb, k, 7), dtype=torch.float32, device=dev)
+            nms_boxes = torch.empty((nb, k, 7), dtype=torch.float32, device=dev)
+            scores = torch.empty((nb, k), dtype=torch.float32, device=dev)
+            cb = (k + 63) // 64
+            mask = torch.empty(nb * k * cb, dtype=torch.int64, device=dev)
+            keep = torch.empty((nb, k), dtype=torch.int64, device=dev)
+            meta = torch.empty((nb, _hip.META_WORDS), dtype=torch.int32, device=dev)
+            check(lib.aabr_rpn_proposals_batch(
+                n_maps, _hip.ptrs([g.coords for g in grids]), _hip.ptrs(obj), _hip.ptrs(reg), nb, seg_h, site_h,
+                _hip.f32xn([v for st in strides for v in st]), ptr(ba), A, float(voxel_scale), _hip.f32xn(weights),
+                float(bbox_xform_clip), float(nms_aug_thickness[0]), float(nms_aug_thickness[1]), ptr(sel), k,
+                ptr(boxes), ptr(nms_boxes), ptr(scores), float(nms_thresh), int(_nms.REFERENCE_DEBUG_ONLY_XY),
+                int(post_nms_top_n), ptr(mask), ptr(keep), ptr(meta), stream()))
+            kept = meta[:, 0].tolist()              # the one read of the stage
+            out = []
+            for bi in range(nb):
+                kk = keep[bi, :kept[bi]]
+                out.append((boxes[bi][kk], scores[bi][kk]))
+            return out
     coords_p, obj_p, reg_p = _hip.ptrs([g.coords for g in grids]), _hip.ptrs(obj), _hip.ptrs(reg)
     strides_h = _hip.f32xn([v for st in strides for v in st])
     weights_h = _hip.f32xn(weights)

@@ -208,7 +208,9 @@ class Workload(object):
             with torch.no_grad(), torch.cuda.stream(self.side):
                 self.side.wait_event(ev_fwd)
                 props = rpn_glue.rpn_proposals(rpn_maps, [o.detach() for o in objs], [r.detach() for r in regs],
-                                               self.base, self.strides, float(VOXEL_SCALE), 2000, 1000, 0.5, (0.3, 0.3))
+                                               self.base, self.strides, float(VOXEL_SCALE), 2000, 1000, 0.5, (0.3, 0.3),
+                                               batch_size=SCENES_PER_STEP,
+                                               batched=os.environ.get("AABR_BENCH_BATCHED_PROPOSALS", "0") != "0")
             main.wait_stream(self.side)
         self.last = (rpn_maps, props)
         return loss

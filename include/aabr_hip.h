@@ -286,6 +286,24 @@ int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *ou
                           const float *save_invstd, const float *weight, const float *bias, float *d_weight,
                           float *d_bias, float leakiness, float *scratch, void *stream);
 
+/* ---- the proposal stage of a whole batch (extension) --------------------------------------------
+ * The reference's RPNPostProcessor loops over the examples in Python (rpn/inference_3d.py:95-149).
+ * aabr_rpn_gather_logits: out[b][j] = j-th logit of example b's cross-scale anchor list (maps in order; tables
+ *   [nb][n_maps+1] / [nb][n_maps] on the host as for aabr_rpn_decode_maps), -inf from its end to lmax -- one
+ *   top-k over dim 1 then selects for every example.
+ * aabr_rpn_proposals_batch: per example aabr_rpn_decode_maps on selected[b] followed by aabr_rotate_nms_sorted of
+ *   the decoded list; boxes / nms_boxes [nb,k,7], scores [nb,k], mask [nb][k*ceil(k/64)], keep [nb,k],
+ *   meta [nb][AABR_META_WORDS] (meta[b][0] = number kept, left on the device).  At most 8 maps, 16 examples.  */
+int aabr_rpn_gather_logits(int n_maps, const void *const *logit_ptrs, int nb, const int32_t *seg_begin_host,
+                           const int32_t *site_begin_host, int num_anchors, int64_t lmax, float *out, void *stream);
+int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_ptrs, const void *const *logit_ptrs,
+                             const void *const *regression_ptrs, int nb, const int32_t *seg_begin_host,
+                             const int32_t *site_begin_host, const float *strides_host, const float *base_anchors,
+                             int num_anchors, float voxel_scale, const float *weights_host, float clip,
+                             float nms_min_yx, float nms_min_z, const int64_t *selected, int64_t k, float *boxes,
+                             float *nms_boxes, float *scores, float nms_thresh, int only_xy, int64_t post_max,
+                             uint64_t *mask, int64_t *keep, int32_t *meta, void *stream);
+
 /* ---- compiled launch plans (extension) --------------------------------------------------------
  * The reference enters its library once per layer and direction from Python (SCN/pybind.cpp:134-221 behind
  * sparseconvnet/ layer modules).  A host that has compiled the static part of a network into a list of launches hands

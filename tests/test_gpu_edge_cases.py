@@ -479,6 +479,26 @@ def test_rpn_proposals_cross_scale_on_device():
         assert bd.shape[0] == bw.shape[0] > 10
         np.testing.assert_allclose(bd.cpu().numpy(), bw, rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(sd.cpu().numpy(), sw, rtol=1e-5, atol=1e-6)
+    # the whole batch in one go (one top-k over the padded matrix, one library call for decode + NMS of every
+    # example): the same proposals as example by example
+    import _hip
+    before = []
+    lib = _hip.load()
+    resb = rpn_glue.rpn_proposals(maps, [_t(o) for o in objs], [_t(r) for r in regs],
+                                  [torch.as_tensor(b) for b in bases], strides, 20.0, 600, 150, 0.5, (0.3, 0.3), weights,
+                                  10000.0, batch_size=2, batched=True)
+    assert len(resb) == 2
+    for (bd, sd), (be, se) in zip(res, resb):
+        assert torch.equal(bd, be) and torch.equal(sd, se)
+    # an example with fewer anchors than pre_nms_top_n: the batched form steps aside (same result as before)
+    resc = rpn_glue.rpn_proposals(maps, [_t(o) for o in objs], [_t(r) for r in regs],
+                                  [torch.as_tensor(b) for b in bases], strides, 20.0, 100000, 150, 0.5, (0.3, 0.3),
+                                  weights, 10000.0, batch_size=2, batched=True)
+    resd = rpn_glue.rpn_proposals(maps, [_t(o) for o in objs], [_t(r) for r in regs],
+                                  [torch.as_tensor(b) for b in bases], strides, 20.0, 100000, 150, 0.5, (0.3, 0.3),
+                                  weights, 10000.0)
+    for (bd, sd), (be, se) in zip(resc, resd):
+        assert torch.equal(bd, be) and torch.equal(sd, se)
 
 
 def test_input_layer_prepare_is_matched_by_identity_and_works_for_int32_coords():
