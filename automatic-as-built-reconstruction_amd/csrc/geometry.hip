@@ -291,28 +291,33 @@ __global__ __launch_bounds__(256) void k_conv_table_in(const int32_t *__restrict
                                                        const uint64_t *__restrict__ out_keys,
                                                        const int32_t *__restrict__ out_vals,
                                                        uint64_t out_mask, ConvGeom g,
-                                                       int32_t *__restrict__ table) {
+                                                       int32_t *__restrict__ table,
+                                                       int32_t *__restrict__ counts) {
   const int k = blockIdx.y;
   int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= V_in) return;
-  int d[3];
-  d[2] = k % g.size[2];
-  int t = k / g.size[2];
-  d[1] = t % g.size[1];
-  d[0] = t / g.size[1];
-  int4 c = *reinterpret_cast<const int4 *>(in_coords + 4 * u);
-  int p[3] = {c.x, c.y, c.z}, j[3];
-  bool ok = true;
+  int hit = 0;
+  if (u < V_in) {
+    int d[3];
+    d[2] = k % g.size[2];
+    int t = k / g.size[2];
+    d[1] = t % g.size[1];
+    d[0] = t / g.size[1];
+    int4 c = *reinterpret_cast<const int4 *>(in_coords + 4 * u);
+    int p[3] = {c.x, c.y, c.z}, j[3];
+    bool ok = true;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    int q = p[i] - d[i];
-    if (q < 0 || q % g.stride[i] != 0) { ok = false; break; }
-    j[i] = q / g.stride[i];
-    if (j[i] > g.out_sp[i] - 1) { ok = false; break; }
+    for (int i = 0; i < 3; ++i) {
+      int q = p[i] - d[i];
+      if (q < 0 || q % g.stride[i] != 0) { ok = false; break; }
+      j[i] = q / g.stride[i];
+      if (j[i] > g.out_sp[i] - 1) { ok = false; break; }
+    }
+    int r = -1;
+    if (ok) r = grid_find(out_keys, out_vals, out_mask, pack_key(c.w, j[0], j[1], j[2]));
+    table[(int64_t)k * V_in + u] = r;
+    hit = r >= 0;
   }
-  int r = -1;
-  if (ok) r = grid_find(out_keys, out_vals, out_mask, pack_key(c.w, j[0], j[1], j[2]));
-  table[(int64_t)k * V_in + u] = r;
+  if (counts) block_count_store(hit, counts, k);   // per 256-row block and offset, like k_conv_table_out
 }
 
 // one block per filter offset: ordered compaction of the table row into (entry, row) pairs
@@ -449,12 +454,30 @@ extern "C" int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, co
   return AABR_OK;
 }
 
+extern "C" int aabr_convolution_tables2(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
+                                        const int32_t *in_vals, int64_t in_cap, const int32_t *out_coords,
+                                        int64_t V_out, const uint64_t *out_keys, const int32_t *out_vals,
+                                        int64_t out_cap, const int32_t *size_host, const int32_t *stride_host,
+                                        const int32_t *out_spatial_host, int32_t *table_out, int32_t *table_in,
+                                        int32_t *counts, int32_t *counts_in, void *stream_);
+
 extern "C" int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
                                        const int32_t *in_vals, int64_t in_cap, const int32_t *out_coords,
                                        int64_t V_out, const uint64_t *out_keys, const int32_t *out_vals,
                                        int64_t out_cap, const int32_t *size_host, const int32_t *stride_host,
                                        const int32_t *out_spatial_host, int32_t *table_out, int32_t *table_in,
                                        int32_t *counts, void *stream_) {
+  return aabr_convolution_tables2(in_coords, V_in, in_keys, in_vals, in_cap, out_coords, V_out, out_keys, out_vals,
+                                  out_cap, size_host, stride_host, out_spatial_host, table_out, table_in, counts,
+                                  nullptr, stream_);
+}
+
+extern "C" int aabr_convolution_tables2(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
+                                        const int32_t *in_vals, int64_t in_cap, const int32_t *out_coords,
+                                        int64_t V_out, const uint64_t *out_keys, const int32_t *out_vals,
+                                        int64_t out_cap, const int32_t *size_host, const int32_t *stride_host,
+                                        const int32_t *out_spatial_host, int32_t *table_out, int32_t *table_in,
+                                        int32_t *counts, int32_t *counts_in, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(V_in >= 0 && V_out >= 0 && size_host && stride_host && out_spatial_host, "bad arguments");
   AABR_CHECK_ARG(is_pow2(in_cap) && is_pow2(out_cap), "capacities must be powers of two");
@@ -469,7 +492,7 @@ extern "C" int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, c
   if (V_in > 0 && table_in) {
     AABR_CHECK_ARG(in_coords && out_keys && out_vals, "null pointer");
     hipLaunchKernelGGL(k_conv_table_in, dim3((unsigned)ceil_div(V_in, 256), (unsigned)vol), dim3(256), 0, st,
-                       in_coords, V_in, out_keys, out_vals, (uint64_t)(out_cap - 1), g, table_in);
+                       in_coords, V_in, out_keys, out_vals, (uint64_t)(out_cap - 1), g, table_in, counts_in);
   }
   AABR_CHECK_LAUNCH();
   return AABR_OK;

@@ -570,11 +570,12 @@ class Metadata_3(object):
                 t_out = torch.empty((vol, V_out), dtype=torch.int32, device=dev)
                 t_in = torch.empty((vol, gi.V), dtype=torch.int32, device=dev)
                 counts = torch.empty(vol * ((V_out + 255) // 256), dtype=torch.int32, device=dev)
-                check(lib.aabr_convolution_tables(ptr(gi.coords), gi.V, ptr(gi.keys), ptr(gi.vals), gi.cap,
-                                                  ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
-                                                  _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),
-                                                  ptr(t_in), ptr(counts), stream()))
-                tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, None, vol, gi.V), vol, V_out, gi.V)
+                counts_in = torch.empty(vol * ((gi.V + 255) // 256), dtype=torch.int32, device=dev)
+                check(lib.aabr_convolution_tables2(ptr(gi.coords), gi.V, ptr(gi.keys), ptr(gi.vals), gi.cap,
+                                                   ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
+                                                   _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),
+                                                   ptr(t_in), ptr(counts), ptr(counts_in), stream()))
+                tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, counts_in, vol, gi.V), vol, V_out, gi.V)
                 self.rulebooks[k] = tb
                 return tb
             maxout = 1
@@ -597,11 +598,12 @@ class Metadata_3(object):
             t_out = torch.empty((vol, V_out), dtype=torch.int32, device=dev)
             t_in = torch.empty((vol, gi.V), dtype=torch.int32, device=dev)
             counts = torch.empty(vol * ((V_out + 255) // 256), dtype=torch.int32, device=dev)
-            check(lib.aabr_convolution_tables(ptr(gi.coords), gi.V, ptr(gi.keys), ptr(gi.vals), gi.cap,
-                                              ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
-                                              _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),
-                                              ptr(t_in), ptr(counts), stream()))
-            tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, None, vol, gi.V), vol, V_out, gi.V)
+            counts_in = torch.empty(vol * ((gi.V + 255) // 256), dtype=torch.int32, device=dev)
+            check(lib.aabr_convolution_tables2(ptr(gi.coords), gi.V, ptr(gi.keys), ptr(gi.vals), gi.cap,
+                                               ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
+                                               _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),
+                                               ptr(t_in), ptr(counts), ptr(counts_in), stream()))
+            tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, counts_in, vol, gi.V), vol, V_out, gi.V)
             self.rulebooks[k] = tb
         return tb
 

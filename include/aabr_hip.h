@@ -128,6 +128,15 @@ int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, const uint64
                             const int32_t *stride_host, const int32_t *out_spatial_host,
                             int32_t *table_out, int32_t *table_in, int32_t *counts,
                             void *stream);
+/* the same with the per-block rule counts of table_in as well (counts_in int32 [vol * ceil(V_in/256)], may be
+ * NULL): what the weight-gradient pass of a transposed convolution sizes its chunks with.               */
+int aabr_convolution_tables2(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
+                            const int32_t *in_vals, int64_t in_cap,
+                            const int32_t *out_coords, int64_t V_out, const uint64_t *out_keys,
+                            const int32_t *out_vals, int64_t out_cap, const int32_t *size_host,
+                            const int32_t *stride_host, const int32_t *out_spatial_host,
+                            int32_t *table_out, int32_t *table_in, int32_t *counts,
+                             int32_t *counts_in, void *stream);
 
 /* Reference-format rule book from a gather table: for offset k the (in,out) pairs in
  * ascending `out` order -- the layout of RuleBook = vector<vector<Int>> (Metadata.h:34).
