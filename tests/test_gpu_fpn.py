@@ -406,3 +406,33 @@ def test_fpn_compiled_graph_is_bit_reproducible():
         assert len(a[2]) == len(other[2]) > 100
         for x, y in zip(a[2], other[2]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_fpn_compiled_graph_with_partial_output_gradients():
+    """only some of the returned maps feed the loss: the compiled graph's backward list is generated for that
+    pattern (no launches for branches nothing flows back through) and must agree with autograd over the modules --
+    same set of parameters with a gradient, same values"""
+    torch.manual_seed(9)
+    net = _fpn().to(DEV)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    locs, feats = S.make_batch(2, 20000, 47, 20)
+    l = _t(locs)
+
+    def run(compiled):
+        net.load_state_dict(state)
+        net.compiled_graph = compiled
+        f = _t(feats).requires_grad_(True)
+        net.zero_grad()
+        rpn, roi = net([l, f])
+        (rpn[0].features.square().mean() + rpn[4].features.abs().mean()).backward()
+        torch.cuda.synchronize()
+        return f.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    (fa, ga), (fb, gb) = run(False), run(True)
+    assert torch.equal(fa, fb)
+    nz_a = {n for n, g in ga.items() if float(g.abs().max()) > 0}
+    nz_b = {n for n, g in gb.items() if float(g.abs().max()) > 0}
+    assert nz_a == nz_b and 10 < len(nz_b) < len(list(net.parameters()))
+    for n in nz_a:
+        assert float((ga[n] - gb[n]).abs().max()) <= 1e-6 * float(ga[n].abs().max()), n
