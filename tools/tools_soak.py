@@ -1,31 +1,33 @@
-"""Dev tool: determinism soak.  Runs the bench's training step N times from fixed seeds and prints a checksum
-of the parameters; two invocations must print the same line (no float atomics, fixed summation orders)."""
+"""Dev tool: determinism soak.  Runs the bench's training step (BASELINE configs[2], compiled graph, weight gradients
+on the second stream, proposals and geometry prefetch on the side stream) N times from fixed seeds and prints a
+checksum of the parameters + BatchNorm buffers and one of the last step's proposals; every invocation must print the\nsame parameter checksum (no float
+atomics, fixed summation orders, stream interleaving never changes a result).
+The proposal checksum may differ between runs when objectness logits tie exactly (bf16 storage produces such
+ties): torch.topk leaves the order of equal values unspecified, as it does in the reference's post-processor.
+usage: tools_soak.py [steps] [f32|bf16]"""
 import hashlib, importlib, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 importlib.import_module("automatic-as-built-reconstruction_amd")
 import torch
 import sparseconvnet as scn
-import synth_scenes as S
 import bench, dp
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+dtype = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 dev = torch.device("cuda", 0)
-torch.manual_seed(123)
-m = bench.build_model(scn, dev)
-flat = dp.FlatParams([v for k, v in m.items() if k != "inp"])
-scenes = []
-for i in range(6):
-    locs, feats = S.make_batch(1, 30000 + 9000 * i, 50 + i, 20)
-    scenes.append((torch.as_tensor(locs).to(dev), torch.as_tensor(feats).to(dev).requires_grad_(True)))
-g = torch.Generator(device=dev).manual_seed(7)
+wl = bench.Workload(scn, torch, dp, dev, dtype, 0, 1, 3)
 for i in range(n):
-    l, f = scenes[i % len(scenes)]
-    flat.zero_grad()
-    out = bench.forward(scn, m, l, f)
-    out.features.backward(torch.ones_like(out.features) * 1e-3)
-    f.grad = None
-    flat.sgd_step(1e-6)
+    wl.step(i)
 torch.cuda.synchronize()
-h = hashlib.sha256(flat.flat.detach().cpu().numpy().tobytes()).hexdigest()
-print("steps %d  params sha256 %s  |w| %.6f  macs %.6g" % (n, h[:24], float(flat.flat.norm()), float(scn.forward_pass_multiplyAdd_count)))
+h = hashlib.sha256(wl.flat.flat.detach().cpu().numpy().tobytes())
+for k, b in wl.net.named_buffers():
+    h.update(b.cpu().numpy().tobytes())
+hp = hashlib.sha256()
+ties = 0
+for boxes, scores in wl.last[1]:
+    hp.update(boxes.cpu().numpy().tobytes())
+    hp.update(scores.cpu().numpy().tobytes())
+    ties += int((scores[1:] == scores[:-1]).sum())
+print("steps %d  %s  params+buffers sha256 %s  proposals sha256 %s (%d equal neighbouring scores)  |w| %.6f" %
+      (n, str(dtype).split(".")[-1], h.hexdigest()[:24], hp.hexdigest()[:16], ties, float(wl.flat.flat.norm())))
