@@ -535,11 +535,14 @@ extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_i
   if (n_in <= 0 || n_out <= 0 || (n_in & 63) || (n_out & 63) || vol <= 0 || vol > kMaxVol) return 0;
   if (rows_in >= (1ll << 23) || rows_in * n_in * 2 >= (1ll << 31)) return 0;
   if (n_in > 256 && (n_in & 255)) return 0; // channel groups of 256: every load of the inner loop unconditional
-  int T = 128;
+  // bf16: two MFMAs per block and 64-channel chunk -- the gather / stage / barrier skeleton sets the pace, so more
+  // resident workgroups pay: 96-row tiles with a single stage buffer (measured on the bench's rule books: convolution
+  // time of a bf16 step 5.25 -> 5.01 ms against 128 rows + two buffers; 64 rows: 5.24)
+  int T = 96;
   {
     const int64_t slabs = n_out / 64;
-    if (((V_out + 127) / 128) * slabs <= 512)
-      for (int t = 64; t < 128; t += 16)
+    if (((V_out + 95) / 96) * slabs <= 512)
+      for (int t = 64; t < 96; t += 16)
         if (((V_out + t - 1) / t) * slabs <= 512) { T = t; break; }
   }
   if (const char *ov = getenv("AABR_WIDE_ROWS")) { // tuning experiments only
@@ -576,7 +579,7 @@ extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, i
   dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / 64));
   const int flip = (flags >> 1) & 1;
   const int kg = nkc >= 4 ? 4 : nkc;
-  int nbuf = kg == 4 ? 1 : 2;
+  int nbuf = 1;
   if (const char *ov = getenv("AABR_WIDE_NBUF")) { // tuning experiments only
     if (ov[0] == '1') nbuf = 1;
     if (ov[0] == '2') nbuf = 2;
