@@ -8,6 +8,8 @@ assignment the reference lacks (data3d/data.py:39-40 has no DistributedSampler).
 parameters and gradients of the module live in two flat buffers so a step issues ONE
 all-reduce (~85 MB fp32 for the full FPN_Net; xGMI ring is per-link bound, so one large
 message beats many small buckets) and ONE fused SGD update."""
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -28,6 +30,7 @@ class FlatParams(object):
         self.flat = torch.empty(n, device=dev, dtype=dt)
         self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
         self.grad_views = []
+        self.wait_ms = []
         o = 0
         for p in params:
             k = p.numel()
@@ -68,7 +71,11 @@ class FlatParams(object):
         work = getattr(self, "_pending", None)
         if work is None:
             return False
+        t0 = time.perf_counter()
         work.wait()
+        # host time spent in wait(): ~0 for nccl (stream-ordered wait), the collective's remaining time for gloo
+        self.wait_ms.append((time.perf_counter() - t0) * 1e3)
+        del self.wait_ms[:-512]
         self._pending = None
         self.flat.add_(self.flat_grad, alpha=-lr / world_size)
         return True

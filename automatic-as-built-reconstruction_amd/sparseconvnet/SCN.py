@@ -782,8 +782,8 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
                                               ptr(_opt(bias)), flags & 3, ptr(wpack), stream()))
     elif tile_rows:
         # wide layer: big tiles, weights shared per offset (csrc/conv_wide.hip)
-        if not (flags & 4):
-            check(lib.aabr_conv_pack_weights(ptr(w), gather.vol, w.size(2), w.size(3), flags & 1, ptr(wpack), stream()))
+        if not (flags & 4):   # the LAUNCH's (n_in, n_out): for a transposed launch these are (w.size(3), w.size(2))
+            check(lib.aabr_conv_pack_weights(ptr(w), gather.vol, n_in, n_out, flags & 1, ptr(wpack), stream()))
         check(lib.aabr_conv_forward_wide(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
                                          ptr(gather.blocks_wide(tile_rows)), tile_rows, gather.vol, ptr(_opt(bias)),
                                          flags & 3, ptr(wpack), stream()))

@@ -196,3 +196,28 @@ def test_wide_bf16_storage_matches_oracle_on_rounded_operands(nIn, nOut, npts, v
     check(lib.aabr_conv_forward_wide_bf16(ptr(f), nIn, V, ptr(out2), nOut, V, ptr(blocks), T, vol, None, 0, ptr(pf),
                                           stream()))
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("nIn,nOut", [(64, 128), (128, 64)])
+def test_wide_backward_pybind_api_without_prepack(force_wide, nIn, nOut):
+    """`SCN.SubmanifoldConvolution_backward` called the pybind way (pack_t=None, no
+    WeightPackPlan) on a NON-SQUARE wide-eligible layer packs its own transposed weights; the pack call must get
+    the launch's (n_in, n_out) = (nOut, nIn), not the weight's (size(2), size(3))."""
+    from sparseconvnet import SCN
+    rng = np.random.default_rng(nIn + 3 * nOut)
+    coords, feats = _scene(rng, 1500, (12, 11, 5), 2, nIn)
+    il = O.input_layer(coords, feats, 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    md = SCN.Metadata_3()
+    sz, fs = torch.LongTensor([16, 16, 8]), torch.LongTensor([3, 3, 3])
+    x = torch.empty(0, device=DEV)
+    SCN.InputLayer_updateOutput(md, sz, _t(coords), _t(feats), x, 2, 4)
+    W = (rng.standard_normal((27, 1, nIn, nOut)) * 0.1).astype(np.float32)
+    g = rng.standard_normal((il["V"], nOut)).astype(np.float32)
+    d_in, d_w = torch.empty(0, device=DEV), torch.zeros((27, 1, nIn, nOut), device=DEV)
+    SCN.SubmanifoldConvolution_backward(sz, fs, md, x, d_in, _t(g), _t(W), d_w, torch.empty(0, device=DEV))
+    assert SCN.pack_stats["own"] > 0
+    want_in, want_w, _ = O.conv_bwd(il["out"], g, W.reshape(27, nIn, nOut), rb)
+    np.testing.assert_allclose(d_in.cpu().numpy(), want_in, rtol=1e-4, atol=2e-6 * np.abs(want_in).max() * nOut)
+    np.testing.assert_allclose(d_w.cpu().numpy().reshape(27, nIn, nOut), want_w, rtol=1e-4,
+                               atol=1e-5 * np.abs(want_w).max())
