@@ -33,6 +33,7 @@ _SIGS = {
                                           _i32p, _vp, _vp, _vp, _vp]),
     "aabr_convolution_tables2": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32p, _i32p,
                                            _i32p, _vp, _vp, _vp, _vp, _vp]),
+    "aabr_sample_offsets": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "aabr_table_to_rulebook": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "aabr_spatial_locations": (C.c_int, [_vp, _i64, _vp, _vp]),
     "aabr_conv_last_variant": (C.c_char_p, []),

@@ -32,7 +32,8 @@ def boxes_iou_3d(targets, anchors, aug=(0.0, 0.0, 0.0, 0.0), criterion=-1, only_
     targets = _dev(targets)
     anchors = _dev(anchors, targets.device)
     M, K = targets.size(0), anchors.size(0)
-    iou = torch.zeros((M, K), dtype=torch.float32, device=targets.device)
+    # every entry is written by the kernel; only an empty side leaves the matrix untouched (and it is empty then)
+    iou = torch.empty((M, K), dtype=torch.float32, device=targets.device)
     check(_hip.load().aabr_boxes_iou_3d(ptr(targets), M, ptr(anchors), K, _hip.f32x4(aug), int(criterion),
                                         int(bool(only_xy)), ptr(iou), stream()))
     return iou

@@ -373,6 +373,26 @@ __global__ __launch_bounds__(256) void k_spatial_locations(const int32_t *__rest
   if (i < n4) loc[i] = sc[i];
 }
 
+// Row offset of every sample in a batch-contiguous site list (what the reference keeps as SparseGrid::ctr,
+// Metadata.h:24-33): out[0] = V, out[1 + b] = first row whose batch index is >= b (b = 0 .. max_samples), so
+// sample b owns rows [out[1+b], out[2+b]).  V is read from device memory (meta[0] of the grid builder), so the
+// launch can follow the builder without a host read in between.
+__global__ __launch_bounds__(64) void k_sample_offsets(const int32_t *__restrict__ sc, const int32_t *__restrict__ meta,
+                                                       int64_t V_max, int max_samples, int32_t *__restrict__ out) {
+  int64_t V = meta[0];
+  if (V > V_max) V = V_max;
+  if (V < 0) V = 0;
+  for (int b = threadIdx.x; b <= max_samples; b += 64) {
+    int64_t lo = 0, hi = V;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if (sc[mid * 4 + 3] < b) lo = mid + 1; else hi = mid;
+    }
+    out[1 + b] = (int32_t)lo;
+  }
+  if (threadIdx.x == 0) out[0] = (int32_t)V;
+}
+
 static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)ceil_div(n > 0 ? n : 1, bs)); }
 
 } // namespace aabr
@@ -538,6 +558,15 @@ extern "C" int aabr_spatial_locations(const int32_t *site_coords, int64_t V, int
   AABR_CHECK_ARG(site_coords && locations, "null pointer");
   hipLaunchKernelGGL(k_spatial_locations, grid1(4 * V, 256), dim3(256), 0, (hipStream_t)stream_, site_coords,
                      4 * V, locations);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t V_max, int max_samples,
+                                   int32_t *out, void *stream_) {
+  AABR_CHECK_ARG(site_coords && meta && out && V_max >= 0 && max_samples >= 1 && max_samples <= 4096, "bad arguments");
+  hipLaunchKernelGGL(k_sample_offsets, dim3(1), dim3(64), 0, (hipStream_t)stream_, site_coords, meta, V_max,
+                     max_samples, out);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

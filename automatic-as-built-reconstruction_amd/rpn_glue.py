@@ -22,6 +22,22 @@ def grid_anchors(site_coords, base_anchors, voxel_scale, stride):
     return (c + base_anchors.view(1, -1, 7).to(c.device)).reshape(-1, 7)
 
 
+_anchor_cache = {}
+
+
+def _device_anchors(base_anchors, A, dev):
+    """the maps' base anchors as one [n_maps * A, 7] device tensor; constants of the config, uploaded once per
+    (tensor objects, versions, device) -- a pageable host->device copy blocks the host until the stream gets there"""
+    key = (tuple((id(b), b._version) for b in base_anchors), str(dev))
+    hit = _anchor_cache.get(key)
+    if hit is None or any(a is not b for a, b in zip(hit[0], base_anchors)):
+        if len(_anchor_cache) > 64:
+            _anchor_cache.clear()
+        t = torch.cat([b.reshape(A, 7).to(torch.float32).cpu() for b in base_anchors], 0).to(dev).contiguous()
+        hit = _anchor_cache[key] = (list(base_anchors), t)
+    return hit[1]
+
+
 def rpn_proposals_single_map(tensor, objectness, box_regression, base_anchors, voxel_scale, stride,
                              pre_nms_top_n=2000, post_nms_top_n=1000, nms_thresh=0.5,
                              nms_aug_thickness=(0.3, 0.3), weights=(1.0,) * 7, bbox_xform_clip=10000.0):
@@ -81,7 +97,7 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
     grids = [t.metadata.grids[tuple(int(v) for v in t.spatial_size.tolist())] for t in maps]
     dev = objectness[0].device
     A = int(base_anchors[0].shape[0])
-    ba = torch.cat([b.reshape(A, 7) for b in base_anchors], 0).to(device=dev, dtype=torch.float32).contiguous()
+    ba = _device_anchors(base_anchors, A, dev)
     obj = [o.reshape(-1).contiguous().float() for o in objectness]
     reg = [r.reshape(-1, 7).contiguous().float() for r in box_regression]
     # `batch_size` (extension): the number of examples when the caller knows it -- saves the read of the last site's
@@ -92,8 +108,12 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
         nb = int(batch_size)
     else:
         nb = max((int(g.coords[-1, 3].item()) + 1 if g.V else 0) for g in grids[:1])
-    counts = torch.stack([torch.bincount(g.coords[:, 3].long(), minlength=nb)[:nb] if g.V else
-                          torch.zeros(nb, dtype=torch.int64, device=dev) for g in grids]).tolist()   # [map][example]
+    # sites per (map, example): the per-sample row offsets every grid got with its site-count read
+    # (SparseGrid::ctr, Metadata.h:24-33); only a grid built without them costs a read here
+    counts = [g.sample_counts(nb) for g in grids]
+    if any(c is None for c in counts):
+        counts = torch.stack([torch.bincount(g.coords[:, 3].long(), minlength=nb)[:nb] if g.V else
+                              torch.zeros(nb, dtype=torch.int64, device=dev) for g in grids]).tolist()
     if batched and 1 <= nb <= 16 and n_maps <= 8:
         segs, sites, site0 = [], [], [0] * n_maps
         for bi in range(nb):
@@ -167,6 +187,66 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
             k = keep[:nk]
             out[i] = (boxes[k], scores[k])
     return out
+
+
+def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thickness, criterion=6,
+                      fg_iou=0.55, bg_iou=0.2, batch_size=None):
+    """The label-generation half of the RPN's training step on the device: per example the IoU matrix of its
+    ground-truth boxes against the anchors of ALL maps, `boxlist_iou_3d(target, anchor, aug_thickness, criterion,
+    flag='rpn_label_generation')` (RPNLossComputation.match_targets_to_anchors, modeling/rpn/loss_3d.py:91-96;
+    criterion = cfg.MODEL.IOU_CRITERIA = 6, config/defaults.py:44), followed by the core of `Matcher.__call__`
+    (modeling/matcher.py:57-100): best ground truth per anchor, BELOW_LOW_THRESHOLD (-1) / BETWEEN_THRESHOLDS (-2)
+    by the two IoU thresholds (defaults.py:147,151).  The matcher's yaw / centre-distance refinements, the
+    sampler and the losses are plain torch in the reference and are not part of this path.
+
+    maps / base_anchors / strides as in `rpn_proposals`; targets[b] = [G_b, 7] yx_zb boxes of example b.
+    Anchors are materialised per map for the whole batch (AnchorGenerator.grid_anchors,
+    anchor_generator_sparse3d.py:88-104) and regrouped example-major like `cat_scales_anchor`; the per-example
+    row ranges come from the grids' per-sample offsets (no host read).  Returns a list over examples of
+    (matched_idxs int64 [N_b], matched_vals fp32 [N_b], iou [G_b, N_b])."""
+    from utils3d.rotate_nms_3d_torch import boxes_iou_3d
+    n_maps = len(maps)
+    grids = [t.metadata.grids[tuple(int(v) for v in t.spatial_size.tolist())] for t in maps]
+    dev = grids[0].coords.device
+    A = int(base_anchors[0].shape[0])
+    ba = _device_anchors(base_anchors, A, dev)
+    nb = int(batch_size) if batch_size is not None else len(targets)
+    counts = [g.sample_counts(nb) for g in grids]
+    if any(c is None for c in counts):
+        counts = torch.stack([torch.bincount(g.coords[:, 3].long(), minlength=nb)[:nb] if g.V else
+                              torch.zeros(nb, dtype=torch.int64, device=dev) for g in grids]).tolist()
+    anchors = []
+    for m, g in enumerate(grids):     # [V_m * A, 7], flatten order [site, yaw]
+        c = torch.zeros((g.V, 1, 7), dtype=torch.float32, device=dev)
+        c[:, 0, 0:3] = g.coords[:, 0:3].to(torch.float32) / float(voxel_scale) * _stride_t(strides[m], dev)
+        anchors.append((c + ba[m * A:(m + 1) * A].view(1, A, 7)).reshape(-1, 7))
+    out, site0 = [], [0] * n_maps
+    for bi in range(nb):
+        an = torch.cat([anchors[m][site0[m] * A:(site0[m] + counts[m][bi]) * A] for m in range(n_maps)], 0)
+        for m in range(n_maps):
+            site0[m] += counts[m][bi]
+        tg = targets[bi]
+        if tg.shape[0] == 0 or an.shape[0] == 0:
+            out.append((torch.full((an.shape[0],), -1, dtype=torch.int64, device=dev),
+                        torch.zeros(an.shape[0], device=dev), torch.zeros((tg.shape[0], an.shape[0]), device=dev)))
+            continue
+        iou = boxes_iou_3d(tg, an, aug_thickness, criterion, flag="rpn_label_generation")
+        vals, idx = iou.max(dim=0)
+        idx = torch.where(vals < bg_iou, torch.full_like(idx, -1),
+                          torch.where(vals < fg_iou, torch.full_like(idx, -2), idx))
+        out.append((idx, vals, iou))
+    return out
+
+
+_stride_cache = {}
+
+
+def _stride_t(stride, dev):
+    key = (tuple(float(v) for v in stride), str(dev))
+    t = _stride_cache.get(key)
+    if t is None:
+        t = _stride_cache[key] = torch.tensor(key[0], dtype=torch.float32).to(dev).view(1, 3)
+    return t
 
 
 def cat_scales_obj_reg(objectness, rpn_box_regression, examples_idxscope):

@@ -161,10 +161,23 @@ def _key(t):
 
 class _Grid(object):
     """one scale of the scene: site list + hash table (replaces SparseGrids, Metadata.h:24-34)"""
-    __slots__ = ("coords", "keys", "vals", "cap", "V", "batch_size")
+    __slots__ = ("coords", "keys", "vals", "cap", "V", "batch_size", "sample_off")
 
-    def __init__(self, coords, keys, vals, cap, V):
+    def __init__(self, coords, keys, vals, cap, V, sample_off=None):
         self.coords, self.keys, self.vals, self.cap, self.V = coords, keys, vals, cap, V
+        # host list: first row of sample b (SparseGrid::ctr, Metadata.h:24-33) for b = 0 .. MAX_SAMPLES, or None
+        # when the grid was built without the ride-along read
+        self.sample_off = sample_off
+
+    def sample_counts(self, nb):
+        """sites per sample for samples 0..nb-1 from the offsets read with V, or None"""
+        o = self.sample_off
+        if o is None or nb + 1 > len(o):
+            return None
+        return [o[b + 1] - o[b] for b in range(nb)]
+
+
+MAX_SAMPLES = 61     # per-sample offsets that ride along with a grid's site-count read (64-word rows)
 
 
 class _Gather(object):
@@ -532,6 +545,7 @@ class Metadata_3(object):
         cap = _hip.next_pow2(2 * E)
         nblk = (max(E, 1) + 255) // 256
         metas = torch.empty((max(len(specs), 1), _hip.META_WORDS), dtype=torch.int32, device=dev)
+        ext = torch.empty((max(len(specs), 1), MAX_SAMPLES + 3), dtype=torch.int32, device=dev)
         pend = []
         for i, (osz, comp) in enumerate(specs):
             osz, comp = _key(osz), _key(comp)
@@ -542,13 +556,19 @@ class Metadata_3(object):
             check(lib.aabr_convolution_sites(ptr(gi.coords), gi.V, _hip.i32x3(comp), _hip.i32x3(comp),
                                              _hip.i32x3(osz), ptr(keys), ptr(vals), cap, ptr(scratch),
                                              ptr(out_coords), metas[i].data_ptr(), stream()))
+            # V and the per-sample row offsets (SparseGrid::ctr) of the new grid into one row of `ext`
+            check(lib.aabr_sample_offsets(ptr(out_coords), metas[i].data_ptr(), max(E, 1), MAX_SAMPLES + 1,
+                                          ext[i].data_ptr(), stream()))
             pend.append((osz, out_coords, keys, vals))
         if not pend:
             return
-        counts = metas[:len(pend), 0].tolist()  # the one host sync
+        rows = ext[:len(pend)].tolist()  # the one host sync: site counts + per-sample offsets of every grid
         pre = self.__dict__.setdefault("_pregrids", set())
-        for (osz, out_coords, keys, vals), V_out in zip(pend, counts):
-            self.grids[osz] = _Grid(out_coords[:V_out], keys, vals, cap, V_out)
+        for (osz, out_coords, keys, vals), row in zip(pend, rows):
+            V_out = row[0]
+            off = row[1:]
+            self.grids[osz] = _Grid(out_coords[:V_out], keys, vals, cap, V_out,
+                                    off if off[-1] == V_out else None)   # more than MAX_SAMPLES samples: no list
             pre.add(osz)
 
     def getRuleBook(self, in_spatial, out_spatial, filter_size, filter_stride):

@@ -104,6 +104,13 @@ int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t
                            const int32_t *vals, int64_t cap, const int32_t *filter_size_host,
                            int32_t *table, int32_t *counts, void *stream);
 
+/* Per-sample row offsets of a batch-contiguous site list -- replaces SparseGrid::ctr (Metadata.h:24-33; read by
+ * Metadata::getSpatialLocations, Metadata.cpp:147-168, and by the anchor generator's per-example index scopes,
+ * anchor_generator_sparse3d.py:137-147).  out int32 [max_samples + 2]: out[0] = V (read from meta[0] on the device,
+ * clipped to V_max), out[1 + b] = first row with batch index >= b for b = 0 .. max_samples.                    */
+int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t V_max, int max_samples,
+                        int32_t *out, void *stream);
+
 /* Strided convolution geometry -- replaces Metadata<3>::getRuleBook ->
  * Convolution_InputSgToRulesAndOutputSg (Metadata.cpp:484-510, ConvolutionRules.h:11-34,
  * RectangularRegions.h:95-119).  Creates the output grid (sites numbered in first-seen order

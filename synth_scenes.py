@@ -63,6 +63,19 @@ def make_batch(batch_size, npts=80000, base_seed=0, voxel_scale=20, ext=(16.0, 1
     return np.concatenate(L, 0), np.concatenate(F, 0)
 
 
+def make_gt_boxes(n_gt=40, seed=0, ext=(16.0, 12.0)):
+    """[n_gt,7] yx_zb ground-truth wall boxes: the same draw `make_nms_boxes` clusters its candidates around"""
+    rng = np.random.default_rng(seed)
+    gt = np.zeros((n_gt, 7))
+    gt[:, 0] = rng.random(n_gt) * ext[0]
+    gt[:, 1] = rng.random(n_gt) * ext[1]
+    gt[:, 3] = 0.09 + rng.random(n_gt) * 0.21
+    gt[:, 4] = 0.5 + rng.random(n_gt) * 5.5
+    gt[:, 5] = 2.4 + rng.random(n_gt) * 0.4
+    gt[:, 6] = rng.choice([0.0, np.pi / 2, -np.pi / 2], n_gt)
+    return gt.astype(np.float32)
+
+
 def make_nms_boxes(n=2000, seed=0, n_gt=40, ext=(16.0, 12.0)):
     """[n,7] yx_zb boxes (xc,yc,zb,thick,len,h,yaw) clustered around n_gt walls + scores."""
     rng = np.random.default_rng(seed)

@@ -109,3 +109,31 @@ def test_strided_grids_in_rounds_equal_level_by_level():
         assert torch.equal(t0[k][0], t1[k][0]) and torch.equal(t0[k][1], t1[k][1]), k
     for x, y in zip(o0, o1):
         assert torch.equal(x, y)
+
+
+def test_grids_carry_per_sample_row_offsets():
+    """the per-sample row offsets that ride along with a grid's site-count read (SparseGrid::ctr, Metadata.h:24-33;
+    aabr_sample_offsets) equal a bincount of the grid's batch column, for every grid of a 3-sample pass whose
+    middle sample is tiny; rpn_proposals then needs no read of its own to slice the maps per example."""
+    from test_cabi_and_host import default_fpn
+    torch.manual_seed(4)
+    net = default_fpn().to(DEV)
+    la, fa = S.make_batch(1, 20000, 5, 20)
+    lb, fb = S.make_batch(1, 40, 6, 20)
+    lc, fc = S.make_batch(1, 9000, 7, 20)
+    lb[:, 3], lc[:, 3] = 1, 2
+    locs, feats = np.concatenate([la, lb, lc]), np.concatenate([fa, fb, fc])
+    with torch.no_grad():
+        rpn, _ = net([torch.as_tensor(locs).to(DEV), torch.as_tensor(feats).to(DEV)])
+    md = rpn[0].metadata
+    n_with = 0
+    for k, g in md.grids.items():
+        if g.sample_off is None:
+            continue
+        n_with += 1
+        want = torch.bincount(g.coords[:, 3].long(), minlength=3).tolist()
+        assert g.sample_counts(3) == want, (k, g.sample_counts(3), want)
+        assert g.sample_off[0] == 0 and g.sample_off[3] == g.V and g.sample_counts(5)[3:] == [0, 0]
+    assert n_with >= 12
+    for m in rpn:   # every RPN map's grid has them
+        assert md.grids[tuple(int(v) for v in m.spatial_size.tolist())].sample_off is not None
