@@ -46,6 +46,10 @@ _SIGS = {
     "aabr_conv_forward_wide_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "aabr_conv_forward_wide_res": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp,
                                              _vp]),
+    "aabr_rs_words": (C.c_int64, [_i64, _i32, _i32]),
+    "aabr_build_rs": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "aabr_conv_rs_unit_rows": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
+    "aabr_conv_forward_rs_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "aabr_conv_wpack_floats": (C.c_int64, [_i32, _i32, _i32]),
     "aabr_conv_forward": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "aabr_conv_dw_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),

@@ -196,6 +196,12 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
                                            (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
                                            (const float *)p[5], (const float *)p[3], st);
       break;
+    case AABR_PLAN_CONV_RS:
+      AABR_CHECK_ARG(bf, "AABR_PLAN_CONV_RS exists for bf16 storage only");
+      rc = aabr_conv_forward_rs_bf16((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1], o.i64[1],
+                                     (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
+                                     (const uint16_t *)p[5], st);
+      break;
     case AABR_PLAN_CONV_DW:
       rc = bf ? aabr_conv_backward_weight_bf16((const uint16_t *)p[0], o.i32[0], (const uint16_t *)p[1], o.i32[1],
                                                o.i64[0], (const int32_t *)p[2], o.i32[2], o.i64[1], (float *)p[3],

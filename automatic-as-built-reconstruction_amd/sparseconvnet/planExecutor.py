@@ -39,7 +39,7 @@ from .deconvolution import Deconvolution
 
 _OP = struct.Struct("<ii6i4f4q12Q")          # AabrPlanOp (include/aabr_hip.h)
 assert _OP.size == 176
-K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST = 1, 2, 3, 4, 5, 6, 7
+K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST, K_RS = 1, 2, 3, 4, 5, 6, 7, 8
 F_BF16, F_TO_BF16, F_SIDE, F_JOIN = 1, 2, 4, 8
 _ALIGN = 256
 BF16 = torch.bfloat16
@@ -424,6 +424,11 @@ class _Pass(object):
         """the record of the launch SCN._conv_fwd makes for a prepacked weight; returns the new write offset"""
         if rows_out == 0:
             return off
+        U = SCN.rs_unit_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf) if not res else 0
+        if U:     # bf16 storage, row-stationary form (csrc/conv_rs.hip): the same choice SCN._conv_fwd makes
+            pack(buf, off, K_RS, xf | F_BF16, n_in, n_out, gather.vol, flags & 3, U, 0, 0.0, 0.0, 0.0, 0.0, rows_in,
+                 rows_out, 0, 0, src, dst, gather.rs_stream(U).data_ptr(), 0, 0, p_pack, 0, 0, 0, 0, 0, 0)
+            return off + 176
         T = self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf)
         assert T or not res
         if T:

@@ -311,8 +311,22 @@ def conv_kernel_table(torch, wl, dtype):
             else:
                 wpack = torch.empty(lib.aabr_conv_wpack_floats(ga.vol, w.size(2), w.size(3)), device=dev)
                 conv = lib.aabr_conv_forward
-            tile_rows = SCN.wide_tile_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
-            if tile_rows and bf:   # the same dispatch as sparseconvnet.SCN._conv_fwd
+            unit_rows = SCN.rs_unit_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)   # the dispatch of SCN._conv_fwd
+            tile_rows = 0 if unit_rows else SCN.wide_tile_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
+            if unit_rows:
+                words = ga.rs_stream(unit_rows)
+                wt = torch.empty_like(wpack)
+                if tr_:     # w is the layer's own weight; the input-gradient launch reads its transposed pack
+                    check(lib.aabr_conv_pack_weights2_bf16(ptr(w), ga.vol, w.size(2), w.size(3), ptr(wt), ptr(wpack),
+                                                           stream()))
+                else:
+                    check(lib.aabr_conv_pack_weights2_bf16(ptr(w), ga.vol, w.size(2), w.size(3), ptr(wpack), ptr(wt),
+                                                           stream()))
+
+                def fn():
+                    check(lib.aabr_conv_forward_rs_bf16(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(words),
+                                                        unit_rows, ga.vol, None, g["flags"] & 3, ptr(wpack), stream()))
+            elif tile_rows and bf:
                 g["grid_threads"] = ((ga.rows + tile_rows - 1) // tile_rows) * (n_out // 64) * 256
                 blocks = ga.blocks_wide(tile_rows)
                 wt = torch.empty_like(wpack)

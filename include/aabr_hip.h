@@ -320,6 +320,24 @@ int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_ptrs, const v
                              float *nms_boxes, float *scores, float nms_thresh, int only_xy, int64_t post_max,
                              uint64_t *mask, int64_t *keep, int32_t *meta, void *stream);
 
+/* ---- row-stationary form of the same contraction for bf16 feature storage (csrc/conv_rs.hip; extension) -------
+ * out[o] = bias + sum_k in[table[k][o]] @ Wl[k] exactly as aabr_conv_forward_bf16 (reference: the per-offset
+ * gather-GEMM-scatter of SCN/CPU/Convolution.cpp:45-185 / Deconvolution.cpp:7-77), with the accumulators of a unit
+ * of `unit_rows` output rows x up to 128 columns held in registers.  The rule book is compiled once per gather
+ * table into the stream aabr_build_rs writes: the rows of a unit regrouped by their "offsets with a partner" mask
+ * (what SubmanifoldConvolution_SgToRules, SubmanifoldConvolutionRules.h:26-45, appends rule by rule) so that
+ * (16-row group, offset) items without any rule are skipped.
+ *   aabr_rs_words: int32 words of the stream; aabr_conv_rs_unit_rows: 0 = use another kernel, else unit_rows.
+ *   n_in 64 | 128, n_out % 64 == 0, vol <= 32, unit_rows % 16 == 0 and <= 192, wpack = the bf16 pack of
+ *   aabr_conv_pack_weights2_bf16 (forward layout, or the transposed one with flags bit 0 set: input gradient);
+ *   flags bit 1: mirrored offsets (submanifold input gradient).  Bit-reproducible; no atomics.            */
+int64_t aabr_rs_words(int64_t V, int vol, int unit_rows);
+int aabr_build_rs(const int32_t *table, int64_t V, int vol, int unit_rows, int32_t *words, void *stream);
+int aabr_conv_rs_unit_rows(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
+int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
+                              int64_t V_out, const int32_t *rs_stream, int unit_rows, int vol, const float *bias,
+                              int flags, const uint16_t *wpack, void *stream);
+
 /* ---- compiled launch plans (extension) --------------------------------------------------------
  * The reference enters its library once per layer and direction from Python (SCN/pybind.cpp:134-221 behind
  * sparseconvnet/ layer modules).  A host that has compiled the static part of a network into a list of launches hands
@@ -348,6 +366,8 @@ int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_ptrs, const v
 #define AABR_PLAN_BN_BWD 5
 #define AABR_PLAN_ADD 6
 #define AABR_PLAN_CAST 7
+#define AABR_PLAN_CONV_RS 8 /* aabr_conv_forward_rs_bf16(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 rs_stream,
+                               i32[4] unit_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack); bf16 storage only */
 #define AABR_PLAN_BF16 1
 #define AABR_PLAN_TO_BF16 2
 #define AABR_PLAN_JOIN 8 /* the caller's stream waits for the second stream in front of this record */
