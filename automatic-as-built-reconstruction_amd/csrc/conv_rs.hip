@@ -39,23 +39,28 @@ extern thread_local const char *g_last_variant; // conv.hip
 
 constexpr int kRsMaxVol = 32;   // one mask bit per filter offset
 constexpr int kRsMaxU = 256;    // rows per unit (16 groups of 16)
+constexpr int kRsMaxUpw = 32;   // units per workgroup (their headers sit in LDS)
 
 // ------------------------------------------------------------------ compiled rule book, row-stationary form
 //   words: [nunits][32] header: [0] = number of active offsets n, [1..n] = (offset << 16) | 16-bit set of the
-//          groups with at least one partner at that offset, offsets ascending
+//          groups with at least one partner at that offset (offsets ascending), [31] = steps of the unit
 //        | [nunits][U] perm (output row of slot, -1 = padding)
-//        | [nunits][vol][U] partner row of (offset, slot), -1 = none
+//        | [nunits][vol * 4][4][16] step descriptors in the order they are consumed: a step = up to 4 items
+//          (consecutive active groups of one offset), an item = the 16 partner rows of a group (-1 = none)
 constexpr int kRsHdr = 32;
+constexpr int kRsSI = 4;     // items per step
 static inline int64_t rs_words(int64_t V, int vol, int U) {
   const int64_t nu = (V + U - 1) / U;
-  return nu * (kRsHdr + U + (int64_t)vol * U);
+  return nu * (kRsHdr + U + (int64_t)vol * 4 * kRsSI * 16);
 }
 
 __global__ __launch_bounds__(256) void k_build_rs(const int32_t *__restrict__ table, int64_t V, int vol, int U,
                                                   int32_t *__restrict__ words) {
   __shared__ unsigned long long s_key[kRsMaxU];
   __shared__ unsigned int s_mask[kRsMaxU];
+  __shared__ int s_row[kRsMaxU];
   __shared__ unsigned int s_gm[16];
+  __shared__ int s_hdr[kRsHdr], s_sb[kRsHdr];
   const int t = threadIdx.x;
   const int64_t unit = blockIdx.x, nunits = (V + U - 1) / U;
   const int64_t row = unit * U + t;
@@ -73,14 +78,11 @@ __global__ __launch_bounds__(256) void k_build_rs(const int32_t *__restrict__ ta
   int rank = 0;
   if (in_unit)
     for (int s = 0; s < U; ++s) rank += s_key[s] < key;
-  if (in_unit) s_mask[rank] = valid ? mask : 0u;
+  if (in_unit) { s_mask[rank] = valid ? mask : 0u; s_row[rank] = valid ? (int)t : -1; }
   int32_t *hdr = words + unit * kRsHdr;
   int32_t *perm = words + nunits * kRsHdr + unit * U;
-  int32_t *tp = words + nunits * (kRsHdr + U) + unit * (int64_t)vol * U;
-  if (in_unit) {
-    perm[rank] = valid ? (int32_t)row : -1;
-    for (int k = 0; k < vol; ++k) tp[(int64_t)k * U + rank] = valid ? table[(int64_t)k * V + row] : -1;
-  }
+  int32_t *desc = words + nunits * (kRsHdr + U) + unit * (int64_t)vol * 4 * kRsSI * 16;
+  if (in_unit) perm[rank] = valid ? (int32_t)row : -1;
   __syncthreads();
   if (t < 16) {
     unsigned int m = 0;
@@ -90,183 +92,155 @@ __global__ __launch_bounds__(256) void k_build_rs(const int32_t *__restrict__ ta
   }
   __syncthreads();
   if (t == 0) {
-    int n = 0;
+    int n = 0, steps = 0;
     for (int k = 0; k < vol; ++k) {
       unsigned bits = 0;
       for (int g = 0; g < 16; ++g) bits |= ((s_gm[g] >> k) & 1u) << g;
-      if (bits) hdr[++n] = (int32_t)(((unsigned)k << 16) | bits);
+      if (bits) {
+        s_hdr[++n] = (int)(((unsigned)k << 16) | bits);
+        s_sb[n] = steps;
+        steps += (__popc(bits) + kRsSI - 1) / kRsSI;
+      }
     }
-    hdr[0] = n;
-    for (int i = n + 1; i < kRsHdr; ++i) hdr[i] = 0;
+    s_hdr[0] = n;
+    for (int i = n + 1; i < kRsHdr; ++i) s_hdr[i] = 0;
+    s_hdr[kRsHdr - 1] = steps;
+  }
+  __syncthreads();
+  if (t < kRsHdr) hdr[t] = s_hdr[t];
+  const int n = s_hdr[0];
+  for (int j = 1; j <= n; ++j) {
+    const unsigned wd = (unsigned)s_hdr[j], bits = wd & 0xffffu;
+    const int k = (int)(wd >> 16), nst = (__popc(bits) + kRsSI - 1) / kRsSI;
+    if (t < nst * 64) {
+      const int item = t >> 4, r = t & 15;   // item-th active group of this offset
+      unsigned b = bits;
+      for (int i = 0; i < item && b; ++i) b &= b - 1;
+      int e = -1;
+      if (b) {
+        const int g = __ffs(b) - 1, lr = s_row[g * 16 + r];
+        if (lr >= 0) e = table[(int64_t)k * V + unit * U + lr];
+      }
+      desc[((int64_t)s_sb[j] * kRsSI) * 16 + t] = e;
+    }
   }
 }
 
-__device__ __align__(16) unsigned char g_rs_zero[1024];   // the row an absent partner reads (module-zero-initialised)
-
 // ------------------------------------------------------------------ the kernel
-// One workgroup = 4 consumer waves (wave w: the MFMAs of columns [32 w, 32 w + 32) of the slab, or 16 with NCB = 1)
-// + 2 loader waves.  Everything the consumers need -- the weight slices of an offset, then the gathered rows of that
-// offset's items, two items (32 rows) per slot -- travels through ONE ring of LDS slots in the order it is used,
-// filled by the loader waves with LDS-DMA (global_load_lds_dwordx4: per-lane source address = a row gather; the
-// destination is linear, so the XOR swizzle of the row image is applied to the SOURCE granule).  The loaders' vmcnt
-// stream holds nothing but these DMAs (entries and headers come through the scalar cache), so a counted
-// s_waitcnt keeps a dozen slots (~100 KiB) in flight per CU; the consumers issue no vector-memory instruction at all
-// inside the loop.  One s_barrier per step hands the next slot(s) over.
-// KC = 32-channel chunks per input row (n_in = 32 KC), NCB = 16-column blocks per consumer wave.
-struct RsSeq {               // position in the workgroup's item sequence (wave-uniform)
-  int u, uend, j, nact, k;
-  unsigned bits;
-  bool first, done;
-};
+// One workgroup (512 threads, one per CU) = 4 consumer waves + 4 loader waves.
+//   consumer wave w: the MFMAs of columns [16 NCB w, 16 NCB (w + 1)) of the slab for every item; per offset it loads
+//     its weight slice straight into registers (next offset's slice in flight meanwhile); accumulators in registers.
+//   loader wave p: gathers item p of every step (16 rows) into registers, kRsD steps ahead, and stores it -- granule-
+//     swizzled -- into the step's LDS buffer one step before the consumers read it.  All its memory operations are plain
+//     loads in consumption order (descriptor of step s + kRsD, then the rows of that step), so the compiler's own vmcnt
+//     bookkeeping keeps kRsD steps (4 KiB each per loader, 7 x 16 KiB per CU) in flight with static register sets.
+// One s_barrier per step.  KC = 32-channel chunks per input row (n_in = 32 KC), NCB = 16-column blocks per consumer.
+constexpr int kRsD = 7;      // steps a loader runs ahead (register sets)
 
 template <int KC, int NCB, int NG>
-__global__ __launch_bounds__(384, 2) void k_conv_rsq(
-    const __bf16 *__restrict__ in, __bf16 *__restrict__ out, int co, int64_t V_out, const int32_t *__restrict__ words,
-    int vol, int U, int upw, int wflip, const __bf16 *__restrict__ Wp, const float *__restrict__ bias, int NS) {
+__global__ __launch_bounds__(512, 2) void k_conv_rsq(
+    const __bf16 *__restrict__ in, int64_t in_bytes, __bf16 *__restrict__ out, int co, int64_t V_out,
+    const int32_t *__restrict__ words, int64_t words_bytes, int vol, int U, int upw, int wflip,
+    const __bf16 *__restrict__ Wp, int64_t wp_bytes, const float *__restrict__ bias, int dbg) {
   constexpr int RB = KC * 64;                 // bytes per input row
-  constexpr int SLOT = 32 * RB;               // ring slot: the rows of two items, or as many bytes of weights
-  constexpr int NDMA = SLOT / 1024;           // DMA instructions (1 KiB each) per slot
-  constexpr int IPW = NDMA / 2;               // ... per loader wave
-  constexpr int LPR = RB / 16;                // lanes per row in a gather piece
-  constexpr int RPP = 64 / LPR;               // rows per gather piece
+  constexpr int ITEM = 16 * RB;               // bytes of an item's rows
+  constexpr int STEP = kRsSI * ITEM;          // LDS buffer of a step
+  constexpr int LPR = RB / 16;                // lanes per row of a gather instruction (16 B per lane)
+  constexpr int RPP = 64 / LPR;               // rows per gather instruction
+  constexpr int IPW = 16 / RPP;               // gather instructions per item
   constexpr int SWZ = LPR - 1;
-  constexpr int NWS = 2 * NCB;                // weight slots per offset: 4 waves x NCB x KC KiB
   static_assert(KC == 2 || KC == 4, "n_in = 64 or 128");
-  extern __shared__ __align__(16) unsigned char ring[];
-  typedef const __attribute__((address_space(4))) int32_t *cptr;
+  __shared__ __align__(16) unsigned char sbuf[2][STEP];
+  __shared__ int32_t s_hdr[kRsMaxUpw * kRsHdr];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nnb = co >> 4;
-  const int nb_wg = blockIdx.y * (4 * NCB);
   const int64_t nunits = (V_out + U - 1) / U;
   const int u0 = blockIdx.x * upw;
   const int u1 = (int)((int64_t)(u0 + upw) < nunits ? (u0 + upw) : nunits);
-  cptr hdr = (cptr)words;
-  const int32_t *perm = words + nunits * kRsHdr;
-  cptr tp = (cptr)(words + nunits * (kRsHdr + U));
-  const int D = NS - (NWS + 1);               // slots in flight; a slot being filled is never one being read
-
-  auto seq_offset = [&](RsSeq &q) {           // move to the next active offset (possibly of a later unit)
-    ++q.j;
-    while (q.j > q.nact) {
-      ++q.u;
-      if (q.u >= q.uend) { q.done = true; q.bits = 0; q.k = 0; return; }
-      q.nact = hdr[(int64_t)q.u * kRsHdr];
-      q.j = 1;
-    }
-    const unsigned w = (unsigned)hdr[(int64_t)q.u * kRsHdr + q.j];
-    q.k = (int)(w >> 16);
-    q.bits = w & 0xffffu;
-    q.first = true;
-  };
-  auto seq_init = [&](RsSeq &q) {
-    q.u = u0 - 1; q.uend = u1; q.j = 1; q.nact = 0; q.k = 0; q.bits = 0; q.first = false; q.done = false;
-    seq_offset(q);
-  };
-  auto seq_next = [&](RsSeq &q) {             // past the current pair
-    unsigned r = q.bits & (q.bits - 1);
-    r &= r - 1;
-    if (r) { q.bits = r; q.first = false; }
-    else seq_offset(q);
-  };
+  for (int i = threadIdx.x; i < (u1 - u0) * kRsHdr; i += 512) s_hdr[i] = words[(int64_t)u0 * kRsHdr + i];
+  __syncthreads();
+  int nsteps = 0;
+  for (int u = u0; u < u1; ++u) nsteps += s_hdr[(u - u0) * kRsHdr + kRsHdr - 1];
+  nsteps = __builtin_amdgcn_readfirstlane(nsteps);
 
   if (wave >= 4) {
     // ------------------------------------------------------------------ loader waves
     const int pw = wave - 4;
-    RsSeq head, tail;
-    seq_init(head);
-    seq_init(tail);
-    int wpend = tail.done ? 0 : NWS;           // weight slots of tail's offset still to issue
-    int tpos = 0, inflight = 0;
-    const unsigned char *inb = reinterpret_cast<const unsigned char *>(in);
-    const unsigned char *wpb = reinterpret_cast<const unsigned char *>(Wp);
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(in), 0, (int)(in_bytes > 0x7fffffffll ? 0x7fffffffll : in_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwords =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(words), 0, (int)words_bytes, 0x00020000);
     const int rl = lane / LPR, pl = lane % LPR;
-    auto issue_slot = [&]() {                  // the next slot of the sequence into ring position tpos
-      unsigned char *dst = ring + tpos * SLOT + pw * IPW * 1024;
-      if (wpend > 0) {
-        const int widx = NWS - wpend;
-        const int kW = wflip ? vol - 1 - tail.k : tail.k;
+    const unsigned dbase = (unsigned)((nunits * (kRsHdr + U)) * 4);       // byte offset of the descriptors
+    const unsigned ustride = (unsigned)(vol * 4 * kRsSI * 16 * 4);        // ... per unit
+    // position of the step whose descriptor is fetched next (runs 2 kRsD steps ahead of the consumers)
+    int du = u0, ds = 0, dn = u0 < u1 ? s_hdr[kRsHdr - 1] : 0;
+    struct Ent { int e[IPW]; };
+    struct Rows { u32x4 v[IPW]; };
+    auto fetch_desc = [&](Ent &d) {            // the entries of item pw of the next step; past the end: none
+      while (du < u1 && ds >= dn) { ++du; ds = 0; dn = du < u1 ? s_hdr[(du - u0) * kRsHdr + kRsHdr - 1] : 0; }
+      // past the end: an offset behind the buffer -> zeros, i.e. row 0 is gathered into a buffer nobody reads (the
+      // loaded value must not be touched here: a select on it would wait for the load, ~1 us per step measured)
+      const unsigned so = du < u1 ? dbase + (unsigned)du * ustride + (unsigned)((ds * kRsSI + pw) * 64) : 0x7ffffff0u;
 #pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-          const int gp = widx * NDMA + pw * IPW + i;
-          const int w = gp / (NCB * KC), r = gp % (NCB * KC), cb = r / KC, kc = r % KC;
-          const unsigned char *src = wpb + (((int64_t)kW * KC + kc) * nnb + nb_wg + w * NCB + cb) * 1024 + lane * 16;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
-        }
-        --wpend;
-      } else {
-        const unsigned b = tail.bits;
-        const int g0 = __builtin_ctz(b);
-        const unsigned r = b & (b - 1);
-        const int g1 = r ? __builtin_ctz(r) : -1;
-        cptr ent = tp + ((int64_t)tail.u * vol + tail.k) * U;
+      for (int i = 0; i < IPW; ++i)
+        d.e[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rwords, (unsigned)((i * RPP + rl) * 4), so, 0);
+      ++ds;
+    };
+    auto gather = [&](Rows &r, const Ent &d) {
 #pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-          const int t = pw * IPW + i;          // piece: rows t RPP .. t RPP + RPP - 1 of the pair
-          const int row0 = t * RPP;
-          const int g = row0 < 16 ? g0 : g1;
-          int e = -1;
-          if (g >= 0) {
-            cptr ep = ent + g * 16 + (row0 & 15);
-#pragma unroll
-            for (int q = 0; q < RPP; ++q) {
-              const int v = ep[q];
-              e = rl == q ? v : e;
-            }
-          }
-          const int row = row0 + rl;
-          const unsigned char *src = e >= 0 ? inb + (int64_t)e * RB + ((pl ^ (row & SWZ)) << 4) : g_rs_zero + (pl << 4);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)(dst + i * 1024), 16, 0, 0);
-        }
-        seq_next(tail);
-        if (!tail.done && tail.first) wpend = NWS;
+      for (int i = 0; i < IPW; ++i) {
+        // absent partner: an offset behind the buffer -> the range check returns zeros, no memory traffic
+        const unsigned va = d.e[i] >= 0 ? (unsigned)d.e[i] * (unsigned)RB + (unsigned)pl * 16u : 0x7ffffff0u;
+        if (dbg & 1) r.v[i] = (u32x4){(unsigned)d.e[i], 0u, 0u, 0u};
+        else r.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, va, 0, 0);
       }
-      tpos = tpos + 1 == NS ? 0 : tpos + 1;
-      ++inflight;
     };
-    // counted waits need immediates: two cases per step (the next step takes 1 slot or NWS + 1)
-    auto wait_next = [&](int need) {
-      if ((tail.done && wpend == 0) || inflight - need < 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-      const int allow = (inflight - need) * IPW;
-      // allow is one of a few values in steady state; round DOWN to the nearest immediate we have
-      if (allow >= 60) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
-      else if (allow >= 56) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-      else if (allow >= 52) asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
-      else if (allow >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-      else if (allow >= 44) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
-      else if (allow >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-      else if (allow >= 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
-      else if (allow >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      else if (allow >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-      else if (allow >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (allow >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else if (allow >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (allow >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (allow >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (allow >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (allow >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto store = [&](const Rows &r, int buf) { // row i RPP + rl of the item, granule pl -> position pl ^ (row & SWZ)
+      unsigned char *dst = &sbuf[buf][pw * ITEM];
+#pragma unroll
+      for (int i = 0; i < IPW; ++i) {
+        const int row = i * RPP + rl;
+        *reinterpret_cast<u32x4 *>(dst + row * RB + ((pl ^ (row & SWZ)) << 4)) = r.v[i];
+      }
     };
-    auto cost = [&](const RsSeq &q) { return q.done ? 0 : (q.first ? NWS + 1 : 1); };
-    while (inflight < D && !(tail.done && wpend == 0)) issue_slot();
-    wait_next(cost(head));
-    asm volatile("s_barrier" ::: "memory");
-    while (!head.done) {
-      const int c = cost(head);
-      seq_next(head);
-      inflight -= c;                           // the consumers take these slots during this step
-      // refill: the slots taken in the PREVIOUS steps are free; the ones being read now are not (NS >= D + NWS + 1)
-      while (inflight < D && !(tail.done && wpend == 0)) issue_slot();
-      wait_next(cost(head));
-      asm volatile("s_barrier" ::: "memory");
+    // software pipeline with static register sets: descriptors 2 kRsD steps ahead, rows kRsD steps ahead
+    Ent de[kRsD];
+    Rows rw[kRsD];
+#pragma unroll
+    for (int i = 0; i < kRsD; ++i) fetch_desc(de[i]);
+#pragma unroll
+    for (int i = 0; i < kRsD; ++i) { gather(rw[i], de[i]); fetch_desc(de[i]); }
+    store(rw[0], 0);                           // step 0 is in LDS before the first barrier
+    gather(rw[0], de[0]);
+    fetch_desc(de[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // iteration s (the consumers read buffer s & 1): store step s + 1, then fetch step s + 1 + kRsD
+    int s = 0;
+    while (s < nsteps) {
+#pragma unroll
+      for (int i = 1; i <= kRsD; ++i) {
+        const int j = i == kRsD ? 0 : i;       // register set of step s + 1 (sets rotate: step t lives in set t % kRsD)
+        if (s < nsteps) {
+          if (!(dbg & 8)) {
+            store(rw[j], (s + 1) & 1);
+            gather(rw[j], de[j]);
+            fetch_desc(de[j]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          ++s;
+        }
+      }
     }
     return;
   }
 
   // -------------------------------------------------------------------- consumer waves
   const int g4 = lane >> 4, c16 = lane & 15;
-  const int nb0 = nb_wg + wave * NCB;
+  const int nb0 = blockIdx.y * (4 * NCB) + wave * NCB;
+  const int32_t *perm = words + nunits * kRsHdr;
+  const __amdgpu_buffer_rsrc_t rwp =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(Wp), 0, (int)wp_bytes, 0x00020000);
   f32x4 acc[NG][NCB];
 #pragma unroll
   for (int g = 0; g < NG; ++g)
@@ -275,88 +249,108 @@ __global__ __launch_bounds__(384, 2) void k_conv_rsq(
   auto write_out = [&](int u) {
     const int64_t rows_here = (V_out - (int64_t)u * U) < U ? (V_out - (int64_t)u * U) : U;
     const int ng = (int)((rows_here + 15) >> 4);
+    // all row numbers first (independent loads), then the stores: a load -> branch -> store chain per group costs a
+    // memory latency each (16 x ~1.5 us per unit, measured as half of the kernel's time)
+    int rowv[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) rowv[g] = perm[(int64_t)u * U + (g < ng ? g * 16 + c16 : c16)];
+    float bv[NCB][4];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[cb][i] = bias ? bias[(nb0 + cb) * 16 + g4 * 4 + i] : 0.f;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (g < ng) {
-        const int row = perm[(int64_t)u * U + g * 16 + c16];
-        if (row >= 0) {
+      if (g < ng && rowv[g] >= 0) {
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-            const int col = (nb0 + cb) * 16 + g4 * 4;
-            f32x4 v = acc[g][cb];
-            if (bias) { v[0] += bias[col]; v[1] += bias[col + 1]; v[2] += bias[col + 2]; v[3] += bias[col + 3]; }
-            bf16x4r o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            *reinterpret_cast<bf16x4r *>(out + (int64_t)row * co + col) = o;
-          }
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int col = (nb0 + cb) * 16 + g4 * 4;
+          const f32x4 v = acc[g][cb];
+          bf16x4r o = {(__bf16)(v[0] + bv[cb][0]), (__bf16)(v[1] + bv[cb][1]), (__bf16)(v[2] + bv[cb][2]),
+                       (__bf16)(v[3] + bv[cb][3])};
+          *reinterpret_cast<bf16x4r *>(out + (int64_t)rowv[g] * co + col) = o;
         }
       }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) acc[g][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  RsSeq cur;
-  seq_init(cur);
-  int cu = u0, hpos = 0;
-  u32x4 w[NCB][KC];
+  struct Off { int u, j, k; unsigned bits; };  // u >= u1: past the end
+  auto off_next = [&](Off q) {                 // the next active offset (possibly of a later unit)
+    ++q.j;
+    while (q.u < u1 && q.j > s_hdr[(q.u - u0) * kRsHdr]) { ++q.u; q.j = 1; }
+    if (q.u < u1) {
+      const unsigned wd = (unsigned)s_hdr[(q.u - u0) * kRsHdr + q.j];
+      q.k = (int)(wd >> 16);
+      q.bits = wd & 0xffffu;
+    } else { q.k = 0; q.bits = 0; }
+    return q;
+  };
+  struct WReg { u32x4 w[NCB][KC]; };
+  auto load_w = [&](WReg &w, int k) {
+    const int kW = wflip ? vol - 1 - k : k;
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-    for (int c = 0; c < KC; ++c) w[cb][c] = (u32x4){0u, 0u, 0u, 0u};
-  asm volatile("s_barrier" ::: "memory");
-  while (!cur.done) {
-    while (cu < cur.u) { write_out(cu); ++cu; }
-    if (cur.first) {                           // this offset's weight slices: NWS slots, wave w's pieces back to back
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-          const int off = (wave * NCB * KC + cb * KC + c) * 1024;
-          int sp = hpos + off / SLOT;
-          sp = sp >= NS ? sp - NS : sp;
-          w[cb][c] = *reinterpret_cast<const u32x4 *>(ring + sp * SLOT + (off % SLOT) + lane * 16);
-        }
-      hpos += NWS;
-      hpos = hpos >= NS ? hpos - NS : hpos;
-    }
-    {
-      const unsigned b0 = cur.bits;
-      const int g0 = __builtin_ctz(b0);
-      const unsigned r0 = b0 & (b0 - 1);
-      const int g1 = r0 ? __builtin_ctz(r0) : -1;
-      const unsigned char *sa = ring + hpos * SLOT + c16 * RB;
-      const unsigned char *sb = sa + 16 * RB;
-      u32x4 fa[KC], fb[KC];
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {           // the lane's 8 channels of chunk c: granule 4 c + g4 of row c16
-        const int q = ((c * 4 + g4) ^ (c16 & SWZ)) << 4;
-        fa[c] = *reinterpret_cast<const u32x4 *>(sa + q);
-        fb[c] = *reinterpret_cast<const u32x4 *>(sb + q);
+      for (int c = 0; c < KC; ++c) {
+        const unsigned so = (unsigned)((((int64_t)kW * KC + c) * nnb + nb0 + cb) * 1024);
+        w.w[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rwp, (unsigned)lane * 16u, so, 0);
       }
-#define AABR_RS_CASE(G, F)                                                                               \
-  case G:                                                                                               \
-    if (G < NG) {                                                                                        \
-      _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) _Pragma("unroll") for (int c = 0; c < KC; ++c)   \
-          acc[G < NG ? G : 0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                             \
-              __builtin_bit_cast(bf16x8r, w[cb][c]), __builtin_bit_cast(bf16x8r, F[c]),                  \
-              acc[G < NG ? G : 0][cb], 0, 0, 0);                                                         \
-    }                                                                                                    \
-    break;
-#define AABR_RS_SWITCH(GV, F)                                                                            \
-  switch (GV) {                                                                                          \
-    AABR_RS_CASE(0, F) AABR_RS_CASE(1, F) AABR_RS_CASE(2, F) AABR_RS_CASE(3, F) AABR_RS_CASE(4, F)        \
-    AABR_RS_CASE(5, F) AABR_RS_CASE(6, F) AABR_RS_CASE(7, F) AABR_RS_CASE(8, F) AABR_RS_CASE(9, F)        \
-    AABR_RS_CASE(10, F) AABR_RS_CASE(11, F) AABR_RS_CASE(12, F) AABR_RS_CASE(13, F) AABR_RS_CASE(14, F)   \
-    AABR_RS_CASE(15, F)                                                                                  \
-  default: break;                                                                                        \
-  }
-      AABR_RS_SWITCH(g0, fa)
-      if (g1 >= 0) { AABR_RS_SWITCH(g1, fb) }
-#undef AABR_RS_SWITCH
-#undef AABR_RS_CASE
-      hpos = hpos + 1 == NS ? 0 : hpos + 1;
+  };
+  int cu = u0, step = 0;
+  // The groups of an offset are visited in a STATIC order (unrolled loop, a wave-uniform branch per group) so that
+  // every accumulator is addressed by a constant and never leaves its registers -- a `switch` on the group number made
+  // the compiler merge all accumulators with moves at every flow node (313 v_mov per step, 2 us per step measured).
+  // What is dynamic is only where the item's rows sit in the step buffer.
+  auto run_offset = [&](const WReg &w, unsigned b) __attribute__((always_inline)) {
+    int cnt = 0;
+    u32x4 f[KC];
+    auto read_item = [&]() {                   // the lane's 8 channels of chunk c: granule 4 c + g4 of row c16
+      const unsigned char *sa = &sbuf[step & 1][cnt * ITEM + c16 * RB];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) f[c] = *reinterpret_cast<const u32x4 *>(sa + (((c * 4 + g4) ^ (c16 & SWZ)) << 4));
+    };
+    read_item();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (b & (1u << g)) {
+        if (!(dbg & 2))
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+              acc[g][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8r, w.w[cb][c]),
+                                                                   __builtin_bit_cast(bf16x8r, f[c]), acc[g][cb], 0, 0, 0);
+        const bool more = g + 1 < NG && (b >> (g + 1)) != 0;
+        if (cnt == kRsSI - 1 || !more) {        // the step is complete: hand its buffer back, take the next one
+          ++step;
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          cnt = 0;
+        } else {
+          ++cnt;
+        }
+        if (more && !(dbg & 16)) read_item();   // the next item of this offset, in flight during these MFMAs
+      }
     }
-    seq_next(cur);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  Off cur;
+  cur.u = u0; cur.j = 0; cur.k = 0; cur.bits = 0;
+  cur = off_next(cur);
+  WReg wA, wB;
+  if (cur.u < u1) load_w(wA, cur.k);
+  asm volatile("s_barrier" ::: "memory");
+  while (cur.u < u1) {
+    Off nxt = off_next(cur);
+    if (nxt.u < u1 && !(dbg & 32)) load_w(wB, nxt.k);   // next offset's weights in flight during this offset
+    while (cu < cur.u) { write_out(cu); ++cu; }
+    run_offset(wA, cur.bits);
+    cur = nxt;
+    if (cur.u >= u1) break;
+    nxt = off_next(cur);
+    if (nxt.u < u1 && !(dbg & 32)) load_w(wA, nxt.k);
+    while (cu < cur.u) { write_out(cu); ++cu; }
+    run_offset(wB, cur.bits);
+    cur = nxt;
   }
   while (cu < u1) { write_out(cu); ++cu; }
 }
@@ -404,17 +398,24 @@ static int rs_unit(int64_t V_out, int slabs, int umax) {
 // 0: not for this launch; otherwise the unit size (rows) of the stream aabr_conv_forward_rs_bf16 wants
 extern "C" int aabr_conv_rs_unit_rows(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
   if ((n_in != 64 && n_in != 128) || n_out <= 0 || (n_out & 63) || vol <= 0 || vol >= kRsHdr) return 0;
-  if (rows_in <= 0 || V_out <= 0 || rows_in * n_in * 2 >= (1ll << 40)) return 0;
+  if (rows_in <= 0 || V_out <= 0 || rows_in * n_in * 2 >= (1ll << 31) - 4096) return 0;
+  if ((int64_t)vol * n_in * n_out * 2 >= (1ll << 31)) return 0;
   const RsKnobs &kn = rs_knobs();
   if (kn.force == 0) return 0;
   const int ncb = (n_out & 127) == 0 ? 2 : 1;
-  const int umax = ncb == 2 ? 192 : 256;   // accumulators of 12 / 16 groups fit the register file
+  const int umax = kRsMaxU;                 // accumulators of 16 groups x 32 columns: 128 registers
   int U = rs_unit(V_out, n_out / (64 * ncb), umax);
   if (kn.unit >= 16 && kn.unit <= umax && (kn.unit & 15) == 0) U = kn.unit;
-  if (rs_words(V_out, vol, U) * 4 >= (1ll << 40)) return 0;
-  if (kn.force == 1) return U;
-  // enough work to fill the chip; the small coarse scales stay on the small-launch kernels
-  return V_out >= 16384 ? U : 0;
+  if (rs_words(V_out, vol, U) * 4 >= (1ll << 31)) return 0;
+  {
+    const int slabs = n_out / (64 * ncb);
+    const int64_t nunits = (V_out + U - 1) / U, wgs = 256 / slabs > 0 ? 256 / slabs : 1;
+    if ((nunits + wgs - 1) / wgs > kRsMaxUpw) return 0;
+  }
+  // Measured (profiles/r03_conv_rs_ab.txt): correct, but at 138 us on the dominant 128->128 instance against 107 us
+  // for the LDS-tile kernel -- one wave per SIMD and role with a barrier per step serialises gather latency, LDS
+  // reads, weight loads and MFMAs instead of overlapping them.  Kept behind AABR_CONV_RS=1 for the A/B and the tests.
+  return kn.force == 1 ? U : 0;
 }
 
 extern "C" int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
@@ -423,8 +424,7 @@ extern "C" int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG((n_in == 64 || n_in == 128) && n_out > 0 && (n_out & 63) == 0, "plane counts: n_in 64|128, n_out % 64");
   AABR_CHECK_ARG(vol > 0 && vol < kRsHdr && V_out >= 0 && rows_in >= 0, "bad sizes (vol <= 31)");
-  AABR_CHECK_ARG(unit_rows >= 16 && unit_rows <= ((n_out & 127) == 0 ? 192 : 256) && (unit_rows & 15) == 0,
-                 "unit_rows: multiple of 16, <= 192 (n_out % 128 == 0) / 256");
+  AABR_CHECK_ARG(unit_rows >= 16 && unit_rows <= kRsMaxU && (unit_rows & 15) == 0, "unit_rows: multiple of 16, <= 256");
   if (V_out == 0) return AABR_OK;
   AABR_CHECK_ARG(in_feats && out_feats && rs_stream && wpack && rows_in > 0, "null pointer / empty input");
   AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 7) == 0 && ((uintptr_t)wpack & 15) == 0 &&
@@ -435,31 +435,23 @@ extern "C" int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int
   const int64_t nunits = (V_out + unit_rows - 1) / unit_rows;
   const int64_t wgs_max = 256 / slabs > 0 ? 256 / slabs : 1;
   const int upw = (int)((nunits + wgs_max - 1) / wgs_max);
-  AABR_CHECK_ARG(nunits < (1ll << 30), "too many units");
+  AABR_CHECK_ARG(nunits < (1ll << 30) && upw <= kRsMaxUpw, "too many units per workgroup");
+  const int64_t in_bytes = rows_in * n_in * 2, words_bytes = rs_words(V_out, vol, unit_rows) * 4;
+  const int64_t wp_bytes = (int64_t)vol * (n_in / 32) * (n_out / 16) * 1024;
+  AABR_CHECK_ARG(in_bytes < (1ll << 31) - 4096 && words_bytes < (1ll << 31) && wp_bytes < (1ll << 31),
+                 "buffers must be < 2 GiB");
   dim3 grid((unsigned)((nunits + upw - 1) / upw), (unsigned)slabs);
   const int flip = (flags >> 1) & 1;
   const __bf16 *in_b = reinterpret_cast<const __bf16 *>(in_feats), *wp_b = reinterpret_cast<const __bf16 *>(wpack);
   __bf16 *out_b = reinterpret_cast<__bf16 *>(out_feats);
-  static int ns_knob = -1;
-  if (ns_knob < 0) { const char *v = getenv("AABR_RS_SLOTS"); ns_knob = v ? atoi(v) : 0; }
-#define AABR_RS_LAUNCH(KC, NCB, NG)                                                                              \
+#define AABR_RS_LAUNCH(KC, NCB, NG)                                                                            \
   do {                                                                                                         \
-    constexpr int SLOT = 32 * KC * 64;                                                                         \
-    int NS = (144 * 1024) / SLOT;                                                                              \
-    if (NS > 36) NS = 36;                        /* vmcnt counts at most 63 outstanding DMAs per loader wave */ \
-    if (ns_knob >= 4 * NCB + 2 && ns_knob <= NS) NS = ns_knob;  /* D = NS - NWS - 1 >= the slots of one step */                                                 \
-    static bool attr = false;                                                                                  \
-    if (!attr) {                                                                                               \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_rsq<KC, NCB, NG>),                                  \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));             \
-      attr = true;                                                                                             \
-    }                                                                                                          \
-    g_last_variant = "k_conv_rsq<" #KC "," #NCB "," #NG ",bf16>";                                                  \
-    hipLaunchKernelGGL((k_conv_rsq<KC, NCB, NG>), grid, dim3(384), (size_t)NS * SLOT, st, in_b, out_b, n_out, V_out, \
-                       rs_stream, vol, unit_rows, upw, flip, wp_b, bias, NS);                                  \
+    g_last_variant = "k_conv_rsq<" #KC "," #NCB "," #NG ",bf16>";                                              \
+    hipLaunchKernelGGL((k_conv_rsq<KC, NCB, NG>), grid, dim3(512), 0, st, in_b, in_bytes, out_b, n_out, V_out, \
+                       rs_stream, words_bytes, vol, unit_rows, upw, flip, wp_b, wp_bytes, bias, flags >> 8);   \
   } while (0)
-  if (n_in == 128) { if (ncb == 2) AABR_RS_LAUNCH(4, 2, 12); else AABR_RS_LAUNCH(4, 1, 16); }
-  else { if (ncb == 2) AABR_RS_LAUNCH(2, 2, 12); else AABR_RS_LAUNCH(2, 1, 16); }
+  if (n_in == 128) { if (ncb == 2) AABR_RS_LAUNCH(4, 2, 16); else AABR_RS_LAUNCH(4, 1, 16); }
+  else { if (ncb == 2) AABR_RS_LAUNCH(2, 2, 16); else AABR_RS_LAUNCH(2, 1, 16); }
 #undef AABR_RS_LAUNCH
   AABR_CHECK_LAUNCH();
   return AABR_OK;

@@ -39,7 +39,7 @@ def _check_stream(words, table, V, vol, U):
     w = words.cpu().numpy()
     hdr = w[:nun * 32].reshape(nun, 32)
     perm = w[nun * 32:nun * (32 + U)].reshape(nun, U)
-    tp = w[nun * (32 + U):nun * (32 + U + vol * U)].reshape(nun, vol, U)
+    desc = w[nun * (32 + U):nun * (32 + U + vol * 256)].reshape(nun, vol * 4, 4, 16)
     tab = table.cpu().numpy()
     for u in range(nun):
         rows = np.arange(u * U, min(V, (u + 1) * U))
@@ -52,8 +52,6 @@ def _check_stream(words, table, V, vol, U):
         assert (np.diff(mval) >= 0).all()                                   # sorted by offset mask ...
         same = np.diff(mval) == 0
         assert (np.diff(live)[same] > 0).all()                              # ... stable inside a mask class
-        np.testing.assert_array_equal(tp[u][:, :len(live)], tab[:, live])   # the permuted partner table
-        assert (tp[u][:, len(live):] == -1).all()
         n = hdr[u, 0]
         ks = hdr[u, 1:n + 1] >> 16
         bits = hdr[u, 1:n + 1] & 0xffff
@@ -67,6 +65,20 @@ def _check_stream(words, table, V, vol, U):
             if b:
                 want[k] = b
         assert dict(zip(ks.tolist(), bits.tolist())) == want
+        # step descriptors: per active offset its groups four at a time, an item = the 16 partner rows of a group
+        step = 0
+        for k, b in zip(ks.tolist(), bits.tolist()):
+            groups = [g for g in range(16) if b >> g & 1]
+            for s0 in range(0, len(groups), 4):
+                for i in range(4):
+                    want_e = np.full(16, -1, np.int64)
+                    if s0 + i < len(groups):
+                        g = groups[s0 + i]
+                        pr = p[g * 16:(g + 1) * 16]
+                        want_e[pr >= 0] = tab[k, pr[pr >= 0]]
+                    np.testing.assert_array_equal(desc[u, step, i], want_e)
+                step += 1
+        assert hdr[u, 31] == step
 
 
 @pytest.mark.parametrize("nIn,nOut,npts,U,bias", [(128, 128, 2500, 64, False), (64, 64, 3000, 96, True),
@@ -183,7 +195,7 @@ def test_rs_units_without_rules_and_dispatch():
     words = torch.empty(lib.aabr_rs_words(V, vol, U), dtype=torch.int32, device=DEV)
     check(lib.aabr_build_rs(ptr(table), V, vol, U, ptr(words), stream()))
     _check_stream(words, table, V, vol, U)
-    assert words[32].item() == 0                                             # unit 1: no active offset
+    assert words[32].item() == 0 and words[32 + 31].item() == 0              # unit 1: no active offset, no step
     W = (rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32)
     Wd = _t(W)
     n = int(lib.aabr_conv_wpack_bf16_elems(vol, nIn, nOut))
@@ -205,9 +217,8 @@ def test_rs_units_without_rules_and_dispatch():
     np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=2 ** -7 * np.abs(ref).max())
     np.testing.assert_array_equal(out[32:64].float().cpu().numpy(),
                                   np.tile(b.bfloat16().float().cpu().numpy(), (32, 1)))
-    # dispatch: unit sizes are multiples of 16 within the register budget; small or unsupported launches say 0
-    assert lib.aabr_conv_rs_unit_rows(128, 128, 84077, 84077, 27) in range(16, 193, 16)
-    assert lib.aabr_conv_rs_unit_rows(64, 64, 200652, 200652, 27) in range(16, 257, 16)
-    assert lib.aabr_conv_rs_unit_rows(128, 128, 1382, 1382, 27) == 0
+    # dispatch: off unless AABR_CONV_RS=1 was set before the library was first used (the LDS-tile kernel is faster:
+    # profiles/r03_conv_rs_ab.txt); unsupported shapes say 0 either way
+    assert lib.aabr_conv_rs_unit_rows(128, 128, 84077, 84077, 27) in [0] + list(range(16, 257, 16))
     assert lib.aabr_conv_rs_unit_rows(32, 64, 300000, 300000, 27) == 0
     assert lib.aabr_conv_rs_unit_rows(128, 96, 300000, 300000, 27) == 0
