@@ -49,24 +49,34 @@ __host__ __device__ inline uint64_t mix64(uint64_t k) {
   return k;
 }
 
-// read-only probe of a finished table
-__device__ inline int grid_find(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals,
-                                uint64_t mask, uint64_t key) {
+// One slot of a hash grid: key, the smallest item index that hit the slot (first-seen numbering) and the site row,
+// INTERLEAVED in 16 bytes -- the CAS on the key, the atomicMin on `first`, the later read of `first`, the store and
+// every probe of `val` touch ONE 64-byte sector (round 2 kept three arrays: three sectors per point, 119 B of
+// write-back per point counted for k_voxel_insert alone).  The library's `keys` parameters point at these entries.
+struct __align__(16) GridEnt {
+  unsigned long long key;
+  uint32_t first;
+  int32_t val;
+};
+static_assert(sizeof(GridEnt) == 16, "GridEnt is 16 bytes");
+
+// read-only probe of a finished table: one 16-byte load per slot visited
+__device__ inline int grid_find(const GridEnt *__restrict__ g, uint64_t mask, uint64_t key) {
   uint64_t h = mix64(key) & mask;
   for (;;) {
-    uint64_t k = keys[h];
-    if (k == key) return vals[h];
+    const uint4 e = *reinterpret_cast<const uint4 *>(g + h);
+    const uint64_t k = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    if (k == key) return (int)e.w;
     if (k == kEmptyKey) return -1;
     h = (h + 1) & mask;
   }
 }
 
 // insert-or-find; returns the slot
-__device__ inline uint32_t grid_insert(uint64_t *keys, uint64_t mask, uint64_t key) {
+__device__ inline uint32_t grid_insert(GridEnt *g, uint64_t mask, uint64_t key) {
   uint64_t h = mix64(key) & mask;
   for (;;) {
-    unsigned long long prev = atomicCAS((unsigned long long *)&keys[h], (unsigned long long)kEmptyKey,
-                                       (unsigned long long)key);
+    unsigned long long prev = atomicCAS(&g[h].key, (unsigned long long)kEmptyKey, (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) return (uint32_t)h;
     h = (h + 1) & mask;
   }

@@ -47,12 +47,12 @@ constexpr int kScanTile = kScanThreads * kScanItems; // 256 items per block
 constexpr int kInlinePrefixBlocks = 2048;            // up to 512k items: block prefix summed in k_assign_sites
 
 // "first" flag of encounter e: it won the atomicMin on its slot.
-__device__ inline void first_flag(const int32_t *slot, const uint32_t *minidx, const uint32_t *slotcnt,
+__device__ inline void first_flag(const int32_t *slot, const GridEnt *minidx, const uint32_t *slotcnt,
                                   int64_t e, int64_t n, int &f, int &c) {
   f = 0; c = 0;
   if (e < n) {
     int s = slot[e];
-    if (s >= 0 && minidx[s] == (uint32_t)e) {
+    if (s >= 0 && minidx[s].first == (uint32_t)e) {
       f = 1;
       c = slotcnt ? (int)(slotcnt[s] + 1u) : 1; // slotcnt starts at 0xFFFFFFFF
     }
@@ -60,7 +60,7 @@ __device__ inline void first_flag(const int32_t *slot, const uint32_t *minidx, c
 }
 
 __global__ __launch_bounds__(kScanThreads) void k_scan_blocksums(
-    const int32_t *__restrict__ slot, const uint32_t *__restrict__ minidx,
+    const int32_t *__restrict__ slot, const GridEnt *__restrict__ minidx,
     const uint32_t *__restrict__ slotcnt, int64_t n, int32_t *__restrict__ blocksums) {
   int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   int a = 0, b = 0;
@@ -126,9 +126,9 @@ __device__ inline bool output_region_lth(const ConvGeom &g, const int p[3], int 
 // MODE 0: input layer (items = points); MODE 1: strided-conv output sites (items = encounters)
 template <int MODE>
 __global__ __launch_bounds__(kScanThreads) void k_assign_sites(
-    const int32_t *__restrict__ slot, const uint32_t *__restrict__ minidx,
+    const int32_t *__restrict__ slot, GridEnt *__restrict__ minidx,
     const uint32_t *__restrict__ slotcnt, int64_t n, const int32_t *__restrict__ prefix,
-    const int32_t *__restrict__ blocksums, int32_t *__restrict__ vals, int32_t *__restrict__ site_coords, int32_t *__restrict__ site_off,
+    const int32_t *__restrict__ blocksums, int32_t *__restrict__ site_coords, int32_t *__restrict__ site_off,
     int32_t *__restrict__ meta, const int64_t *__restrict__ coords64, int ncols,
     const int32_t *__restrict__ in_coords, ConvGeom g) {
   int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kScanThreads) void k_assign_sites(
   for (int j = 0; j < kScanItems; ++j) {
     if (f[j]) {
       int64_t e = base + j;
-      vals[slot[e]] = ra;
+      minidx[slot[e]].val = ra;
       if (MODE == 0) {
         const int64_t *cp = coords64 + e * ncols;
         int4 sc = make_int4((int)cp[0], (int)cp[1], (int)cp[2], ncols == 4 ? (int)cp[3] : 0);
@@ -219,8 +219,8 @@ __device__ inline void block_count_store(int hit, int32_t *__restrict__ counts, 
 }
 
 __global__ __launch_bounds__(256) void k_submanifold_table(const int32_t *__restrict__ site_coords,
-                                                           int64_t V, const uint64_t *__restrict__ keys,
-                                                           const int32_t *__restrict__ vals, uint64_t mask,
+                                                           int64_t V, const GridEnt *__restrict__ keys,
+                                                           uint64_t mask,
                                                            Filter3 fs, int32_t *__restrict__ table,
                                                            int32_t *__restrict__ counts) {
   const int k = blockIdx.y;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_submanifold_table(const int32_t *__rest
     int x = c.x + dx - fs.size[0] / 2, y = c.y + dy - fs.size[1] / 2, z = c.z + dz - fs.size[2] / 2;
     int r = -1;
     if (coord_in_range(x) && coord_in_range(y) && coord_in_range(z))
-      r = grid_find(keys, vals, mask, pack_key(c.w, x, y, z));
+      r = grid_find(keys, mask, pack_key(c.w, x, y, z));
     table[(int64_t)k * V + v] = r;
     hit = r >= 0;
   }
@@ -242,9 +242,8 @@ __global__ __launch_bounds__(256) void k_submanifold_table(const int32_t *__rest
 }
 
 __global__ __launch_bounds__(256) void k_conv_insert_sites(const int32_t *__restrict__ in_coords,
-                                                           int64_t V_in, ConvGeom g, uint64_t *keys,
-                                                           uint64_t mask, uint32_t *minidx,
-                                                           int32_t *__restrict__ slot) {
+                                                           int64_t V_in, ConvGeom g, GridEnt *keys,
+                                                           uint64_t mask, int32_t *__restrict__ slot) {
   int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= V_in) return;
   int4 ic = *reinterpret_cast<const int4 *>(in_coords + 4 * u);
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(256) void k_conv_insert_sites(const int32_t *__rest
     int64_t e = u * g.maxout + l;
     if (output_region_lth(g, p, l, j)) {
       uint32_t h = grid_insert(keys, mask, pack_key(ic.w, j[0], j[1], j[2]));
-      atomicMin(&minidx[h], (uint32_t)e);
+      atomicMin(&keys[h].first, (uint32_t)e);
       slot[e] = (int32_t)h;
     } else {
       slot[e] = -1;
@@ -263,8 +262,7 @@ __global__ __launch_bounds__(256) void k_conv_insert_sites(const int32_t *__rest
 
 // table_out[k][o]: input row at o*stride + koff (InputRegionCalculator, :95-105)
 __global__ __launch_bounds__(256) void k_conv_table_out(const int32_t *__restrict__ out_coords,
-                                                        int64_t V_out, const uint64_t *__restrict__ in_keys,
-                                                        const int32_t *__restrict__ in_vals,
+                                                        int64_t V_out, const GridEnt *__restrict__ in_keys,
                                                         uint64_t in_mask, ConvGeom g,
                                                         int32_t *__restrict__ table,
                                                         int32_t *__restrict__ counts) {
@@ -278,7 +276,7 @@ __global__ __launch_bounds__(256) void k_conv_table_out(const int32_t *__restric
     int x = c.x * g.stride[0] + dx, y = c.y * g.stride[1] + dy, z = c.z * g.stride[2] + dz;
     int r = -1;
     if (coord_in_range(x) && coord_in_range(y) && coord_in_range(z))
-      r = grid_find(in_keys, in_vals, in_mask, pack_key(c.w, x, y, z));
+      r = grid_find(in_keys, in_mask, pack_key(c.w, x, y, z));
     table[(int64_t)k * V_out + o] = r;
     hit = r >= 0;
   }
@@ -288,8 +286,7 @@ __global__ __launch_bounds__(256) void k_conv_table_out(const int32_t *__restric
 // table_in[k][u]: the output row whose window holds input u at offset k, if that output cell
 // is inside [0, out_spatial) (OutputRegionCalculator clamps, :109-119)
 __global__ __launch_bounds__(256) void k_conv_table_in(const int32_t *__restrict__ in_coords, int64_t V_in,
-                                                       const uint64_t *__restrict__ out_keys,
-                                                       const int32_t *__restrict__ out_vals,
+                                                       const GridEnt *__restrict__ out_keys,
                                                        uint64_t out_mask, ConvGeom g,
                                                        int32_t *__restrict__ table,
                                                        int32_t *__restrict__ counts) {
@@ -313,7 +310,7 @@ __global__ __launch_bounds__(256) void k_conv_table_in(const int32_t *__restrict
       if (j[i] > g.out_sp[i] - 1) { ok = false; break; }
     }
     int r = -1;
-    if (ok) r = grid_find(out_keys, out_vals, out_mask, pack_key(c.w, j[0], j[1], j[2]));
+    if (ok) r = grid_find(out_keys, out_mask, pack_key(c.w, j[0], j[1], j[2]));
     table[(int64_t)k * V_in + u] = r;
     hit = r >= 0;
   }
@@ -413,9 +410,9 @@ extern "C" int aabr_submanifold_table(const int32_t *site_coords, int64_t V, con
   }
   AABR_CHECK_ARG(vol <= 65535, "filter volume too large");
   if (V == 0) return AABR_OK;
-  AABR_CHECK_ARG(site_coords && keys && vals && table, "null pointer");
+  AABR_CHECK_ARG(site_coords && keys && table && ((uintptr_t)keys & 15) == 0, "null / misaligned pointer");
   hipLaunchKernelGGL(k_submanifold_table, dim3((unsigned)ceil_div(V, 256), (unsigned)vol), dim3(256), 0, st,
-                     site_coords, V, keys, vals, (uint64_t)(cap - 1), fs, table, counts);
+                     site_coords, V, reinterpret_cast<const GridEnt *>(keys), (uint64_t)(cap - 1), fs, table, counts);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -448,27 +445,27 @@ extern "C" int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, co
   AABR_CHECK_ARG(E < (int64_t)0x7fffffff, "too many encounters");
   AABR_CHECK_ARG(is_pow2(out_cap) && out_cap >= 2 * E && out_cap >= 64,
                  "out_cap must be a power of two >= max(64, 2*V_in*max_out_per_in)");
-  AABR_CHECK_ARG(out_keys && out_vals && scratch && out_site_coords && meta, "null pointer");
+  AABR_CHECK_ARG(out_keys && scratch && out_site_coords && meta && ((uintptr_t)out_keys & 15) == 0,
+                 "null / misaligned pointer");
   int64_t nblk = ceil_div(E > 0 ? E : 1, kScanTile);
-  uint32_t *minidx = (uint32_t *)scratch;
-  int32_t *slot = (int32_t *)(minidx + out_cap);
+  GridEnt *grid = reinterpret_cast<GridEnt *>(out_keys);
+  int32_t *slot = scratch;
   int32_t *blocksums = slot + E;
   int32_t *prefix = blocksums + 2 * nblk;
-  hipMemsetAsync(out_keys, 0xFF, out_cap * sizeof(uint64_t), st);
-  hipMemsetAsync(minidx, 0xFF, out_cap * sizeof(uint32_t), st);
+  hipMemsetAsync(grid, 0xFF, out_cap * sizeof(GridEnt), st);   // key = empty, first = max, val = -1
   hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st);
   if (V_in > 0)
-    hipLaunchKernelGGL(k_conv_insert_sites, grid1(V_in, 256), dim3(256), 0, st, in_coords, V_in, g, out_keys,
-                       (uint64_t)(out_cap - 1), minidx, slot);
-  hipLaunchKernelGGL(k_scan_blocksums, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx,
+    hipLaunchKernelGGL(k_conv_insert_sites, grid1(V_in, 256), dim3(256), 0, st, in_coords, V_in, g, grid,
+                       (uint64_t)(out_cap - 1), slot);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, grid,
                      (const uint32_t *)nullptr, E, blocksums);
   const bool inline_prefix = nblk <= kInlinePrefixBlocks;
   if (!inline_prefix)
     hipLaunchKernelGGL(k_scan_blockprefix, dim3(1), dim3(1024), 0, st, blocksums, nblk, prefix, meta,
                        (int32_t *)nullptr);
-  hipLaunchKernelGGL(k_assign_sites<1>, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, minidx,
+  hipLaunchKernelGGL(k_assign_sites<1>, dim3((unsigned)nblk), dim3(kScanThreads), 0, st, slot, grid,
                      (const uint32_t *)nullptr, E, prefix,
-                     inline_prefix ? (const int32_t *)blocksums : (const int32_t *)nullptr, out_vals, out_site_coords, (int32_t *)nullptr, meta,
+                     inline_prefix ? (const int32_t *)blocksums : (const int32_t *)nullptr, out_site_coords, (int32_t *)nullptr, meta,
                      (const int64_t *)nullptr, 0, in_coords, g);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
@@ -505,14 +502,16 @@ extern "C" int aabr_convolution_tables2(const int32_t *in_coords, int64_t V_in, 
   AABR_CHECK_ARG(make_geom(size_host, stride_host, out_spatial_host, g) == 0, "bad filter geometry");
   int vol = g.size[0] * g.size[1] * g.size[2];
   if (V_out > 0 && table_out) {
-    AABR_CHECK_ARG(out_coords && in_keys && in_vals, "null pointer");
+    AABR_CHECK_ARG(out_coords && in_keys && ((uintptr_t)in_keys & 15) == 0, "null / misaligned pointer");
     hipLaunchKernelGGL(k_conv_table_out, dim3((unsigned)ceil_div(V_out, 256), (unsigned)vol), dim3(256), 0, st,
-                       out_coords, V_out, in_keys, in_vals, (uint64_t)(in_cap - 1), g, table_out, counts);
+                       out_coords, V_out, reinterpret_cast<const GridEnt *>(in_keys), (uint64_t)(in_cap - 1), g,
+                       table_out, counts);
   }
   if (V_in > 0 && table_in) {
-    AABR_CHECK_ARG(in_coords && out_keys && out_vals, "null pointer");
+    AABR_CHECK_ARG(in_coords && out_keys && ((uintptr_t)out_keys & 15) == 0, "null / misaligned pointer");
     hipLaunchKernelGGL(k_conv_table_in, dim3((unsigned)ceil_div(V_in, 256), (unsigned)vol), dim3(256), 0, st,
-                       in_coords, V_in, out_keys, out_vals, (uint64_t)(out_cap - 1), g, table_in, counts_in);
+                       in_coords, V_in, reinterpret_cast<const GridEnt *>(out_keys), (uint64_t)(out_cap - 1), g,
+                       table_in, counts_in);
   }
   AABR_CHECK_LAUNCH();
   return AABR_OK;

@@ -37,7 +37,7 @@ static inline int vs_items(int64_t) { return 4; }
 constexpr int kMetaTicket = 4;                  // meta word used as the chunk ticket counter
 
 __global__ __launch_bounds__(256) void k_voxel_insert(const int64_t *__restrict__ coords, int64_t n, int ncols,
-                                                      uint64_t *keys, uint64_t mask, uint32_t *first,
+                                                      GridEnt *keys, uint64_t mask,
                                                       int32_t *__restrict__ slot, int32_t *__restrict__ cnt_extra,
                                                       int32_t *__restrict__ head,
                                                       unsigned long long *__restrict__ status, int64_t nchunks,
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_voxel_insert(const int64_t *__restrict_
     return;                 // K2 rewrites the word as 0 / 1
   }
   uint32_t h = grid_insert(keys, mask, pack_key((int)b, (int)x, (int)y, (int)z));
-  atomicMin(&first[h], (uint32_t)i);
+  atomicMin(&keys[h].first, (uint32_t)i);   // same 64-byte sector as the CAS just done
   slot[i] = (int32_t)h;
 }
 
@@ -71,7 +71,7 @@ __device__ inline unsigned long long st_pack(unsigned flag, unsigned v) {
 template <int kVsItems>
 __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
     const int64_t *__restrict__ coords, int64_t n, int ncols, const int32_t *__restrict__ slot,
-    const uint32_t *__restrict__ first, int32_t *vals, int32_t *__restrict__ site_coords,
+    GridEnt *grid, int32_t *__restrict__ site_coords,
     int32_t *__restrict__ first_pt, int32_t *__restrict__ point_site, int32_t *cnt_extra, int32_t *head,
     int32_t *__restrict__ nxt, unsigned long long *status, int32_t *meta) {
   constexpr int kVsChunk = kVsThreads * kVsItems;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
   for (int j = 0; j < kVsItems; ++j) {
     const int64_t i = base + j;
     s[j] = i < n ? slot[i] : -1;
-    f[j] = (s[j] >= 0 && first[s[j]] == (uint32_t)i) ? 1 : 0;
+    f[j] = (s[j] >= 0 && grid[s[j]].first == (uint32_t)i) ? 1 : 0;
     a += f[j];
   }
   // chunk-exclusive scan of `a`: wave scan + 4 wave totals through LDS
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
       *reinterpret_cast<int4 *>(site_coords + 4 * (int64_t)v) =
           make_int4((int)cp[0], (int)cp[1], (int)cp[2], ncols == 4 ? (int)cp[3] : 0);
       first_pt[v] = (int32_t)i;
-      __hip_atomic_store(&vals[s[j]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // self-contained value
+      __hip_atomic_store(&grid[s[j]].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // self-contained value
     }
   }
   // the other points of a voxel: their first point lies in this or an earlier (already running) chunk
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
     int v = mysite[j];
     if (!f[j] && s[j] >= 0) {
       do {
-        v = __hip_atomic_load(&vals[s[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load(&grid[s[j]].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v < 0) __builtin_amdgcn_s_sleep(1);
       } while (v < 0);
       nxt[i] = atomicExch(&head[v], (int32_t)i);
@@ -402,33 +402,32 @@ extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncol
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(n >= 0 && n < (1ll << 31) - 65536 && (ncols == 3 || ncols == 4), "0 <= n < 2^31, ncols in {3,4}");
   AABR_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "cap must be a power of two >= max(64, 2n)");
-  AABR_CHECK_ARG(keys && first && vals && slot && point_site && site_coords && first_pt && cnt_extra && head && nxt &&
-                     status && meta, "null pointer");
-  AABR_CHECK_ARG(((uintptr_t)status & 7) == 0 && ((uintptr_t)site_coords & 15) == 0, "status 8-, site_coords 16-byte aligned");
+  AABR_CHECK_ARG(keys && slot && point_site && site_coords && first_pt && cnt_extra && head && nxt && status && meta,
+                 "null pointer");
+  AABR_CHECK_ARG(((uintptr_t)status & 7) == 0 && ((uintptr_t)site_coords & 15) == 0 && ((uintptr_t)keys & 15) == 0,
+                 "status 8-, site_coords / grid entries 16-byte aligned");
   AABR_CHECK_ARG(n == 0 || coords, "null coords");
+  (void)first; (void)vals;   // round-2 layout (separate arrays); the grid's 16-byte entries hold them now
+  GridEnt *grid = reinterpret_cast<GridEnt *>(keys);
   const int items = vs_items(n);
   const int64_t nchunks = ceil_div(n > 0 ? n : 1, (int64_t)kVsThreads * items);
   if (n == 0) {
-    hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st);
+    hipMemsetAsync(grid, 0xFF, cap * sizeof(GridEnt), st);
     hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st);
     AABR_CHECK_LAUNCH();
     return AABR_OK;
   }
-  if ((void *)(keys + cap) == (void *)first && (void *)(first + cap) == (void *)vals &&
-      (void *)(vals + cap) == (void *)meta) // contiguous (the layout the Python side uses): ONE fill
-    hipMemsetAsync(keys, 0xFF, cap * (sizeof(uint64_t) + sizeof(uint32_t) + sizeof(int32_t)) +
-                                   AABR_META_WORDS * sizeof(int32_t), st);
+  if ((void *)(grid + cap) == (void *)meta) // contiguous (the layout the Python side uses): ONE fill
+    hipMemsetAsync(grid, 0xFF, cap * sizeof(GridEnt) + AABR_META_WORDS * sizeof(int32_t), st);
   else {
-    hipMemsetAsync(keys, 0xFF, cap * sizeof(uint64_t), st);
-    hipMemsetAsync(first, 0xFF, cap * sizeof(uint32_t), st);
-    hipMemsetAsync(vals, 0xFF, cap * sizeof(int32_t), st);
+    hipMemsetAsync(grid, 0xFF, cap * sizeof(GridEnt), st);
     hipMemsetAsync(meta, 0xFF, AABR_META_WORDS * sizeof(int32_t), st);
   }
   // K1 also clears the chunk status words and the per-site chain heads / counts (consumed by K2 only)
-  hipLaunchKernelGGL(k_voxel_insert, grid1(n > nchunks ? n : nchunks, 256), dim3(256), 0, st, coords, n, ncols, keys,
-                     (uint64_t)(cap - 1), first, slot, cnt_extra, head, (unsigned long long *)status, nchunks, meta);
+  hipLaunchKernelGGL(k_voxel_insert, grid1(n > nchunks ? n : nchunks, 256), dim3(256), 0, st, coords, n, ncols, grid,
+                     (uint64_t)(cap - 1), slot, cnt_extra, head, (unsigned long long *)status, nchunks, meta);
   hipLaunchKernelGGL(k_voxel_number<4>, dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
-                     first, vals, site_coords, first_pt, point_site, cnt_extra, head, nxt,
+                     grid, site_coords, first_pt, point_site, cnt_extra, head, nxt,
                      (unsigned long long *)status, meta);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
@@ -440,7 +439,10 @@ extern "C" int aabr_input_layer_forward(const float *in_feats, float *out_feats,
   AABR_CHECK_ARG(V >= 0 && planes > 0 && mode >= 1 && mode <= 4, "bad V/planes/mode");
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(in_feats && out_feats && first_pt && cnt_extra && head && nxt && meta, "null pointer");
-  if (planes <= 16)
+  static const int mean_knob = [] { const char *v = getenv("AABR_VOXEL_MEAN"); return v ? atoi(v) : 0; }();
+  // one thread per (site, plane): consecutive lanes read consecutive floats of consecutive first points -- 73 us
+  // instead of 100 us at 1.5 M points for the one-thread-per-site form (AABR_VOXEL_MEAN=2 selects that one)
+  if (planes <= 16 && mean_knob == 2)
     hipLaunchKernelGGL(k_voxel_mean_row<16>, grid1(V, 256), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats, V,
                        planes, first_pt, cnt_extra, head, nxt, last_pt, mode, meta);
   else

@@ -352,7 +352,7 @@ class Metadata_3(object):
         if pend is not None:
             ts += [pend["buf"]]
         for g in self.grids.values():
-            ts += [g.coords, g.keys, g.vals]
+            ts += [g.coords, g.keys]
         if self.input is not None:
             ts += [self.input["point_site"]]
         for tb in list(self.submanifold.values()) + list(self.rulebooks.values()):
@@ -462,10 +462,10 @@ class Metadata_3(object):
         cap = _hip.next_pow2(2 * n)
         n1 = max(n, 1)
         nst = int(lib.aabr_input_layer_status_words(n))
-        # int32 words, 16-byte aligned pieces; keys | first | vals | meta sit back to back so the library clears
-        # them with ONE fill:  keys(2*cap) first(cap) vals(cap) meta(8) | slot(n) point_site(n) nxt(n)
+        # int32 words, 16-byte aligned pieces; the grid's 16-byte entries {key, first, val} and meta sit back to back
+        # so the library clears them with ONE fill:  grid(4*cap) meta(8) | slot(n) point_site(n) nxt(n)
         #                      site_coords(4*n1) first_pt(n1) cnt_extra(n1) head(n1) last_pt(n1) status(nst)
-        names = [("keys", 2 * cap), ("first", cap), ("vals", cap), ("meta", _hip.META_WORDS), ("slot", n),
+        names = [("keys", 4 * cap), ("meta", _hip.META_WORDS), ("slot", n),
                  ("point_site", n), ("nxt", n), ("site_coords", 4 * n1), ("first_pt", n1), ("cnt_extra", n1),
                  ("head", n1), ("last_pt", n1), ("status", nst)]
         offs, tot = {}, 0
@@ -474,14 +474,14 @@ class Metadata_3(object):
             tot += (sz + 3) & ~3
         buf = torch.empty(tot, dtype=torch.int32, device=device)
         piece = {name: buf[offs[name]:offs[name] + sz] for name, sz in names}
-        keys = piece["keys"].view(torch.int64)
-        vals, meta = piece["vals"], piece["meta"]
+        keys = piece["keys"].view(torch.int64)    # cap entries of 16 bytes: {uint64 key, uint32 first, int32 val}
+        vals, meta = None, piece["meta"]
         site_coords = piece["site_coords"].view(n1, 4)
         base = buf.data_ptr()
         P = lambda name: base + 4 * offs[name]
         host = ev = None
         if n > 0:
-            check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, P("keys"), P("first"), P("vals"), cap, P("slot"),
+            check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, P("keys"), None, None, cap, P("slot"),
                                              P("point_site"), P("site_coords"), P("first_pt"), P("cnt_extra"),
                                              P("head"), P("nxt"), P("status"), P("meta"), stream()))
             if asynchronous:
@@ -564,9 +564,9 @@ class Metadata_3(object):
         pend = []
         for i, (osz, comp) in enumerate(specs):
             osz, comp = _key(osz), _key(comp)
-            keys = torch.empty(cap, dtype=torch.int64, device=dev)
-            vals = torch.empty(cap, dtype=torch.int32, device=dev)
-            scratch = torch.empty(3 * cap + 2 * E + 4 * nblk + 16, dtype=torch.int32, device=dev)
+            keys = torch.empty(2 * cap, dtype=torch.int64, device=dev)   # cap 16-byte entries {key, first, val}
+            vals = None
+            scratch = torch.empty(E + 4 * nblk + 16, dtype=torch.int32, device=dev)
             out_coords = torch.empty((max(E, 1), 4), dtype=torch.int32, device=dev)
             check(lib.aabr_convolution_sites(ptr(gi.coords), gi.V, _hip.i32x3(comp), _hip.i32x3(comp),
                                              _hip.i32x3(osz), ptr(keys), ptr(vals), cap, ptr(scratch),
@@ -619,9 +619,9 @@ class Metadata_3(object):
             E = gi.V * maxout
             cap = _hip.next_pow2(2 * E)
             nblk = (max(E, 1) + 255) // 256
-            keys = torch.empty(cap, dtype=torch.int64, device=dev)
-            vals = torch.empty(cap, dtype=torch.int32, device=dev)
-            scratch = torch.empty(3 * cap + 2 * E + 4 * nblk + 16, dtype=torch.int32, device=dev)
+            keys = torch.empty(2 * cap, dtype=torch.int64, device=dev)   # cap 16-byte entries {key, first, val}
+            vals = None
+            scratch = torch.empty(E + 4 * nblk + 16, dtype=torch.int32, device=dev)
             out_coords = torch.empty((max(E, 1), 4), dtype=torch.int32, device=dev)
             meta = torch.empty(_hip.META_WORDS, dtype=torch.int32, device=dev)
             check(lib.aabr_convolution_sites(ptr(gi.coords), gi.V, _hip.i32x3(fs), _hip.i32x3(st),

@@ -51,8 +51,10 @@ int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale
                          float *feats_xyz, int feat_stride, void *stream);
 
 /* ---- hash grid ---------------------------------------------------------------------------
- * A grid is an open-addressing table: keys uint64[cap] (packed b,x,y,z), vals int32[cap]
- * (row of the site).  cap must be a power of two >= 2 * (number of inserted keys).
+ * A grid is an open-addressing table of cap 16-byte entries {uint64 key (packed b,x,y,z), uint32 first, int32 val
+ * (row of the site)}, handed over through the `keys` parameters (16-byte aligned); the `vals` parameters are the
+ * round-2 layout's second array and are ignored (pass NULL).  cap must be a power of two >= 2 * (number of
+ * inserted keys).
  * Replaces SparseGrid / SparseGridMap (SCN/Metadata/Metadata.h:24-33).                       */
 
 /* Voxel scatter, geometry half -- replaces Metadata<3>::inputLayer -> inputLayerRules
@@ -61,7 +63,10 @@ int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale
  * voxels in first-seen order (chunk scan + decoupled look-back) and links every further point of a voxel into
  * the site's chain.
  *   coords       int64 [n, ncols] (ncols 3 or 4; 4th column = batch index)   (API layout)
- *   keys, first, vals  hash grid storage, capacity cap each (uint64 / uint32 / int32; contents overwritten);
+ *   keys         the hash grid: cap entries of 16 bytes {uint64 key, uint32 first, int32 val}, 16-byte aligned,
+ *                contents overwritten (round 3: interleaved so that the insert's CAS, its first-seen minimum and
+ *                every later probe of a slot touch one 64-byte sector); first, vals: ignored, pass NULL (round-2
+ *                layout of separate arrays, kept in the signature);
  *                laid out back to back and followed by `meta` they are cleared with a single fill
  *   slot         int32 [n]   scratch: hash slot of every point
  *   point_site   int32 [n]   out: output row of every input row (-1: dropped)
@@ -115,7 +120,8 @@ int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t
  * Convolution_InputSgToRulesAndOutputSg (Metadata.cpp:484-510, ConvolutionRules.h:11-34,
  * RectangularRegions.h:95-119).  Creates the output grid (sites numbered in first-seen order
  * over input rows ascending, then output-region order) and reports V_out in meta[0].
- *   scratch int32 [3*out_cap + 2*E + 4*ceil(E/256) + 16], E = V_in * max_out_per_in,
+ *   out_keys: out_cap 16-byte grid entries as in aabr_input_layer_sites (out_vals ignored, pass NULL);
+ *   scratch int32 [E + 4*ceil(E/256) + 16], E = V_in * max_out_per_in,
  *   max_out_per_in = prod(ceil(size/stride)); out_site_coords int32 [E,4].
  * size, stride <= 64 per axis; for size == stride (one output site per input site) up to 65536, so that a chain of
  * non-overlapping levels can be built from its FIRST grid in one step each (size = stride = product of the chain's

@@ -226,7 +226,8 @@ def test_bench_gpus2_rehearsal_on_one_gpu():
     assert abs(d["rank_ms_per_step_max"] - out["ms_per_step"]) < 1e-6
     t = out["timing"]
     assert out["steps"] == 3 and t["prewarm_steps"] % 5 == 0 and t["prewarm_steps"] >= 10
-    assert t["extended"]["steps"] >= 1 and t["extended"]["timed_region_s"] >= 0.15
+    if out["timed_region_s"] < 0.2:      # a region shorter than --min-timed-s is cross-checked by a second, longer one
+        assert t["extended"]["steps"] >= 1 and t["extended"]["timed_region_s"] >= 0.15
     assert set(t["step_ms"]) >= {"p50", "p90", "min", "max", "first5"}
 
 
