@@ -21,6 +21,7 @@ _f32p = C.POINTER(C.c_float)
 _SIGS = {
     "aabr_version": (C.c_int, []),
     "aabr_last_error": (C.c_char_p, []),
+    "aabr_set_knob": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "aabr_quantize_points": (C.c_int, [_vp, _i32, _i64, C.c_double, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "aabr_input_layer_status_words": (C.c_int64, [_i64]),
     "aabr_input_layer_sites": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -144,6 +145,11 @@ def require_gpu(t=None):
                         "there is no CPU fallback")
     if t is not None and not t.is_cuda:
         raise AabrError("expected a tensor in device memory, got %s" % t.device)
+
+
+def set_knob(name, value=None):
+    """tuning knob of the library (tests / tools): value None = back to "no value" (the shipped default)"""
+    check(load().aabr_set_knob(name.encode(), 0 if value is None else int(value), 1 if value is None else 0))
 
 
 def check(rc):

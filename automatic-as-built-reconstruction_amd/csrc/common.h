@@ -9,6 +9,14 @@ namespace aabr {
 
 void set_error(const char *fmt, ...);
 
+// Tuning knobs (experiments and tests only; the defaults are what ships).  Each is read from its environment
+// variable AABR_<NAME> ONCE, at its first use in the process, and can be set explicitly through aabr_set_knob --
+// no entry point calls getenv on its launch path.
+enum Knob { K_CONV_WLDS, K_CONV_SMALL, K_CONV_NBW, K_CONV_WPB, K_CONV_RS, K_RS_UNIT, K_WIDE_ROWS, K_CONV_WIDE,
+            K_WIDE_NBUF, K_CONV_WIDE_BF16, K_VOXEL_MEAN, K_COUNT };
+constexpr int kKnobUnset = -2147483647 - 1;
+int knob(Knob k);            // kKnobUnset when neither the environment nor aabr_set_knob gave a value
+
 #define AABR_CHECK_ARG(cond, msg)                                   \
   do {                                                              \
     if (!(cond)) { aabr::set_error("%s: %s", __func__, msg); return AABR_EINVAL; } \

@@ -1903,8 +1903,8 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
   const bool lean = aligned && lean_any;
   // LDS-resident weights: the slab's packed filter bank + enough per-wave output tiles fit in 160 KiB
   if (nkc <= 2 && in_bytes < (1ll << 31) && words_bytes < (1ll << 31) && !(flags >> 8)) {
-    const char *ov = getenv("AABR_CONV_WLDS"); // tuning experiments only: 0 disables, 1/2/4 forces the slab width
-    const int forced = ov ? atoi(ov) : -1;
+    const int kv = knob(K_CONV_WLDS);          // tuning experiments only: 0 disables, 1/2/4 forces the slab width
+    const int forced = kv == kKnobUnset ? -1 : kv;
     const int64_t ntiles = ceil_div(V_out, 64);
     // Measured (tools_conv_bench.py, S80k and 1.5 M points): 16-column slabs with 8 waves per CU beat
     // wider slabs (fewer waves fit beside the larger filter bank) and beat the streaming kernel when the
@@ -1958,8 +1958,7 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
   }
   // tiny rule books with wide layers (coarse FPN scales): (pair, chunk) items over 8 waves x 16-column slabs
   if (lean && nkc >= 2 && ceil_div(V_out, 64) * nnb < 512) {
-    const char *ov = getenv("AABR_CONV_SMALL"); // tuning experiments only: 0 disables
-    if (!(ov && ov[0] == '0')) {
+    if (knob(K_CONV_SMALL) != 0) {             // tuning experiments only: 0 disables
       constexpr int kW = 8;
       g_last_variant = "k_conv_blocks_mfma_small<8>";
       hipLaunchKernelGGL((k_conv_blocks_mfma_small<kW>), dim3((unsigned)ceil_div(V_out, 64), (unsigned)nnb),
@@ -2011,8 +2010,8 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
   // the private LDS tile) edge out the 64-column weight-prefetch kernel: 39.4 -> 40.3 % / 41.9 -> 42.8 % of
   // the fp32 MFMA peak at 128 / 256 planes, 1.5 M points
   if (nbw == 4 && ceil_div(V_out, 64) * ceil_div(nnb, 4) >= 8192) nbw = 2;
-  if (const char *ov = getenv("AABR_CONV_NBW")) { // tuning experiments only
-    int v = atoi(ov);
+  {                                              // tuning experiments only
+    const int v = knob(K_CONV_NBW);
     if ((v == 1 || v == 2 || v == 4) && v <= nbw) nbw = v;
   }
   const int64_t wgs = ceil_div(V_out, 64) * ceil_div(nnb, nbw);
@@ -2029,8 +2028,8 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
     int64_t cost = rounds * ceil_div(vol, wpb);
     if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_wpb = wpb; }
   }
-  if (const char *ov = getenv("AABR_CONV_WPB")) { // tuning experiments only
-    int v = atoi(ov);
+  {                                              // tuning experiments only
+    const int v = knob(K_CONV_WPB);
     if (v >= 2 && v <= (nbw == 4 ? 3 : 4)) best_wpb = v;
   }
   if (nbw == 1) {
@@ -2172,8 +2171,8 @@ extern "C" int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_
                        n_out, transpose, wp);
   int nbw = nnb == 2 ? 2 : 4;
   if (nbw == 4 && ceil_div(V_out, 64) * ceil_div(nnb, 4) < 512) nbw = 2; // small rule book: more, shorter workgroups
-  if (const char *ov = getenv("AABR_CONV_NBW")) { // tuning experiments only
-    int v = atoi(ov);
+  {                                              // tuning experiments only
+    const int v = knob(K_CONV_NBW);
     if ((v == 2 || v == 4) && v <= nbw) nbw = v;
   }
   const int kg = nkc >= 3 ? 4 : nkc;
@@ -2190,8 +2189,8 @@ extern "C" int aabr_conv_forward_bf16(const uint16_t *in_feats, int n_in, int64_
     int64_t cost = rounds * ceil_div(vol, wpb);
     if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best_wpb = wpb; }
   }
-  if (const char *ov = getenv("AABR_CONV_WPB")) { // tuning experiments only
-    int v = atoi(ov);
+  {                                              // tuning experiments only
+    const int v = knob(K_CONV_WPB);
     if (v >= 2 && v <= (nbw == 4 ? 3 : 4)) best_wpb = v;
   }
 #define AABR_LAUNCH_CONV16(NBW, WPB, KG)                                                                 \

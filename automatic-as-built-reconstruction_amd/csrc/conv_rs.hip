@@ -371,19 +371,6 @@ extern "C" int aabr_build_rs(const int32_t *table, int64_t V, int vol, int unit_
   return AABR_OK;
 }
 
-namespace {
-struct RsKnobs { int force; int unit; };
-const RsKnobs &rs_knobs() {          // tuning knobs, read once per process
-  static const RsKnobs k = [] {
-    RsKnobs r{-1, 0};
-    if (const char *v = getenv("AABR_CONV_RS")) r.force = v[0] == '0' ? 0 : (v[0] == '1' ? 1 : -1);
-    if (const char *v = getenv("AABR_RS_UNIT")) r.unit = atoi(v);
-    return r;
-  }();
-  return k;
-}
-} // namespace
-
 // unit size for V_out rows: the number of units is a multiple of the workgroups the chip runs at once (one per
 // CU and slab), so every workgroup gets the same number of units; a unit holds at most 256 rows (16 groups)
 static int rs_unit(int64_t V_out, int slabs, int umax) {
@@ -400,12 +387,12 @@ extern "C" int aabr_conv_rs_unit_rows(int n_in, int n_out, int64_t rows_in, int6
   if ((n_in != 64 && n_in != 128) || n_out <= 0 || (n_out & 63) || vol <= 0 || vol >= kRsHdr) return 0;
   if (rows_in <= 0 || V_out <= 0 || rows_in * n_in * 2 >= (1ll << 31) - 4096) return 0;
   if ((int64_t)vol * n_in * n_out * 2 >= (1ll << 31)) return 0;
-  const RsKnobs &kn = rs_knobs();
-  if (kn.force == 0) return 0;
+  const int force = knob(K_CONV_RS), unit = knob(K_RS_UNIT);
+  if (force != 1) return 0;
   const int ncb = (n_out & 127) == 0 ? 2 : 1;
   const int umax = kRsMaxU;                 // accumulators of 16 groups x 32 columns: 128 registers
   int U = rs_unit(V_out, n_out / (64 * ncb), umax);
-  if (kn.unit >= 16 && kn.unit <= umax && (kn.unit & 15) == 0) U = kn.unit;
+  if (unit >= 16 && unit <= umax && (unit & 15) == 0) U = unit;
   if (rs_words(V_out, vol, U) * 4 >= (1ll << 31)) return 0;
   {
     const int slabs = n_out / (64 * ncb);
@@ -415,7 +402,7 @@ extern "C" int aabr_conv_rs_unit_rows(int n_in, int n_out, int64_t rows_in, int6
   // Measured (profiles/r03_conv_rs_ab.txt): correct, but at 138 us on the dominant 128->128 instance against 107 us
   // for the LDS-tile kernel -- one wave per SIMD and role with a barrier per step serialises gather latency, LDS
   // reads, weight loads and MFMAs instead of overlapping them.  Kept behind AABR_CONV_RS=1 for the A/B and the tests.
-  return kn.force == 1 ? U : 0;
+  return U;
 }
 
 extern "C" int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
@@ -444,11 +431,16 @@ extern "C" int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int
   const int flip = (flags >> 1) & 1;
   const __bf16 *in_b = reinterpret_cast<const __bf16 *>(in_feats), *wp_b = reinterpret_cast<const __bf16 *>(wpack);
   __bf16 *out_b = reinterpret_cast<__bf16 *>(out_feats);
+#ifdef AABR_DEV
+#define AABR_RS_DBG(f) ((f) >> 8)   /* timing experiments (tools/tools_rs_probe.py, `make DEV=1`) */
+#else
+#define AABR_RS_DBG(f) 0
+#endif
 #define AABR_RS_LAUNCH(KC, NCB, NG)                                                                            \
   do {                                                                                                         \
     g_last_variant = "k_conv_rsq<" #KC "," #NCB "," #NG ",bf16>";                                              \
     hipLaunchKernelGGL((k_conv_rsq<KC, NCB, NG>), grid, dim3(512), 0, st, in_b, in_bytes, out_b, n_out, V_out, \
-                       rs_stream, words_bytes, vol, unit_rows, upw, flip, wp_b, wp_bytes, bias, flags >> 8);   \
+                       rs_stream, words_bytes, vol, unit_rows, upw, flip, wp_b, wp_bytes, bias, AABR_RS_DBG(flags));   \
   } while (0)
   if (n_in == 128) { if (ncb == 2) AABR_RS_LAUNCH(4, 2, 16); else AABR_RS_LAUNCH(4, 1, 16); }
   else { if (ncb == 2) AABR_RS_LAUNCH(2, 2, 16); else AABR_RS_LAUNCH(2, 1, 16); }

@@ -130,8 +130,22 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   const int g = lane >> 4, c16 = lane & 15;
   const int pr = wave * 8 + (lane >> 3), seg = lane & 7; // gather role: pair row 0..31, 16-byte segment
   const int nkc = BF ? ci >> 6 : ci >> 5, nnb = co >> 4;   // 128-byte chunks per row
-  const int nb0 = blockIdx.y * kNB;
-  const int64_t tile = blockIdx.x, row0 = tile * kT2;
+  // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own 4 MiB L2.  Give every XCD a
+  // CONTIGUOUS range of (tile, slab) work items instead of every eighth one: the slabs of a tile and the tiles next to
+  // it gather the same input rows (consecutive sites lie on the same surface), so they hit that XCD's L2 instead of
+  // all eight L2s fetching the whole input (round 2: 580 MB of fetches per launch for 91 MB of operands).  Speed
+  // only -- which workgroup computes a tile does not change a bit of it.
+  int64_t tile;
+  int nb0;
+  {
+    const unsigned ny = gridDim.y, total = gridDim.x * ny;
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned per = total >> 3, rem = total & 7u, x = lin & 7u;
+    const unsigned wi = x * per + (x < rem ? x : rem) + (lin >> 3);
+    tile = wi / ny;
+    nb0 = (int)(wi % ny) * kNB;
+  }
+  const int64_t row0 = tile * kT2;
   const int64_t ntiles = (V_out + kT2 - 1) / kT2;
   const int maxb = (kT2 / 16) * vol;
   const int vpre = lane <= vol ? words[tile * (vol + 1) + lane] : 0;
@@ -428,16 +442,17 @@ extern "C" int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, in
       for (int t = 64; t < 128; t += 16)
         if (((V_out + t - 1) / t) * slabs <= 512) { T = t; break; }
   }
-  if (const char *ov = getenv("AABR_WIDE_ROWS")) { // tuning experiments only
-    const int v = atoi(ov);
+  {                                                // tuning experiments only
+    const int v = knob(K_WIDE_ROWS);
     if (v >= 16 && v <= kMaxTileRows && (v & 15) == 0) T = v;
   }
   if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
   if ((int64_t)vol * n_in * n_out * 4 >= (1ll << 31)) return 0;
   if (n_in > 128 && (n_in & 127)) return 0; // channel groups of 128: every load of the inner loop unconditional
-  if (const char *ov = getenv("AABR_CONV_WIDE")) { // tuning experiments only: 0 = never, 1 = whenever supported
-    if (ov[0] == '0') return 0;
-    if (ov[0] == '1') return T;
+  {                                                // tuning experiments / tests only: 0 = never, 1 = whenever supported
+    const int v = knob(K_CONV_WIDE);
+    if (v == 0) return 0;
+    if (v == 1) return T;
   }
   // enough workgroups to fill the chip twice over (measured, profiles/r02_conv_wide_ab.txt: wins from ~340
   // workgroups up, loses below ~180)
@@ -484,9 +499,9 @@ extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64
   // single buffer three (49 KiB each) at the price of a second barrier per pair: measured +4...+10 % (128->128 at 84k
   // rows 380 -> 367 us, 256->256 1366 -> 1272 us); narrower groups fit three workgroups with the double buffer
   int nbuf = kg == 4 ? 1 : 2;
-  if (const char *ov = getenv("AABR_WIDE_NBUF")) { // tuning experiments only
-    if (ov[0] == '1') nbuf = 1;
-    if (ov[0] == '2') nbuf = 2;
+  {                                                // tuning experiments only
+    const int v = knob(K_WIDE_NBUF);
+    if (v == 1 || v == 2) nbuf = v;
   }
 #define AABR_LAUNCH_WIDE(KERNEL, NAME, LDS, ...)                                                          \
   do {                                                                                                    \
@@ -496,11 +511,6 @@ extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64
       attr = true;                                                                                        \
     }                                                                                                     \
     g_last_variant = NAME;                                                                                \
-    if (getenv("AABR_WIDE_OCC")) { /* tuning experiments only */                                          \
-      int nb_ = 0;                                                                                        \
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (const void *)KERNEL, 256, (LDS));               \
-      fprintf(stderr, "%s: %d workgroups per CU at %zu B LDS\n", NAME, nb_, (size_t)(LDS));               \
-    }                                                                                                     \
     hipLaunchKernelGGL(KERNEL, grid, dim3(256), (LDS), st, __VA_ARGS__);                                  \
   } while (0)
   {
@@ -512,12 +522,17 @@ extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64
   do {                                                                                                    \
     if (nbuf == 1) AABR_WIDE_CS_N(KG, D, 1); else AABR_WIDE_CS_N(KG, D, 2);                               \
   } while (0)
-    if (dbg & 7) { // timing experiments (tools/): only the 128-channel-group instance carries the debug variants
+#ifdef AABR_DEV
+    if (dbg & 7) { // timing experiments (tools/, `make DEV=1`): only the 128-channel-group instance carries the debug variants
       AABR_CHECK_ARG(kg == 4, "debug variants exist for n_in >= 128 only");
       nbuf = 2;
       if (dbg & 4) AABR_WIDE_CS(4, 4);
       else if ((dbg & 3) == 1) AABR_WIDE_CS(4, 1); else if ((dbg & 3) == 2) AABR_WIDE_CS(4, 2); else AABR_WIDE_CS(4, 3);
-    } else {
+    } else
+#else
+    AABR_CHECK_ARG(!(dbg & 7), "the timing-experiment variants of k_conv_cs exist in a `make DEV=1` build only");
+#endif
+    {
       if (kg == 1) AABR_WIDE_CS(1, 0); else if (kg == 2) AABR_WIDE_CS(2, 0); else if (kg == 3) AABR_WIDE_CS(3, 0);
       else AABR_WIDE_CS(4, 0);
     }
@@ -545,15 +560,16 @@ extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_i
       for (int t = 64; t < 96; t += 16)
         if (((V_out + t - 1) / t) * slabs <= 512) { T = t; break; }
   }
-  if (const char *ov = getenv("AABR_WIDE_ROWS")) { // tuning experiments only
-    const int v = atoi(ov);
+  {                                                // tuning experiments only
+    const int v = knob(K_WIDE_ROWS);
     if (v >= 16 && v <= kMaxTileRows && (v & 15) == 0) T = v;
   }
   if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
   if ((int64_t)vol * n_in * n_out * 2 >= (1ll << 31)) return 0;
-  if (const char *ov = getenv("AABR_CONV_WIDE_BF16")) { // tuning experiments only: 0 = never, 1 = whenever supported
-    if (ov[0] == '0') return 0;
-    if (ov[0] == '1') return T;
+  {                                                // tuning experiments / tests only: 0 = never, 1 = whenever supported
+    const int v = knob(K_CONV_WIDE_BF16);
+    if (v == 0) return 0;
+    if (v == 1) return T;
   }
   return (((V_out + T - 1) / T) * (n_out / 64) >= 320) ? T : 0;
 }
@@ -580,9 +596,9 @@ extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, i
   const int flip = (flags >> 1) & 1;
   const int kg = nkc >= 4 ? 4 : nkc;
   int nbuf = 1;
-  if (const char *ov = getenv("AABR_WIDE_NBUF")) { // tuning experiments only
-    if (ov[0] == '1') nbuf = 1;
-    if (ov[0] == '2') nbuf = 2;
+  {                                                // tuning experiments only
+    const int v = knob(K_WIDE_NBUF);
+    if (v == 1 || v == 2) nbuf = v;
   }
   const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
   float *out_f = reinterpret_cast<float *>(out_feats);

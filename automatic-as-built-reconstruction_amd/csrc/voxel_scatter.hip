@@ -439,7 +439,7 @@ extern "C" int aabr_input_layer_forward(const float *in_feats, float *out_feats,
   AABR_CHECK_ARG(V >= 0 && planes > 0 && mode >= 1 && mode <= 4, "bad V/planes/mode");
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(in_feats && out_feats && first_pt && cnt_extra && head && nxt && meta, "null pointer");
-  static const int mean_knob = [] { const char *v = getenv("AABR_VOXEL_MEAN"); return v ? atoi(v) : 0; }();
+  const int mean_knob = knob(K_VOXEL_MEAN);
   // one thread per (site, plane): consecutive lanes read consecutive floats of consecutive first points -- 73 us
   // instead of 100 us at 1.5 M points for the one-thread-per-site form (AABR_VOXEL_MEAN=2 selects that one)
   if (planes <= 16 && mean_knob == 2)

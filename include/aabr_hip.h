@@ -33,6 +33,12 @@ extern "C" {
 
 const char *aabr_last_error(void);
 int aabr_version(void);
+/* Tuning knobs for experiments and tests (no counterpart in the reference; the defaults are what ships): CONV_WIDE,
+ * CONV_WIDE_BF16, CONV_RS (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, RS_UNIT, CONV_WLDS,
+ * CONV_SMALL, CONV_NBW, CONV_WPB, VOXEL_MEAN.  A knob takes its value from the environment variable AABR_<NAME>,
+ * read ONCE at its first use in the process; aabr_set_knob overrides it (unset != 0: back to "no value").  No entry
+ * point reads the environment on its launch path.                                                              */
+int aabr_set_knob(const char *name, int value, int unset);
 /* number of int32 words of the `meta` block written by the geometry builders */
 #define AABR_META_WORDS 8
 /* meta[0] = number of active sites, meta[1] = max points per site (input layer only),

@@ -217,8 +217,13 @@ def test_rs_units_without_rules_and_dispatch():
     np.testing.assert_allclose(got, ref, rtol=2 ** -7, atol=2 ** -7 * np.abs(ref).max())
     np.testing.assert_array_equal(out[32:64].float().cpu().numpy(),
                                   np.tile(b.bfloat16().float().cpu().numpy(), (32, 1)))
-    # dispatch: off unless AABR_CONV_RS=1 was set before the library was first used (the LDS-tile kernel is faster:
-    # profiles/r03_conv_rs_ab.txt); unsupported shapes say 0 either way
-    assert lib.aabr_conv_rs_unit_rows(128, 128, 84077, 84077, 27) in [0] + list(range(16, 257, 16))
-    assert lib.aabr_conv_rs_unit_rows(32, 64, 300000, 300000, 27) == 0
-    assert lib.aabr_conv_rs_unit_rows(128, 96, 300000, 300000, 27) == 0
+    # dispatch: off unless the CONV_RS knob says 1 (the LDS-tile kernel is faster: profiles/r03_conv_rs_ab.txt);
+    # unsupported shapes say 0 either way
+    assert lib.aabr_conv_rs_unit_rows(128, 128, 84077, 84077, 27) == 0
+    _hip.set_knob("CONV_RS", 1)
+    try:
+        assert lib.aabr_conv_rs_unit_rows(128, 128, 84077, 84077, 27) in range(16, 257, 16)
+        assert lib.aabr_conv_rs_unit_rows(32, 64, 300000, 300000, 27) == 0
+        assert lib.aabr_conv_rs_unit_rows(128, 96, 300000, 300000, 27) == 0
+    finally:
+        _hip.set_knob("CONV_RS", None)

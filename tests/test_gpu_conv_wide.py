@@ -1,6 +1,6 @@
 """The wide-layer convolution kernel (csrc/conv_wide.hip, k_conv_cs) against the oracle.  The library's own
-dispatch only picks it for launches of >= 320 workgroups; here AABR_CONV_WIDE=1 (a tuning knob the library reads
-on every call) forces it for every supported shape, so tile edges, single-tile rule books, odd pair counts, bias,
+dispatch only picks it for launches of >= 320 workgroups; here the library's CONV_WIDE knob (aabr_set_knob; the
+environment is read once per process, never on a launch path) forces it for every supported shape, so tile edges, single-tile rule books, odd pair counts, bias,
 strided / transposed tables and several channel groups are all exercised at sizes the oracle finishes in seconds.
 One case runs at a size where the default dispatch takes the wide path by itself."""
 import os
@@ -26,13 +26,10 @@ def _t(a):
 
 @pytest.fixture
 def force_wide():
-    old = os.environ.get("AABR_CONV_WIDE")
-    os.environ["AABR_CONV_WIDE"] = "1"
+    import _hip
+    _hip.set_knob("CONV_WIDE", 1)
     yield
-    if old is None:
-        del os.environ["AABR_CONV_WIDE"]
-    else:
-        os.environ["AABR_CONV_WIDE"] = old
+    _hip.set_knob("CONV_WIDE", None)
 
 
 def _scene(rng, n, size, batch, C):
@@ -118,7 +115,6 @@ def test_default_dispatch_takes_the_wide_kernel_on_a_large_layer():
     """no env knob: 60k sites x 128 output planes = 940 workgroups -> the library picks k_conv_cs by itself"""
     scn = _scn()
     import synth_scenes as S
-    assert "AABR_CONV_WIDE" not in os.environ
     locs, feats = S.make_batch(1, 80000, 3, 20)
     rng = np.random.default_rng(1)
     feats = rng.standard_normal((locs.shape[0], 64)).astype(np.float32)
@@ -154,11 +150,11 @@ def test_wide_bf16_storage_matches_oracle_on_rounded_operands(nIn, nOut, npts, v
     il = O.input_layer(coords, np.zeros((npts, 1), np.float32), 4)
     rb = O.submanifold_rules(il["coords"], fsz)
     T = lib.aabr_conv_wide_tile_rows_bf16(nIn, nOut, V, V, vol) or 128
-    os.environ["AABR_CONV_WIDE_BF16"] = "1"
+    _hip.set_knob("CONV_WIDE_BF16", 1)
     try:
         T = lib.aabr_conv_wide_tile_rows_bf16(nIn, nOut, V, V, vol)
     finally:
-        del os.environ["AABR_CONV_WIDE_BF16"]
+        _hip.set_knob("CONV_WIDE_BF16", None)
     assert T in (64, 80, 96, 112, 128)
     W = (rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32)
     Wd = _t(W)
@@ -181,11 +177,11 @@ def test_wide_bf16_storage_matches_oracle_on_rounded_operands(nIn, nOut, npts, v
     g = torch.as_tensor(rng.standard_normal((V, nOut)).astype(np.float32)).to(DEV).bfloat16()
     d_in = torch.empty((V, nIn), dtype=torch.bfloat16, device=DEV)
     Tb = T
-    os.environ["AABR_CONV_WIDE_BF16"] = "1"
+    _hip.set_knob("CONV_WIDE_BF16", 1)
     try:
         Tb = lib.aabr_conv_wide_tile_rows_bf16(nOut, nIn, V, V, vol)
     finally:
-        del os.environ["AABR_CONV_WIDE_BF16"]
+        _hip.set_knob("CONV_WIDE_BF16", None)
     if Tb:
         check(lib.aabr_conv_forward_wide_bf16(ptr(g), nOut, V, ptr(d_in), nIn, V, ptr(ga.blocks_wide(Tb)), Tb, vol,
                                               None, 1 | 2, ptr(pt), stream()))
