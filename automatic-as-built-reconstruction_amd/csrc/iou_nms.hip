@@ -442,6 +442,97 @@ struct RpnGatherParams {
   int n_maps, nb;
 };
 
+// RPN label generation, fused (reference: RPNLossComputation.match_targets_to_anchors, modeling/rpn/loss_3d.py:91-96:
+// `boxlist_iou_3d(target, anchor, aug_thickness, criterion, flag='rpn_label_generation')` over the anchors of ALL maps
+// of an example, then Matcher.__call__'s core, modeling/matcher.py:57-100: best ground truth per anchor and the two
+// thresholds).  One thread per anchor of one example: the anchor is generated from its site (anchor_generator_sparse3d
+// .py:88-104) through the same segment table as k_rpn_decode_maps, the example's ground-truth boxes sit in LDS with the
+// target-side thickness clamps applied (rotate_nms_3d_torch.py:59-66), every pair goes through the same
+// iou_eval_entry as aabr_boxes_iou_3d.  The [G, N] matrix is written only when the caller asks for it.
+struct RpnLabelParams {
+  const int32_t *coords[kMaxRpnMaps];
+  const float *targets[kMaxRpnBatch];               // [G_b, 7] yx_zb
+  int32_t n_targets[kMaxRpnBatch];
+  int32_t seg_begin[kMaxRpnBatch][kMaxRpnMaps + 1]; // in anchors, per example
+  int32_t site_begin[kMaxRpnBatch][kMaxRpnMaps];
+  int64_t out_begin[kMaxRpnBatch];                  // first anchor of example b in the concatenated outputs
+  int64_t iou_begin[kMaxRpnBatch];                  // first float of example b's [G_b, N_b] matrix
+  float stride[kMaxRpnMaps][3];
+  float aug[4];                                     // target_Y, target_Z, anchor_Y, anchor_Z
+  int n_maps, A, criterion, only_xy;
+  float voxel_scale, fg, bg;
+};
+constexpr int kLabelTgtChunk = 128;
+
+__global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const float *__restrict__ base_anchors,
+                                                        int64_t *__restrict__ matched_idx,
+                                                        float *__restrict__ matched_val, float *__restrict__ iou_out) {
+  __shared__ float s_t5[kLabelTgtChunk][5];
+  __shared__ float s_tz[kLabelTgtChunk][2];
+  const int b = blockIdx.y;
+  const int64_t N = p.seg_begin[b][p.n_maps];
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int G = p.n_targets[b];
+  float a5[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, az0 = 0.f, az1 = 0.f;
+  if (t < N) {
+    int m = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxRpnMaps; ++q)
+      if (q < p.n_maps && t >= p.seg_begin[b][q]) m = q;
+    const int32_t r = (int32_t)(t - p.seg_begin[b][m]);
+    const int64_t site = (int64_t)p.site_begin[b][m] + r / p.A;
+    const int a = r % p.A;
+    const int32_t *sc = p.coords[m] + 4 * site;
+    const float *ba = base_anchors + 7 * ((int64_t)m * p.A + a);
+    float an[7];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) an[d] = (float)sc[d] / p.voxel_scale * p.stride[m][d] + ba[d];
+#pragma unroll
+    for (int d = 3; d < 7; ++d) an[d] = 0.0f + ba[d];
+    const float th = an[3] < p.aug[2] ? p.aug[2] : an[3];
+    const float h = an[5] < p.aug[3] ? p.aug[3] : an[5];
+    a5[0] = an[0]; a5[1] = an[1]; a5[2] = th; a5[3] = an[4]; a5[4] = an[6];
+    az0 = an[2]; az1 = an[2] + h;
+  }
+  float best = -__builtin_inff();
+  int best_g = 0;
+  for (int g0 = 0; g0 < G; g0 += kLabelTgtChunk) {
+    const int gn = G - g0 < kLabelTgtChunk ? G - g0 : kLabelTgtChunk;
+    __syncthreads();
+    if ((int)threadIdx.x < gn) {
+      const float *tb = p.targets[b] + 7 * (int64_t)(g0 + threadIdx.x);
+      const float th = tb[3] < p.aug[0] ? p.aug[0] : tb[3];
+      const float h = tb[5] < p.aug[1] ? p.aug[1] : tb[5];
+      s_t5[threadIdx.x][0] = tb[0]; s_t5[threadIdx.x][1] = tb[1]; s_t5[threadIdx.x][2] = th;
+      s_t5[threadIdx.x][3] = tb[4]; s_t5[threadIdx.x][4] = tb[6];
+      s_tz[threadIdx.x][0] = tb[2]; s_tz[threadIdx.x][1] = tb[2] + h;
+    }
+    __syncthreads();
+    if (t < N) {
+      for (int g = 0; g < gn; ++g) {
+        float t5[5];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) t5[d] = s_t5[g][d];
+        float v = iou_eval_entry(t5, a5, p.criterion);
+        if (!p.only_xy) {
+          const float t0 = s_tz[g][0], t1 = s_tz[g][1];
+          const float overlap = fminf(az1, t1) - fmaxf(az0, t0);
+          const float common = fmaxf(az1, t1) - fminf(az0, t0);
+          v = v * (overlap / common);
+        }
+        if (iou_out) iou_out[p.iou_begin[b] + (int64_t)(g0 + g) * N + t] = v;
+        if (v > best) { best = v; best_g = g0 + g; }   // first maximum, like torch.max(dim=0)
+      }
+    }
+  }
+  if (t < N) {
+    const int64_t o = p.out_begin[b] + t;
+    if (G == 0) { matched_idx[o] = -1; matched_val[o] = 0.f; return; }
+    matched_val[o] = best;
+    matched_idx[o] = best < p.bg ? -1 : (best < p.fg ? -2 : best_g);   // BELOW_LOW_THRESHOLD / BETWEEN_THRESHOLDS
+  }
+}
+
 __global__ __launch_bounds__(256) void k_rpn_gather_logits(RpnGatherParams p, int64_t lmax, float *__restrict__ out) {
   const int b = blockIdx.y;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -501,5 +592,55 @@ extern "C" int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_pt
                                 mask + (int64_t)b * k * cb, keep + (int64_t)b * k, meta + b * AABR_META_WORDS, stream_);
     if (rc != AABR_OK) return rc;
   }
+  return AABR_OK;
+}
+
+extern "C" int aabr_rpn_label_generation(int n_maps, const void *const *coords_ptrs, int nb,
+                                         const int32_t *seg_begin_host, const int32_t *site_begin_host,
+                                         const float *strides_host, const float *base_anchors, int num_anchors,
+                                         float voxel_scale, const void *const *target_ptrs,
+                                         const int32_t *n_targets_host, const float *aug_host, int criterion,
+                                         int only_xy, float fg_iou, float bg_iou, int64_t *matched_idx,
+                                         float *matched_val, float *iou_out, void *stream_) {
+  AABR_CHECK_ARG(n_maps >= 1 && n_maps <= kMaxRpnMaps && nb >= 0 && nb <= kMaxRpnBatch && num_anchors > 0 &&
+                     voxel_scale > 0, "bad arguments (<= 8 maps, <= 16 examples)");
+  AABR_CHECK_ARG(coords_ptrs && seg_begin_host && site_begin_host && strides_host && target_ptrs && n_targets_host &&
+                     aug_host, "null host table");
+  if (nb == 0) return AABR_OK;
+  RpnLabelParams p;
+  for (int m = 0; m < kMaxRpnMaps; ++m) {
+    p.coords[m] = m < n_maps ? (const int32_t *)coords_ptrs[m] : nullptr;
+    for (int d = 0; d < 3; ++d) p.stride[m][d] = m < n_maps ? strides_host[3 * m + d] : 0.f;
+  }
+  int64_t out = 0, mat = 0, nmax = 0;
+  for (int b = 0; b < kMaxRpnBatch; ++b) {
+    const bool on = b < nb;
+    for (int m = 0; m <= kMaxRpnMaps; ++m)
+      p.seg_begin[b][m] = on ? seg_begin_host[b * (n_maps + 1) + (m <= n_maps ? m : n_maps)] : 0;
+    for (int m = 0; m < kMaxRpnMaps; ++m) p.site_begin[b][m] = on && m < n_maps ? site_begin_host[b * n_maps + m] : 0;
+    p.targets[b] = on ? (const float *)target_ptrs[b] : nullptr;
+    p.n_targets[b] = on ? n_targets_host[b] : 0;
+    p.out_begin[b] = out;
+    p.iou_begin[b] = mat;
+    if (on) {
+      AABR_CHECK_ARG(p.n_targets[b] >= 0 && (p.n_targets[b] == 0 || p.targets[b]), "null target list");
+      for (int m = 0; m < n_maps; ++m) {
+        AABR_CHECK_ARG(p.seg_begin[b][m + 1] >= p.seg_begin[b][m], "segment table must be non-decreasing");
+        AABR_CHECK_ARG(p.seg_begin[b][m + 1] == p.seg_begin[b][m] || p.coords[m], "null map pointer");
+      }
+      const int64_t n = p.seg_begin[b][n_maps];
+      out += n;
+      mat += n * p.n_targets[b];
+      if (n > nmax) nmax = n;
+    }
+  }
+  if (nmax == 0) return AABR_OK;
+  AABR_CHECK_ARG(base_anchors && matched_idx && matched_val, "null pointer");
+  for (int d = 0; d < 4; ++d) p.aug[d] = aug_host[d];
+  p.n_maps = n_maps; p.A = num_anchors; p.criterion = criterion; p.only_xy = only_xy;
+  p.voxel_scale = voxel_scale; p.fg = fg_iou; p.bg = bg_iou;
+  hipLaunchKernelGGL(k_rpn_label_maps, dim3((unsigned)ceil_div(nmax, 256), (unsigned)nb), dim3(256), 0,
+                     (hipStream_t)stream_, p, base_anchors, matched_idx, matched_val, iou_out);
+  AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

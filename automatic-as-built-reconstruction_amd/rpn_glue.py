@@ -190,51 +190,68 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
 
 
 def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thickness, criterion=6,
-                      fg_iou=0.55, bg_iou=0.2, batch_size=None):
-    """The label-generation half of the RPN's training step on the device: per example the IoU matrix of its
-    ground-truth boxes against the anchors of ALL maps, `boxlist_iou_3d(target, anchor, aug_thickness, criterion,
+                      fg_iou=0.55, bg_iou=0.2, batch_size=None, return_matrix=False):
+    """The label-generation half of the RPN's training step on the device: per example the IoU of its ground-truth
+    boxes against the anchors of ALL maps, `boxlist_iou_3d(target, anchor, aug_thickness, criterion,
     flag='rpn_label_generation')` (RPNLossComputation.match_targets_to_anchors, modeling/rpn/loss_3d.py:91-96;
     criterion = cfg.MODEL.IOU_CRITERIA = 6, config/defaults.py:44), followed by the core of `Matcher.__call__`
     (modeling/matcher.py:57-100): best ground truth per anchor, BELOW_LOW_THRESHOLD (-1) / BETWEEN_THRESHOLDS (-2)
     by the two IoU thresholds (defaults.py:147,151).  The matcher's yaw / centre-distance refinements, the
     sampler and the losses are plain torch in the reference and are not part of this path.
 
-    maps / base_anchors / strides as in `rpn_proposals`; targets[b] = [G_b, 7] yx_zb boxes of example b.
-    Anchors are materialised per map for the whole batch (AnchorGenerator.grid_anchors,
-    anchor_generator_sparse3d.py:88-104) and regrouped example-major like `cat_scales_anchor`; the per-example
-    row ranges come from the grids' per-sample offsets (no host read).  Returns a list over examples of
-    (matched_idxs int64 [N_b], matched_vals fp32 [N_b], iou [G_b, N_b])."""
-    from utils3d.rotate_nms_3d_torch import boxes_iou_3d
+    maps / base_anchors / strides as in `rpn_proposals`; targets[b] = [G_b, 7] yx_zb boxes of example b (device).
+    ONE library call for the whole batch (`aabr_rpn_label_generation`): anchors are generated inside the kernel from
+    the maps' site lists (AnchorGenerator.grid_anchors, anchor_generator_sparse3d.py:88-104, example-major like
+    `cat_scales_anchor`), the per-example row ranges come from the grids' per-sample offsets (no host read), the
+    [G_b, N_b] matrices are written only with `return_matrix`.
+    Returns a list over examples of (matched_idxs int64 [N_b], matched_vals fp32 [N_b], iou [G_b, N_b] or None)."""
+    from utils3d import rotate_nms_3d_torch as R
+    lib = _hip.load()
     n_maps = len(maps)
     grids = [t.metadata.grids[tuple(int(v) for v in t.spatial_size.tolist())] for t in maps]
     dev = grids[0].coords.device
     A = int(base_anchors[0].shape[0])
     ba = _device_anchors(base_anchors, A, dev)
     nb = int(batch_size) if batch_size is not None else len(targets)
+    assert aug_thickness["anchor_Y"] == 0 and aug_thickness["target_Y"] >= 0.3     # rotate_nms_3d_torch.py:34-36
     counts = [g.sample_counts(nb) for g in grids]
     if any(c is None for c in counts):
         counts = torch.stack([torch.bincount(g.coords[:, 3].long(), minlength=nb)[:nb] if g.V else
                               torch.zeros(nb, dtype=torch.int64, device=dev) for g in grids]).tolist()
-    anchors = []
-    for m, g in enumerate(grids):     # [V_m * A, 7], flatten order [site, yaw]
-        c = torch.zeros((g.V, 1, 7), dtype=torch.float32, device=dev)
-        c[:, 0, 0:3] = g.coords[:, 0:3].to(torch.float32) / float(voxel_scale) * _stride_t(strides[m], dev)
-        anchors.append((c + ba[m * A:(m + 1) * A].view(1, A, 7)).reshape(-1, 7))
-    out, site0 = [], [0] * n_maps
-    for bi in range(nb):
-        an = torch.cat([anchors[m][site0[m] * A:(site0[m] + counts[m][bi]) * A] for m in range(n_maps)], 0)
-        for m in range(n_maps):
-            site0[m] += counts[m][bi]
-        tg = targets[bi]
-        if tg.shape[0] == 0 or an.shape[0] == 0:
-            out.append((torch.full((an.shape[0],), -1, dtype=torch.int64, device=dev),
-                        torch.zeros(an.shape[0], device=dev), torch.zeros((tg.shape[0], an.shape[0]), device=dev)))
-            continue
-        iou = boxes_iou_3d(tg, an, aug_thickness, criterion, flag="rpn_label_generation")
-        vals, idx = iou.max(dim=0)
-        idx = torch.where(vals < bg_iou, torch.full_like(idx, -1),
-                          torch.where(vals < fg_iou, torch.full_like(idx, -2), idx))
-        out.append((idx, vals, iou))
+    out = []
+    for b0 in range(0, nb, 16):            # the library takes up to 16 examples per call
+        b1 = min(nb, b0 + 16)
+        seg, site, site0 = [], [], [sum(counts[m][:b0]) for m in range(n_maps)]
+        n_anch, tg = [], []
+        for bi in range(b0, b1):
+            s_ = [0]
+            for m in range(n_maps):
+                s_.append(s_[-1] + counts[m][bi] * A)
+            seg += s_
+            site += list(site0)
+            for m in range(n_maps):
+                site0[m] += counts[m][bi]
+            n_anch.append(s_[-1])
+            t = targets[bi].to(device=dev, dtype=torch.float32).contiguous()
+            tg.append(t)
+        total = sum(n_anch)
+        midx = torch.empty(total, dtype=torch.int64, device=dev)
+        mval = torch.empty(total, dtype=torch.float32, device=dev)
+        mat = torch.empty(sum(n * int(t.shape[0]) for n, t in zip(n_anch, tg)), dtype=torch.float32,
+                          device=dev) if return_matrix else None
+        aug = (aug_thickness["target_Y"], aug_thickness["target_Z"], aug_thickness["anchor_Y"],
+               aug_thickness["anchor_Z"])
+        check(lib.aabr_rpn_label_generation(
+            n_maps, _hip.ptrs([g.coords for g in grids]), b1 - b0, _hip.i32xn(seg), _hip.i32xn(site),
+            _hip.f32xn([v for st in strides for v in st]), ptr(ba), A, float(voxel_scale), _hip.ptrs(tg),
+            _hip.i32xn([int(t.shape[0]) for t in tg]), _hip.f32x4(aug), int(criterion), int(bool(R.DEBUG)),
+            float(fg_iou), float(bg_iou), ptr(midx), ptr(mval), ptr(mat), stream()))
+        o = mo = 0
+        for n, t in zip(n_anch, tg):
+            G = int(t.shape[0])
+            out.append((midx[o:o + n], mval[o:o + n], mat[mo:mo + G * n].view(G, n) if return_matrix else None))
+            o += n
+            mo += G * n
     return out
 
 

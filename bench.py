@@ -765,10 +765,10 @@ def main():
                 pairs = float(sum(n_anch)) * N_GT
                 line["label_generation"] = dict(label_iou_us=round(t_lab * 1e6, 1), pairs=int(pairs),
                                                 pairs_per_s=round(pairs / t_lab, 1),
-                                                note="4 scenes: anchors of six maps materialised + %d x anchors "
-                                                     "criterion-6 IoU matrix + best match per anchor, timed alone "
-                                                     "(HIP events); inside the timed step it runs on the side "
-                                                     "stream beside the RPN head" % N_GT)
+                                                note="4 scenes in one library call: anchors of six maps generated in the "
+                                                     "kernel, %d x anchors criterion-6 IoUs + best match and threshold "
+                                                     "labels per anchor, timed alone (HIP events); inside the timed "
+                                                     "step it runs on the side stream beside the RPN head" % N_GT)
             if world == 1:
                 extras = {}
                 try:

@@ -417,6 +417,22 @@ int aabr_rotate_iou_eval(const float *boxes, int64_t N, const float *query, int6
 int aabr_boxes_iou_3d(const float *targets, int64_t M, const float *anchors, int64_t K,
                       const float *aug_host, int criterion, int only_xy, float *iou,
                       void *stream);
+/* RPN label generation, fused and batched over the examples of a step.  Per example b and per
+ * anchor of its concatenated list [map][site][yaw] (maps / segment tables as in aabr_rpn_decode_maps, one row of
+ * seg_begin_host [nb][n_maps+1] and site_begin_host [nb][n_maps] per example): the IoU with every ground-truth box of
+ * the example -- boxlist_iou_3d(target, anchor, aug_thickness, criterion, flag='rpn_label_generation'),
+ * modeling/rpn/loss_3d.py:91-96, i.e. aabr_boxes_iou_3d on the anchors of anchor_generator_sparse3d.py:88-104 --
+ * and the core of Matcher.__call__ (modeling/matcher.py:57-100): matched_val = best IoU, matched_idx = its
+ * ground-truth index, or -1 below bg_iou / -2 below fg_iou (all -1 for an example without ground truth).
+ * Outputs are concatenated over the examples in order (sum_b N_b entries); iou_out (optional, may be NULL) receives
+ * the [G_b, N_b] matrices back to back.  target_ptrs[b] = device [G_b, 7] yx_zb boxes; aug_host[4] = {target_Y,
+ * target_Z, anchor_Y, anchor_Z}.                                                                              */
+int aabr_rpn_label_generation(int n_maps, const void *const *coords_ptrs, int nb, const int32_t *seg_begin_host,
+                              const int32_t *site_begin_host, const float *strides_host, const float *base_anchors,
+                              int num_anchors, float voxel_scale, const void *const *target_ptrs,
+                              const int32_t *n_targets_host, const float *aug_host, int criterion, int only_xy,
+                              float fg_iou, float bg_iou, int64_t *matched_idx, float *matched_val, float *iou_out,
+                              void *stream);
 /* RPN glue: anchors of the selected flat indices t = site*A + yaw, generated from
  * the sparse site coordinates (modeling/rpn/anchor_generator_sparse3d.py:88-104:
  * centroid = loc / voxel_scale * stride, + base anchor), fused with BoxCoder3D.decode_centroid_box

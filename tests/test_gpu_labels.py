@@ -79,7 +79,9 @@ def test_rpn_label_matches_vs_oracle_composition():
     base = [torch.tensor([[0.0, 0.0, 0.0] + list(s) + [y] for y in yaws], dtype=torch.float32) for s in sizes]
     strides = [[2.0 ** s] * 3 for s in (5, 6, 7)] + [[2.0 ** s] * 3 for s in (4, 5, 6)]
     targets = [S.make_gt_boxes(25, 8), S.make_gt_boxes(1, 9)]
-    res = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, [_t(t) for t in targets], LABEL_AUG, 6)
+    res = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, [_t(t) for t in targets], LABEL_AUG, 6,
+                                     return_matrix=True)
+    lean = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, [_t(t) for t in targets], LABEL_AUG, 6)
     assert len(res) == 2
     coords = [m.get_spatial_locations().numpy() for m in rpn]
     for b in range(2):
@@ -87,6 +89,7 @@ def test_rpn_label_matches_vs_oracle_composition():
                              for m, c in enumerate(coords)], 0).astype(np.float32)
         want = O.boxes_iou_3d(targets[b], an, (0.4, 0.8, 0.0, 0.0), 6, True)
         idx, vals, iou = [t.cpu().numpy() for t in res[b]]
+        assert lean[b][2] is None and torch.equal(lean[b][0], res[b][0]) and torch.equal(lean[b][1], res[b][1])
         assert iou.shape == want.shape and an.shape[0] > 1000
         np.testing.assert_allclose(iou, want, atol=2e-5)
         np.testing.assert_allclose(vals, want.max(0), atol=2e-5)
@@ -100,7 +103,7 @@ def test_rpn_label_matches_vs_oracle_composition():
     # an example without ground truth: every anchor is background (loss_3d.py:91-93)
     res0 = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, [_t(targets[0]), torch.zeros((0, 7), device=DEV)],
                                       LABEL_AUG, 6)
-    assert (res0[1][0] == -1).all() and res0[1][2].shape[0] == 0
+    assert (res0[1][0] == -1).all() and res0[1][2] is None and res0[1][0].numel() > 1000
 
 
 def test_boxlist_nms_3d_roi_post():
