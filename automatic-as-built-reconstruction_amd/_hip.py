@@ -59,6 +59,7 @@ _SIGS = {
     "aabr_conv_pack_weights2": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "aabr_conv_pack_weights2_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "aabr_plan_run": (C.c_int, [_vp, _i32, _vp]),
+    "aabr_geom_run": (C.c_int, [_vp, _i32, _vp]),
     "aabr_add": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "aabr_cast_storage": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "aabr_sum_counts": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),

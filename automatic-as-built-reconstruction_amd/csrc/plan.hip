@@ -251,3 +251,54 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
   }
   return AABR_OK;
 }
+
+// ---- geometry plan: the rule-book builders of a pass as one list ------------------------------------------------
+// The geometry pre-pass of a network (sparseconvnet/fpn_net.py: every rule table, block stream and offset-pair list
+// of a pass, ~250 launches) went out one ctypes call at a time: 2.8 ms of interpreter time per step.  A record names
+// one of the builders declared in include/aabr_hip.h and carries its arguments; nothing is computed differently.
+static_assert(sizeof(AabrGeomOp) == 144, "AabrGeomOp layout is part of the C ABI");
+
+extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
+  AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
+  for (int j = 0; j < n_ops; ++j) {
+    const AabrGeomOp &o = ops[j];
+    void *const *p = o.p;
+    int rc = AABR_OK;
+    switch (o.kind) {
+    case AABR_GEOM_SUBM_TABLE:
+      rc = aabr_submanifold_table((const int32_t *)p[0], o.i64[0], (const uint64_t *)p[1], nullptr, o.i64[1], &o.i32[0],
+                                  (int32_t *)p[2], (int32_t *)p[3], st);
+      break;
+    case AABR_GEOM_CONV_TABLES:
+      rc = aabr_convolution_tables2((const int32_t *)p[0], o.i64[0], (const uint64_t *)p[1], nullptr, o.i64[1],
+                                    (const int32_t *)p[2], o.i64[2], (const uint64_t *)p[3], nullptr, o.i64[3],
+                                    &o.i32[0], &o.i32[3], &o.i32[6], (int32_t *)p[4], (int32_t *)p[5], (int32_t *)p[6],
+                                    (int32_t *)p[7], st);
+      break;
+    case AABR_GEOM_TILE_BLOCKS:
+      rc = aabr_build_tile_blocks((const int32_t *)p[0], o.i64[0], o.i32[0], (int32_t *)p[1], st);
+      break;
+    case AABR_GEOM_WIDE_BLOCKS:
+      rc = aabr_build_wide_blocks((const int32_t *)p[0], o.i64[0], o.i32[0], o.i32[1], (int32_t *)p[1], st);
+      break;
+    case AABR_GEOM_OFFSET_PAIRS:
+      rc = aabr_build_offset_pairs((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st);
+      break;
+    case AABR_GEOM_RS:
+      rc = aabr_build_rs((const int32_t *)p[0], o.i64[0], o.i32[0], o.i32[1], (int32_t *)p[1], st);
+      break;
+    case AABR_GEOM_CONV_SITES:
+      rc = aabr_convolution_sites((const int32_t *)p[0], o.i64[0], &o.i32[0], &o.i32[3], &o.i32[6], (uint64_t *)p[1],
+                                  nullptr, o.i64[1], (int32_t *)p[2], (int32_t *)p[3], (int32_t *)p[4], st);
+      break;
+    case AABR_GEOM_SAMPLE_OFFSETS:
+      rc = aabr_sample_offsets((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st);
+      break;
+    default:
+      aabr::set_error("aabr_geom_run: op %d has unknown kind %d", j, o.kind);
+      return AABR_EINVAL;
+    }
+    if (rc != AABR_OK) return rc;
+  }
+  return AABR_OK;
+}

@@ -159,6 +159,82 @@ def _key(t):
     return v[1]
 
 
+# ------------------------------------------------------------------------------------------------
+# geometry plan (extension): inside `with geom_plan():` the rule-book builders below do not launch, they append an
+# AabrGeomOp record; the list goes to the library in ONE call (aabr_geom_run) at `flush_geom()` / the end of the block.
+# Same entry points, same arguments, same order on the same stream -- only the ~10 us of interpreter + ctypes time per
+# launch (x ~250 launches per FPN_Net pass) leave the host's critical path.
+# ------------------------------------------------------------------------------------------------
+import struct as _struct
+
+_GEOM = _struct.Struct("<ii10i4q8Q")
+assert _GEOM.size == 144
+G_SUBM, G_TABLES, G_TILE, G_WIDE, G_PAIRS, G_RS, G_SITES, G_SOFF = 1, 2, 3, 4, 5, 6, 7, 8
+_geom_rec = None      # None: launch immediately; else [bytearray, count, keep-alive list]
+geom_stats = {"plans": 0, "ops": 0}
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else 0
+
+
+def _geom(kind, i32=(), i64=(), ps=()):
+    """record (inside a geom_plan block) or launch (outside) one builder call"""
+    i32 = list(i32) + [0] * (10 - len(i32))
+    i64 = list(i64) + [0] * (4 - len(i64))
+    ps = list(ps) + [0] * (8 - len(ps))
+    r = _geom_rec
+    if r is not None:
+        r[0] += _GEOM.pack(kind, 0, *i32, *i64, *ps)
+        r[1] += 1
+        return
+    buf = C.create_string_buffer(_GEOM.pack(kind, 0, *i32, *i64, *ps), 144)
+    check(_hip.load().aabr_geom_run(buf, 1, stream()))
+
+
+def flush_geom():
+    """hand the records collected so far to the library (call before anything reads what they produce)"""
+    r = _geom_rec
+    if r is None or r[1] == 0:
+        return
+    buf = (C.c_char * len(r[0])).from_buffer(r[0])
+    n = r[1]
+    geom_stats["plans"] += 1
+    geom_stats["ops"] += n
+    try:
+        check(_hip.load().aabr_geom_run(buf, n, stream()))
+    finally:
+        del buf
+        r[0] = bytearray()
+        r[1] = 0
+        del r[2][:]
+
+
+class geom_plan(object):
+    def __enter__(self):
+        global _geom_rec
+        self.outer = _geom_rec
+        if _geom_rec is None:
+            _geom_rec = [bytearray(), 0, []]
+        return self
+
+    def __exit__(self, *exc):
+        global _geom_rec
+        if self.outer is None:
+            try:
+                if exc[0] is None:
+                    flush_geom()
+            finally:
+                _geom_rec = None
+        return False
+
+
+def _keep(*ts):
+    """scratch tensors of recorded launches stay alive until the plan has been handed over"""
+    if _geom_rec is not None:
+        _geom_rec[2].extend(ts)
+
+
 class _Grid(object):
     """one scale of the scene: site list + hash table (replaces SparseGrids, Metadata.h:24-34)"""
     __slots__ = ("coords", "keys", "vals", "cap", "V", "batch_size", "sample_off")
@@ -197,13 +273,14 @@ class _Gather(object):
             lib = _hip.load()
             w = torch.empty(max(lib.aabr_rs_words(self.rows, self.vol, unit_rows), 4), dtype=torch.int32,
                             device=self.table.device)
-            check(lib.aabr_build_rs(ptr(self.table), self.rows, self.vol, unit_rows, ptr(w), stream()))
+            _geom(G_RS, (self.vol, unit_rows), (self.rows,), (_p(self.table), _p(w)))
             self._rs[unit_rows] = w
         return w
 
     def total_slot(self):
         """(ring, generation, index) of this rule book's rule total on the device"""
         if self._total is None:
+            flush_geom()
             ring = _ring(self.table.device)
             gen, idx = ring.alloc()
             torch.sum(self._ensure_counts(), (0,), dtype=torch.float64, out=ring.buf[idx])
@@ -212,6 +289,7 @@ class _Gather(object):
 
     def _ensure_counts(self):
         if self.counts is None:  # table built without counts (input side of a strided book)
+            flush_geom()         # torch reads the table right away
             nb = (self.rows + 255) // 256
             c = (self.table >= 0).to(torch.int32)
             pad = nb * 256 - self.rows
@@ -226,7 +304,7 @@ class _Gather(object):
             lib = _hip.load()
             w = torch.empty(max(lib.aabr_tile_blocks_words(self.rows, self.vol), 1), dtype=torch.int32,
                             device=self.table.device)
-            check(lib.aabr_build_tile_blocks(ptr(self.table), self.rows, self.vol, ptr(w), stream()))
+            _geom(G_TILE, (self.vol,), (self.rows,), (_p(self.table), _p(w)))
             self._blocks = w
         return self._blocks
 
@@ -239,7 +317,7 @@ class _Gather(object):
             lib = _hip.load()
             w = torch.empty(max(lib.aabr_wide_blocks_words(self.rows, self.vol, tile_rows), 1), dtype=torch.int32,
                             device=self.table.device)
-            check(lib.aabr_build_wide_blocks(ptr(self.table), self.rows, self.vol, tile_rows, ptr(w), stream()))
+            _geom(G_WIDE, (self.vol, tile_rows), (self.rows,), (_p(self.table), _p(w)))
             self._blocks256[tile_rows] = w
         return w
 
@@ -249,8 +327,7 @@ class _Gather(object):
             lib = _hip.load()
             w = torch.empty(max(lib.aabr_offset_pairs_words(self.rows, self.vol), 1), dtype=torch.int32,
                             device=self.table.device)
-            check(lib.aabr_build_offset_pairs(ptr(self.table), ptr(self._ensure_counts()), self.rows, self.vol,
-                                              ptr(w), stream()))
+            _geom(G_PAIRS, (self.vol,), (self.rows,), (_p(self.table), _p(self._ensure_counts()), _p(w)))
             self._pairs = w
         return self._pairs
 
@@ -258,6 +335,7 @@ class _Gather(object):
         """per-offset rule counts (host list); one small D2H read, cached"""
         if self._host_counts is None:
             c = self._ensure_counts()
+            flush_geom()
             self._host_counts = c.view(self.vol, -1).sum(1).tolist() if c.numel() else [0] * self.vol
         return self._host_counts
 
@@ -280,6 +358,7 @@ def prefetch_totals(gathers):
     todo = [g for g in gathers if g is not None and g._total is None and g.counts is not None and g.rows > 0]
     if not todo:
         return
+    flush_geom()
     ring = _ring(todo[0].table.device)
     es = ring.buf.element_size()
     cs, ns, os_ = [], [], []
@@ -534,8 +613,8 @@ class Metadata_3(object):
             dev = g.keys.device
             table = torch.empty((vol, g.V), dtype=torch.int32, device=dev)
             counts = torch.empty(vol * ((g.V + 255) // 256), dtype=torch.int32, device=dev)
-            check(_hip.load().aabr_submanifold_table(ptr(g.coords), g.V, ptr(g.keys), ptr(g.vals), g.cap,
-                                                     _hip.i32x3(fs), ptr(table), ptr(counts), stream()))
+            if g.V > 0:
+                _geom(G_SUBM, fs, (g.V, g.cap), (_p(g.coords), _p(g.keys), _p(table), _p(counts)))
             # odd filters: the input-gradient gather is the same table read with the mirrored
             # offset (u = v + off_k  <=>  v = u + off_{vol-1-k})
             tb = _Table(_Gather(table, counts, vol, g.V), None, vol, g.V, g.V,
@@ -568,15 +647,16 @@ class Metadata_3(object):
             vals = None
             scratch = torch.empty(E + 4 * nblk + 16, dtype=torch.int32, device=dev)
             out_coords = torch.empty((max(E, 1), 4), dtype=torch.int32, device=dev)
-            check(lib.aabr_convolution_sites(ptr(gi.coords), gi.V, _hip.i32x3(comp), _hip.i32x3(comp),
-                                             _hip.i32x3(osz), ptr(keys), ptr(vals), cap, ptr(scratch),
-                                             ptr(out_coords), metas[i].data_ptr(), stream()))
+            _geom(G_SITES, comp + comp + osz, (gi.V, cap),
+                  (_p(gi.coords), _p(keys), _p(scratch), _p(out_coords), metas[i].data_ptr()))
             # V and the per-sample row offsets (SparseGrid::ctr) of the new grid into one row of `ext`
-            check(lib.aabr_sample_offsets(ptr(out_coords), metas[i].data_ptr(), max(E, 1), MAX_SAMPLES + 1,
-                                          ext[i].data_ptr(), stream()))
+            _geom(G_SOFF, (MAX_SAMPLES + 1,), (max(E, 1),), (_p(out_coords), metas[i].data_ptr(), ext[i].data_ptr()))
+            _keep(scratch)
             pend.append((osz, out_coords, keys, vals))
         if not pend:
             return
+        _keep(metas)
+        flush_geom()
         rows = ext[:len(pend)].tolist()  # the one host sync: site counts + per-sample offsets of every grid
         pre = self.__dict__.setdefault("_pregrids", set())
         for (osz, out_coords, keys, vals), row in zip(pend, rows):
@@ -606,13 +686,13 @@ class Metadata_3(object):
                 t_in = torch.empty((vol, gi.V), dtype=torch.int32, device=dev)
                 counts = torch.empty(vol * ((V_out + 255) // 256), dtype=torch.int32, device=dev)
                 counts_in = torch.empty(vol * ((gi.V + 255) // 256), dtype=torch.int32, device=dev)
-                check(lib.aabr_convolution_tables2(ptr(gi.coords), gi.V, ptr(gi.keys), ptr(gi.vals), gi.cap,
-                                                   ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
-                                                   _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),
-                                                   ptr(t_in), ptr(counts), ptr(counts_in), stream()))
+                _geom(G_TABLES, fs + st + osz, (gi.V, gi.cap, V_out, go.cap),
+                      (_p(gi.coords), _p(gi.keys), _p(go.coords), _p(go.keys), _p(t_out), _p(t_in), _p(counts),
+                       _p(counts_in)))
                 tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, counts_in, vol, gi.V), vol, V_out, gi.V)
                 self.rulebooks[k] = tb
                 return tb
+            flush_geom()           # the calls below launch (and read) right away
             maxout = 1
             for a, b in zip(fs, st):
                 maxout *= (a + b - 1) // b

@@ -257,12 +257,14 @@ class FPN_Net(torch.nn.Module):
         dev = coords.device if coords.is_cuda else torch.device("cuda", torch.cuda.current_device())
         inp_layer.prepare(coords, dev, stream)
         src, ver, c64, md = inp_layer._prepared[-1]
+        from . import SCN
         with torch.cuda.stream(stream):
             md.inputLayerFinish()
             stub = scn.SparseConvNetTensor(None, md, inp_layer.spatial_size)
-            sizes = self._prebuild_geometry(stub)
-            in_channels = self.layers_in[1].nIn
-            self._compile_streams(md, sizes, in_channels)
+            with SCN.geom_plan():     # the builders' launches as a few lists (one per blocking read) instead of ~250 calls
+                sizes = self._prebuild_geometry(stub)
+                in_channels = self.layers_in[1].nIn
+                self._compile_streams(md, sizes, in_channels)
         md.prepared_on = stream
 
     def _refresh_weight_packs(self):
@@ -287,7 +289,9 @@ class FPN_Net(torch.nn.Module):
     def _forward(self, net0):
         net1 = self.layers_in(net0)
         if self.prebuild_geometry:
-            self._prebuild_geometry(net1)
+            from . import SCN
+            with SCN.geom_plan():
+                self._prebuild_geometry(net1)
         if self.compiled_graph and self.prepack_weights:
             from . import planExecutor
             out = planExecutor.run_fpn(self, net1)

@@ -393,6 +393,37 @@ typedef struct AabrPlanOp {
   void *p[12];
 } AabrPlanOp; /* 176 bytes, no padding */
 int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *stream);
+/* Geometry plan (extension): the rule-book builders of a pass handed over as ONE list, each record = one of the
+ * entry points above called with the record's fields -- nothing is computed differently:
+ *   AABR_GEOM_SUBM_TABLE    aabr_submanifold_table(p0 coords, i64[0] V, p1 grid, NULL, i64[1] cap, i32[0..2] filter,
+ *                           p2 table, p3 counts)
+ *   AABR_GEOM_CONV_TABLES   aabr_convolution_tables2(p0 in_coords, i64[0] V_in, p1 in_grid, NULL, i64[1] in_cap,
+ *                           p2 out_coords, i64[2] V_out, p3 out_grid, NULL, i64[3] out_cap, i32[0..2] size,
+ *                           i32[3..5] stride, i32[6..8] out_spatial, p4 table_out, p5 table_in, p6 counts, p7 counts_in)
+ *   AABR_GEOM_TILE_BLOCKS   aabr_build_tile_blocks(p0 table, i64[0] V, i32[0] vol, p1 blocks)
+ *   AABR_GEOM_WIDE_BLOCKS   aabr_build_wide_blocks(p0 table, i64[0] V, i32[0] vol, i32[1] tile_rows, p1 blocks)
+ *   AABR_GEOM_OFFSET_PAIRS  aabr_build_offset_pairs(p0 table, p1 block_counts, i64[0] V, i32[0] vol, p2 pairs)
+ *   AABR_GEOM_RS            aabr_build_rs(p0 table, i64[0] V, i32[0] vol, i32[1] unit_rows, p1 words)
+ *   AABR_GEOM_CONV_SITES    aabr_convolution_sites(p0 in_coords, i64[0] V_in, i32[0..2] size, i32[3..5] stride,
+ *                           i32[6..8] out_spatial, p1 out_grid, NULL, i64[1] out_cap, p2 scratch, p3 out_coords, p4 meta)
+ *   AABR_GEOM_SAMPLE_OFFSETS aabr_sample_offsets(p0 coords, p1 meta, i64[0] V_max, i32[0] max_samples, p2 out)
+ * Stops at the first failing record and returns its code.                                                      */
+#define AABR_GEOM_SUBM_TABLE 1
+#define AABR_GEOM_CONV_TABLES 2
+#define AABR_GEOM_TILE_BLOCKS 3
+#define AABR_GEOM_WIDE_BLOCKS 4
+#define AABR_GEOM_OFFSET_PAIRS 5
+#define AABR_GEOM_RS 6
+#define AABR_GEOM_CONV_SITES 7
+#define AABR_GEOM_SAMPLE_OFFSETS 8
+typedef struct AabrGeomOp {
+  int32_t kind, pad;
+  int32_t i32[10];
+  int64_t i64[4];
+  void *p[8];
+} AabrGeomOp; /* 144 bytes, no padding */
+int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *stream);
+
 /* out = a + b elementwise over n elements (fp32, or bf16 storage with the sum formed in fp32 and rounded to
  * nearest even); fp32 <-> bf16 storage cast.  What the layer API gets from torch (`a + b`, `.to(dtype)`; the
  * reference: AddTable, tables.py:27-41) as plan records.                                           */

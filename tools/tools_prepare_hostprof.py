@@ -31,3 +31,5 @@ torch.cuda.synchronize()
 buf = io.StringIO()
 pstats.Stats(pr, stream=buf).sort_stats(sys.argv[1] if len(sys.argv) > 1 else "tottime").print_stats(45)
 print(buf.getvalue()[:9000])
+from sparseconvnet import SCN
+print("geom plans %d ops %d (over %d prepares)" % (SCN.geom_stats["plans"], SCN.geom_stats["ops"], 2 * n + 4))
