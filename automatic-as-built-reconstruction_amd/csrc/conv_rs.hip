@@ -43,10 +43,11 @@ constexpr int kRsMaxUpw = 32;   // units per workgroup (their headers sit in LDS
 
 // ------------------------------------------------------------------ compiled rule book, row-stationary form
 //   words: [nunits][32] header: [0] = number of active offsets n, [1..n] = (offset << 16) | 16-bit set of the
-//          groups with at least one partner at that offset (offsets ascending), [31] = steps of the unit
+//          QUADS (4 consecutive groups = 64 slots) with at least one partner at that offset (offsets ascending),
+//          [31] = steps of the unit
 //        | [nunits][U] perm (output row of slot, -1 = padding)
-//        | [nunits][vol * 4][4][16] step descriptors in the order they are consumed: a step = up to 4 items
-//          (consecutive active groups of one offset), an item = the 16 partner rows of a group (-1 = none)
+//        | [nunits][vol * 4][4][16] step descriptors in the order they are consumed: a step = the 4 groups of one
+//          active quad at one offset, an item = the 16 partner rows of a group (-1 = none)
 constexpr int kRsHdr = 32;
 constexpr int kRsSI = 4;     // items per step
 static inline int64_t rs_words(int64_t V, int vol, int U) {
@@ -78,6 +79,8 @@ __global__ __launch_bounds__(256) void k_build_rs(const int32_t *__restrict__ ta
   int rank = 0;
   if (in_unit)
     for (int s = 0; s < U; ++s) rank += s_key[s] < key;
+  for (int i = t; i < kRsMaxU; i += 256) { s_mask[i] = 0u; s_row[i] = -1; }
+  __syncthreads();
   if (in_unit) { s_mask[rank] = valid ? mask : 0u; s_row[rank] = valid ? (int)t : -1; }
   int32_t *hdr = words + unit * kRsHdr;
   int32_t *perm = words + nunits * kRsHdr + unit * U;
@@ -94,12 +97,12 @@ __global__ __launch_bounds__(256) void k_build_rs(const int32_t *__restrict__ ta
   if (t == 0) {
     int n = 0, steps = 0;
     for (int k = 0; k < vol; ++k) {
-      unsigned bits = 0;
-      for (int g = 0; g < 16; ++g) bits |= ((s_gm[g] >> k) & 1u) << g;
+      unsigned bits = 0;      // quads (4 consecutive groups = 64 slots) with at least one partner at this offset
+      for (int g = 0; g < 16; ++g) bits |= ((s_gm[g] >> k) & 1u) << (g >> 2);
       if (bits) {
         s_hdr[++n] = (int)(((unsigned)k << 16) | bits);
         s_sb[n] = steps;
-        steps += (__popc(bits) + kRsSI - 1) / kRsSI;
+        steps += __popc(bits);
       }
     }
     s_hdr[0] = n;
@@ -110,18 +113,13 @@ __global__ __launch_bounds__(256) void k_build_rs(const int32_t *__restrict__ ta
   if (t < kRsHdr) hdr[t] = s_hdr[t];
   const int n = s_hdr[0];
   for (int j = 1; j <= n; ++j) {
-    const unsigned wd = (unsigned)s_hdr[j], bits = wd & 0xffffu;
-    const int k = (int)(wd >> 16), nst = (__popc(bits) + kRsSI - 1) / kRsSI;
+    const unsigned wd = (unsigned)s_hdr[j], bits = wd & 0xfu;
+    const int k = (int)(wd >> 16), nst = __popc(bits);
     if (t < nst * 64) {
-      const int item = t >> 4, r = t & 15;   // item-th active group of this offset
-      unsigned b = bits;
-      for (int i = 0; i < item && b; ++i) b &= b - 1;
-      int e = -1;
-      if (b) {
-        const int g = __ffs(b) - 1, lr = s_row[g * 16 + r];
-        if (lr >= 0) e = table[(int64_t)k * V + unit * U + lr];
-      }
-      desc[((int64_t)s_sb[j] * kRsSI) * 16 + t] = e;
+      unsigned b = bits;                       // the (t / 64)-th active quad of this offset
+      for (int i = 0; i < (t >> 6); ++i) b &= b - 1;
+      const int q = __ffs(b) - 1, lr = s_row[q * 64 + (t & 63)];
+      desc[((int64_t)s_sb[j] * kRsSI) * 16 + t] = lr >= 0 ? table[(int64_t)k * V + unit * U + lr] : -1;
     }
   }
 }
@@ -217,26 +215,43 @@ __global__ __launch_bounds__(512, 2) void k_conv_rsq(
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // iteration s (the consumers read buffer s & 1): store step s + 1, then fetch step s + 1 + kRsD
     int s = 0;
+    long long stamp[5] = {0, 0, 0, 0, 0};
     while (s < nsteps) {
 #pragma unroll
       for (int i = 1; i <= kRsD; ++i) {
         const int j = i == kRsD ? 0 : i;       // register set of step s + 1 (sets rotate: step t lives in set t % kRsD)
         if (s < nsteps) {
+          long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+          if (dbg & 64) t0 = __builtin_amdgcn_s_memtime();
           if (!(dbg & 8)) {
             store(rw[j], (s + 1) & 1);
+            if (dbg & 64) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
             gather(rw[j], de[j]);
             fetch_desc(de[j]);
           }
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (dbg & 64) { __builtin_amdgcn_sched_barrier(0); t2 = __builtin_amdgcn_s_memtime(); }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (dbg & 64) t3 = __builtin_amdgcn_s_memtime();
+          asm volatile("s_barrier" ::: "memory");
+          if (dbg & 64) {
+            const long long t4 = __builtin_amdgcn_s_memtime();
+            stamp[0] += t1 - t0; stamp[1] += t2 - t1; stamp[2] += t3 - t2; stamp[3] += t4 - t3; stamp[4] += 1;
+          }
           ++s;
         }
       }
+    }
+    if ((dbg & 64) && lane == 0) {   // timing experiments: per-wave phase clocks -> the buffer passed as `bias`
+      long long *d = reinterpret_cast<long long *>(const_cast<float *>(bias)) + ((int64_t)blockIdx.x * 8 + wave) * 8;
+      for (int q = 0; q < 5; ++q) d[q] = stamp[q];
     }
     return;
   }
 
   // -------------------------------------------------------------------- consumer waves
   const int g4 = lane >> 4, c16 = lane & 15;
+  const float *bias_dbg = bias;
+  if (dbg & 64) bias = nullptr;
   const int nb0 = blockIdx.y * (4 * NCB) + wave * NCB;
   const int32_t *perm = words + nunits * kRsHdr;
   const __amdgpu_buffer_rsrc_t rwp =
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_rsq(
     if (q.u < u1) {
       const unsigned wd = (unsigned)s_hdr[(q.u - u0) * kRsHdr + q.j];
       q.k = (int)(wd >> 16);
-      q.bits = wd & 0xffffu;
+      q.bits = wd & 0xfu;
     } else { q.k = 0; q.bits = 0; }
     return q;
   };
@@ -298,38 +313,49 @@ __global__ __launch_bounds__(512, 2) void k_conv_rsq(
       }
   };
   int cu = u0, step = 0;
+  long long cstamp[6] = {0, 0, 0, 0, 0, 0};
   // The groups of an offset are visited in a STATIC order (unrolled loop, a wave-uniform branch per group) so that
   // every accumulator is addressed by a constant and never leaves its registers -- a `switch` on the group number made
   // the compiler merge all accumulators with moves at every flow node (313 v_mov per step, 2 us per step measured).
   // What is dynamic is only where the item's rows sit in the step buffer.
   auto run_offset = [&](const WReg &w, unsigned b) __attribute__((always_inline)) {
-    int cnt = 0;
-    u32x4 f[KC];
-    auto read_item = [&]() {                   // the lane's 8 channels of chunk c: granule 4 c + g4 of row c16
-      const unsigned char *sa = &sbuf[step & 1][cnt * ITEM + c16 * RB];
+    u32x4 f[2][KC];
+    auto read_item = [&](int set, int item) {  // the lane's 8 channels of chunk c: granule 4 c + g4 of row c16
+      const unsigned char *sa = &sbuf[step & 1][item * ITEM + c16 * RB];
 #pragma unroll
-      for (int c = 0; c < KC; ++c) f[c] = *reinterpret_cast<const u32x4 *>(sa + (((c * 4 + g4) ^ (c16 & SWZ)) << 4));
+      for (int c = 0; c < KC; ++c)
+        f[set][c] = *reinterpret_cast<const u32x4 *>(sa + (((c * 4 + g4) ^ (c16 & SWZ)) << 4));
     };
-    read_item();
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (b & (1u << g)) {
-        if (!(dbg & 2))
+    for (int q = 0; q < NG / 4; ++q) {
+      if (b & (1u << q)) {                     // a step: the four groups of quad q, accumulators addressed statically
+        long long t0 = 0, t1 = 0, t2 = 0;
+        if (dbg & 64) t0 = __builtin_amdgcn_s_memtime();
+        read_item(0, 0);
+        read_item(1, 1);
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb)
+        for (int i = 0; i < 4; ++i) {
+          if (!(dbg & 2))
 #pragma unroll
-            for (int c = 0; c < KC; ++c)
-              acc[g][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8r, w.w[cb][c]),
-                                                                   __builtin_bit_cast(bf16x8r, f[c]), acc[g][cb], 0, 0, 0);
-        const bool more = g + 1 < NG && (b >> (g + 1)) != 0;
-        if (cnt == kRsSI - 1 || !more) {        // the step is complete: hand its buffer back, take the next one
-          ++step;
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          cnt = 0;
-        } else {
-          ++cnt;
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+              for (int c = 0; c < KC; ++c)
+                acc[4 * q + i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8r, w.w[cb][c]), __builtin_bit_cast(bf16x8r, f[i & 1][c]), acc[4 * q + i][cb],
+                    0, 0, 0);
+          if (i + 2 < 4) read_item(i & 1, i + 2);   // in flight during the next item's MFMAs
         }
-        if (more && !(dbg & 16)) read_item();   // the next item of this offset, in flight during these MFMAs
+        ++step;
+        if (dbg & 64) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_amdgcn_s_memtime(); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (dbg & 64) t2 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_barrier" ::: "memory");
+        if (dbg & 64) {
+          const long long t3 = __builtin_amdgcn_s_memtime();
+          cstamp[0] += t1 - t0; cstamp[1] += t2 - t1; cstamp[2] += t3 - t2; cstamp[3] += 1;
+          if (cstamp[5]) cstamp[4] += t0 - cstamp[5];   // from the previous step's barrier to this step's start
+          cstamp[5] = t3;
+        }
       }
     }
   };
@@ -352,7 +378,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_rsq(
     run_offset(wB, cur.bits);
     cur = nxt;
   }
+  if (dbg & 64) bias = nullptr;
   while (cu < u1) { write_out(cu); ++cu; }
+  if ((dbg & 64) && lane == 0) {
+    long long *d = reinterpret_cast<long long *>(const_cast<float *>(bias_dbg)) + ((int64_t)blockIdx.x * 8 + wave) * 8;
+    for (int q = 0; q < 5; ++q) d[q] = cstamp[q];
+  }
 }
 
 } // namespace aabr

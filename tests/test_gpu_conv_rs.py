@@ -57,25 +57,25 @@ def _check_stream(words, table, V, vol, U):
         bits = hdr[u, 1:n + 1] & 0xffff
         assert (np.diff(ks) > 0).all()
         want = {}
-        for k in range(vol):
+        for k in range(vol):          # quads (4 groups = 64 slots) with at least one partner at offset k
             b = 0
-            for g in range((len(live) + 15) // 16):
-                if (tab[k, live[g * 16:(g + 1) * 16]] >= 0).any():
-                    b |= 1 << g
+            for q in range((len(live) + 63) // 64):
+                if (tab[k, live[q * 64:(q + 1) * 64]] >= 0).any():
+                    b |= 1 << q
             if b:
                 want[k] = b
         assert dict(zip(ks.tolist(), bits.tolist())) == want
-        # step descriptors: per active offset its groups four at a time, an item = the 16 partner rows of a group
+        # step descriptors: per active offset one step per active quad, its four groups as four items of 16 rows
         step = 0
         for k, b in zip(ks.tolist(), bits.tolist()):
-            groups = [g for g in range(16) if b >> g & 1]
-            for s0 in range(0, len(groups), 4):
+            for q in range(4):
+                if not (b >> q & 1):
+                    continue
                 for i in range(4):
                     want_e = np.full(16, -1, np.int64)
-                    if s0 + i < len(groups):
-                        g = groups[s0 + i]
-                        pr = p[g * 16:(g + 1) * 16]
-                        want_e[pr >= 0] = tab[k, pr[pr >= 0]]
+                    pr = p[q * 64 + i * 16:q * 64 + (i + 1) * 16]
+                    if len(pr):
+                        want_e[:len(pr)][pr >= 0] = tab[k, pr[pr >= 0]]
                     np.testing.assert_array_equal(desc[u, step, i], want_e)
                 step += 1
         assert hdr[u, 31] == step
