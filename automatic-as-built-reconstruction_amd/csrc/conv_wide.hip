@@ -112,7 +112,10 @@ constexpr int kMaxTileRows = 240; // (240 + 1) rows x 256 B + 16 KiB stage = 76 
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
 
-template <int KG, int DBG, int NBUF, bool BF = false>
+// NCB = 16-column blocks per wave: 1 = 64-column slabs; 2 (bf16 storage) = 128-column slabs -- the kernel is bound by
+// the rate at which a CU gathers random rows (~20 GB/s per CU measured in both this and the row-stationary kernel,
+// profiles/r03_conv_rs_ab.txt), and a 128-column layer gathered every row once per 64-column slab, i.e. twice
+template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2>
 __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   constexpr int STAGE = 2 * 16 * RF;       // floats per stage buffer (two blocks)
   extern __shared__ __align__(16) float smem[];
   float *Ct = smem;                        // [kT2 + 1][64] floats, granule-swizzled; the last row swallows padding entries
-  float *St = smem + (kT2 + 1) * kWS;      // [2][2][16][RF]
+  constexpr int WS = kWS * NCB;            // tile row stride in floats = slab width
+  float *St = smem + (kT2 + 1) * WS;       // [2][2][16][RF]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
   const int pr = wave * 8 + (lane >> 3), seg = lane & 7; // gather role: pair row 0..31, 16-byte segment
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
     const unsigned per = total >> 3, rem = total & 7u, x = lin & 7u;
     const unsigned wi = x * per + (x < rem ? x : rem) + (lin >> 3);
     tile = wi / ny;
-    nb0 = (int)(wi % ny) * kNB;
+    nb0 = (int)(wi % ny) * (kNB * NCB);
   }
   const int64_t row0 = tile * kT2;
   const int64_t ntiles = (V_out + kT2 - 1) / kT2;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 *c4 = reinterpret_cast<f32x4 *>(Ct);
-    for (int i = threadIdx.x; i < (kT2 + 1) * kWS / 4; i += 256) c4[i] = z;
+    for (int i = threadIdx.x; i < (kT2 + 1) * WS / 4; i += 256) c4[i] = z;
   }
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
     while (k < vol && pre_of(k + 1) == pre_of(k)) ++k;
     return k;
   };
-  struct WReg { u32x4 w0[KG], w1[KG]; };
+  struct WReg { u32x4 w0[NCB][KG], w1[NCB][KG]; };
   struct GReg { u32x4 v[KG]; };
   struct Ent { int eg, ea, eb, hb; };      // gather-role entry of this lane's pair row; compute-role entries (A, B);
                                            // hb (wave-uniform): the pair has a second block
@@ -178,18 +182,20 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   auto load_w = [&](WReg &w, int k, int kg) {
     const int kW = wflip ? vol - 1 - k : k;
 #pragma unroll
-    for (int c = 0; c < KG; ++c) { // nkc % KG == 0 (dispatch): every load is unconditional, so the compiler's
-      const int kc = kg * KG + c;  // vmcnt bookkeeping stays exact and nothing waits for a prefetch it does not use
-      if (BF) { // two 32-channel MFMA chunks per 128-byte row chunk, 1 KiB of packed weights each
-        const unsigned so = (unsigned)((((int64_t)kW * (2 * nkc) + 2 * kc) * nnb + nb0 + wave) * 1024);
-        w.w0[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, so, 0);
-        w.w1[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, so + (unsigned)nnb * 1024u, 0);
-      } else {
-        const unsigned so = (unsigned)((((int64_t)kW * nkc + kc) * nnb + nb0 + wave) * 2048);
-        w.w0[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, so, 0);
-        w.w1[c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16u, so, 0);
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int c = 0; c < KG; ++c) { // nkc % KG == 0 (dispatch): every load is unconditional, so the compiler's
+        const int kc = kg * KG + c;  // vmcnt bookkeeping stays exact and nothing waits for a prefetch it does not use
+        if (BF) { // two 32-channel MFMA chunks per 128-byte row chunk, 1 KiB of packed weights each
+          const unsigned so = (unsigned)((((int64_t)kW * (2 * nkc) + 2 * kc) * nnb + nb0 + wave * NCB + cb) * 1024);
+          w.w0[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, so, 0);
+          w.w1[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, so + (unsigned)nnb * 1024u, 0);
+        } else {
+          const unsigned so = (unsigned)((((int64_t)kW * nkc + kc) * nnb + nb0 + wave * NCB + cb) * 2048);
+          w.w0[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, so, 0);
+          w.w1[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16u, so, 0);
+        }
       }
-    }
   };
   // entries of the pair (bb, bb+1) of offset kk; the second block only if it belongs to the same offset,
   // otherwise block A again with the discard bit
@@ -221,13 +227,18 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   };
   // branch-free: a padding entry (bit 31) lands in the dummy row; the two blocks of a pair never share a real row,
   // so both reads go out before either write
-  auto accumulate2 = [&](int ea, const f32x4 &accA, int eb, const f32x4 &accB) {
+  auto accumulate2 = [&](int ea, const f32x4 (&accA)[NCB], int eb, const f32x4 (&accB)[NCB]) {
     const int ra = ea >= 0 ? (ea & 255) : kT2, rb = eb >= 0 ? (eb & 255) : kT2;
-    f32x4 *da = reinterpret_cast<f32x4 *>(Ct + ra * kWS + (((wave * 4 + g) ^ (ra & 15)) << 2));
-    f32x4 *db = reinterpret_cast<f32x4 *>(Ct + rb * kWS + (((wave * 4 + g) ^ (rb & 15)) << 2));
-    const f32x4 va = *da, vb = *db;
-    *da = va + accA;
-    *db = vb + accB;
+    // (LDS float adds without return, ds_add_f32, instead of this read-add-write: measured 10x slower -- 1147 us
+    // instead of 100 us on the dominant bf16 instance, profiles/r03_conv_bf16_ab.txt)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      f32x4 *da = reinterpret_cast<f32x4 *>(Ct + ra * WS + ((((wave * NCB + cb) * 4 + g) ^ (ra & 15)) << 2));
+      f32x4 *db = reinterpret_cast<f32x4 *>(Ct + rb * WS + ((((wave * NCB + cb) * 4 + g) ^ (rb & 15)) << 2));
+      const f32x4 va = *da, vb = *db;
+      *da = va + accA[cb];
+      *db = vb + accB[cb];
+    }
   };
   // Software pipeline over the tile's block pairs (pairs never straddle an offset):
   //   entries two pairs ahead (registers), gathered rows one pair ahead (registers -> LDS stage after this pair's
@@ -246,30 +257,39 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   int par = 0;
   long long dbg_t[5] = {0, 0, 0, 0, 0};
   for (int kg = 0; kg < ngroups; ++kg) {
-    Pos p0;
-    p0.k = next_offset(-1);
-    if (p0.k >= vol) break;
-    p0.b = pre_of(p0.k);
-    Pos p1 = adv(p0), p2 = adv(p1), p3 = adv(p2);
-    auto ent_of = [&](const Pos &q) { const bool v = q.k < vol; return load_ent(v ? q.b : p0.b, v ? q.k : p0.k); };
-    Ent e0 = ent_of(p0), e1 = ent_of(p1), e2 = ent_of(p2), e3 = e0;
-    // gathered rows travel TWO pairs ahead of the MFMAs (a random-row gather takes ~2 us, one pair's MFMAs ~1 us):
-    // two register sets, used alternately by the two copies (PAR) of the step body
-    GReg gqA, gqB;
-    gather(gqA, e0.eg, kg);
+    // NSET register sets of gathered rows: the rows of pair i + NSET are requested while pair i is multiplied (fp32:
+    // NSET = 2 -- a pair's MFMAs take ~1 us, a random-row gather ~2 us; bf16 storage: the MFMAs of a pair take 0.1 us,
+    // so the workgroup's pace is NSET pairs per gather latency and NSET = 4 nearly doubles it, measured).  Entries run
+    // one pair further ahead.  Pair i lives in set i % NSET; the step body exists once per set (static registers).
+    Pos pp[NSET + 2];
+    pp[0].k = next_offset(-1);
+    if (pp[0].k >= vol) break;
+    pp[0].b = pre_of(pp[0].k);
+#pragma unroll
+    for (int i = 1; i < NSET + 2; ++i) pp[i] = adv(pp[i - 1]);
+    auto ent_of = [&](const Pos &q) { const bool v = q.k < vol; return load_ent(v ? q.b : pp[0].b, v ? q.k : pp[0].k); };
+    Ent ee[NSET + 2];
+#pragma unroll
+    for (int i = 0; i <= NSET; ++i) ee[i] = ent_of(pp[i]);
+    ee[NSET + 1] = ee[0];
+    GReg gq[NSET];
+    gather(gq[0], ee[0].eg, kg);
     __syncthreads();                       // zero fill done / previous group's stage reads done
-    par = 0;                               // (the register-set roles below are tied to the stage parity)
-    stage_store(gqA, par);
-    gather(gqB, e1.eg, kg);                // pair p1: stored at the end of the first step
+    par = 0;
+    int gs = 0;                            // register set of the current pair
+    stage_store(gq[0], par);
+#pragma unroll
+    for (int i = 1; i < NSET; ++i) gather(gq[i], ee[i].eg, kg);   // pairs 1 .. NSET-1: stored one step before their turn
     __syncthreads();
-    // one pipeline step: pair p0 with the weight registers `w` (passed by reference: the two weight sets are
+    // one pipeline step: pair pp[0] with the weight registers `w` (passed by reference: the two weight sets are
     // used from fixed registers by separate copies of this body -- no register shuffling at an offset change)
     auto step = [&](const WReg &w, GReg &g_issue, GReg &g_store) __attribute__((always_inline)) {
       long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
       if (DBG & 4) t0 = __builtin_amdgcn_s_memtime();
       // unconditional: past the tile's last pair the loads repeat a valid pair and their results are dropped
-      gather(g_issue, e2.eg, kg);                            // pair p2; its entry was loaded an iteration ago
-      e3 = ent_of(p3);
+      gather(g_issue, ee[NSET].eg, kg);                      // pair i + NSET; its entry was loaded an iteration ago
+      ee[NSET + 1] = ent_of(pp[NSET + 1]);
+      const Ent e0 = ee[0];
       __builtin_amdgcn_sched_barrier(0);                     // the prefetches are issued HERE, ahead of the MFMAs
       if (DBG & 4) { t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 
@@ -289,59 +309,69 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
           a1[c] = *reinterpret_cast<const u32x4 *>(sa + q1);
           b1[c] = *reinterpret_cast<const u32x4 *>(sb + q1);
         }
-        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = accA;
+        f32x4 accA[NCB], accB[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) { accA[cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[cb] = accA[cb]; }
         if (DBG & 1) { // timing experiments: operands consumed, no MFMAs
 #pragma unroll
           for (int c = 0; c < KG; ++c) {
-            accA[0] += bcf_(a0[c][0]) + bcf_(a1[c][0]) + bcf_(w.w0[c][0]) + bcf_(w.w1[c][0]);
-            accB[0] += bcf_(b0[c][0]) + bcf_(b1[c][0]);
+            accA[0][0] += bcf_(a0[c][0]) + bcf_(a1[c][0]) + bcf_(w.w0[0][c][0]) + bcf_(w.w1[0][c][0]);
+            accB[0][0] += bcf_(b0[c][0]) + bcf_(b1[c][0]);
           }
         } else if (BF) {
 #pragma unroll
-          for (int c = 0; c < KG; ++c) {
-            accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[c]),
-                                                           __builtin_bit_cast(bf16x8w, a0[c]), accA, 0, 0, 0);
-            accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[c]),
-                                                           __builtin_bit_cast(bf16x8w, a1[c]), accA, 0, 0, 0);
-          }
-          if (e0.hb) {
+          for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int c = 0; c < KG; ++c) {
-              accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[c]),
-                                                             __builtin_bit_cast(bf16x8w, b0[c]), accB, 0, 0, 0);
-              accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[c]),
-                                                             __builtin_bit_cast(bf16x8w, b1[c]), accB, 0, 0, 0);
+              accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[cb][c]),
+                                                                 __builtin_bit_cast(bf16x8w, a0[c]), accA[cb], 0, 0, 0);
+              accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[cb][c]),
+                                                                 __builtin_bit_cast(bf16x8w, a1[c]), accA[cb], 0, 0, 0);
             }
+          if (e0.hb) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+              for (int c = 0; c < KG; ++c) {
+                accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[cb][c]),
+                                                                   __builtin_bit_cast(bf16x8w, b0[c]), accB[cb], 0, 0, 0);
+                accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[cb][c]),
+                                                                   __builtin_bit_cast(bf16x8w, b1[c]), accB[cb], 0, 0, 0);
+              }
           }
         } else {
           // block A, then block B only if the pair has one (sparse rule books: most offsets of a tile hold a single
           // block; the branch is wave-uniform and covers nothing but MFMAs, so no load waits move)
 #pragma unroll
-          for (int c = 0; c < KG; ++c) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              accA = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[c][t]), bcf_(a0[c][t]), accA, 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              accA = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[c][t]), bcf_(a1[c][t]), accA, 0, 0, 0);
-          }
-          if (e0.hb) {
+          for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int c = 0; c < KG; ++c) {
 #pragma unroll
               for (int t = 0; t < 4; ++t)
-                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[c][t]), bcf_(b0[c][t]), accB, 0, 0, 0);
+                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[cb][c][t]), bcf_(a0[c][t]), accA[cb], 0, 0, 0);
 #pragma unroll
               for (int t = 0; t < 4; ++t)
-                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[c][t]), bcf_(b1[c][t]), accB, 0, 0, 0);
+                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[cb][c][t]), bcf_(a1[c][t]), accA[cb], 0, 0, 0);
             }
+          if (e0.hb) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+              for (int c = 0; c < KG; ++c) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[cb][c][t]), bcf_(b0[c][t]), accB[cb], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[cb][c][t]), bcf_(b1[c][t]), accB[cb], 0, 0, 0);
+              }
           }
         }
-        if (DBG & 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(accA), "v"(accB)); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        if (DBG & 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(accA[0]), "v"(accB[0])); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         accumulate2(e0.ea, accA, e0.eb, accB);
       }
       if (NBUF == 1) wg_barrier();                           // single stage: every wave is done reading it
-      if (p1.k < vol) stage_store(g_store, par ^ 1);         // pair p1, gathered during the previous step
+      if (pp[1].k < vol) stage_store(g_store, par ^ 1);      // the next pair, gathered NSET - 1 steps ago
       if (DBG & 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); }
       wg_barrier();
       if (DBG & 4) {
@@ -349,26 +379,35 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
         dbg_t[0] += t1 - t0; dbg_t[1] += t2 - t1; dbg_t[2] += t3 - t2; dbg_t[3] += t4 - t3; dbg_t[4] += 1;
       }
       par ^= 1;
-      p0 = p1; p1 = p2; p2 = p3; p3 = adv(p3);
-      e0 = e1; e1 = e2; e2 = e3;
+#pragma unroll
+      for (int i = 0; i < NSET + 1; ++i) { pp[i] = pp[i + 1]; ee[i] = ee[i + 1]; }
+      pp[NSET + 1] = adv(pp[NSET + 1]);
     };
-    // stage parity 0: issue into gqA, store gqB; parity 1: the other way round
+    // the current pair's set takes the new request, the next pair's set is stored
     auto step2 = [&](const WReg &w) __attribute__((always_inline)) {
-      if (par == 0) step(w, gqA, gqB);
-      else step(w, gqB, gqA);
+      if (NSET == 2) {
+        if (gs == 0) step(w, gq[0], gq[1]);
+        else step(w, gq[1], gq[0]);
+      } else {
+        if (gs == 0) step(w, gq[0], gq[1 % NSET]);
+        else if (gs == 1) step(w, gq[1 % NSET], gq[2 % NSET]);
+        else if (gs == 2) step(w, gq[2 % NSET], gq[3 % NSET]);
+        else step(w, gq[3 % NSET], gq[0]);
+      }
+      gs = gs + 1 == NSET ? 0 : gs + 1;
     };
     WReg wA, wB;
-    int k = p0.k;
+    int k = pp[0].k;
     load_w(wA, k, kg);
     for (;;) {
       int kn = next_offset(k);
       if (kn < vol) load_w(wB, kn, kg);                      // next offset's weights in flight during this offset
-      while (p0.k == k) step2(wA);
+      while (pp[0].k == k) step2(wA);
       if (kn >= vol) break;
       k = kn;
       kn = next_offset(k);
       if (kn < vol) load_w(wA, kn, kg);
-      while (p0.k == k) step2(wB);
+      while (pp[0].k == k) step2(wB);
       if (kn >= vol) break;
       k = kn;
     }
@@ -384,9 +423,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   __syncthreads();
   const int nrows = (int)((V_out - row0) < kT2 ? (V_out - row0) : kT2);
 #pragma unroll 4
-  for (int i = threadIdx.x; i < nrows * 16; i += 256) {
-    const int r = i >> 4, q = i & 15;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + r * kWS + ((q ^ (r & 15)) << 2));
+  for (int i = threadIdx.x; i < nrows * 16 * NCB; i += 256) {
+    const int r = i / (16 * NCB), q = i % (16 * NCB);
+    f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + r * WS + ((q ^ (r & 15)) << 2));
     if (bias) {
       const float *bb = bias + nb0 * 16 + q * 4;
       v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
@@ -545,6 +584,13 @@ extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64
 }
 
 // ---- bf16 feature storage (extension): the same kernel on 128-byte row chunks of 64 bf16 channels ------------------
+// 16-column blocks per wave of the bf16 launch: 2 (128-column slabs) for n_out % 128 == 0 up to 128 input channels
+// (two weight register sets of 16 x NCB x KG registers), else 1; WIDE_NCB knob: 1 forces 64-column slabs
+static int wide_bf16_ncb(int n_in, int n_out) {
+  if (knob(K_WIDE_NCB) == 1) return 1;
+  return ((n_out & 127) == 0 && n_in <= 128) ? 2 : 1;
+}
+
 // 0: use aabr_conv_forward_bf16 (64-row tiles); otherwise rows per tile for aabr_conv_forward_wide_bf16
 extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
   if (n_in <= 0 || n_out <= 0 || (n_in & 63) || (n_out & 63) || vol <= 0 || vol > kMaxVol) return 0;
@@ -553,11 +599,15 @@ extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_i
   // bf16: two MFMAs per block and 64-channel chunk -- the gather / stage / barrier skeleton sets the pace, so more
   // resident workgroups pay: 96-row tiles with a single stage buffer (measured on the bench's rule books: convolution
   // time of a bf16 step 5.25 -> 5.01 ms against 128 rows + two buffers; 64 rows: 5.24)
-  int T = 96;
+  // 128-column slabs when the layer has them: the kernel is bound by the CU's random-row gather rate and a 64-column
+  // slab gathers every row once per slab.  Their fp32 tile is 512 B per row: 64 rows (33 KiB + 8 KiB of stage) keep
+  // three workgroups per CU; 64-column slabs keep the 96-row tiles of round 2.
+  const int ncb = wide_bf16_ncb(n_in, n_out);
+  int T = ncb == 2 ? 64 : 96;
   {
-    const int64_t slabs = n_out / 64;
-    if (((V_out + 95) / 96) * slabs <= 512)
-      for (int t = 64; t < 96; t += 16)
+    const int64_t slabs = n_out / (64 * ncb);
+    if (((V_out + T - 1) / T) * slabs <= 512)
+      for (int t = 64; t < T; t += 16)
         if (((V_out + t - 1) / t) * slabs <= 512) { T = t; break; }
   }
   {                                                // tuning experiments only
@@ -571,7 +621,7 @@ extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_i
     if (v == 0) return 0;
     if (v == 1) return T;
   }
-  return (((V_out + T - 1) / T) * (n_out / 64) >= 320) ? T : 0;
+  return (((V_out + T - 1) / T) * (n_out / (64 * ncb)) >= 320) ? T : 0;
 }
 
 extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
@@ -592,7 +642,8 @@ extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, i
   const int64_t wp_bytes = (int64_t)vol * (n_in / 32) * (n_out / 16) * 1024;
   AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
   AABR_CHECK_ARG(n_in <= 256 || (n_in & 255) == 0, "n_in above 256 must be a multiple of 256");
-  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / 64));
+  const int ncb = wide_bf16_ncb(n_in, n_out);
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / (64 * ncb)));
   const int flip = (flags >> 1) & 1;
   const int kg = nkc >= 4 ? 4 : nkc;
   int nbuf = 1;
@@ -602,28 +653,57 @@ extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, i
   }
   const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
   float *out_f = reinterpret_cast<float *>(out_feats);
-#define AABR_WIDE_BF(KG, NB)                                                                                       \
+constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: measured slower, 100 -> 112 us)
+#define AABR_WIDE_BF(KG, NB, NCB) AABR_WIDE_BF_S(KG, NB, NCB, ((KG) <= 2 ? kBfSets : 2))
+#define AABR_WIDE_BF_D(KG, NB, NCB, D)                                                                              \
+  do {                                                                                                             \
+    AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, D, NB, true, NCB, kBfSets>),                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                    \
+    hipLaunchKernelGGL((k_conv_cs<KG, D, NB, true, NCB, kBfSets>), grid, dim3(256),                                \
+                       (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
+                       n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
+                       tile_rows, (const float *)nullptr);                                                         \
+  } while (0)
+#define AABR_WIDE_BF_S(KG, NB, NCB, NS)                                                                                  \
   do {                                                                                                             \
     static bool attr = false;                                                                                      \
     if (!attr) {                                                                                                   \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB, true>),                               \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB, true, NCB, NS>),                          \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                  \
       attr = true;                                                                                                 \
     }                                                                                                              \
-    g_last_variant = "k_conv_cs<" #KG ",0," #NB ",bf16>";                                                          \
-    hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true>), grid, dim3(256),                                              \
-                       (size_t)((tile_rows + 1) * kWS + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f, n_in,    \
-                       in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,        \
+    g_last_variant = NCB == 2 ? "k_conv_cs<" #KG ",0," #NB ",bf16,x128>" : "k_conv_cs<" #KG ",0," #NB ",bf16>";    \
+    hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS>), grid, dim3(256),                                         \
+                       (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
+                       n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
                        tile_rows, (const float *)nullptr);                                                         \
   } while (0)
 #define AABR_WIDE_BF_K(KG)                                                                                         \
   do {                                                                                                             \
-    if (nbuf == 1) AABR_WIDE_BF(KG, 1); else AABR_WIDE_BF(KG, 2);                                                  \
+    if (ncb == 2) { if (nbuf == 1) AABR_WIDE_BF(KG, 1, 2); else AABR_WIDE_BF(KG, 2, 2); }                          \
+    else { if (nbuf == 1) AABR_WIDE_BF(KG, 1, 1); else AABR_WIDE_BF(KG, 2, 1); }                                   \
   } while (0)
-  if (kg == 1) AABR_WIDE_BF_K(1); else if (kg == 2) AABR_WIDE_BF_K(2); else if (kg == 3) AABR_WIDE_BF_K(3);
-  else AABR_WIDE_BF_K(4);
+#define AABR_WIDE_BF_K1(KG) /* more than 128 input channels: 64-column slabs only (wide_bf16_ncb) */                 \
+  do {                                                                                                             \
+    if (nbuf == 1) AABR_WIDE_BF(KG, 1, 1); else AABR_WIDE_BF(KG, 2, 1);                                            \
+  } while (0)
+  AABR_CHECK_ARG(ncb == 1 || kg <= 2, "128-column slabs need n_in <= 128");
+#ifdef AABR_DEV
+  if ((flags >> 8) & 4) {   // timing experiments (tools/tools_cs_phases.py bf16): phase clocks of the 128-channel instance
+    AABR_CHECK_ARG(kg == 2, "the bf16 phase-clock variant exists for n_in = 128 only");
+    if (ncb == 2) AABR_WIDE_BF_D(2, 1, 2, 4);
+    else AABR_WIDE_BF_D(2, 1, 1, 4);
+    AABR_CHECK_LAUNCH();
+    return AABR_OK;
+  }
+#endif
+  if (kg == 1) AABR_WIDE_BF_K(1); else if (kg == 2) AABR_WIDE_BF_K(2); else if (kg == 3) AABR_WIDE_BF_K1(3);
+  else AABR_WIDE_BF_K1(4);
+#undef AABR_WIDE_BF_K1
 #undef AABR_WIDE_BF_K
 #undef AABR_WIDE_BF
+#undef AABR_WIDE_BF_S
+#undef AABR_WIDE_BF_D
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

@@ -332,7 +332,8 @@ def conv_kernel_table(torch, wl, dtype):
                     check(lib.aabr_conv_forward_rs_bf16(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(words),
                                                         unit_rows, ga.vol, None, g["flags"] & 3, ptr(wpack), stream()))
             elif tile_rows and bf:
-                g["grid_threads"] = ((ga.rows + tile_rows - 1) // tile_rows) * (n_out // 64) * 256
+                ncb_ = 2 if (n_out % 128 == 0 and n_in <= 128) else 1      # 128-column slabs (conv_wide.hip)
+                g["grid_threads"] = ((ga.rows + tile_rows - 1) // tile_rows) * (n_out // (64 * ncb_)) * 256
                 blocks = ga.blocks_wide(tile_rows)
                 wt = torch.empty_like(wpack)
                 if tr_:     # w is the layer's own weight; the input-gradient launch reads its transposed pack
