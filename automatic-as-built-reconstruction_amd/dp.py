@@ -91,6 +91,60 @@ class FlatParams(object):
             if ps:
                 torch._foreach_add_(ps, gs, alpha=-lr)
 
+    # ---- bucketed form: collectives start while backward is still running ------------------------------------------
+    def begin_bucketed(self, group=None):
+        """Arm the compiled backward's hook (sparseconvnet/planExecutor.py `on_grads_ready`): every piece of the
+        backward list hands over the slice of the pass's gradient buffer it has completed, and that slice's
+        all-reduce is launched at once, in place, underneath the remaining backward kernels -- what the reference
+        gets from DistributedDataParallel's buckets (tools/train_net_sparse3d.py:64-69).  Call before `backward()`;
+        `finish_bucketed` after it."""
+        from sparseconvnet import planExecutor
+        self._bk = dict(works=[], params=[], grads=[], group=group, bytes=0, launched_early=0)
+
+        def ready(piece, n_pieces, flat, pairs):
+            bk = self._bk
+            bk["works"].append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            bk["bytes"] += flat.numel() * flat.element_size()
+            bk["launched_early"] += 1 if piece < n_pieces - 1 else 0
+            for p_, g_ in pairs:
+                bk["params"].append(p_)
+                bk["grads"].append(g_)
+
+        planExecutor.on_grads_ready = ready
+
+    def finish_bucketed(self, lr, world_size):
+        """after backward(): all-reduce what the hook did not see (parameters outside the compiled graph: the input
+        convolution, the RPN head) as one last bucket, wait for every bucket, apply the SGD update from the reduced
+        buffers.  Returns the number of buckets."""
+        from sparseconvnet import planExecutor
+        planExecutor.on_grads_ready = None
+        bk = self._bk
+        seen = {id(p_) for p_ in bk["params"]}
+        rest = [p_ for p_ in self.params if id(p_) not in seen and p_.grad is not None]
+        if rest:
+            n = sum(p_.numel() for p_ in rest)
+            buf = torch.empty(n, device=self.flat.device, dtype=self.flat.dtype)
+            views, o = [], 0
+            for p_ in rest:
+                views.append(buf[o:o + p_.numel()].view_as(p_))
+                o += p_.numel()
+            torch._foreach_copy_(views, [p_.grad for p_ in rest])
+            bk["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=bk["group"], async_op=True))
+            bk["bytes"] += n * buf.element_size()
+            bk["params"] += rest
+            bk["grads"] += views
+        t0 = time.perf_counter()
+        for w in bk["works"]:
+            w.wait()
+        self.wait_ms.append((time.perf_counter() - t0) * 1e3)
+        del self.wait_ms[:-512]
+        if bk["params"]:
+            torch._foreach_add_([p_.data for p_ in bk["params"]], bk["grads"], alpha=-lr / world_size)
+        self.bucket_stats = dict(buckets=len(bk["works"]), launched_during_backward=bk["launched_early"],
+                                 bytes=bk["bytes"])
+        self._bk = None
+        return self.bucket_stats["buckets"]
+
     def broadcast(self, src=0, group=None):
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.flat, src, group=group)

@@ -58,6 +58,17 @@ lateral_side_stream = os.environ.get("AABR_PLAN_LATERAL_SIDE", "0") != "0"
 fuse_adds = os.environ.get("AABR_PLAN_FUSE_ADDS", "1") != "0"
 
 
+# Data-parallel hook (extension; the reference wraps the model in DistributedDataParallel, whose bucketed all-reduce
+# starts while backward is still running, tools/train_net_sparse3d.py:64-69): with `grad_segments` = S > 1 and
+# `on_grads_ready` set, the compiled backward list is handed to the library in S pieces and after each piece the hook
+# receives the gradients that are final by then -- `on_grads_ready(piece, S, flat, [(parameter, gradient view)])`,
+# `flat` = the contiguous slice of the pass's gradient buffer that holds exactly those views -- so a collective on
+# `flat` runs underneath the rest of the backward pass.  Same launches in the same order; a piece boundary only
+# makes the caller's stream wait for the weight gradients issued so far on the library's second stream.
+grad_segments = 0
+on_grads_ready = None
+
+
 class Unsupported(Exception):
     pass
 
@@ -494,6 +505,14 @@ class _Pass(object):
             res.append(self.arena[offs[b]:offs[b] + n].view(dt).view(V[lvl], planes))
         return res
 
+    @staticmethod
+    def _pinv(bw, byte_off):
+        """parameter index of a gradient slot (byte offset into the pass's gradient buffer)"""
+        inv = bw.get("pinv")
+        if inv is None:
+            inv = bw["pinv"] = {o * 4: i for i, o in bw["poff"].items()}
+        return inv[byte_off]
+
     def backward(self, gouts, need_dx):
         t, V, A = self.t, self.V, self.A
         gouts = [g.contiguous() if g is not None else None for g in gouts]
@@ -522,8 +541,33 @@ class _Pass(object):
         buf = bytearray(len(bops) * 2 * 176)
         pack, off = _OP.pack_into, 0
         dw_side = F_SIDE if dw_side_stream else 0
-        for op in bops:
+        # pieces of the list for the data-parallel hook: cut after every len/S-th record; parameter gradients are laid
+        # out in the order their records appear (pslot), so the ones a piece completes form one slice of `gparams`
+        nseg = grad_segments if (grad_segments > 1 and on_grads_ready is not None) else 1
+        cut = [(len(bops) * (q + 1)) // nseg for q in range(nseg)] if nseg > 1 else []
+        inv = sorted((o, i) for i, o in bw["poff"].items()) if nseg > 1 else []
+        done_floats, seg_no, next_inv = 0, 0, 0
+        for op_no, op in enumerate(bops):
+            if nseg > 1 and seg_no < nseg - 1 and op_no == cut[seg_no]:
+                if off:
+                    check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, stream()))
+                    off = 0
+                pairs = []
+                while next_inv < len(inv) and inv[next_inv][0] < done_floats:
+                    o, i = inv[next_inv]
+                    pairs.append((t.params[i], gparams[o:o + t.params[i].numel()].view_as(t.params[i])))
+                    next_inv += 1
+                if pairs:
+                    lo = pairs[0][1].data_ptr() - pbase
+                    on_grads_ready(seg_no, nseg, gparams[lo // 4:done_floats], pairs)
+                seg_no += 1
             kind = op[0]
+            if kind == "dw":
+                done_floats = max(done_floats, op[8] // 4 + (t.params[self._pinv(bw, op[8])].numel() + 63) // 64 * 64)
+            elif kind == "bn":
+                for po in (op[11], op[12]):
+                    if po >= 0:
+                        done_floats = max(done_floats, po // 4 + (t.params[self._pinv(bw, po)].numel() + 63) // 64 * 64)
             if kind == "din":
                 _, gy, gx, lo, lvl, n_in, n_out, book, side, flags, p_w, pt, flg, res, tmp = op
                 g = books[book][side]
@@ -565,6 +609,15 @@ class _Pass(object):
                 off += 176
         if off:
             check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, stream()))
+        if nseg > 1:                      # the last piece's gradients
+            pairs = []
+            while next_inv < len(inv):
+                o, i = inv[next_inv]
+                pairs.append((t.params[i], gparams[o:o + t.params[i].numel()].view_as(t.params[i])))
+                next_inv += 1
+            if pairs:
+                lo = pairs[0][1].data_ptr() - pbase
+                on_grads_ready(nseg - 1, nseg, gparams[lo // 4:bw["ptotal"]], pairs)
         pgrad = [None] * len(t.params)
         for i, o in bw["poff"].items():
             p = t.params[i]

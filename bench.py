@@ -169,6 +169,7 @@ class Workload(object):
             self.targets.append([torch.as_tensor(S.make_gt_boxes(N_GT, 7000 + sid)).to(dev)
                                  for sid in mine[b * SCENES_PER_STEP:(b + 1) * SCENES_PER_STEP]])
         self.label_generation = os.environ.get("AABR_BENCH_LABELS", "1") != "0"
+        self.grad_buckets = int(os.environ.get("AABR_BENCH_GRAD_BUCKETS", "4"))
         self.last = None
         self.side = torch.cuda.Stream(device=dev)
         self.lab = torch.cuda.Stream(device=dev)
@@ -248,9 +249,18 @@ class Workload(object):
 
     def step(self, i):
         self.flat.zero_grad()
-        if self.world > 1:
-            # one flat all-reduce (RCCL over xGMI), launched asynchronously right after backward; the proposal stage
-            # (top-k, decode, NMS: no dependence on the gradients) runs while it is in flight; the update waits for it
+        if self.world > 1 and self.grad_buckets > 1:
+            # bucketed gradient all-reduce (RCCL over xGMI): the compiled backward hands its gradient buffer over in
+            # `grad_buckets` slices as they become final; each slice's all-reduce starts at once, in place, and runs
+            # under the rest of the backward pass and the proposal stage; the update waits for all of them
+            from sparseconvnet import planExecutor
+            planExecutor.grad_segments = self.grad_buckets
+            self.flat.begin_bucketed()
+            self.forward_backward(i)
+            self.flat.finish_bucketed(1e-5, self.world)
+        elif self.world > 1:
+            # one flat all-reduce, launched asynchronously right after backward; the proposal stage (top-k, decode, NMS:
+            # no dependence on the gradients) runs while it is in flight; the update waits for it
             self.forward_backward(i, after_backward=self.flat.start_allreduce)
             self.flat.finish_update(1e-5, self.world)
         else:
@@ -714,6 +724,7 @@ def main():
                                        allreduce_wait_ms_p50=round(_pct(wl.flat.wait_ms, 0.5), 3) if wl.flat.wait_ms
                                        else None,
                                        allreduce_bytes=int(wl.flat.flat_grad.numel() * wl.flat.flat_grad.element_size()),
+                                       grad_buckets=getattr(wl.flat, "bucket_stats", None),
                                        rank_ms_per_step_min=tinfo.get("rank_ms_per_step_min"),
                                        rank_ms_per_step_max=tinfo.get("rank_ms_per_step_max"))
         if el < MIN_TIMED_S:

@@ -223,6 +223,9 @@ def test_bench_gpus2_rehearsal_on_one_gpu():
     d = out["distributed"]
     assert d["backend"] == "gloo" and d["world_size"] == 2 and d["allreduce_bytes"] > 80e6
     assert d["allreduce_wait_ms_p50"] is not None and d["rank_ms_per_step_min"] <= d["rank_ms_per_step_max"]
+    # the gradient all-reduce runs in buckets, all but the last two launched while backward is still running
+    gb = d["grad_buckets"]
+    assert gb["buckets"] == 5 and gb["launched_during_backward"] == 3 and gb["bytes"] > 70e6
     assert abs(d["rank_ms_per_step_max"] - out["ms_per_step"]) < 1e-6
     t = out["timing"]
     assert out["steps"] == 3 and t["prewarm_steps"] % 5 == 0 and t["prewarm_steps"] >= 10
@@ -446,3 +449,57 @@ def test_fpn_compiled_graph_with_partial_output_gradients():
     assert nz_a == nz_b and 10 < len(nz_b) < len(list(net.parameters()))
     for n in nz_a:
         assert float((ga[n] - gb[n]).abs().max()) <= 1e-6 * float(ga[n].abs().max()), n
+
+
+def test_bucketed_gradient_allreduce_equals_flat_update():
+    """dp.FlatParams.begin_bucketed / finish_bucketed (the compiled backward hands its gradient buffer over in
+    slices, each all-reduced in place while backward runs: planExecutor.on_grads_ready) must leave the parameters
+    bit-equal to the flat path (gradients packed after backward, one all-reduce, one update).  One rank, gloo: the
+    collective is the identity, what is compared is which gradient reaches which parameter."""
+    import torch.distributed as dist
+    import dp
+    from sparseconvnet import planExecutor
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500))
+    try:
+        torch.manual_seed(11)
+        net = _fpn().to(DEV)
+        net.compiled_graph = True
+        head = torch.nn.Linear(128, 4).to(DEV)
+        flat = dp.FlatParams([net, head])
+        locs, feats = S.make_batch(2, 15000, 77, 20)
+        l, f = _t(locs), _t(feats)
+        start = flat.flat.clone()
+
+        def run(bucketed):
+            flat.flat.copy_(start)
+            for b in net.buffers():
+                if b.dtype.is_floating_point:
+                    b.zero_() if "mean" in str(b.shape) else None
+            flat.zero_grad()
+            if bucketed:
+                planExecutor.grad_segments = 4
+                flat.begin_bucketed()
+            rpn, _ = net([l, f])
+            loss = sum(head(m.features).square().mean() for m in rpn)
+            loss.backward()
+            if bucketed:
+                n = flat.finish_bucketed(0.5, 1)
+                planExecutor.grad_segments = 0
+                return n
+            flat.sgd_step(0.5, 1)
+            return 0
+
+        state = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+        run(False)
+        want = flat.flat.clone()
+        net.load_state_dict(state, strict=False)
+        n = run(True)
+        assert n == 5 and flat.bucket_stats["launched_during_backward"] == 3
+        assert flat.bucket_stats["bytes"] >= 4 * sum(p.numel() for p in flat.params if p.grad is not None)
+        assert torch.equal(flat.flat, want)
+        assert planExecutor.on_grads_ready is None
+    finally:
+        if own_group:
+            dist.destroy_process_group()
