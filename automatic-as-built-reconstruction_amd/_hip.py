@@ -47,6 +47,15 @@ _SIGS = {
     "aabr_conv_forward_wide_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "aabr_conv_forward_wide_res": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp,
                                              _vp]),
+    "aabr_conv_wide_stats_doubles": (C.c_int64, [_i64, _i32, _i32]),
+    "aabr_conv_forward_wide_stats": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp,
+                                               _vp, _vp]),
+    "aabr_conv_forward_wide_bf16_stats": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp,
+                                                    _vp, _vp]),
+    "aabr_bn_forward_parts": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp,
+                                        _i32, _vp, _vp]),
+    "aabr_bn_forward_parts_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp,
+                                             _i32, _vp, _vp]),
     "aabr_rs_words": (C.c_int64, [_i64, _i32, _i32]),
     "aabr_build_rs": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "aabr_conv_rs_unit_rows": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),

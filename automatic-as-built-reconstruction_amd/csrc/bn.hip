@@ -273,6 +273,172 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const T *__restrict__ x, 
   st4(d_in, i, r);
 }
 
+
+// ---- small maps: ONE launch -------------------------------------------------------------------------------------
+// A map of <= 8192 (backward: 6144) rows is a few MB: the three launches above cost it ~4 us each of pure
+// launch/drain latency (profiles/r02_bn_bench.txt: 27 us forward / 68 us backward regardless of size below 22k rows).
+// Here a workgroup owns FOUR planes (one 16-byte column of every row) and all rows: each thread keeps its <= 16 rows'
+// values in registers, the statistics are reduced inside the workgroup (shuffle butterfly, then the 8 waves in order:
+// fixed order => bit-reproducible), every thread forms the coefficients from the same sums and applies them to the
+// registers -- one read of x (and d_out), one write, no partials in memory.  Same formulas, float for float, as
+// k_bn_*_finalize / k_bn_*_apply; only the order of the fp64 additions differs from the three-launch path.
+constexpr int kSmallThreads = 512, kSmallRows = 16; // forward: x in registers (64 VGPRs)
+constexpr int kSmallThreadsB = 512, kSmallRowsB = 12; // backward: x and d_out in registers (239 VGPRs, nothing spilled; 16 rows spill)
+
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// sums over the workgroup of a[4], b[4]; every thread returns with the totals
+template <int NT>
+__device__ inline void block_sum8(double (&a)[4], double (&b)[4]) {
+  __shared__ double red[NT / 64][8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a[j] = wave_sum_f64(a[j]); b[j] = wave_sum_f64(b[j]); }
+  if (lane == 0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[wave][j] = a[j]; red[wave][4 + j] = b[j]; }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double s = 0.0, t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { s += red[w][j]; t += red[w][4 + j]; }
+    a[j] = s; b[j] = t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads) void k_bn_fwd_small(const T *__restrict__ x, T *__restrict__ y, int rows,
+                                                                int planes, float *save_mean, float *save_invstd,
+                                                                float *running_mean, float *running_var,
+                                                                const float *weight, const float *bias, float eps,
+                                                                float momentum, float leak) {
+  const int p0 = blockIdx.x * 4;
+  float4 xv[kSmallRows];
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < kSmallRows; ++j) {
+    const int r = (int)threadIdx.x + j * kSmallThreads;
+    if (r < rows) {
+      xv[j] = ld4(x, (int64_t)r * planes + p0);
+      a[0] += (double)xv[j].x; b[0] += (double)xv[j].x * (double)xv[j].x;
+      a[1] += (double)xv[j].y; b[1] += (double)xv[j].y * (double)xv[j].y;
+      a[2] += (double)xv[j].z; b[2] += (double)xv[j].z * (double)xv[j].z;
+      a[3] += (double)xv[j].w; b[3] += (double)xv[j].w * (double)xv[j].w;
+    }
+  }
+  block_sum8<kSmallThreads>(a, b);
+  float w[4], c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { // k_bn_fwd_finalize, train branch
+    const int p = p0 + j;
+    const double m = a[j] / (double)rows;
+    const double var_n = b[j] - m * m * (double)rows;
+    const float mean = (float)m;
+    const float invstd = powf((float)(var_n / (double)rows) + eps, -0.5f);
+    if (threadIdx.x == 0) {
+      running_mean[p] = momentum * running_mean[p] + (1 - momentum) * mean;
+      running_var[p] = momentum * running_var[p] + (1 - momentum) * (float)(var_n / (double)(rows - 1));
+      save_mean[p] = mean;
+      save_invstd[p] = invstd;
+    }
+    w[j] = invstd * (weight ? weight[p] : 1.0f);
+    c[j] = -mean * w[j] + (bias ? bias[p] : 0.0f);
+  }
+#pragma unroll
+  for (int j = 0; j < kSmallRows; ++j) {
+    const int r = (int)threadIdx.x + j * kSmallThreads;
+    if (r < rows) {
+      float4 o;
+      o.x = xv[j].x * w[0] + c[0]; o.y = xv[j].y * w[1] + c[1]; o.z = xv[j].z * w[2] + c[2]; o.w = xv[j].w * w[3] + c[3];
+      o.x = o.x > 0.0f ? o.x : o.x * leak; o.y = o.y > 0.0f ? o.y : o.y * leak;
+      o.z = o.z > 0.0f ? o.z : o.z * leak; o.w = o.w > 0.0f ? o.w : o.w * leak;
+      st4(y, (int64_t)r * planes + p0, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSmallThreadsB) void k_bn_bwd_small(const T *__restrict__ x, T *__restrict__ d_in,
+                                                                const T *__restrict__ out, const T *__restrict__ d_out,
+                                                                int rows, int planes, const float *__restrict__ mean,
+                                                                const float *__restrict__ save_invstd,
+                                                                const float *weight, const float *bias, float *d_weight,
+                                                                float *d_bias, float leak, int recompute,
+                                                                const T *__restrict__ res) {
+  const int p0 = blockIdx.x * 4;
+  float mu[4], is[4], sw[4], bc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = mean[p0 + j];
+    is[j] = save_invstd[p0 + j];
+    sw[j] = is[j] * (weight ? weight[p0 + j] : 1.0f);
+    bc[j] = -mu[j] * sw[j] + (bias ? bias[p0 + j] : 0.0f);
+  }
+  float xv[kSmallRowsB][4], dv[kSmallRowsB][4];
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < kSmallRowsB; ++j) {
+    const int r = (int)threadIdx.x + j * kSmallThreadsB;
+    if (r < rows) {
+      const int64_t i = (int64_t)r * planes + p0;
+      const float4 t = ld4(x, i), d = ld4(d_out, i);
+      float ov[4];
+      xv[j][0] = t.x; xv[j][1] = t.y; xv[j][2] = t.z; xv[j][3] = t.w;
+      dv[j][0] = d.x; dv[j][1] = d.y; dv[j][2] = d.z; dv[j][3] = d.w;
+      if (recompute) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ov[q] = xv[j][q] * sw[q] + bc[q];
+      } else {
+        const float4 o = ld4(out, i);
+        ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        dv[j][q] = (ov[q] > 0.0f) ? dv[j][q] : dv[j][q] * leak;
+        a[q] += (double)dv[j][q];
+        b[q] += (double)(xv[j][q] - mu[q]) * (double)dv[j][q];
+      }
+    }
+  }
+  block_sum8<kSmallThreadsB>(a, b);
+  float gm[4], kk[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { // k_bn_bwd_finalize
+    if (threadIdx.x == 0) {
+      if (d_bias) d_bias[p0 + j] = (float)a[j];
+      if (d_weight) d_weight[p0 + j] = (float)b[j] * is[j];
+    }
+    gm[j] = (float)(a[j] / (double)rows);
+    kk[j] = (float)b[j] * is[j] * is[j] / (float)rows;
+  }
+#pragma unroll
+  for (int j = 0; j < kSmallRowsB; ++j) {
+    const int r = (int)threadIdx.x + j * kSmallThreadsB;
+    if (r < rows) {
+      const int64_t i = (int64_t)r * planes + p0;
+      float4 o;
+      o.x = (dv[j][0] - gm[0] - (xv[j][0] - mu[0]) * kk[0]) * sw[0];
+      o.y = (dv[j][1] - gm[1] - (xv[j][1] - mu[1]) * kk[1]) * sw[1];
+      o.z = (dv[j][2] - gm[2] - (xv[j][2] - mu[2]) * kk[2]) * sw[2];
+      o.w = (dv[j][3] - gm[3] - (xv[j][3] - mu[3]) * kk[3]) * sw[3];
+      if (res) {
+        const float4 q = ld4(res, i);
+        o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+      }
+      st4(d_in, i, o);
+    }
+  }
+}
+
+static bool bn_small(int64_t rows, int planes, bool backward) {
+  const int64_t cap = backward ? (int64_t)kSmallThreadsB * kSmallRowsB : (int64_t)kSmallThreads * kSmallRows;
+  return rows > 1 && rows <= cap && (planes & 3) == 0 && knob(K_BN_SMALL) != 0;
+}
+
 static int bn_parts(int64_t rows, int planes, int vec) {
   int pv = planes / vec, tpr = pv < 256 ? pv : 256, rpi = 256 / tpr;
   int64_t want = ceil_div(rows, (int64_t)rpi * 4); // >= 4 rows per thread
@@ -291,17 +457,29 @@ extern "C" int64_t aabr_bn_scratch_floats(int planes) {
 template <typename T>
 static int bn_forward_t(const T *in, T *out, int64_t rows, int planes, float *save_mean, float *save_invstd,
                         float *running_mean, float *running_var, const float *weight, const float *bias,
-                        float eps, float momentum, int train, float leakiness, float *scratch, void *stream_) {
+                        float eps, float momentum, int train, float leakiness, float *scratch, void *stream_,
+                        const double *pre_part = nullptr, int pre_nparts = 0) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(rows >= 0 && planes > 0, "bad sizes");
   AABR_CHECK_ARG(save_mean && save_invstd && running_mean && running_var && scratch, "null pointer");
   AABR_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
   if (rows == 0) return AABR_OK; // reference: nActive == 0 leaves everything untouched
   AABR_CHECK_ARG(in && out, "null pointer");
-  double *part = reinterpret_cast<double *>(scratch);
+  if (train && !pre_part && bn_small(rows, planes, false) && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+    hipLaunchKernelGGL((k_bn_fwd_small<T>), dim3(planes / 4), dim3(kSmallThreads), 0, st, in, out, (int)rows, planes,
+                       save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, leakiness);
+    AABR_CHECK_LAUNCH();
+    return AABR_OK;
+  }
+  const double *part = reinterpret_cast<double *>(scratch);
   float *coef = scratch + (int64_t)kMaxParts * 2 * planes * 2;
   int nparts = 0;
-  if (train) {
+  if (train && pre_part) { // the statistics' partial sums came with the producing convolution's write-out
+    AABR_CHECK_ARG(pre_nparts > 0, "partial count");
+    part = pre_part;
+    nparts = pre_nparts;
+  } else if (train) {
+    double *part = reinterpret_cast<double *>(scratch);
     const bool v4 = (planes & 3) == 0 && ((uintptr_t)in & 15) == 0;
     nparts = bn_parts(rows, planes, v4 ? 4 : 1);
     if (v4)
@@ -347,6 +525,12 @@ static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int
   double *part = reinterpret_cast<double *>(scratch);
   float *coef = scratch + (int64_t)kMaxParts * 2 * planes * 2;
   const bool v4 = (planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)(recompute ? nullptr : out) | (uintptr_t)d_out) & 15) == 0;
+  if (v4 && bn_small(rows, planes, true) && (((uintptr_t)d_in | (uintptr_t)d_in_add) & 15) == 0) {
+    hipLaunchKernelGGL((k_bn_bwd_small<T>), dim3(planes / 4), dim3(kSmallThreadsB), 0, st, in, d_in, out, d_out, (int)rows,
+                       planes, save_mean, save_invstd, weight, bias, d_weight, d_bias, leakiness, recompute, d_in_add);
+    AABR_CHECK_LAUNCH();
+    return AABR_OK;
+  }
   int nparts = bn_parts(rows, planes, v4 ? 4 : 1);
   if (v4)
     hipLaunchKernelGGL((k_bn_partials<1, 4, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
@@ -374,6 +558,27 @@ extern "C" int aabr_bn_forward(const float *in, float *out, int64_t rows, int pl
                                float leakiness, float *scratch, void *stream_) {
   return bn_forward_t<float>(in, out, rows, planes, save_mean, save_invstd, running_mean, running_var, weight,
                              bias, eps, momentum, train, leakiness, scratch, stream_);
+}
+
+// forward with the training statistics' partial sums already formed (aabr_conv_forward_wide_stats: one [2][planes]
+// fp64 pair per output tile, in tile order): the statistics pass over `in` is skipped
+extern "C" int aabr_bn_forward_parts(const float *in, float *out, int64_t rows, int planes, float *save_mean,
+                                     float *save_invstd, float *running_mean, float *running_var, const float *weight,
+                                     const float *bias, float eps, float momentum, float leakiness, const double *parts,
+                                     int nparts, float *scratch, void *stream_) {
+  AABR_CHECK_ARG(parts && nparts > 0, "partials");
+  return bn_forward_t<float>(in, out, rows, planes, save_mean, save_invstd, running_mean, running_var, weight, bias,
+                             eps, momentum, 1, leakiness, scratch, stream_, parts, nparts);
+}
+extern "C" int aabr_bn_forward_parts_bf16(const uint16_t *in, uint16_t *out, int64_t rows, int planes, float *save_mean,
+                                          float *save_invstd, float *running_mean, float *running_var,
+                                          const float *weight, const float *bias, float eps, float momentum,
+                                          float leakiness, const double *parts, int nparts, float *scratch,
+                                          void *stream_) {
+  AABR_CHECK_ARG(parts && nparts > 0, "partials");
+  return bn_forward_t<__bf16>(reinterpret_cast<const __bf16 *>(in), reinterpret_cast<__bf16 *>(out), rows, planes,
+                              save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, 1,
+                              leakiness, scratch, stream_, parts, nparts);
 }
 
 extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, const float *d_out,

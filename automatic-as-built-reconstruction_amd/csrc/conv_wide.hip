@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
                                                     const float *__restrict__ bias, int kT2,
-                                                    const float *__restrict__ res) {
+                                                    const float *__restrict__ res, double *__restrict__ stats) {
   constexpr int RG = KG * 8;               // 16-byte granules per staged row
   constexpr int RF = KG * 32;              // floats per staged row
   constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
@@ -422,9 +422,14 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   }
   __syncthreads();
   const int nrows = (int)((V_out - row0) < kT2 ? (V_out - row0) : kT2);
+  // `stats`: the following BatchNorm's statistics from the values this tile writes (exactly the stored values: after
+  // bias / residual, after the bf16 rounding) -- per tile one [2][co] pair of fp64 column sums (x, x^2), combined by the
+  // BatchNorm's finalize in tile order, so the result does not depend on which workgroup ran when
+  constexpr int QW = 16 * NCB;             // 16-byte columns of the slab; 256 % QW == 0: a thread keeps its column
+  double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-  for (int i = threadIdx.x; i < nrows * 16 * NCB; i += 256) {
-    const int r = i / (16 * NCB), q = i % (16 * NCB);
+  for (int i = threadIdx.x; i < nrows * QW; i += 256) {
+    const int r = i / QW, q = i % QW;
     f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + r * WS + ((q ^ (r & 15)) << 2));
     if (bias) {
       const float *bb = bias + nb0 * 16 + q * 4;
@@ -437,8 +442,28 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
     if (BF) {
       bf16x4w o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
       *reinterpret_cast<bf16x4w *>(reinterpret_cast<__bf16 *>(out) + (row0 + r) * co + nb0 * 16 + q * 4) = o;
+      if (stats) { v[0] = (float)o[0]; v[1] = (float)o[1]; v[2] = (float)o[2]; v[3] = (float)o[3]; }
     } else {
       *reinterpret_cast<f32x4 *>(out + (row0 + r) * co + nb0 * 16 + q * 4) = v;
+    }
+    if (stats) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sa[j] += (double)v[j]; sb[j] += (double)v[j] * (double)v[j]; }
+    }
+  }
+  if (stats) {
+    __syncthreads();                       // every read of the tile is done: its LDS holds the partial sums now
+    double *red = reinterpret_cast<double *>(smem); // [256][8] = 16 KiB <= (kT2 + 1) * WS * 4 for kT2 >= 64
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = sa[j]; red[threadIdx.x * 8 + 4 + j] = sb[j]; }
+    __syncthreads();
+    if (threadIdx.x < 64 * NCB) {
+      const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int t = 0; t < 256 / QW; ++t) { a += red[(t * QW + q) * 8 + j]; b += red[(t * QW + q) * 8 + 4 + j]; }
+      stats[(tile * 2 + 0) * co + nb0 * 16 + threadIdx.x] = a;
+      stats[(tile * 2 + 1) * co + nb0 * 16 + threadIdx.x] = b;
     }
   }
 }
@@ -510,12 +535,31 @@ extern "C" int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t r
                                     flags, wpack, nullptr, stream_);
 }
 
+extern "C" int64_t aabr_conv_wide_stats_doubles(int64_t V_out, int tile_rows, int n_out) {
+  if (V_out <= 0 || tile_rows <= 0 || n_out <= 0) return 0;
+  return ((V_out + tile_rows - 1) / tile_rows) * 2 * n_out;
+}
+
+extern "C" int aabr_conv_forward_wide_stats(const float *in_feats, int n_in, int64_t rows_in, float *out_feats,
+                                            int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                            const float *bias, int flags, const float *wpack, const float *residual,
+                                            double *stats, void *stream_);
+
 extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64_t rows_in, float *out_feats,
                                           int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
                                           const float *bias, int flags, const float *wpack, const float *residual,
                                           void *stream_) {
+  return aabr_conv_forward_wide_stats(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias,
+                                      flags, wpack, residual, nullptr, stream_);
+}
+
+extern "C" int aabr_conv_forward_wide_stats(const float *in_feats, int n_in, int64_t rows_in, float *out_feats,
+                                            int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                            const float *bias, int flags, const float *wpack, const float *residual,
+                                            double *stats, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(((uintptr_t)residual & 15) == 0, "residual must be 16-byte aligned");
+  AABR_CHECK_ARG(!stats || (tile_rows >= 64 && ((uintptr_t)stats & 7) == 0), "statistics need tiles of >= 64 rows");
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 31) == 0 && (n_out & 63) == 0, "plane counts: n_in % 32, n_out % 64");
   AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
   AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
@@ -556,7 +600,7 @@ extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64
 #define AABR_WIDE_CS_N(KG, D, NB)                                                                         \
   AABR_LAUNCH_WIDE((k_conv_cs<KG, D, NB>), "k_conv_cs<" #KG "," #D "," #NB ">",                           \
                    (size_t)((tile_rows + 1) * kWS + NB * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes,   \
-                   out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows, residual)
+                   out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows, residual, stats)
 #define AABR_WIDE_CS(KG, D)                                                                               \
   do {                                                                                                    \
     if (nbuf == 1) AABR_WIDE_CS_N(KG, D, 1); else AABR_WIDE_CS_N(KG, D, 2);                               \
@@ -624,10 +668,24 @@ extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_i
   return (((V_out + T - 1) / T) * (n_out / (64 * ncb)) >= 320) ? T : 0;
 }
 
+extern "C" int aabr_conv_forward_wide_bf16_stats(const uint16_t *in_feats, int n_in, int64_t rows_in,
+                                                 uint16_t *out_feats, int n_out, int64_t V_out, const int32_t *blocks,
+                                                 int tile_rows, int vol, const float *bias, int flags,
+                                                 const uint16_t *wpack, double *stats, void *stream_);
+
 extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
                                            int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
                                            const float *bias, int flags, const uint16_t *wpack, void *stream_) {
+  return aabr_conv_forward_wide_bf16_stats(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias,
+                                           flags, wpack, nullptr, stream_);
+}
+
+extern "C" int aabr_conv_forward_wide_bf16_stats(const uint16_t *in_feats, int n_in, int64_t rows_in,
+                                                 uint16_t *out_feats, int n_out, int64_t V_out, const int32_t *blocks,
+                                                 int tile_rows, int vol, const float *bias, int flags,
+                                                 const uint16_t *wpack, double *stats, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(!stats || (tile_rows >= 64 && ((uintptr_t)stats & 7) == 0), "statistics need tiles of >= 64 rows");
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 63) == 0 && (n_out & 63) == 0, "plane counts: n_in % 64, n_out % 64");
   AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
   AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
@@ -662,7 +720,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
     hipLaunchKernelGGL((k_conv_cs<KG, D, NB, true, NCB, kBfSets>), grid, dim3(256),                                \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr);                                                         \
+                       tile_rows, (const float *)nullptr, stats);                                                      \
   } while (0)
 #define AABR_WIDE_BF_S(KG, NB, NCB, NS)                                                                                  \
   do {                                                                                                             \
@@ -676,7 +734,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
     hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS>), grid, dim3(256),                                         \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr);                                                         \
+                       tile_rows, (const float *)nullptr, stats);                                                      \
   } while (0)
 #define AABR_WIDE_BF_K(KG)                                                                                         \
   do {                                                                                                             \

@@ -189,12 +189,12 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
                                   (float *)p[5], st);
       break;
     case AABR_PLAN_CONV_WIDE:
-      rc = bf ? aabr_conv_forward_wide_bf16((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
-                                            o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4],
-                                            o.i32[3], (const uint16_t *)p[5], st)
-              : aabr_conv_forward_wide_res((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
-                                           (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
-                                           (const float *)p[5], (const float *)p[3], st);
+      rc = bf ? aabr_conv_forward_wide_bf16_stats((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
+                                                  o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2],
+                                                  (const float *)p[4], o.i32[3], (const uint16_t *)p[5], (double *)p[6], st)
+              : aabr_conv_forward_wide_stats((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
+                                             (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
+                                             (const float *)p[5], (const float *)p[3], (double *)p[6], st);
       break;
     case AABR_PLAN_CONV_RS:
       AABR_CHECK_ARG(bf, "AABR_PLAN_CONV_RS exists for bf16 storage only");
@@ -211,6 +211,18 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
                                           (float *)p[5], st);
       break;
     case AABR_PLAN_BN_FWD:
+      if (p[9]) { // the statistics' partial sums came with the producing convolution (p9, i32[2] of them)
+        AABR_CHECK_ARG(o.i32[1], "precomputed statistics in training mode only");
+        rc = bf ? aabr_bn_forward_parts_bf16((const uint16_t *)p[0], (uint16_t *)p[1], o.i64[0], o.i32[0], (float *)p[2],
+                                             (float *)p[3], (float *)p[4], (float *)p[5], (const float *)p[6],
+                                             (const float *)p[7], o.f32[0], o.f32[1], o.f32[2], (const double *)p[9],
+                                             o.i32[2], (float *)p[8], st)
+                : aabr_bn_forward_parts((const float *)p[0], (float *)p[1], o.i64[0], o.i32[0], (float *)p[2],
+                                        (float *)p[3], (float *)p[4], (float *)p[5], (const float *)p[6],
+                                        (const float *)p[7], o.f32[0], o.f32[1], o.f32[2], (const double *)p[9], o.i32[2],
+                                        (float *)p[8], st);
+        break;
+      }
       rc = bf ? aabr_bn_forward_bf16((const uint16_t *)p[0], (uint16_t *)p[1], o.i64[0], o.i32[0], (float *)p[2],
                                      (float *)p[3], (float *)p[4], (float *)p[5], (const float *)p[6],
                                      (const float *)p[7], o.f32[0], o.f32[1], o.i32[1], o.f32[2], (float *)p[8], st)

@@ -170,7 +170,15 @@ import struct as _struct
 _GEOM = _struct.Struct("<ii10i4q8Q")
 assert _GEOM.size == 144
 G_SUBM, G_TABLES, G_TILE, G_WIDE, G_PAIRS, G_RS, G_SITES, G_SOFF = 1, 2, 3, 4, 5, 6, 7, 8
-_geom_rec = None      # None: launch immediately; else [bytearray, count, keep-alive list]
+import threading as _threading
+
+
+class _GeomTLS(_threading.local):
+    rec = None        # None: launch immediately; else [bytearray, count, keep-alive list] -- per THREAD: a prefetch
+                      # thread records the next batch's builders while the training thread runs its own
+
+
+_gtls = _GeomTLS()
 geom_stats = {"plans": 0, "ops": 0}
 
 
@@ -183,7 +191,7 @@ def _geom(kind, i32=(), i64=(), ps=()):
     i32 = list(i32) + [0] * (10 - len(i32))
     i64 = list(i64) + [0] * (4 - len(i64))
     ps = list(ps) + [0] * (8 - len(ps))
-    r = _geom_rec
+    r = _gtls.rec
     if r is not None:
         r[0] += _GEOM.pack(kind, 0, *i32, *i64, *ps)
         r[1] += 1
@@ -194,7 +202,7 @@ def _geom(kind, i32=(), i64=(), ps=()):
 
 def flush_geom():
     """hand the records collected so far to the library (call before anything reads what they produce)"""
-    r = _geom_rec
+    r = _gtls.rec
     if r is None or r[1] == 0:
         return
     buf = (C.c_char * len(r[0])).from_buffer(r[0])
@@ -212,27 +220,25 @@ def flush_geom():
 
 class geom_plan(object):
     def __enter__(self):
-        global _geom_rec
-        self.outer = _geom_rec
-        if _geom_rec is None:
-            _geom_rec = [bytearray(), 0, []]
+        self.outer = _gtls.rec
+        if self.outer is None:
+            _gtls.rec = [bytearray(), 0, []]
         return self
 
     def __exit__(self, *exc):
-        global _geom_rec
         if self.outer is None:
             try:
                 if exc[0] is None:
                     flush_geom()
             finally:
-                _geom_rec = None
+                _gtls.rec = None
         return False
 
 
 def _keep(*ts):
     """scratch tensors of recorded launches stay alive until the plan has been handed over"""
-    if _geom_rec is not None:
-        _geom_rec[2].extend(ts)
+    if _gtls.rec is not None:
+        _gtls.rec[2].extend(ts)
 
 
 class _Grid(object):

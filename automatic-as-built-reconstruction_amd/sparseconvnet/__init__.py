@@ -20,4 +20,4 @@ from .submanifoldConvolution import SubmanifoldConvolution, ValidConvolution  # 
 from .tables import JoinTable, AddTable, ConcatTable  # noqa: E402
 from .utils import add_feature_planes, concatenate_feature_planes, toLongTensor, optionalTensor, \
     optionalTensorReturn  # noqa: E402
-from .fpn_net import FPN_Net  # noqa: E402
+from .fpn_net import FPN_Net, GeometryPrefetcher  # noqa: E402

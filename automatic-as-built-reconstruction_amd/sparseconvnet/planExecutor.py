@@ -56,6 +56,9 @@ lateral_side_stream = os.environ.get("AABR_PLAN_LATERAL_SIDE", "0") != "0"
 # a residual / lateral add whose second operand comes straight from a wide-kernel convolution rides in that
 # convolution's write-out (forward only; the backward list is unchanged)
 fuse_adds = os.environ.get("AABR_PLAN_FUSE_ADDS", "1") != "0"
+# a training-mode BatchNorm right behind a wide-kernel convolution takes its statistics' partial sums from that
+# convolution's write-out (aabr_conv_forward_wide_stats -> aabr_bn_forward_parts): one pass over the matrix less
+conv_bn_stats = os.environ.get("AABR_PLAN_CONV_BN_STATS", "1") != "0"
 
 
 # Data-parallel hook (extension; the reference wraps the model in DistributedDataParallel, whose bucketed all-reduce
@@ -97,6 +100,7 @@ class _Template(object):
         self.params, self.pidx = [], {}
         self.stat_floats = 0
         self.bn_floats = 0
+        self.max_planes = 1
         self.hidden = []                     # (level, planes) of every convolution output (hidden-state counter)
         self.macs = []                       # (book, weight) per convolution, in order
         self.bns = []
@@ -250,6 +254,7 @@ class _Template(object):
             self._param(b)
         self.bns.append(m)
         self.bn_floats = max(self.bn_floats, int(self.lib.aabr_bn_scratch_floats(planes)))
+        self.max_planes = max(self.max_planes, planes)
         self.fops.append(("bn", x[0], y, lvl, planes, F_BF16 if dt == BF16 else 0, 1 if m.training else 0,
                           float(m.eps), float(m.momentum), float(m.leakiness), st, _dp(m.running_mean),
                           _dp(m.running_var), _dp(w), _dp(b), m))
@@ -433,6 +438,7 @@ class _Pass(object):
     def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf,
                     xf=0, res=0):
         """the record of the launch SCN._conv_fwd makes for a prepacked weight; returns the new write offset"""
+        self._lw = 0      # tile rows when the record is a K_WIDE one (its write-out can form BatchNorm statistics)
         if rows_out == 0:
             return off
         U = SCN.rs_unit_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf) if not res else 0
@@ -442,6 +448,7 @@ class _Pass(object):
             return off + 176
         T = self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf)
         assert T or not res
+        self._lw = T
         if T:
             pack(buf, off, K_WIDE, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0,
                  0.0, rows_in, rows_out, 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), res, 0, p_pack, 0, 0, 0, 0,
@@ -465,24 +472,44 @@ class _Pass(object):
         books = self.books
         fbufs = t.fbufs
         fuse, skip = t.fuse, set()
+        # BatchNorm statistics from the producing convolution's write-out: a training-mode BatchNorm that is the NEXT
+        # record on its stream after the k_conv_cs launch that wrote its input gets the per-tile partial sums from
+        # that launch (record p6 -> BatchNorm p9) and skips its own statistics pass over the matrix
+        last = {0: None, F_SIDE: None}     # per stream: (buffer index written, record offset, tile rows, planes)
+        cstat = {}
         for op, xf in t.emit:
             kind = op[0]
+            sk = xf & F_SIDE
             if kind == "conv":
                 x, y, lvl, lo, n_in, n_out, book, side, p_w, pf = op[1:11]
                 fz = fuse.get(id(op))
                 if fz is not None and V[lo] and self.wide_rows(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
                     add_op, other = fz           # out = conv + other, written where the add would have written
                     skip.add(id(add_op))
+                    off0 = off
                     off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[add_op[3]], V[lo], n_out,
                                            books[book][side], p_w, pf, 0, False, xf, A[other])
+                    last[sk] = (add_op[3], off0, self._lw, n_out) if self._lw >= 64 else None
                 else:
+                    off0 = off
                     off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[y], V[lo], n_out, books[book][side],
                                            p_w, pf, 0, fbufs[x][2] == BF16, xf)
+                    last[sk] = (y, off0, self._lw, n_out) if self._lw >= 64 else None
+                continue
             elif kind == "bn":
                 _, x, y, lvl, planes, flg, train, eps, mom, leak, st, p_rm, p_rv, p_w, p_b, m = op
                 if V[lvl]:
-                    pack(buf, off, K_BNF, flg | xf, planes, train, 0, 0, 0, 0, eps, mom, leak, 0.0, V[lvl], 0, 0, 0,
-                         A[x], A[y], sbase + st * 4, sbase + (st + planes) * 4, p_rm, p_rv, p_w, p_b, bnws, 0, 0, 0)
+                    parts, nparts, lw = 0, 0, last[sk]
+                    if conv_bn_stats and train and lw is not None and lw[0] == x and lw[3] == planes:
+                        nparts = (V[lvl] + lw[2] - 1) // lw[2]
+                        ws = cstat.get(sk)
+                        if ws is None:   # one buffer per stream: written by the convolution, read by the very next record
+                            ws = cstat[sk] = _hip.workspace("conv_stats%d" % sk, (max(V) // 64 + 1) * 2 * t.max_planes,
+                                                            torch.float64, self.dev).data_ptr()
+                        parts = ws
+                        struct.pack_into("<Q", buf, lw[1] + 128, ws)          # the convolution record's p6
+                    pack(buf, off, K_BNF, flg | xf, planes, train, nparts, 0, 0, 0, eps, mom, leak, 0.0, V[lvl], 0, 0, 0,
+                         A[x], A[y], sbase + st * 4, sbase + (st + planes) * 4, p_rm, p_rv, p_w, p_b, bnws, parts, 0, 0)
                     off += 176
             elif kind == "add":
                 if id(op) in skip:
@@ -496,6 +523,7 @@ class _Pass(object):
                 pack(buf, off, K_CAST, flg | xf, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
                      A[x], A[y], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
                 off += 176
+            last[sk] = None
         if off:
             check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, stream()))
         res = []

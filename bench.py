@@ -171,9 +171,26 @@ class Workload(object):
         self.label_generation = os.environ.get("AABR_BENCH_LABELS", "1") != "0"
         self.grad_buckets = int(os.environ.get("AABR_BENCH_GRAD_BUCKETS", "4"))
         self.last = None
-        self.side = torch.cuda.Stream(device=dev)
-        self.lab = torch.cuda.Stream(device=dev)
+        self.marks = None            # tools/tools_step_timeline.py: [(name, host time, HIP event on the main stream)]
+        # AABR_BENCH_SIDE_PRIORITY=1: higher queue priority for the proposal / label streams (chains of small launches
+        # beside the backward pass's long workgroups); measured 14.47 -> 14.78 ms, off
+        prio = -1 if os.environ.get("AABR_BENCH_SIDE_PRIORITY", "0") != "0" else 0
+        self.side = torch.cuda.Stream(device=dev, priority=prio)
+        self.lab = torch.cuda.Stream(device=dev, priority=prio)
         self.prefetch_geometry = os.environ.get("AABR_BENCH_PREFETCH", "1") != "0"
+        # AABR_BENCH_PREFETCH_THREAD=1: the next batch's geometry on a helper thread (sparseconvnet.GeometryPrefetcher)
+        # instead of on this thread between the forward and backward enqueues.  Measured (tools/tools_step_timeline.py,
+        # profiles/r03_step_timeline.txt): 14.4 -> 15.5 ms -- the step is bound by the main stream's kernels, this
+        # thread already enqueues the forward pass 5 ms ahead of the device, and the helper's interpreter time comes out
+        # of this thread's (one GIL); off by default
+        self.prefetch_thread = self.prefetch_geometry and os.environ.get("AABR_BENCH_PREFETCH_THREAD", "0") != "0"
+
+    def _mark(self, name):
+        if self.marks is not None:
+            import time
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.marks.append((name, time.perf_counter(), ev))
 
     def head_loss(self, rpn_maps):
         """The shared RPN head over the rows of all six maps in one call (the reference applies the same head map
@@ -195,7 +212,17 @@ class Workload(object):
         if self.label_generation:
             ev_start = torch.cuda.Event()
             ev_start.record()          # the main stream is here behind everything the previous step left on the side stream
+        threaded = proposals and self.prefetch_thread
+        self._mark("step start")
+        if threaded:
+            self.net.prefetcher().wait()       # this batch's geometry has been built (by the previous step)
         rpn_maps, _ = self.net([locs, feats])
+        self._mark("forward enqueued")
+        if threaded:
+            # the NEXT batch's geometry (voxel grid, strided grids, rule tables, block streams: coordinates only) is built
+            # by the helper thread on its own stream while this batch trains -- a data-loader-style prefetch; every step
+            # still builds one batch's geometry from scratch, one step ahead
+            self.net.prefetcher().submit(self.batches[(i + 1) % len(self.batches)])
         labels = ev_lab = None
         if self.label_generation:
             # RPN label generation (rpn/loss_3d.py:91-96): per scene the criterion-6 IoUs of its ground-truth boxes
@@ -211,7 +238,9 @@ class Workload(object):
                                                     batch_size=SCENES_PER_STEP)
                 ev_lab = torch.cuda.Event()
                 ev_lab.record()
+        self._mark("labels enqueued")
         loss, objs, regs = self.head_loss(rpn_maps)
+        self._mark("head + loss enqueued")
         if ev_lab is not None:
             torch.cuda.current_stream().wait_event(ev_lab)
         # The proposal stage reads only forward results.  It is a chain of small launches (one-workgroup NMS scan,
@@ -220,18 +249,21 @@ class Workload(object):
         # reads wait for the side stream only.
         ev_fwd = torch.cuda.Event()
         ev_fwd.record()
-        early = proposals and self.prefetch_geometry and os.environ.get("AABR_BENCH_PREFETCH_EARLY", "1") == "1"
+        early = (proposals and self.prefetch_geometry and not threaded
+                 and os.environ.get("AABR_BENCH_PREFETCH_EARLY", "1") == "1")
         if early:
             with torch.no_grad():
                 self.net.prepare(self.batches[(i + 1) % len(self.batches)], self.side)
+        self._mark("geometry prefetch (inline) done")
         loss.backward()
+        self._mark("backward enqueued")
         feats.grad = None
         if after_backward is not None:
             after_backward()      # N > 1: the gradient all-reduce starts here and runs under the proposal stage
         props = None
         if proposals:
             main = torch.cuda.current_stream()
-            if self.prefetch_geometry and not early:
+            if self.prefetch_geometry and not early and not threaded:
                 # the NEXT batch's geometry (voxel grid, strided grids, rule tables, block streams: coordinates only)
                 # is built on the side stream while this batch's backward runs -- a data-loader-style prefetch; every
                 # step still builds its geometry from scratch, one step ahead
@@ -243,6 +275,7 @@ class Workload(object):
                                                self.base, self.strides, float(VOXEL_SCALE), 2000, 1000, 0.5, (0.3, 0.3),
                                                batch_size=SCENES_PER_STEP,
                                                batched=os.environ.get("AABR_BENCH_BATCHED_PROPOSALS", "0") != "0")
+            self._mark("proposals read back")
             main.wait_stream(self.side)
         self.last = (rpn_maps, props, labels)
         return loss
@@ -266,6 +299,7 @@ class Workload(object):
         else:
             self.forward_backward(i)
             self.flat.sgd_step(1e-5, 1)
+            self._mark("update enqueued")
 
 
 # ------------------------------------------------------------------------------------------------ measurement

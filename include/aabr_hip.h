@@ -207,6 +207,30 @@ int aabr_conv_forward_wide(const float *in_feats, int n_in, int64_t rows_in, flo
 int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
                                int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
                                int flags, const float *wpack, const float *residual, void *stream);
+/* the same, and the write-out also forms the TRAINING STATISTICS of the BatchNormalization that reads this output
+ * (replaces the statistics loop of SCN/CPU/BatchNormalization.cpp:20-32 / the first reduction of
+ * SCN/CUDA/BatchNormalization.cu:14-72 -- one read pass over the feature matrix less): per output tile one
+ * [2][n_out] pair of fp64 column sums (sum x, sum x^2) of exactly the values stored (after bias / residual, after the
+ * bf16 rounding), at stats[tile * 2 * n_out ...]; aabr_conv_wide_stats_doubles() doubles, tile_rows >= 64.  Hand
+ * them to aabr_bn_forward_parts with nparts = ceil(V_out / tile_rows): it combines them in tile order, so the
+ * result is reproducible bit for bit.  stats == NULL: plain aabr_conv_forward_wide_res.                        */
+int64_t aabr_conv_wide_stats_doubles(int64_t V_out, int tile_rows, int n_out);
+int aabr_conv_forward_wide_stats(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
+                                 int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                                 int flags, const float *wpack, const float *residual, double *stats, void *stream);
+int aabr_conv_forward_wide_bf16_stats(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
+                                      int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                      const float *bias, int flags, const uint16_t *wpack, double *stats, void *stream);
+/* BatchNormalization forward in training mode with the statistics' partial sums given (layout above; any producer
+ * that writes [nparts][2][planes] fp64 sums of x and x^2 will do): everything else as aabr_bn_forward[_bf16].   */
+int aabr_bn_forward_parts(const float *in, float *out, int64_t rows, int planes, float *save_mean,
+                          float *save_invstd, float *running_mean, float *running_var, const float *weight,
+                          const float *bias, float eps, float momentum, float leakiness, const double *parts,
+                          int nparts, float *scratch, void *stream);
+int aabr_bn_forward_parts_bf16(const uint16_t *in, uint16_t *out, int64_t rows, int planes, float *save_mean,
+                               float *save_invstd, float *running_mean, float *running_var, const float *weight,
+                               const float *bias, float eps, float momentum, float leakiness, const double *parts,
+                               int nparts, float *scratch, void *stream);
 
 /* Name of the kernel instance (template arguments included) the last aabr_conv_forward[_bf16] /
  * aabr_conv_backward_weight[_bf16] call on this thread dispatched -- measurement provenance only.   */
@@ -357,13 +381,14 @@ int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int64_t rows_i
  * record's fields in the order given here -- nothing is computed differently.
  *   kind AABR_PLAN_CONV       aabr_conv_forward[_bf16](p0 in, i32[0] n_in, i64[0] rows_in, p1 out, i32[1] n_out,
  *                             i64[1] V_out, p2 blocks, i32[2] vol, p3 W, p4 bias, i32[3] flags, p5 wpack)
- *        AABR_PLAN_CONV_WIDE  aabr_conv_forward_wide_res(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
- *                             i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual)
+ *        AABR_PLAN_CONV_WIDE  aabr_conv_forward_wide_stats(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
+ *                             i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual, p6 stats)
  *        AABR_PLAN_CONV_DW    aabr_conv_backward_weight[_bf16](p0 in, i32[0] n_in, p1 d_out, i32[1] n_out,
  *                             i64[0] V_out, p2 pairs, i32[2] vol, i64[1] max_chunks, p3 dW, p4 d_bias, p5 scratch)
  *        AABR_PLAN_BN_FWD     aabr_bn_forward[_bf16](p0 in, p1 out, i64[0] rows, i32[0] planes, p2 save_mean,
  *                             p3 save_invstd, p4 running_mean, p5 running_var, p6 weight, p7 bias, f32[0] eps,
- *                             f32[1] momentum, i32[1] train, f32[2] leakiness, p8 scratch)
+ *                             f32[1] momentum, i32[1] train, f32[2] leakiness, p8 scratch); p9 != NULL:
+ *                             aabr_bn_forward_parts[_bf16](..., p9 parts, i32[2] nparts, p8 scratch)
  *        AABR_PLAN_BN_BWD     aabr_bn_backward[_bf16](p0 in, p1 d_in, p2 out, p3 d_out, i64[0] rows, i32[0] planes,
  *                             p4 save_mean, p5 save_invstd, p6 weight, p10 bias, p7 d_weight, p8 d_bias,
  *                             f32[2] leakiness, p9 scratch); fp32 with p11 != NULL: aabr_bn_backward_add(..., p11)

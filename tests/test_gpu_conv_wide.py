@@ -217,3 +217,85 @@ def test_wide_backward_pybind_api_without_prepack(force_wide, nIn, nOut):
     np.testing.assert_allclose(d_in.cpu().numpy(), want_in, rtol=1e-4, atol=2e-6 * np.abs(want_in).max() * nOut)
     np.testing.assert_allclose(d_w.cpu().numpy().reshape(27, nIn, nOut), want_w, rtol=1e-4,
                                atol=1e-5 * np.abs(want_w).max())
+
+
+@pytest.mark.parametrize("bf,nIn,nOut,npts,use_res", [(False, 64, 64, 3000, False), (False, 128, 128, 2500, True),
+                                                      (False, 32, 192, 700, False), (True, 64, 128, 2500, False),
+                                                      (True, 128, 64, 129, False)])
+def test_wide_write_out_statistics_feed_batchnorm(bf, nIn, nOut, npts, use_res):
+    """aabr_conv_forward_wide[_bf16]_stats: the per-tile fp64 column sums of the write-out equal the sums of the
+    STORED output (numpy fp64, same tile grouping: <= 1 ulp of fp64 apart), leave the output bits unchanged, and
+    aabr_bn_forward_parts fed with them reproduces aabr_bn_forward (which makes its own statistics pass) to fp32
+    rounding of the same statistics (SCN/CPU/BatchNormalization.cpp:20-48)."""
+    import _hip
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(nIn + 5 * nOut + npts)
+    coords, _ = _scene(rng, npts, (12, 11, 5), 2, 1)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    knob = "CONV_WIDE_BF16" if bf else "CONV_WIDE"
+    _hip.set_knob(knob, 1)
+    try:
+        T = (lib.aabr_conv_wide_tile_rows_bf16 if bf else lib.aabr_conv_wide_tile_rows)(nIn, nOut, V, V, vol)
+    finally:
+        _hip.set_knob(knob, None)
+    assert T >= 64
+    ntile = (V + T - 1) // T
+    assert lib.aabr_conv_wide_stats_doubles(V, T, nOut) == ntile * 2 * nOut
+    W = _t((rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32))
+    blocks = ga.blocks_wide(T)
+    dt = torch.bfloat16 if bf else torch.float32
+    f = _t(rng.standard_normal((V, nIn)).astype(np.float32)).to(dt)
+    out, out0 = torch.empty((V, nOut), dtype=dt, device=DEV), torch.empty((V, nOut), dtype=dt, device=DEV)
+    stats = torch.full((ntile, 2, nOut), float("nan"), dtype=torch.float64, device=DEV)
+    bias = _t(rng.standard_normal(nOut).astype(np.float32))
+    res = _t(rng.standard_normal((V, nOut)).astype(np.float32)) if use_res else None
+    if bf:
+        n = int(lib.aabr_conv_wpack_bf16_elems(vol, nIn, nOut))
+        pf, pt = (torch.empty(n, dtype=dt, device=DEV) for _ in range(2))
+        check(lib.aabr_conv_pack_weights2_bf16(ptr(W), vol, nIn, nOut, ptr(pf), ptr(pt), stream()))
+        args = (ptr(f), nIn, V, None, nOut, V, ptr(blocks), T, vol, ptr(bias), 0, ptr(pf))
+        check(lib.aabr_conv_forward_wide_bf16_stats(*args[:3], ptr(out), *args[4:], ptr(stats), stream()))
+        check(lib.aabr_conv_forward_wide_bf16(*args[:3], ptr(out0), *args[4:], stream()))
+    else:
+        wp = torch.empty(lib.aabr_conv_wpack_floats(vol, nIn, nOut), device=DEV)
+        check(lib.aabr_conv_pack_weights(ptr(W), vol, nIn, nOut, 0, ptr(wp), stream()))
+        args = (ptr(f), nIn, V, None, nOut, V, ptr(blocks), T, vol, ptr(bias), 0, ptr(wp), ptr(res) if use_res else None)
+        check(lib.aabr_conv_forward_wide_stats(*args[:3], ptr(out), *args[4:], ptr(stats), stream()))
+        check(lib.aabr_conv_forward_wide_res(*args[:3], ptr(out0), *args[4:], stream()))
+    assert torch.equal(out, out0)                      # the statistics do not touch the output
+    o64 = out.double().cpu().numpy()
+    st = stats.cpu().numpy()
+    assert np.isfinite(st).all()
+    for j in range(ntile):
+        blk = o64[j * T:(j + 1) * T]
+        np.testing.assert_allclose(st[j, 0], blk.sum(0), rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(st[j, 1], (blk * blk).sum(0), rtol=1e-13, atol=1e-12)
+    # BatchNorm from the partials == BatchNorm with its own statistics pass
+    ws = torch.empty(int(lib.aabr_bn_scratch_floats(nOut)), device=DEV)
+    gam, bet = _t(rng.uniform(0.5, 1.5, nOut).astype(np.float32)), _t(rng.standard_normal(nOut).astype(np.float32))
+
+    def run(parts):
+        y = torch.empty_like(out)
+        sm, si, rm, rv = (torch.zeros(nOut, device=DEV) for _ in range(4))
+        rv.fill_(1.0)
+        a = (ptr(out), ptr(y), V, nOut, ptr(sm), ptr(si), ptr(rm), ptr(rv), ptr(gam), ptr(bet), 1e-4, 0.9)
+        if parts:
+            fn = lib.aabr_bn_forward_parts_bf16 if bf else lib.aabr_bn_forward_parts
+            check(fn(*a, 0.2, ptr(stats), ntile, ptr(ws), stream()))
+        else:
+            _hip.set_knob("BN_SMALL", 0)   # the three-launch path, whatever the row count
+            try:
+                fn = lib.aabr_bn_forward_bf16 if bf else lib.aabr_bn_forward
+                check(fn(*a, 1, 0.2, ptr(ws), stream()))
+            finally:
+                _hip.set_knob("BN_SMALL", None)
+        return [t.float().cpu().numpy() for t in (y, sm, si, rm, rv)]
+
+    got, want = run(True), run(False)
+    for g_, w_ in zip(got[1:], want[1:]):
+        np.testing.assert_allclose(g_, w_, rtol=3e-7, atol=1e-9)       # the same sums up to the last fp64 bits
+    np.testing.assert_allclose(got[0], want[0], rtol=2 ** -7 if bf else 1e-6, atol=2 ** -7 if bf else 1e-6)

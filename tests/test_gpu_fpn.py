@@ -268,6 +268,58 @@ def test_fpn_prepare_on_side_stream_is_bit_identical():
 
 
 @pytest.mark.gpu
+def test_geometry_prefetch_thread_is_bit_identical_and_overlaps_training():
+    """sparseconvnet.GeometryPrefetcher: the next batch's geometry built by the helper thread (its own stream, its own
+    geometry recorder) WHILE the training thread runs forward + backward of the current batch gives the same bits as
+    building it inline, over several alternating batches; an exception in the helper surfaces in wait()."""
+    torch.manual_seed(5)
+    net = _fpn().to(DEV)
+    batches = []
+    for seed in (41, 43, 47):
+        locs, feats = S.make_batch(2, 15000, seed, 20)
+        batches.append((_t(locs), _t(feats)))
+
+    def train(l, f):
+        f = f.clone().requires_grad_(True)
+        net.zero_grad()
+        rpn, _ = net([l, f])
+        sum(m.features.square().mean() for m in rpn).backward()
+        return [m.features.detach().clone() for m in rpn], f.grad.clone()
+
+    order = [0, 1, 2, 1, 0, 2]
+    inline = [train(*batches[i]) for i in order]
+    torch.cuda.synchronize()
+    pf = net.prefetcher()
+    assert pf is net.prefetcher()
+    got = []
+    pf.submit(list(batches[order[0]]))
+    for j, i in enumerate(order):
+        pf.wait()
+        assert len(net.layers_in[0]._prepared) == 1
+        l, f = batches[i]
+        f2 = f.clone().requires_grad_(True)
+        net.zero_grad()
+        rpn, _ = net([l, f2])                                   # picks the helper's Metadata up (matched by `l`)
+        assert len(net.layers_in[0]._prepared) == 0 and rpn[0].metadata._fpn_prebuilt is not None
+        if j + 1 < len(order):
+            pf.submit(list(batches[order[j + 1]]))              # built while this batch's backward runs
+        sum(m.features.square().mean() for m in rpn).backward()
+        got.append(([m.features.detach().clone() for m in rpn], f2.grad.clone()))
+    torch.cuda.synchronize()
+    for a, b in zip(inline, got):
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(a[1], b[1])
+    pf.submit([None, None])                                     # not a batch: fails on the host, before any launch
+    with pytest.raises(AttributeError):
+        pf.wait()
+    pf.submit(list(batches[0]))                                 # the helper survives its own exception
+    pf.wait()
+    net.layers_in[0]._prepared.clear()
+    pf.close()
+
+
+@pytest.mark.gpu
 def test_fpn_weights_packed_once_per_version_is_bit_identical():
     """FPN_Net packs every convolution weight (both orientations) with one launch per weight version
     (SCN.WeightPackPlan) instead of one launch per layer call: same bits as the per-call packing, the packs are
