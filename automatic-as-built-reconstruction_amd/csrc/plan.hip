@@ -12,6 +12,7 @@
 // Also the two elementwise launches such a plan needs that the layer API gets from torch: residual add and the
 // fp32 <-> bf16 storage casts (round-to-nearest-even, as torch's `.to(torch.bfloat16)`).
 #include "common.h"
+#include <string.h>
 #include <vector>
 
 namespace aabr {
@@ -312,5 +313,51 @@ extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
     }
     if (rc != AABR_OK) return rc;
   }
+  return AABR_OK;
+}
+
+// ---- mailbox: a small result handed to the host WITHOUT a stream / event wait ----------------------------------------
+// The host side of the path reads a few small counts back per step (sites per grid, proposals kept per scene).  With
+// hipStreamSynchronize / hipEventSynchronize -- and even with hipEventQuery polling -- on the stream that produced
+// them, such a read was measured to return only when the OTHER streams of the process had drained too: the proposal
+// stage's read, complete on the device at 8.3 ms of the bench step, came back at 13.6 ms, behind the last kernel of the
+// backward pass (tools/tools_step_timeline.py, profiles/r03_step_timeline.txt).  A mailbox is host memory the device
+// writes directly (hipHostMalloc, coherent): the posting kernel copies the payload, fences at system scope and then
+// stores the caller's sequence number; the host spins on that word.  No HIP call on the waiting side.
+namespace aabr {
+__global__ void k_mailbox_post(const uint32_t *__restrict__ src, int words, uint32_t *box, uint32_t seq) {
+  for (int i = threadIdx.x; i < words; i += blockDim.x) box[2 + i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    box[1] = (uint32_t)wall_clock64();     // device real-time counter (100 MHz), low word: when the post ran (tools/)
+    __threadfence_system();
+    __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+} // namespace aabr
+
+extern "C" int aabr_mailbox_create(int64_t payload_bytes, void **box) {
+  AABR_CHECK_ARG(box && payload_bytes > 0 && payload_bytes <= (1 << 20) && (payload_bytes & 3) == 0, "payload: 4..1 MiB, % 4");
+  void *p = nullptr;
+  AABR_CHECK_HIP(hipHostMalloc(&p, (size_t)payload_bytes + 8, hipHostMallocCoherent | hipHostMallocMapped));
+  memset(p, 0, (size_t)payload_bytes + 8);
+  *box = p;
+  return AABR_OK;
+}
+
+extern "C" int aabr_mailbox_destroy(void *box) {
+  if (box) AABR_CHECK_HIP(hipHostFree(box));
+  return AABR_OK;
+}
+
+extern "C" int aabr_mailbox_post(const void *src, int64_t bytes, void *box, uint32_t seq, void *stream_) {
+  AABR_CHECK_ARG(src && box && bytes > 0 && (bytes & 3) == 0 && ((uintptr_t)src & 3) == 0, "payload");
+  AABR_CHECK_ARG(seq != 0, "sequence numbers start at 1 (a fresh mailbox reads 0)");
+  void *dbox = nullptr;
+  AABR_CHECK_HIP(hipHostGetDevicePointer(&dbox, box, 0));
+  hipLaunchKernelGGL(k_mailbox_post, dim3(1), dim3(256), 0, (hipStream_t)stream_, (const uint32_t *)src, (int)(bytes / 4),
+                     (uint32_t *)dbox, seq);
+  AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

@@ -77,9 +77,12 @@ def rpn_proposals_single_map(tensor, objectness, box_regression, base_anchors, v
     return out
 
 
+_trace = None     # tools/tools_step_timeline.py: called with a label at the stage's host-side boundaries
+
+
 def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel_scale, pre_nms_top_n=2000,
                   post_nms_top_n=1000, nms_thresh=0.5, nms_aug_thickness=(0.3, 0.3), weights=(1.0,) * 7,
-                  bbox_xform_clip=10000.0, batch_size=None, batched=False):
+                  bbox_xform_clip=10000.0, batch_size=None, batched=False, defer=False):
     """Cross-scale proposals, the shape the reference runs in (RPNModule.forward, rpn_sparse3d.py:184-209):
     `cat_scales_obj_reg` regroups the scales example-major and RPNPostProcessor then does, per example, ONE
     sigmoid -> top-k(2000) -> decode -> boxlist_nms_3d(1000) over the anchors of all maps
@@ -145,7 +148,7 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
                 float(bbox_xform_clip), float(nms_aug_thickness[0]), float(nms_aug_thickness[1]), ptr(sel), k,
                 ptr(boxes), ptr(nms_boxes), ptr(scores), float(nms_thresh), int(_nms.REFERENCE_DEBUG_ONLY_XY),
                 int(post_nms_top_n), ptr(mask), ptr(keep), ptr(meta), stream()))
-            kept = meta[:, 0].tolist()              # the one read of the stage
+            kept = _hip.read_back(meta[:, 0])       # the one read of the stage
             out = []
             for bi in range(nb):
                 kk = keep[bi, :kept[bi]]
@@ -181,12 +184,22 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
         out.append(None)
         for m in range(n_maps):
             site0[m] += counts[m][bi]
-    if pending:
-        kept = torch.stack([p[4][0] for p in pending]).tolist()      # the one read of the NMS stage
-        for (i, boxes, scores, keep, meta), nk in zip(pending, kept):
-            k = keep[:nk]
-            out[i] = (boxes[k], scores[k])
-    return out
+    def finish():
+        if pending:
+            if _trace is not None:
+                _trace("proposal launches enqueued")
+            kept = _hip.read_back(torch.stack([p[4][0] for p in pending]))      # the one read of the NMS stage
+            if _trace is not None:
+                _trace("proposal counts read")
+            for (i, boxes, scores, keep, meta), nk in zip(pending, kept):
+                k = keep[:nk]
+                out[i] = (boxes[k], scores[k])
+        return out
+
+    # `defer` (extension): every launch of the stage is out; the caller gets the function that does the one read and
+    # slices the lists, to be called (on the same stream) when it wants the result -- e.g. after it has enqueued
+    # other work that does not depend on the proposals
+    return finish if defer else finish()
 
 
 def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thickness, criterion=6,

@@ -241,6 +241,17 @@ def _keep(*ts):
         _gtls.rec[2].extend(ts)
 
 
+_parked = []          # (event on the consumer stream, tensors) of dead Metadata objects whose geometry was built elsewhere
+_park_lock = _threading.Lock()
+
+
+def _reap_handed_over():
+    """drop the parked geometry whose consumer stream has passed its last use"""
+    with _park_lock:
+        while _parked and _parked[0][0].query():
+            _parked.pop(0)
+
+
 class _Grid(object):
     """one scale of the scene: site list + hash table (replaces SparseGrids, Metadata.h:24-34)"""
     __slots__ = ("coords", "keys", "vals", "cap", "V", "batch_size", "sample_off")
@@ -429,6 +440,28 @@ class Metadata_3(object):
         loc = torch.empty((g.V, 4), dtype=torch.int64, device=g.coords.device)
         check(_hip.load().aabr_spatial_locations(ptr(g.coords), g.V, ptr(loc), stream()))
         return loc
+
+    def hand_over(self, consumer):
+        """Geometry built on another stream (FPN_Net.prepare) is about to be used on `consumer`.  Its tensors' memory
+        belongs to the producer stream's pool; it must not be reused there before `consumer` has passed every launch
+        that reads it.  `tensor.record_stream(consumer)` does that PER TENSOR: at free time the allocator records one
+        event on the consumer stream for each of the ~200 geometry tensors of a pass -- 200 marker packets between two
+        training steps, measured as 1.07 ms of idle main stream per 14.4 ms step (tools/tools_step_timeline.py,
+        profiles/r03_step_timeline.txt).  Instead the tensors are kept until this object dies, then parked with ONE
+        event recorded on the consumer stream and dropped when that event has passed (`_reap_handed_over`)."""
+        self._handed_over = (consumer, self.device_tensors())
+
+    def __del__(self):
+        ho = getattr(self, "_handed_over", None)
+        if ho is None:
+            return
+        try:
+            ev = torch.cuda.Event()
+            ev.record(ho[0])
+            with _park_lock:
+                _parked.append((ev, ho[1]))
+        except Exception:     # interpreter shutdown: the process's memory goes away with it
+            pass
 
     def device_tensors(self):
         """every device tensor this object owns (for cross-stream hand-over of geometry prepared ahead of time)"""

@@ -59,8 +59,8 @@ class InputLayer(Module):
             cur = torch.cuda.current_stream()
             if md.prepared_on != cur:
                 cur.wait_stream(md.prepared_on)  # tensors were produced on the side stream
-                for t in md.device_tensors():
-                    t.record_stream(cur)
+                md.hand_over(cur)                # ... and their memory stays theirs until `cur` is done with it
+            SCN._reap_handed_over()
         output = SparseConvNetTensor(metadata=md if md is not None else Metadata(self.dimension),
                                      spatial_size=self.spatial_size)
         output.features = InputLayerFunction.apply(

@@ -247,7 +247,7 @@ class Workload(object):
         # top-k, decode) with a few host reads of counts; enqueued on a side stream AFTER the backward pass has been
         # enqueued on the main one, it runs on otherwise idle CUs underneath the backward kernels and its host
         # reads wait for the side stream only.
-        ev_fwd = torch.cuda.Event()
+        ev_fwd = torch.cuda.Event(enable_timing=os.environ.get("AABR_BENCH_EVFWD_TIMING", "0") == "1")
         ev_fwd.record()
         early = (proposals and self.prefetch_geometry and not threaded
                  and os.environ.get("AABR_BENCH_PREFETCH_EARLY", "1") == "1")
@@ -255,12 +255,27 @@ class Workload(object):
             with torch.no_grad():
                 self.net.prepare(self.batches[(i + 1) % len(self.batches)], self.side)
         self._mark("geometry prefetch (inline) done")
+        props = finish = None
+        launch_first = proposals and os.environ.get("AABR_BENCH_PROPOSALS_FIRST", "1") == "1"
+
+        def launch_proposals(defer):
+            with torch.no_grad(), torch.cuda.stream(self.side):
+                self.side.wait_event(ev_fwd)
+                return rpn_glue.rpn_proposals(rpn_maps, [o.detach() for o in objs], [r.detach() for r in regs],
+                                              self.base, self.strides, float(VOXEL_SCALE), 2000, 1000, 0.5, (0.3, 0.3),
+                                              batch_size=SCENES_PER_STEP, defer=defer,
+                                              batched=os.environ.get("AABR_BENCH_BATCHED_PROPOSALS", "0") != "0")
+
+        if launch_first:
+            # every launch of the proposal stage goes out (side stream) BEFORE the backward pass is enqueued; its one
+            # read of counts is done after the backward pass and the update have been enqueued
+            finish = launch_proposals(True)
+            self._mark("proposal launches out")
         loss.backward()
         self._mark("backward enqueued")
         feats.grad = None
         if after_backward is not None:
-            after_backward()      # N > 1: the gradient all-reduce starts here and runs under the proposal stage
-        props = None
+            after_backward()      # N = 1: the update; N > 1: the gradient all-reduce starts here and runs under the proposal stage
         if proposals:
             main = torch.cuda.current_stream()
             if self.prefetch_geometry and not early and not threaded:
@@ -269,18 +284,24 @@ class Workload(object):
                 # step still builds its geometry from scratch, one step ahead
                 with torch.no_grad():
                     self.net.prepare(self.batches[(i + 1) % len(self.batches)], self.side)
-            with torch.no_grad(), torch.cuda.stream(self.side):
-                self.side.wait_event(ev_fwd)
-                props = rpn_glue.rpn_proposals(rpn_maps, [o.detach() for o in objs], [r.detach() for r in regs],
-                                               self.base, self.strides, float(VOXEL_SCALE), 2000, 1000, 0.5, (0.3, 0.3),
-                                               batch_size=SCENES_PER_STEP,
-                                               batched=os.environ.get("AABR_BENCH_BATCHED_PROPOSALS", "0") != "0")
-            self._mark("proposals read back")
-            main.wait_stream(self.side)
+            if launch_first:
+                with torch.no_grad(), torch.cuda.stream(self.side):
+                    props = finish() if callable(finish) else finish
+            else:
+                props = launch_proposals(False)
+            self._mark("proposals stage left")
+            if os.environ.get("AABR_BENCH_JOIN_SIDE", "1") == "1":
+                main.wait_stream(self.side)
+            self._mark("main waits for the proposal stream")
         self.last = (rpn_maps, props, labels)
         return loss
 
+    def _update_now(self):
+        self.flat.sgd_step(1e-5, 1)
+        self._mark("update enqueued")
+
     def step(self, i):
+        self._mark("step() entered")
         self.flat.zero_grad()
         if self.world > 1 and self.grad_buckets > 1:
             # bucketed gradient all-reduce (RCCL over xGMI): the compiled backward hands its gradient buffer over in
@@ -296,10 +317,16 @@ class Workload(object):
             # no dependence on the gradients) runs while it is in flight; the update waits for it
             self.forward_backward(i, after_backward=self.flat.start_allreduce)
             self.flat.finish_update(1e-5, self.world)
-        else:
+        elif os.environ.get("AABR_BENCH_UPDATE_LAST", "0") == "1":      # round-2 order, for the A/B
             self.forward_backward(i)
             self.flat.sgd_step(1e-5, 1)
             self._mark("update enqueued")
+        else:
+            # the update is enqueued right behind the backward pass, BEFORE this thread goes to read the proposal
+            # stage's counts: the main stream runs forward, backward, update back to back instead of idling between the
+            # last backward kernel and an update the host had not enqueued yet (1.1 ms of 14.4 per step measured,
+            # profiles/r03_step_timeline.txt).  The proposal stage reads forward activations only.
+            self.forward_backward(i, after_backward=self._update_now)
 
 
 # ------------------------------------------------------------------------------------------------ measurement

@@ -449,6 +449,17 @@ typedef struct AabrGeomOp {
 } AabrGeomOp; /* 144 bytes, no padding */
 int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *stream);
 
+/* Mailbox (extension): a small result (counts the host needs to size the next launches) handed over WITHOUT a stream or
+ * event wait on the receiving side.  aabr_mailbox_create: coherent pinned host memory, [0] = sequence word (starts 0),
+ * [1] reserved, payload from byte 8.  aabr_mailbox_post (one small kernel on `stream`): copies `bytes` (% 4) from
+ * device memory into the payload, then stores `seq` (!= 0) into the sequence word with a system-scope release; the
+ * host spins on that word and then reads the payload.  Why: hipStreamSynchronize / hipEventSynchronize / polling
+ * hipEventQuery on the producing stream were measured to return only when the process's OTHER streams had drained
+ * (csrc/plan.hip, profiles/r03_step_timeline.txt).  One post in flight per mailbox.                             */
+int aabr_mailbox_create(int64_t payload_bytes, void **box);
+int aabr_mailbox_destroy(void *box);
+int aabr_mailbox_post(const void *src, int64_t bytes, void *box, uint32_t seq, void *stream);
+
 /* out = a + b elementwise over n elements (fp32, or bf16 storage with the sum formed in fp32 and rounded to
  * nearest even); fp32 <-> bf16 storage cast.  What the layer API gets from torch (`a + b`, `.to(dtype)`; the
  * reference: AddTable, tables.py:27-41) as plan records.                                           */

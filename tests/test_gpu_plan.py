@@ -137,3 +137,39 @@ def test_grids_carry_per_sample_row_offsets():
     assert n_with >= 12
     for m in rpn:   # every RPN map's grid has them
         assert md.grids[tuple(int(v) for v in m.spatial_size.tolist())].sample_off is not None
+
+
+def test_mailbox_read_back_matches_tolist_and_does_not_wait_for_other_streams():
+    """_hip.read_back (aabr_mailbox_post): values equal tensor.tolist() for the dtypes / shapes the host side reads;
+    repeated posts reuse the mailbox (sequence numbers); and a read issued on a side stream returns while a long
+    queue of kernels is still pending on the main stream (the reason the mailbox exists)."""
+    import time
+    import _hip
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(5)
+    for dt, shape in ((torch.int32, (7,)), (torch.int64, (3, 5)), (torch.float32, (4,)), (torch.int64, ()),
+                      (torch.int32, (6, 2, 3))):
+        a = torch.as_tensor(rng.integers(-2 ** 31, 2 ** 31 - 1, size=shape)).to(dt).to(dev)
+        for _ in range(3):
+            assert _hip.read_back(a) == a.tolist()
+    nc = torch.arange(40, device=dev, dtype=torch.int64)[::2]          # non-contiguous view
+    assert _hip.read_back(nc) == nc.tolist()
+    assert _hip.read_back(torch.zeros(0, dtype=torch.int32, device=dev)) == []
+    big = torch.randn(6144, 6144, device=dev)
+    side = torch.cuda.Stream()
+    small = torch.arange(8, device=dev, dtype=torch.int32)
+    big @ big
+    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    ev.record()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        big @ big                                                      # ~3 ms each on the main stream
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        got = _hip.read_back(small * 3)
+    t_read = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    assert got == [0, 3, 6, 9, 12, 15, 18, 21]
+    assert t_read < 0.5 * t_all, (t_read, t_all)
