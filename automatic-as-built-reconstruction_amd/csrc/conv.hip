@@ -130,7 +130,15 @@ __global__ __launch_bounds__(256) void k_pack_weights_jobs(const PackJob *__rest
   float v = 0.0f;
   if (c < ci && n < co) v = tr ? jb.W[((int64_t)k * co + n) * ci + c] : jb.W[((int64_t)k * ci + c) * co + n];
   void *dst = tr ? jb.Wt : jb.Wf;
-  if (jb.bf16) reinterpret_cast<__bf16 *>(dst)[idx] = (__bf16)v;
+  if (jb.bf16 == 2) { // three bf16 term planes of the fp32 weight (k_conv_cs<.., X3>): w = w1 + w2 + w3 to 2^-27 |w|
+    const int64_t plane = tr ? total_t : total_f;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const __bf16 b = (__bf16)v;
+      reinterpret_cast<__bf16 *>(dst)[pl * plane + idx] = b;
+      v -= (float)b;
+    }
+  } else if (jb.bf16) reinterpret_cast<__bf16 *>(dst)[idx] = (__bf16)v;
   else reinterpret_cast<float *>(dst)[idx] = v;
 }
 

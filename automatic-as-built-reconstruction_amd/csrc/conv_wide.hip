@@ -111,12 +111,20 @@ constexpr int kMaxTileRows = 240; // (240 + 1) rows x 256 B + 16 KiB stage = 76 
 // channels; KG then counts 128-BYTE row chunks (64 channels), so the gather / stage code is the same byte for byte
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // NCB = 16-column blocks per wave: 1 = 64-column slabs; 2 (bf16 storage) = 128-column slabs -- the kernel is bound by
 // the rate at which a CU gathers random rows (~20 GB/s per CU measured in both this and the row-stationary kernel,
 // profiles/r03_conv_rs_ab.txt), and a 128-column layer gathered every row once per 64-column slab, i.e. twice
-template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2>
-__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
+// X3 (fp32 storage, fp32-equivalent arithmetic on the bf16 matrix pipe): every fp32 operand is split into three bf16
+// terms x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 mantissa bits in 3 x 8, the
+// residual is <= 2^-27 |x|), the gathered rows at the stage store, the weights at pack time; a product a * w is formed as
+// the six terms a1w1 + a1w2 + a2w1 + a2w2 + a1w3 + a3w1 (each exact in the MFMA's fp32 accumulator; the dropped terms
+// are <= 2^-25 |a w|, below the rounding of an fp32 FMA chain) with v_mfma_f32_16x16x32_bf16: 6 x 16 cycles per 16 x 16
+// x 32 block instead of 8 x 32 cycles of v_mfma_f32_16x16x4_f32 -- 2.7x the matrix rate at fp32 accuracy.  KG counts
+// 64-channel chunks as for BF; rows are gathered and written in fp32.
+template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2, bool X3 = false>
+__global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
@@ -126,6 +134,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   constexpr int RF = KG * 32;              // floats per staged row
   constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
   constexpr int STAGE = 2 * 16 * RF;       // floats per stage buffer (two blocks)
+  constexpr bool BFM = BF || X3;           // bf16 operands in the stage and the weight pack
+  constexpr int NP = X3 ? 3 : 1;           // bf16 terms per operand
+  constexpr int NGL = X3 ? 2 * KG : KG;    // 16-byte gather loads per lane and pair (X3: fp32 rows, 32 channels per 128 B)
   extern __shared__ __align__(16) float smem[];
   float *Ct = smem;                        // [kT2 + 1][64] floats, granule-swizzled; the last row swallows padding entries
   constexpr int WS = kWS * NCB;            // tile row stride in floats = slab width
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
   const int pr = wave * 8 + (lane >> 3), seg = lane & 7; // gather role: pair row 0..31, 16-byte segment
-  const int nkc = BF ? ci >> 6 : ci >> 5, nnb = co >> 4;   // 128-byte chunks per row
+  const int nkc = BFM ? ci >> 6 : ci >> 5, nnb = co >> 4;  // chunks per row (64 channels with bf16 operands, else 32)
   // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own 4 MiB L2.  Give every XCD a
   // CONTIGUOUS range of (tile, slab) work items instead of every eighth one: the slabs of a tile and the tiles next to
   // it gather the same input rows (consecutive sites lie on the same surface), so they hit that XCD's L2 instead of
@@ -173,8 +184,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
     while (k < vol && pre_of(k + 1) == pre_of(k)) ++k;
     return k;
   };
-  struct WReg { u32x4 w0[NCB][KG], w1[NCB][KG]; };
-  struct GReg { u32x4 v[KG]; };
+  struct WReg { u32x4 w0[NP][NCB][KG], w1[NP][NCB][KG]; };
+  struct GReg { u32x4 v[NGL]; };
   struct Ent { int eg, ea, eb, hb; };      // gather-role entry of this lane's pair row; compute-role entries (A, B);
                                            // hb (wave-uniform): the pair has a second block
   const int ngroups = (nkc + KG - 1) / KG;
@@ -186,14 +197,18 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
 #pragma unroll
       for (int c = 0; c < KG; ++c) { // nkc % KG == 0 (dispatch): every load is unconditional, so the compiler's
         const int kc = kg * KG + c;  // vmcnt bookkeeping stays exact and nothing waits for a prefetch it does not use
-        if (BF) { // two 32-channel MFMA chunks per 128-byte row chunk, 1 KiB of packed weights each
+        if (BFM) { // two 32-channel MFMA chunks per 64-channel row chunk, 1 KiB of packed weights each; X3: three term planes
           const unsigned so = (unsigned)((((int64_t)kW * (2 * nkc) + 2 * kc) * nnb + nb0 + wave * NCB + cb) * 1024);
-          w.w0[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, so, 0);
-          w.w1[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, so + (unsigned)nnb * 1024u, 0);
+#pragma unroll
+          for (int pl = 0; pl < NP; ++pl) {
+            const unsigned po = so + (unsigned)pl * (unsigned)(wp_bytes / NP);
+            w.w0[pl][cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, po, 0);
+            w.w1[pl][cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u, po + (unsigned)nnb * 1024u, 0);
+          }
         } else {
           const unsigned so = (unsigned)((((int64_t)kW * nkc + kc) * nnb + nb0 + wave * NCB + cb) * 2048);
-          w.w0[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, so, 0);
-          w.w1[cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16u, so, 0);
+          w.w0[0][cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32, so, 0);
+          w.w1[0][cb][c] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane32 + 16u, so, 0);
         }
       }
   };
@@ -213,14 +228,41 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   auto gather = [&](GReg &q, int eg, int kg) {
     const unsigned va = (((unsigned)eg & 0x7fffffffu) >> 8) * rowbytes + (unsigned)seg * 16u;
 #pragma unroll
-    for (int i = 0; i < KG; ++i) { // granule seg + 8 i of the row's current channel group
-      const unsigned so = (unsigned)(kg * KG + i) * 128u;
+    for (int i = 0; i < NGL; ++i) { // granule seg + 8 i of the row's current channel group
+      const unsigned so = (unsigned)(kg * NGL + i) * 128u;
       if (DBG & 2) q.v[i] = (u32x4){(unsigned)eg, 0u, 0u, 0u}; // timing experiments: no global gathers
       else q.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
     }
   };
   auto stage_store = [&](const GReg &q, int buf) {
-    float *rowp = St + (NBUF == 2 ? buf : 0) * STAGE + pr * RF;
+    float *rowp = St + (NBUF == 2 ? buf : 0) * (NP * STAGE) + pr * RF;
+    if (X3) {
+      // four fp32 channels (fp32 granule G = seg + 8 i) -> their three bf16 terms, 8 bytes each, into half G & 1 of the
+      // bf16 granule G >> 1 of the three term planes
+#pragma unroll
+      for (int i = 0; i < NGL; ++i) {
+        const int G = seg + 8 * i;
+        float r[4];
+        u32x2 t[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = bcf_(q.v[i][j]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          unsigned h[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const __bf16 b = (__bf16)r[j];                       // round to nearest even
+            h[j] = (unsigned)__builtin_bit_cast(unsigned short, b);
+            r[j] -= bcf_(h[j] << 16);                            // exact: the difference has fewer bits than fp32 holds
+          }
+          t[pl] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          *reinterpret_cast<u32x2 *>(rowp + pl * STAGE + (((G >> 1) ^ (pr & SWZ)) << 2) + (G & 1) * 2) = t[pl];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < KG; ++i)
       *reinterpret_cast<u32x4 *>(rowp + (((seg + 8 * i) ^ (pr & SWZ)) << 2)) = q.v[i];
@@ -296,6 +338,51 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
       {
         const float *sa = St + (NBUF == 2 ? par : 0) * STAGE + c16 * RF;
         const float *sb = sa + 16 * RF;
+        f32x4 accA[NCB], accB[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) { accA[cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[cb] = accA[cb]; }
+        if constexpr (X3) {
+          // term planes of the staged rows: plane pl at sa + pl * STAGE.  Products in the order small -> large:
+          // a1 w3, a3 w1, a2 w2, a1 w2, a2 w1, a1 w1 (plane indices 0-based below)
+          const float *sa = St + (NBUF == 2 ? par : 0) * (NP * STAGE) + c16 * RF;
+          const float *sb = sa + 16 * RF;
+          u32x4 a0[3][KG], a1[3][KG], b0[3][KG], b1[3][KG];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int c = 0; c < KG; ++c) {
+              const int q0 = ((c * 8 + g) ^ (c16 & SWZ)) << 2, q1 = ((c * 8 + 4 + g) ^ (c16 & SWZ)) << 2;
+              a0[pl][c] = *reinterpret_cast<const u32x4 *>(sa + pl * STAGE + q0);
+              b0[pl][c] = *reinterpret_cast<const u32x4 *>(sb + pl * STAGE + q0);
+              a1[pl][c] = *reinterpret_cast<const u32x4 *>(sa + pl * STAGE + q1);
+              b1[pl][c] = *reinterpret_cast<const u32x4 *>(sb + pl * STAGE + q1);
+            }
+          constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TW[6] = {2, 0, 1, 1, 0, 0};   // (row term, weight term)
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+              for (int c = 0; c < KG; ++c) {
+                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[TW[t]][cb][c]),
+                                                                   __builtin_bit_cast(bf16x8w, a0[TA[t]][c]), accA[cb], 0, 0, 0);
+                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[TW[t]][cb][c]),
+                                                                   __builtin_bit_cast(bf16x8w, a1[TA[t]][c]), accA[cb], 0, 0, 0);
+              }
+          if (e0.hb) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int c = 0; c < KG; ++c) {
+                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[TW[t]][cb][c]),
+                                                                     __builtin_bit_cast(bf16x8w, b0[TA[t]][c]), accB[cb], 0, 0, 0);
+                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[TW[t]][cb][c]),
+                                                                     __builtin_bit_cast(bf16x8w, b1[TA[t]][c]), accB[cb], 0, 0, 0);
+                }
+          }
+        } else {
         // all of the pair's B operands leave LDS before the first MFMA (counted lgkmcnt waits follow)
         u32x4 a0[KG], a1[KG], b0[KG], b1[KG];
 #pragma unroll
@@ -309,13 +396,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
           a1[c] = *reinterpret_cast<const u32x4 *>(sa + q1);
           b1[c] = *reinterpret_cast<const u32x4 *>(sb + q1);
         }
-        f32x4 accA[NCB], accB[NCB];
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) { accA[cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[cb] = accA[cb]; }
         if (DBG & 1) { // timing experiments: operands consumed, no MFMAs
 #pragma unroll
           for (int c = 0; c < KG; ++c) {
-            accA[0][0] += bcf_(a0[c][0]) + bcf_(a1[c][0]) + bcf_(w.w0[0][c][0]) + bcf_(w.w1[0][c][0]);
+            accA[0][0] += bcf_(a0[c][0]) + bcf_(a1[c][0]) + bcf_(w.w0[0][0][c][0]) + bcf_(w.w1[0][0][c][0]);
             accB[0][0] += bcf_(b0[c][0]) + bcf_(b1[c][0]);
           }
         } else if (BF) {
@@ -323,9 +407,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
           for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int c = 0; c < KG; ++c) {
-              accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[cb][c]),
+              accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[0][cb][c]),
                                                                  __builtin_bit_cast(bf16x8w, a0[c]), accA[cb], 0, 0, 0);
-              accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[cb][c]),
+              accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[0][cb][c]),
                                                                  __builtin_bit_cast(bf16x8w, a1[c]), accA[cb], 0, 0, 0);
             }
           if (e0.hb) {
@@ -333,9 +417,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
               for (int c = 0; c < KG; ++c) {
-                accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[cb][c]),
+                accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[0][cb][c]),
                                                                    __builtin_bit_cast(bf16x8w, b0[c]), accB[cb], 0, 0, 0);
-                accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[cb][c]),
+                accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[0][cb][c]),
                                                                    __builtin_bit_cast(bf16x8w, b1[c]), accB[cb], 0, 0, 0);
               }
           }
@@ -348,10 +432,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
             for (int c = 0; c < KG; ++c) {
 #pragma unroll
               for (int t = 0; t < 4; ++t)
-                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[cb][c][t]), bcf_(a0[c][t]), accA[cb], 0, 0, 0);
+                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[0][cb][c][t]), bcf_(a0[c][t]), accA[cb], 0, 0, 0);
 #pragma unroll
               for (int t = 0; t < 4; ++t)
-                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[cb][c][t]), bcf_(a1[c][t]), accA[cb], 0, 0, 0);
+                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[0][cb][c][t]), bcf_(a1[c][t]), accA[cb], 0, 0, 0);
             }
           if (e0.hb) {
 #pragma unroll
@@ -360,12 +444,13 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
               for (int c = 0; c < KG; ++c) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[cb][c][t]), bcf_(b0[c][t]), accB[cb], 0, 0, 0);
+                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[0][cb][c][t]), bcf_(b0[c][t]), accB[cb], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[cb][c][t]), bcf_(b1[c][t]), accB[cb], 0, 0, 0);
+                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[0][cb][c][t]), bcf_(b1[c][t]), accB[cb], 0, 0, 0);
               }
           }
+        }
         }
         if (DBG & 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(accA[0]), "v"(accB[0])); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         accumulate2(e0.ea, accA, e0.eb, accB);
@@ -762,6 +847,106 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
 #undef AABR_WIDE_BF
 #undef AABR_WIDE_BF_S
 #undef AABR_WIDE_BF_D
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+
+// ---- fp32 storage on the bf16 matrix pipe (three-term split, k_conv_cs<.., X3>) -------------------------------------
+// weight pack: three bf16 term planes, each in the layout of aabr_conv_pack_weights2_bf16 (plane p at p * plane bytes)
+extern "C" int64_t aabr_conv_wpack_x3_elems(int vol, int n_in, int n_out) {
+  if (vol <= 0 || n_in <= 0 || n_out <= 0) return 0;
+  return 3 * (int64_t)vol * (n_in / 32) * (n_out / 16) * 512;
+}
+
+// form of the launch: 1 = 64-channel groups x 128-column slabs, 2 = 128-channel groups x 64-column slabs,
+// 3 = 64-channel groups x 64-column slabs; 0 = not supported
+static int x3_form(int n_in, int n_out) {
+  if (n_in <= 0 || n_out <= 0 || (n_in & 63) || (n_out & 63)) return 0;
+  const int v = knob(K_X3_FORM);
+  if (v == 2 && (n_in & 127) == 0) return 2;
+  if (v == 3) return 3;
+  if ((n_out & 127) == 0) return 1;
+  return (n_in & 127) == 0 ? 2 : 3;
+}
+
+// rows per tile for aabr_conv_forward_wide_x3, 0 = use the fp32-MFMA kernels
+extern "C" int aabr_conv_wide_tile_rows_x3(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
+  // measured (profiles/r03_conv_x3_ab.txt): the matrix phase of a step shrinks 2.8x, but the steps are half as big (64
+  // channels or 64 columns: three term planes of weights do not fit the registers otherwise) and the split at the stage
+  // store costs more than the MFMAs saved -- 322-338 us against 326 us of the fp32-MFMA kernel on the dominant
+  // instance.  Off unless the CONV_X3 knob is 1 (tests, tools).
+  if (vol <= 0 || vol > kMaxVol || knob(K_CONV_X3) != 1) return 0;
+  const int form = x3_form(n_in, n_out);
+  if (!form) return 0;
+  if (rows_in >= (1ll << 23) || rows_in * n_in * 4 >= (1ll << 31)) return 0;
+  int T = 64;
+  {                                                // tuning experiments only
+    const int v = knob(K_WIDE_ROWS);
+    if (v >= 64 && v <= kMaxTileRows && (v & 15) == 0) T = v;
+  }
+  if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
+  if ((int64_t)vol * n_in * n_out * 6 >= (1ll << 31)) return 0;
+  return T;
+}
+
+extern "C" int aabr_conv_forward_wide_x3(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
+                                         int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                                         int flags, const uint16_t *wpack, const float *residual, double *stats,
+                                         void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  const int form = x3_form(n_in, n_out);
+  AABR_CHECK_ARG(form != 0, "plane counts: n_in % 64, n_out % 64");
+  AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
+  AABR_CHECK_ARG(tile_rows >= 64 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, 64..240");
+  if (V_out == 0) return AABR_OK;
+  AABR_CHECK_ARG(in_feats && out_feats && blocks && wpack && rows_in > 0, "null pointer / empty input");
+  AABR_CHECK_ARG(rows_in < (1ll << 23), "too many input rows for the wide block format");
+  const int64_t in_bytes = rows_in * n_in * 4, words_bytes = wide_words(V_out, vol, tile_rows) * 4;
+  AABR_CHECK_ARG(in_bytes < (1ll << 31) && words_bytes < (1ll << 31), "buffers must be < 2 GiB");
+  AABR_CHECK_ARG((((uintptr_t)in_feats | (uintptr_t)out_feats | (uintptr_t)wpack | (uintptr_t)residual) & 15) == 0 &&
+                     ((uintptr_t)stats & 7) == 0, "pointers must be 16-byte aligned");
+  const int64_t wp_bytes = 3 * (int64_t)vol * (n_in / 32) * (n_out / 16) * 1024;
+  AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
+  const int flip = (flags >> 1) & 1;
+  const float *wp_f = reinterpret_cast<const float *>(wpack);
+#define AABR_X3(KG, NCB, NAME)                                                                                        \
+  do {                                                                                                                \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, 1, false, NCB, 2, true>),                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                     \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    g_last_variant = NAME;                                                                                            \
+    dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / (64 * NCB)));                       \
+    hipLaunchKernelGGL((k_conv_cs<KG, 0, 1, false, NCB, 2, true>), grid, dim3(256),                                   \
+                       (size_t)((tile_rows + 1) * kWS * NCB + 3 * 2 * 16 * KG * 32) * sizeof(float), st, in_feats,    \
+                       n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias, \
+                       tile_rows, residual, stats);                                                                   \
+  } while (0)
+#ifdef AABR_DEV
+  if ((flags >> 8) & 4) {   // timing experiments (tools/tools_cs_phases.py x3): phase clocks -> the buffer passed as `bias`
+    dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / (form == 1 ? 128 : 64)));
+#define AABR_X3_D(KG, NCB)                                                                                            \
+    do {                                                                                                              \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 4, 1, false, NCB, 2, true>),                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                     \
+      hipLaunchKernelGGL((k_conv_cs<KG, 4, 1, false, NCB, 2, true>), grid, dim3(256),                                 \
+                         (size_t)((tile_rows + 1) * kWS * NCB + 3 * 2 * 16 * KG * 32) * sizeof(float), st, in_feats,  \
+                         n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes,     \
+                         bias, tile_rows, residual, stats);                                                           \
+    } while (0)
+    if (form == 1) AABR_X3_D(1, 2); else if (form == 2) AABR_X3_D(2, 1); else AABR_X3_D(1, 1);
+#undef AABR_X3_D
+    AABR_CHECK_LAUNCH();
+    return AABR_OK;
+  }
+#endif
+  if (form == 1) AABR_X3(1, 2, "k_conv_cs<1,0,1,x3,x128>");
+  else if (form == 2) AABR_X3(2, 1, "k_conv_cs<2,0,1,x3>");
+  else AABR_X3(1, 1, "k_conv_cs<1,0,1,x3>");
+#undef AABR_X3
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

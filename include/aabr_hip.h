@@ -232,6 +232,21 @@ int aabr_bn_forward_parts_bf16(const uint16_t *in, uint16_t *out, int64_t rows, 
                                const float *bias, float eps, float momentum, float leakiness, const double *parts,
                                int nparts, float *scratch, void *stream);
 
+/* fp32 features and weights, fp32-equivalent arithmetic on the bf16 matrix pipe (extension; replaces the same gather-GEMM-
+ * scatter loop as aabr_conv_forward_wide, SCN/CUDA/Convolution.cu:22-114 + RuleBookIterator.h:11-74): every operand is
+ * split into three bf16 terms (x = x1 + x2 + x3 to 2^-27 |x|) and a product is formed from the six largest term
+ * products in the MFMA's fp32 accumulator -- the dropped terms are <= 2^-25 of the product, below the rounding of an
+ * fp32 FMA chain; tests/test_gpu_conv_wide.py measures both paths against fp64.  The weight pack holds the three term
+ * planes (aabr_conv_wpack_x3_elems bf16 elements; written by aabr_conv_pack_weights_jobs with bf16 = 2, each plane in
+ * the layout of aabr_conv_pack_weights2_bf16).  n_in % 64 == 0, n_out % 64 == 0; blocks = aabr_build_wide_blocks with
+ * tile_rows = aabr_conv_wide_tile_rows_x3(...) (0: use aabr_conv_forward_wide).  residual / stats as
+ * aabr_conv_forward_wide_stats.  Knob CONV_X3: 0 = never, 1 = whenever supported.                              */
+int64_t aabr_conv_wpack_x3_elems(int vol, int n_in, int n_out);
+int aabr_conv_wide_tile_rows_x3(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
+int aabr_conv_forward_wide_x3(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
+                              int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias, int flags,
+                              const uint16_t *wpack, const float *residual, double *stats, void *stream);
+
 /* Name of the kernel instance (template arguments included) the last aabr_conv_forward[_bf16] /
  * aabr_conv_backward_weight[_bf16] call on this thread dispatched -- measurement provenance only.   */
 const char *aabr_conv_last_variant(void);
