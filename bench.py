@@ -463,7 +463,8 @@ def pmc_traffic(kernel_name, grid_threads):
     """HBM bytes per launch of the (kernel, grid size) instance from the committed PMC passes of THIS command
     (profiles/, separate --pmc runs, tools/tools_pmc.sh; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note of
     MI355X_MICROARCH.md).  Returns (bytes, source) or (None, reason) -- never a number for a different kernel."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_fetch_write_per_kernel.json")
+    name = "r03_pmc_fetch_write_per_kernel.json"
+    path = os.path.join(REPO, "profiles", name)
     try:
         pm = json.load(open(path))["kernels"]
     except Exception:
@@ -471,9 +472,22 @@ def pmc_traffic(kernel_name, grid_threads):
     key = "%s|grid=%d" % (kernel_name.replace(" ", ""), grid_threads)
     v = pm.get(key)
     if v is None:
+        # the profiler prints every template argument (k_conv_cs<4,0,1,false,1,2,false>), aabr_conv_last_variant() the
+        # leading ones that tell the instances apart (k_conv_cs<4,0,1>): same instance when the leading arguments, the
+        # storage type and the grid size all match
+        kn = kernel_name.replace(" ", "")
+        stem, bf16 = kn.split(",bf16")[0].rstrip(">"), ",bf16" in kn
+        x128 = ",x128" in kn
+        cands = [k for k in pm if k.endswith("|grid=%d" % grid_threads) and k.startswith(stem + ",")
+                 and (",true," in k.split("|")[0]) == bf16]
+        if bf16:
+            cands = [k for k in cands if (k.split("|")[0].split(",")[4] == "2") == x128]
+        if len(cands) == 1:
+            key, v = cands[0], pm[cands[0]]
+    if v is None:
         return None, "instance %s not in the committed PMC profile (dispatch or workload changed since it was taken)" % key
     return int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024), \
-        "committed profile profiles/r02_pmc_fetch_write_per_kernel.json, entry %s (%d launches)" % (key, v["launches"])
+        "committed profile profiles/%s, entry %s (%d launches)" % (name, key, v["launches"])
 
 
 def roofline_block(torch, wl, dtype, step_us):

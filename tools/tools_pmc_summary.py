@@ -1,7 +1,8 @@
-"""Summarise the PMC passes of tools_pmc.sh into profiles/r02_pmc_fetch_write_per_kernel.json and
-profiles/r02_pmc_mfma_conv_kernels.json.  Keys are "<kernel>|grid=<work-items>": one kernel name covers many layer
+"""Summarise the PMC passes of tools_pmc.sh into profiles/<tag>_pmc_fetch_write_per_kernel.json and
+profiles/<tag>_pmc_mfma_conv_kernels.json (tag = argv[1], default r03).  Keys are "<kernel>|grid=<work-items>": one kernel name covers many layer
 instances, the grid size tells them apart (bench.py looks its dominant instance up by both)."""
-import collections, csv, glob, json, os, re
+import collections, csv, glob, json, os, re, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def short(name):
@@ -34,10 +35,10 @@ for k, v in f.items():
     out[k] = {"launches": len(v), "FETCH_SIZE_KB_avg": round(sum(v) / len(v), 1),
               "WRITE_SIZE_KB_avg": round(sum(wv) / len(wv), 1)}
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 6 "
-                   "--warmup 2 --no-cpu-baseline --no-extras` (tools/tools_pmc.sh); KB per launch, averaged over the "
+                   "--warmup 2 --no-cpu-baseline --no-extras --no-prewarm --min-timed-s 0` (tools/tools_pmc.sh); KB per launch, averaged over the "
                    "launches of one (kernel, grid size).  gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x "
                    "(MI355X_MICROARCH.md, HBM section); other access widths are uncalibrated.",
-           "kernels": out}, open("profiles/r02_pmc_fetch_write_per_kernel.json", "w"), indent=1)
+           "kernels": out}, open("profiles/%s_pmc_fetch_write_per_kernel.json" % TAG, "w"), indent=1)
 top = sorted(out.items(), key=lambda kv: -kv[1]["FETCH_SIZE_KB_avg"] * kv[1]["launches"])[:10]
 for k, v in top:
     print(k[:80], v)
@@ -60,6 +61,6 @@ for k in m["SQ_VALU_MFMA_BUSY_CYCLES"]:
 json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES "
                    "SQ_INSTS_VALU_MFMA_MOPS_F32 over the same bench command; averages per (kernel, grid size); "
                    "mfma_busy_frac = MFMA busy cycles / (1024 SIMDs x elapsed cycles)", "kernels": mo},
-          open("profiles/r02_pmc_mfma_conv_kernels.json", "w"), indent=1)
+          open("profiles/%s_pmc_mfma_conv_kernels.json" % TAG, "w"), indent=1)
 for k, v in sorted(mo.items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES_avg"] * kv[1]["launches"])[:10]:
     print(k[:70], v.get("mfma_busy_frac"), v["launches"])
