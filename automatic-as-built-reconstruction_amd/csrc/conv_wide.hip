@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
   const int ngroups = (nkc + KG - 1) / KG;
   const int nblk_all = pre_of(vol);
   auto load_w = [&](WReg &w, int k, int kg) {
-    const int kW = wflip ? vol - 1 - k : k;
+    const int kW = (wflip & 1) ? vol - 1 - k : k;
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
         f32x4 accA[NCB], accB[NCB];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) { accA[cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[cb] = accA[cb]; }
+        if (wflip & 2) __builtin_amdgcn_s_setprio(3);          // experiment (WIDE_PRIO knob): matrix phase at raised priority
         if constexpr (X3) {
           // term planes of the staged rows: plane pl at sa + pl * STAGE.  Products in the order small -> large:
           // a1 w3, a3 w1, a2 w2, a1 w2, a2 w1, a1 w1 (plane indices 0-based below)
@@ -453,6 +454,7 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
         }
         }
         if (DBG & 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(accA[0]), "v"(accB[0])); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        if (wflip & 2) __builtin_amdgcn_s_setprio(0);
         accumulate2(e0.ea, accA, e0.eb, accB);
       }
       if (NBUF == 1) wg_barrier();                           // single stage: every wave is done reading it
@@ -661,7 +663,9 @@ extern "C" int aabr_conv_forward_wide_stats(const float *in_feats, int n_in, int
   AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
   AABR_CHECK_ARG(n_in <= 128 || (n_in & 127) == 0, "n_in above 128 must be a multiple of 128");
   dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / 64));
-  const int flip = (flags >> 1) & 1;
+  // bit 1: the waves raise their priority for the matrix phase of a step (s_setprio): the wave that holds its operands
+  // gets the pipe, the others issue their gathers -- measured 331 -> 323.5 us on the dominant instance; WIDE_PRIO knob 0: off
+  const int flip = ((flags >> 1) & 1) | (knob(K_WIDE_PRIO) == 0 ? 0 : 2);
   const int kg = nkc >= 4 ? 4 : nkc;
   // LDS stage buffers: with 128-channel groups the double-buffered stage (32 KiB) allows two workgroups per CU, a
   // single buffer three (49 KiB each) at the price of a second barrier per pair: measured +4...+10 % (128->128 at 84k
@@ -787,7 +791,7 @@ extern "C" int aabr_conv_forward_wide_bf16_stats(const uint16_t *in_feats, int n
   AABR_CHECK_ARG(n_in <= 256 || (n_in & 255) == 0, "n_in above 256 must be a multiple of 256");
   const int ncb = wide_bf16_ncb(n_in, n_out);
   dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / (64 * ncb)));
-  const int flip = (flags >> 1) & 1;
+  const int flip = ((flags >> 1) & 1) | (knob(K_WIDE_PRIO) == 1 ? 2 : 0);   // bf16: priority only on request (measured below)
   const int kg = nkc >= 4 ? 4 : nkc;
   int nbuf = 1;
   {                                                // tuning experiments only
