@@ -185,10 +185,13 @@ class _Template(object):
         return len(self.fbufs) - 1
 
     def _param(self, p):
+        """one gradient slot per parameter, STORED by its one dW / BatchNorm-backward launch: a parameter used by two
+        operators of the graph (tied weights) would need a sum there, so such a network goes through the modules"""
         i = self.pidx.get(id(p))
-        if i is None:
-            i = self.pidx[id(p)] = len(self.params)
-            self.params.append(p)
+        if i is not None:
+            raise Unsupported("a parameter shared by two operators (tied weights)")
+        i = self.pidx[id(p)] = len(self.params)
+        self.params.append(p)
         return i
 
     def _book(self, kind, key, args):
@@ -668,11 +671,22 @@ class _GraphFunction(Function):
         res = ps.forward()
         ctx.ps = ps
         ctx.need_dx = x.requires_grad
+        # The backward list reads the transposed weight packs of THIS forward and recomputes the BatchNorm activation
+        # signs from the BatchNorm parameters: state held by reference.  An in-place parameter update between forward
+        # and backward (torch would raise "modified by an inplace operation") must not pass silently.
+        ctx.versions = [p._version for p in params]
+        ctx.params = params
         return tuple(res)
 
     @staticmethod
     def backward(ctx, *gouts):
         ps, ctx.ps = ctx.ps, None
+        for p, v in zip(ctx.params, ctx.versions):
+            if p._version != v:
+                raise RuntimeError("a parameter of the compiled FPN_Net graph was modified in place between forward and "
+                                   "backward (version %d -> %d): its packed copy / the BatchNorm coefficients the backward "
+                                   "list reads belong to the forward pass" % (v, p._version))
+        ctx.params = None
         dx, pgrad = ps.backward(gouts, ctx.need_dx)
         return (None, dx) + tuple(pgrad)
 

@@ -170,3 +170,62 @@ def test_mailbox_read_back_matches_tolist_also_from_a_side_stream():
         got = _hip.read_back(small * 3)
     torch.cuda.synchronize()
     assert got == [0, 3, 6, 9, 12, 15, 18, 21]
+
+
+def test_tied_weights_fall_back_to_the_module_path():
+    """the compiled backward gives every parameter ONE gradient slot that its single dW launch stores
+    into; a weight shared by two layers needs the sum of two contributions.  The template builder refuses such a
+    network (planExecutor.Unsupported -> module path), and the shared weight's gradient is the sum."""
+    import synth_scenes as S
+    import sparseconvnet as scn
+    from sparseconvnet import planExecutor
+    from test_cabi_and_host import default_fpn
+    torch.manual_seed(3)
+    net = default_fpn().to(DEV)
+    convs = [m for m in net.modules() if isinstance(m, scn.SubmanifoldConvolution) and m.nIn == m.nOut and m.filter_volume == 27]
+    a = convs[0]
+    b = next(m for m in convs[1:] if m.nIn == a.nIn)
+    b.weight = a.weight                                      # tied
+    locs, feats = S.make_batch(1, 8000, 3, 20)
+    l = torch.as_tensor(locs).to(DEV)
+
+    def run(compiled):
+        net.compiled_graph = compiled
+        net.zero_grad()
+        f = torch.as_tensor(feats).to(DEV).requires_grad_(True)
+        rpn, _ = net([l, f])
+        sum(m.features.square().mean() for m in rpn).backward()
+        return a.weight.grad.clone(), [m.features.detach().clone() for m in rpn]
+
+    before = planExecutor.stats["fallbacks"]
+    g_graph, maps_graph = run(True)
+    assert planExecutor.stats["fallbacks"] == before + 1
+    g_mod, maps_mod = run(False)
+    assert torch.equal(g_graph, g_mod)
+    for x, y in zip(maps_graph, maps_mod):
+        assert torch.equal(x, y)
+    assert g_mod.abs().max().item() > 0
+
+
+def test_parameter_update_between_forward_and_backward_is_refused():
+    """the compiled backward reads weight packs and BatchNorm coefficients by reference; an optimizer
+    step between forward and backward would silently give gradients of mixed weight versions.  It raises instead
+    (as torch does for saved tensors); the standard forward -> backward -> step order is unaffected."""
+    import synth_scenes as S
+    from test_cabi_and_host import default_fpn
+    torch.manual_seed(3)
+    net = default_fpn().to(DEV)
+    locs, feats = S.make_batch(1, 8000, 3, 20)
+    l = torch.as_tensor(locs).to(DEV)
+    f = torch.as_tensor(feats).to(DEV).requires_grad_(True)
+    rpn, _ = net([l, f])
+    loss = sum(m.features.square().mean() for m in rpn)
+    with torch.no_grad():
+        for p in net.m_downs.parameters():                   # in-place update of the weights inside the compiled graph
+            p.add_(1e-3)
+    with pytest.raises(RuntimeError, match="modified (in place|by an inplace operation)"):   # ours, or torch's own check
+        loss.backward()
+    net.zero_grad()
+    rpn, _ = net([l, f])
+    sum(m.features.square().mean() for m in rpn).backward()  # the regular order works
+    assert sum(p.grad is not None for p in net.parameters()) > 100
