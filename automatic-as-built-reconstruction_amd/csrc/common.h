@@ -13,7 +13,7 @@ void set_error(const char *fmt, ...);
 // variable AABR_<NAME> ONCE, at its first use in the process, and can be set explicitly through aabr_set_knob --
 // no entry point calls getenv on its launch path.
 enum Knob { K_CONV_WLDS, K_CONV_SMALL, K_CONV_NBW, K_CONV_WPB, K_CONV_RS, K_RS_UNIT, K_WIDE_ROWS, K_CONV_WIDE,
-            K_WIDE_NBUF, K_CONV_WIDE_BF16, K_VOXEL_MEAN, K_WIDE_NCB, K_BN_SMALL, K_CONV_X3, K_X3_FORM, K_WIDE_PRIO, K_PLAN_SIDE_BATCH, K_COUNT };
+            K_WIDE_NBUF, K_CONV_WIDE_BF16, K_VOXEL_MEAN, K_WIDE_NCB, K_BN_SMALL, K_CONV_X3, K_X3_FORM, K_WIDE_PRIO, K_PLAN_SIDE_BATCH, K_PLAN_SIDE_PRIO, K_COUNT };
 constexpr int kKnobUnset = -2147483647 - 1;
 int knob(Knob k);            // kKnobUnset when neither the environment nor aabr_set_knob gave a value
 

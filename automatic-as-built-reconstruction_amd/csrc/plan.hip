@@ -250,7 +250,16 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
   };
   auto flush = [&]() -> int {
     if (deferred.empty()) return AABR_OK;
-    if (!g_side.stream) AABR_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    if (!g_side.stream) {
+      // PLAN_SIDE_PRIO knob (experiment): 1 = lowest queue priority for the second stream (its launches are not on the
+      // critical chain), 2 = highest
+      int lo = 0, hi = 0;
+      const int v = knob(K_PLAN_SIDE_PRIO);
+      if ((v == 1 || v == 2) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+        AABR_CHECK_HIP(hipStreamCreateWithPriority(&g_side.stream, hipStreamNonBlocking, v == 1 ? lo : hi));
+      else
+        AABR_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    }
     hipEvent_t e = g_side.get(n_events++);
     AABR_CHECK_ARG(e != nullptr, "event creation failed");
     AABR_CHECK_HIP(hipEventRecord(e, main_stream));
