@@ -665,10 +665,31 @@ def timed_steps(torch, dist, wl, steps, warmup, world, dev, min_timed_s=0.0, pre
     region), so the line shows the distribution of step times and the first five.  When that region is shorter
     than `min_timed_s`, a SECOND region long enough to fill it is timed the same way right after and reported
     beside the first (`timing.extended`): a cross-check of a 0.3 s headline against >= 1 s of the same steps."""
+    import gc
     for i in range(warmup):
         wl.step(i)
     torch.cuda.synchronize()
     info = {"prewarm_steps": 0, "prewarm_s": 0.0}
+    # Python's cycle collector: a full (generation-2) collection walks every tracked object of the process -- the
+    # network, the templates, torch's own module state: 60-70 ms measured, once every few hundred steps, i.e. one step
+    # of 72 ms among steps of 8.3 (profiles/r03_bench_line_bf16.json, `extended.step_ms_max`).  The objects that exist
+    # after the warm-up live as long as the process: gc.freeze() moves them to the permanent generation, so the
+    # collections that do run inside the loop look at the step's own garbage only.  AABR_BENCH_GC=default leaves the
+    # collector as it is; the pauses are counted either way (`timing.gc`).
+    gc_mode = os.environ.get("AABR_BENCH_GC", "freeze")
+    gc_log = []
+    t_gc = [0.0]
+
+    def _gc_cb(phase, inf):
+        if phase == "start":
+            t_gc[0] = time.perf_counter()
+        else:
+            gc_log.append((inf.get("generation", -1), (time.perf_counter() - t_gc[0]) * 1e3))
+
+    if gc_mode == "freeze":
+        gc.collect()
+        gc.freeze()
+    gc.callbacks.append(_gc_cb)
     i0 = warmup
     if prewarm:
         n, sec, est, log = settle(torch, dist, wl, i0, world, dev)
@@ -705,6 +726,12 @@ def timed_steps(torch, dist, wl, steps, warmup, world, dev, min_timed_s=0.0, pre
                                 scenes_per_s=round(world * n2 * SCENES_PER_STEP / el2, 2),
                                 step_ms_p50=round(_pct(dev2, 0.5), 3), step_ms_max=round(max(dev2), 3),
                                 ratio_to_headline=round((el2 / n2) / (el / steps), 4))
+    gc.callbacks.remove(_gc_cb)
+    info["gc"] = dict(mode=gc_mode, collections=len(gc_log), full_collections=sum(1 for g, _ in gc_log if g == 2),
+                      pause_ms_max=round(max([m for _, m in gc_log] or [0.0]), 2),
+                      pause_ms_total=round(sum(m for _, m in gc_log), 2),
+                      note="Python cycle-collector runs between the end of the warm-up and the end of the last timed "
+                           "region (pre-warm included)")
     log_path = os.environ.get("AABR_BENCH_STEP_LOG")
     if log_path:
         with open(log_path, "w") as f:
