@@ -10,6 +10,7 @@ generation + decode are one fused HIP kernel; NMS is the device mask + scan.  Co
 import torch
 
 import _hip
+from sparseconvnet import SCN as _SCN
 import _nms
 from _hip import ptr, stream, check
 
@@ -45,7 +46,7 @@ def rpn_proposals_single_map(tensor, objectness, box_regression, base_anchors, v
     box_regression [V*A,7] in the flatten order [site, yaw].  Returns a list over examples of
     (boxes [m,7] yx_zb, objectness [m]) after NMS, all on the device."""
     lib = _hip.load()
-    g = tensor.metadata.grids[tuple(int(v) for v in tensor.spatial_size.tolist())]
+    g = tensor.metadata.grids[_SCN._key(tensor.spatial_size)]
     dev = objectness.device
     A = int(base_anchors.shape[0])
     ba = base_anchors.to(device=dev, dtype=torch.float32).contiguous()
@@ -97,7 +98,7 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
     lib = _hip.load()
     n_maps = len(maps)
     assert n_maps == len(objectness) == len(box_regression) == len(base_anchors) == len(strides)
-    grids = [t.metadata.grids[tuple(int(v) for v in t.spatial_size.tolist())] for t in maps]
+    grids = [t.metadata.grids[_SCN._key(t.spatial_size)] for t in maps]
     dev = objectness[0].device
     A = int(base_anchors[0].shape[0])
     ba = _device_anchors(base_anchors, A, dev)
@@ -221,7 +222,7 @@ def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thi
     from utils3d import rotate_nms_3d_torch as R
     lib = _hip.load()
     n_maps = len(maps)
-    grids = [t.metadata.grids[tuple(int(v) for v in t.spatial_size.tolist())] for t in maps]
+    grids = [t.metadata.grids[_SCN._key(t.spatial_size)] for t in maps]
     dev = grids[0].coords.device
     A = int(base_anchors[0].shape[0])
     ba = _device_anchors(base_anchors, A, dev)

@@ -143,57 +143,76 @@ class FPN_Net(torch.nn.Module):
         md = net.metadata
         if getattr(md, "_fpn_prebuilt", None) is not None:
             return md._fpn_prebuilt
-        sz = net.spatial_size
-        sizes = [sz]
-        three, one = torch.LongTensor([3, 3, 3]), torch.LongTensor([1, 1, 1])
+        sp = self._size_plan(net.spatial_size)
+        sizes = sp["sizes"]
+        three, one = sp["three"], sp["one"]
         nscale = len(self.m_downs)
         if self.grids_from_input:
-            self._grids_from_input(md, sz)
+            self._grids_from_input(md, sp)
         for k in range(nscale):
+            sz = sizes[k]
             md.getSubmanifoldRuleBook(sz, three)
             md.getSubmanifoldRuleBook(sz, one)
             if k + 1 < nscale:
-                ks, st = torch.LongTensor(self.down_kernels[k]), torch.LongTensor(self.down_strides[k])
-                out = (sz - ks) // st + 1
-                md.getRuleBook(sz, out, ks, st)
-                sz = out
-                sizes.append(sz)
-        for i, scale_from_top in enumerate(self.fpn_scales_from_top):
-            msz = sizes[nscale - 1 - scale_from_top]
-            ks = torch.LongTensor([1, 1, int(self.rpn_map_sizes[i][2])])
-            md.getRuleBook(msz, (msz - ks) // one + 1, ks, one)
+                ks, st = sp["down"][k]
+                md.getRuleBook(sz, sizes[k + 1], ks, st)
+        for msz, out, ks in sp["rpn"]:
+            md.getRuleBook(msz, out, ks, one)
         if SCN.count_macs:      # rule totals of all books of the pass (the MAC counter's terms): one launch
             SCN.prefetch_totals([tb.out for tb in list(md.submanifold.values()) + list(md.rulebooks.values())])
         md._fpn_prebuilt = sizes
         return sizes
 
-    def _grids_from_input(self, md, sz0):
-        """the strided grids of the pass in rounds of four levels when the down-sampling levels do not overlap
-        (filter == stride, the reference's default [[2,2,2]]*8): every grid of a round is built straight from the
-        round's base grid (Metadata.buildGridsFromInput) and the round costs ONE host read -- 3 reads per pass
-        instead of 13.  Not all from level 0: a 49-site level built from 310 k sites is 310 k atomics on 49 words
-        (measured: +2 ms); four levels deep the contention stays below ~20 per word on scene data."""
+    def _size_plan(self, sz0):
+        """The spatial sizes of every level of the pass, the filter / stride tensors and the grid specifications of
+        `_grids_from_input`: functions of the input's spatial size and the constructor arguments only.  Computed once
+        per input size and kept as long-lived tensor objects (SCN._key memoises their tuple form per object), instead
+        of ~150 small LongTensor constructions, divisions and .tolist() calls per pass (1 ms of host time)."""
+        from . import SCN
+        plans = self.__dict__.setdefault("_size_plans", {})
+        k0 = SCN._key(sz0)
+        sp = plans.get(k0)
+        if sp is not None:
+            return sp
         nscale = len(self.m_downs)
-        cum = torch.LongTensor([1, 1, 1])
-        sz, lvl = sz0, [(sz0, cum)]
+        three, one = torch.LongTensor([3, 3, 3]), torch.LongTensor([1, 1, 1])
+        sz = torch.LongTensor(list(k0))
+        sizes, down = [sz], []
         for k in range(nscale - 1):
             ks, st = torch.LongTensor(self.down_kernels[k]), torch.LongTensor(self.down_strides[k])
-            if not torch.equal(ks, st):
-                return
             sz = (sz - ks) // st + 1
+            down.append((ks, st))
+            sizes.append(sz)
+        rpn = []
+        for i, scale_from_top in enumerate(self.fpn_scales_from_top):
+            msz = sizes[nscale - 1 - scale_from_top]
+            ks = torch.LongTensor([1, 1, int(self.rpn_map_sizes[i][2])])
+            rpn.append((msz, (msz - ks) // one + 1, ks))
+        sp = dict(sizes=sizes, three=three, one=one, down=down, rpn=rpn, rounds=self._grid_rounds(sizes, down))
+        plans[k0] = sp
+        return sp
+
+    def _grid_rounds(self, sizes, down):
+        """`_grids_from_input`'s rounds for one input size: [(base size, base key, [(out size, out key, cumulative
+        stride relative to the base)])], or None when a down-sampling level overlaps (filter != stride)"""
+        nscale = len(self.m_downs)
+        cum = torch.LongTensor([1, 1, 1])
+        lvl = [(sizes[0], cum)]
+        for k in range(nscale - 1):
+            ks, st = down[k]
+            if not torch.equal(ks, st):
+                return None
             cum = cum * st
-            lvl.append((sz, cum))
+            lvl.append((sizes[k + 1], cum))
         zmaps = {}                                   # level -> z-collapse filter that spans the whole z extent
         for i, scale_from_top in enumerate(self.fpn_scales_from_top):
             k = nscale - 1 - scale_from_top
             z = int(self.rpn_map_sizes[i][2])
             if z == int(lvl[k][0][2]) and z > 1:
                 zmaps[k] = z
-        step = 4
+        step, rounds = 4, []
         for base in range(0, nscale, step):
             bsz, bcum = lvl[base]
-            if tuple(bsz.tolist()) not in md.grids:
-                return
             specs = []
             for k in range(base + 1, min(base + step, nscale - 1) + 1):
                 specs.append((lvl[k][0], lvl[k][1] // bcum))
@@ -202,8 +221,24 @@ class FPN_Net(torch.nn.Module):
                     # a z-collapse grid needs its level's sites only through their (x, y): from the base as well
                     specs.append((torch.LongTensor([int(lvl[k][0][0]), int(lvl[k][0][1]), 1]),
                                   (lvl[k][1] // bcum) * torch.LongTensor([1, 1, z])))
-            specs = [(o, c) for o, c in specs if tuple(o.tolist()) not in md.grids and int(c.max()) <= 65536]
-            md.buildGridsFromInput(bsz, specs)
+            specs = [(o, tuple(int(v) for v in o.tolist()), c) for o, c in specs if int(c.max()) <= 65536]
+            rounds.append((bsz, tuple(int(v) for v in bsz.tolist()), specs))
+        return rounds
+
+    def _grids_from_input(self, md, sp):
+        """the strided grids of the pass in rounds of four levels when the down-sampling levels do not overlap
+        (filter == stride, the reference's default [[2,2,2]]*8): every grid of a round is built straight from the
+        round's base grid (Metadata.buildGridsFromInput) and the round costs ONE host read -- 3 reads per pass
+        instead of 13.  Not all from level 0: a 49-site level built from 310 k sites is 310 k atomics on 49 words
+        (measured: +2 ms); four levels deep the contention stays below ~20 per word on scene data.  The rounds
+        themselves are part of the size plan (`_grid_rounds`)."""
+        if sp["rounds"] is None:
+            return
+        for bsz, bkey, specs in sp["rounds"]:
+            if bkey not in md.grids:
+                return
+            todo = [(o, c) for o, okey, c in specs if okey not in md.grids]
+            md.buildGridsFromInput(bsz, todo)
 
     def _compile_streams(self, md, sizes, in_channels):
         """block streams / offset-pair lists of every convolution of the pass (forward, input-gradient and weight-
@@ -213,7 +248,7 @@ class FPN_Net(torch.nn.Module):
         f32 = torch.float32
         three, one = (3, 3, 3), (1, 1, 1)
         nscale = len(self.m_downs)
-        key = lambda sz: tuple(int(v) for v in sz.tolist())
+        key = SCN._key            # memoised per (long-lived) size tensor of the size plan
 
         def subm(k, fs, ci, co, dtype):
             tb = md.submanifold[key(sizes[k]) + fs]
