@@ -8,14 +8,17 @@ maskrcnn_benchmark/config/defaults.py:48-57, SparseConvNet/sparseconvnet/fpn_net
   -> FPN_Net: 9 scales, 36 SubmanifoldConvolution + 12 Convolution + 8 Deconvolution + 35 BatchNorm(+ReLU)
   -> RPN head (three dense 1x1 layers, torch plumbing as in the reference, rpn_sparse3d.py:81-131; the shared head
      runs once over the rows of all six maps) and a synthetic loss over all anchors
+  -> RPN label generation (rpn/loss_3d.py:91-96: 40 ground-truth boxes per scene x the anchors of all six maps,
+     criterion-6 IoU + matcher thresholds, one fused kernel on its own stream; the loss's backward waits for it)
   -> per scene: cross-scale top-k(2000) -> fused anchor + BoxCoder3D decode -> rotated-3D NMS (1000)
   -> backward through head and backbone (all weight gradients + the input-feature gradient)
-  -> gradient all-reduce (N > 1: ONE flat RCCL all-reduce) -> SGD update.
+  -> gradient all-reduce (N > 1: RCCL, in buckets started from inside the backward pass) -> SGD update.
 The headline runs in fp32, the reference's arithmetic; the same step with bf16 feature storage is reported
 beside it (`extras.bf16`).  Inputs are resident in HBM before the timed region.
 Pipelining inside a step, all of it real work of that step or the next (nothing cached, nothing skipped):
-  * the proposal stage (top-k, decode, NMS: reads forward results only) is enqueued on a side stream after the
-    backward pass has been enqueued, so its small launches and host reads run underneath the backward kernels;
+  * the proposal stage (top-k, decode, NMS: reads forward results only) runs on a side stream underneath the backward
+    kernels: its launches go out before the backward pass is enqueued, its one read of counts (a mailbox post,
+    _hip.read_back) is taken after the backward pass and the SGD update have been enqueued;
   * the NEXT batch's geometry (voxel grid, strided grids, rule tables, block streams -- coordinates only) is built
     on that side stream from the end of this batch's forward pass on (`FPN_Net.prepare`, the device-side analogue
     of a data-loader prefetch; AABR_BENCH_PREFETCH=0 builds it inline instead); every step's geometry is built from scratch, one
@@ -23,7 +26,10 @@ Pipelining inside a step, all of it real work of that step or the next (nothing 
   * the layers between the input layer and the returned maps run through the compiled graph executor
     (sparseconvnet/planExecutor.py: same kernels, arguments and order as the per-layer modules, one launch list
     per pass; AABR_BENCH_COMPILED_GRAPH=0 runs the modules);
-  * N > 1: the gradient all-reduce is started right after backward and waited for before the SGD update.  One process per GPU
+  * N > 1: the gradient all-reduce runs in buckets launched from inside the compiled backward pass
+    (planExecutor.on_grads_ready) and is waited for before the SGD update;
+  * host side: the Python cycle collector is frozen after the warm-up (gc.freeze(): a full collection paused one
+    step in a few hundred for 40-65 ms; `timing.gc` reports the pauses).  One process per GPU
 (`--gpus N` spawns the ranks itself when not already under torchrun); ranks take different scenes of one global
 scene list (weak scaling: per-GPU work fixed); the only collective is the gradient all-reduce.
 
