@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const T *__restrict__ x, 
 
 
 // ---- small maps: ONE launch -------------------------------------------------------------------------------------
-// A map of <= 8192 (backward: 6144) rows is a few MB: the three launches above cost it ~4 us each of pure
+// A map of <= 2048 rows (the kernels hold up to 8192 / 6144) is under 2 MB: the three launches above cost it ~4 us each of pure
 // launch/drain latency (profiles/r02_bn_bench.txt: 27 us forward / 68 us backward regardless of size below 22k rows).
 // Here a workgroup owns FOUR planes (one 16-byte column of every row) and all rows: each thread keeps its <= 16 rows'
 // values in registers, the statistics are reduced inside the workgroup (shuffle butterfly, then the 8 waves in order:
@@ -296,6 +296,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const T *__restrict__ x, 
 // registers -- one read of x (and d_out), one write, no partials in memory.  Same formulas, float for float, as
 // k_bn_*_finalize / k_bn_*_apply; only the order of the fp64 additions differs from the three-launch path.
 constexpr int kSmallThreads = 512, kSmallRows = 16; // forward: x in registers (64 VGPRs)
+constexpr int kSmallDefaultCap = 2048;                // rows up to which the one-launch kernels are used: measured on the
+                                                      // bench step, cap 8192: 13.46 ms, 2048: 13.35, 512: 13.34, never: 13.41
 constexpr int kSmallThreadsB = 512, kSmallRowsB = 12; // backward: x and d_out in registers (239 VGPRs, nothing spilled; 16 rows spill)
 
 __device__ inline double wave_sum_f64(double v) {
@@ -450,8 +452,12 @@ __global__ __launch_bounds__(kSmallThreadsB) void k_bn_bwd_small(const T *__rest
 }
 
 static bool bn_small(int64_t rows, int planes, bool backward) {
-  const int64_t cap = backward ? (int64_t)kSmallThreadsB * kSmallRowsB : (int64_t)kSmallThreads * kSmallRows;
-  return rows > 1 && rows <= cap && (planes & 3) == 0 && knob(K_BN_SMALL) != 0;
+  int64_t cap = backward ? (int64_t)kSmallThreadsB * kSmallRowsB : (int64_t)kSmallThreads * kSmallRows;
+  const int v = knob(K_BN_SMALL);          // 0: never; > 1: row cap (tuning experiments)
+  if (v == 0) return false;
+  if (v > 1 && v < cap) cap = v;
+  else if (v < 0 && kSmallDefaultCap < cap) cap = kSmallDefaultCap;
+  return rows > 1 && rows <= cap && (planes & 3) == 0;
 }
 
 static int bn_parts(int64_t rows, int planes, int vec) {

@@ -229,10 +229,11 @@ def _bn_exact(x, w, b, eps, leak, g):
     return out, mean, var, d_in, dw, db, y
 
 
-@pytest.mark.parametrize("planes,leak,npts", [(32, 0.0, 6000), (64, 0.333, 6000), (128, 0.0, 6000), (9, 0.1, 6000),
-                                              (256, 0.0, 6000), (64, 0.2, 60000), (128, 0.0, 30000), (9, 0.0, 30000)])
+@pytest.mark.parametrize("planes,leak,npts", [(32, 0.0, 6000), (64, 0.333, 1800), (128, 0.0, 1500), (9, 0.1, 6000),
+                                              (256, 0.0, 600), (64, 0.2, 60000), (128, 0.0, 30000), (9, 0.0, 30000),
+                                              (128, 0.1, 6000)])
 def test_batchnorm_forward_backward(planes, leak, npts):
-    """6000 points (<= 8192 sites): the one-launch small-map kernels; 30000 / 60000 points: statistics pass +
+    """<= 1800 points (<= 2048 sites): the one-launch small-map kernels; 6000 / 30000 / 60000 points: statistics pass +
     finalize + apply.  Which side is closer to exact: the device keeps fp64 partial sums, the reference (and the
     oracle, bit-pinned to it) sums sequentially in fp32 -- measured against the fp64 yardstick the device's error is
     the smaller one (asserted below), and the device-vs-oracle tolerances are set from the ORACLE's measured
