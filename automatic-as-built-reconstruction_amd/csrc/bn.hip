@@ -528,7 +528,7 @@ template <typename T>
 static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int64_t rows, int planes,
                          const float *save_mean, const float *save_invstd, const float *weight, const float *bias,
                          float *d_weight, float *d_bias, float leakiness, float *scratch, void *stream_,
-                         const T *d_in_add = nullptr) {
+                         const T *d_in_add = nullptr, const double *pre_part = nullptr, int pre_nparts = 0) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(rows >= 0 && planes > 0, "bad sizes");
   AABR_CHECK_ARG(save_mean && save_invstd && scratch, "null pointer");
@@ -546,20 +546,25 @@ static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int
   double *part = reinterpret_cast<double *>(scratch);
   float *coef = scratch + (int64_t)kMaxParts * 2 * planes * 2;
   const bool v4 = (planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)(recompute ? nullptr : out) | (uintptr_t)d_out) & 15) == 0;
-  if (v4 && bn_small(rows, planes, true) && (((uintptr_t)d_in | (uintptr_t)d_in_add) & 15) == 0) {
+  if (!pre_part && v4 && bn_small(rows, planes, true) && (((uintptr_t)d_in | (uintptr_t)d_in_add) & 15) == 0) {
     hipLaunchKernelGGL((k_bn_bwd_small<T>), dim3(planes / 4), dim3(kSmallThreadsB), 0, st, in, d_in, out, d_out, (int)rows,
                        planes, save_mean, save_invstd, weight, bias, d_weight, d_bias, leakiness, recompute, d_in_add);
     AABR_CHECK_LAUNCH();
     return AABR_OK;
   }
   int nparts = bn_parts(rows, planes, v4 ? 4 : 1);
-  if (v4)
+  const double *fin_part = part;
+  if (pre_part) {   // the statistics' partial sums came with the write-out of the convolution that produced d_out
+    AABR_CHECK_ARG(pre_nparts > 0 && recompute, "precomputed backward statistics: fp32 storage, leakiness >= 0");
+    fin_part = pre_part;
+    nparts = pre_nparts;
+  } else if (v4)
     hipLaunchKernelGGL((k_bn_partials<1, 4, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
                        leakiness, rows, planes, part, save_invstd, weight, bias, recompute);
   else
     hipLaunchKernelGGL((k_bn_partials<1, 1, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
                        leakiness, rows, planes, part, save_invstd, weight, bias, recompute);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, fin_part, nparts,
                      rows, planes, save_invstd, weight, d_weight, d_bias, coef);
   int64_t total = rows * planes;
   if (v4 && (((uintptr_t)d_in | (uintptr_t)save_mean | (uintptr_t)d_in_add) & 15) == 0)
@@ -619,6 +624,18 @@ extern "C" int aabr_bn_backward_add(const float *in, float *d_in, const float *o
                                     float leakiness, float *scratch, const float *d_in_add, void *stream_) {
   return bn_backward_t<float>(in, d_in, out, d_out, rows, planes, save_mean, save_invstd, weight, bias, d_weight,
                               d_bias, leakiness, scratch, stream_, d_in_add);
+}
+
+// backward with the statistics' partial sums given (aabr_conv_forward_wide_bwd_stats: per tile [2][planes] fp64 sums of
+// the masked d_out and of (x - mean) * masked d_out, in tile order): the statistics pass over x and d_out is skipped
+extern "C" int aabr_bn_backward_parts(const float *in, float *d_in, const float *out, const float *d_out, int64_t rows,
+                                      int planes, const float *save_mean, const float *save_invstd,
+                                      const float *weight, const float *bias, float *d_weight, float *d_bias,
+                                      float leakiness, const double *parts, int nparts, float *scratch,
+                                      const float *d_in_add, void *stream_) {
+  AABR_CHECK_ARG(parts && nparts > 0, "partials");
+  return bn_backward_t<float>(in, d_in, out, d_out, rows, planes, save_mean, save_invstd, weight, bias, d_weight,
+                              d_bias, leakiness, scratch, stream_, d_in_add, parts, nparts);
 }
 
 // bf16 feature storage (extension; statistics in fp64, affine maths in fp32, parameters fp32)

@@ -116,6 +116,15 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // NCB = 16-column blocks per wave: 1 = 64-column slabs; 2 (bf16 storage) = 128-column slabs -- the kernel is bound by
 // the rate at which a CU gathers random rows (~20 GB/s per CU measured in both this and the row-stationary kernel,
 // profiles/r03_conv_rs_ab.txt), and a 128-column layer gathered every row once per 64-column slab, i.e. twice
+// `stats` in the input-gradient form: the launch writes d_out of the BatchNorm(+leaky ReLU) whose OUTPUT the convolution
+// consumed in the forward pass; with `x` set the write-out forms that BatchNorm's BACKWARD statistics instead of the
+// forward ones -- per tile [2][co] fp64 sums of d and (x - mean) * d, d = d_out masked by the sign of the forward
+// activation recomputed from x exactly as k_bn_partials<1> does (same floats, same operations)
+struct BnBwdStats {
+  const float *x, *mean, *invstd, *weight, *bias;   // x == nullptr: forward statistics (or none)
+  float leak;
+};
+
 // X3 (fp32 storage, fp32-equivalent arithmetic on the bf16 matrix pipe): every fp32 operand is split into three bf16
 // terms x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 mantissa bits in 3 x 8, the
 // residual is <= 2^-27 |x|), the gathered rows at the stage store, the weights at pack time; a product a * w is formed as
@@ -129,7 +138,8 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
                                                     const float *__restrict__ bias, int kT2,
-                                                    const float *__restrict__ res, double *__restrict__ stats) {
+                                                    const float *__restrict__ res, double *__restrict__ stats,
+                                                    BnBwdStats bn) {
   constexpr int RG = KG * 8;               // 16-byte granules per staged row
   constexpr int RF = KG * 32;              // floats per staged row
   constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
@@ -514,6 +524,16 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
   // BatchNorm's finalize in tile order, so the result does not depend on which workgroup ran when
   constexpr int QW = 16 * NCB;             // 16-byte columns of the slab; 256 % QW == 0: a thread keeps its column
   double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+  float bmu[4] = {0.f, 0.f, 0.f, 0.f}, bwc[4] = {0.f, 0.f, 0.f, 0.f}, bbc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!BF && stats && bn.x) {              // this thread's four columns of the BatchNorm's forward coefficients
+    const int p0 = nb0 * 16 + (threadIdx.x % QW) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bmu[j] = bn.mean[p0 + j];
+      bwc[j] = bn.invstd[p0 + j] * (bn.weight ? bn.weight[p0 + j] : 1.0f);
+      bbc[j] = -bmu[j] * bwc[j] + (bn.bias ? bn.bias[p0 + j] : 0.0f);
+    }
+  }
 #pragma unroll 4
   for (int i = threadIdx.x; i < nrows * QW; i += 256) {
     const int r = i / QW, q = i % QW;
@@ -534,8 +554,19 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
       *reinterpret_cast<f32x4 *>(out + (row0 + r) * co + nb0 * 16 + q * 4) = v;
     }
     if (stats) {
+      if (!BF && bn.x) {                   // backward statistics of the BatchNorm whose d_out this tile is
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(bn.x + (row0 + r) * co + nb0 * 16 + q * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { sa[j] += (double)v[j]; sb[j] += (double)v[j] * (double)v[j]; }
+        for (int j = 0; j < 4; ++j) {
+          const float o = xv[j] * bwc[j] + bbc[j];
+          const float d = (o > 0.0f) ? v[j] : v[j] * bn.leak;
+          sa[j] += (double)d;
+          sb[j] += (double)(xv[j] - bmu[j]) * (double)d;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sa[j] += (double)v[j]; sb[j] += (double)v[j] * (double)v[j]; }
+      }
     }
   }
   if (stats) {
@@ -640,10 +671,35 @@ extern "C" int aabr_conv_forward_wide_res(const float *in_feats, int n_in, int64
                                       flags, wpack, residual, nullptr, stream_);
 }
 
+static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out, int64_t V_out,
+                           const int32_t *blocks, int tile_rows, int vol, const float *bias, int flags,
+                           const float *wpack, const float *residual, double *stats, BnBwdStats bn, void *stream_);
+
 extern "C" int aabr_conv_forward_wide_stats(const float *in_feats, int n_in, int64_t rows_in, float *out_feats,
                                             int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
                                             const float *bias, int flags, const float *wpack, const float *residual,
                                             double *stats, void *stream_) {
+  return wide_launch_f32(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias, flags, wpack,
+                         residual, stats, BnBwdStats{}, stream_);
+}
+
+extern "C" int aabr_conv_forward_wide_bwd_stats(const float *in_feats, int n_in, int64_t rows_in, float *out_feats,
+                                                int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                                const float *bias, int flags, const float *wpack, const float *residual,
+                                                double *stats, const float *bn_in, const float *save_mean,
+                                                const float *save_invstd, const float *bn_weight, const float *bn_bias,
+                                                float leakiness, void *stream_) {
+  AABR_CHECK_ARG(stats && bn_in && save_mean && save_invstd, "null pointer");
+  AABR_CHECK_ARG(leakiness >= 0.0f, "the activation sign is recomputed from the BatchNorm input: leakiness >= 0");
+  AABR_CHECK_ARG(((uintptr_t)bn_in & 15) == 0, "the BatchNorm input must be 16-byte aligned");
+  BnBwdStats bn{bn_in, save_mean, save_invstd, bn_weight, bn_bias, leakiness};
+  return wide_launch_f32(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias, flags, wpack,
+                         residual, stats, bn, stream_);
+}
+
+static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out, int64_t V_out,
+                           const int32_t *blocks, int tile_rows, int vol, const float *bias, int flags,
+                           const float *wpack, const float *residual, double *stats, BnBwdStats bn, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(((uintptr_t)residual & 15) == 0, "residual must be 16-byte aligned");
   AABR_CHECK_ARG(!stats || (tile_rows >= 64 && ((uintptr_t)stats & 7) == 0), "statistics need tiles of >= 64 rows");
@@ -689,7 +745,7 @@ extern "C" int aabr_conv_forward_wide_stats(const float *in_feats, int n_in, int
 #define AABR_WIDE_CS_N(KG, D, NB)                                                                         \
   AABR_LAUNCH_WIDE((k_conv_cs<KG, D, NB>), "k_conv_cs<" #KG "," #D "," #NB ">",                           \
                    (size_t)((tile_rows + 1) * kWS + NB * 2 * 16 * KG * 32) * sizeof(float), in_feats, n_in, in_bytes,   \
-                   out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows, residual, stats)
+                   out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows, residual, stats, bn)
 #define AABR_WIDE_CS(KG, D)                                                                               \
   do {                                                                                                    \
     if (nbuf == 1) AABR_WIDE_CS_N(KG, D, 1); else AABR_WIDE_CS_N(KG, D, 2);                               \
@@ -809,7 +865,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
     hipLaunchKernelGGL((k_conv_cs<KG, D, NB, true, NCB, kBfSets>), grid, dim3(256),                                \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr, stats);                                                      \
+                       tile_rows, (const float *)nullptr, stats, BnBwdStats{});                                                      \
   } while (0)
 #define AABR_WIDE_BF_S(KG, NB, NCB, NS)                                                                                  \
   do {                                                                                                             \
@@ -823,7 +879,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
     hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS>), grid, dim3(256),                                         \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr, stats);                                                      \
+                       tile_rows, (const float *)nullptr, stats, BnBwdStats{});                                                      \
   } while (0)
 #define AABR_WIDE_BF_K(KG)                                                                                         \
   do {                                                                                                             \
@@ -927,7 +983,7 @@ extern "C" int aabr_conv_forward_wide_x3(const float *in_feats, int n_in, int64_
     hipLaunchKernelGGL((k_conv_cs<KG, 0, 1, false, NCB, 2, true>), grid, dim3(256),                                   \
                        (size_t)((tile_rows + 1) * kWS * NCB + 3 * 2 * 16 * KG * 32) * sizeof(float), st, in_feats,    \
                        n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias, \
-                       tile_rows, residual, stats);                                                                   \
+                       tile_rows, residual, stats, BnBwdStats{});                                                     \
   } while (0)
 #ifdef AABR_DEV
   if ((flags >> 8) & 4) {   // timing experiments (tools/tools_cs_phases.py x3): phase clocks -> the buffer passed as `bias`
@@ -939,7 +995,7 @@ extern "C" int aabr_conv_forward_wide_x3(const float *in_feats, int n_in, int64_
       hipLaunchKernelGGL((k_conv_cs<KG, 4, 1, false, NCB, 2, true>), grid, dim3(256),                                 \
                          (size_t)((tile_rows + 1) * kWS * NCB + 3 * 2 * 16 * KG * 32) * sizeof(float), st, in_feats,  \
                          n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes,     \
-                         bias, tile_rows, residual, stats);                                                           \
+                         bias, tile_rows, residual, stats, BnBwdStats{});                                             \
     } while (0)
     if (form == 1) AABR_X3_D(1, 2); else if (form == 2) AABR_X3_D(2, 1); else AABR_X3_D(1, 1);
 #undef AABR_X3_D

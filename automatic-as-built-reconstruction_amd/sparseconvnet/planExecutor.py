@@ -59,6 +59,9 @@ fuse_adds = os.environ.get("AABR_PLAN_FUSE_ADDS", "1") != "0"
 # a training-mode BatchNorm right behind a wide-kernel convolution takes its statistics' partial sums from that
 # convolution's write-out (aabr_conv_forward_wide_stats -> aabr_bn_forward_parts): one pass over the matrix less
 conv_bn_stats = os.environ.get("AABR_PLAN_CONV_BN_STATS", "1") != "0"
+# ... and a BatchNorm backward right behind the wide-kernel input-gradient launch that produced its d_out takes its
+# statistics from that launch's write-out (aabr_conv_forward_wide_bwd_stats -> aabr_bn_backward_parts; fp32 storage)
+conv_bn_bwd_stats = os.environ.get("AABR_PLAN_CONV_BN_BWD_STATS", "1") != "0"
 
 
 # Data-parallel hook (extension; the reference wraps the model in DistributedDataParallel, whose bucketed all-reduce
@@ -578,8 +581,10 @@ class _Pass(object):
         cut = [(len(bops) * (q + 1)) // nseg for q in range(nseg)] if nseg > 1 else []
         inv = sorted((o, i) for i, o in bw["poff"].items()) if nseg > 1 else []
         done_floats, seg_no, next_inv = 0, 0, 0
+        last_din, bstat = None, None     # the last wide input-gradient record of the main stream / statistics workspace
         for op_no, op in enumerate(bops):
             if nseg > 1 and seg_no < nseg - 1 and op_no == cut[seg_no]:
+                last_din = None          # its record has been handed over
                 if off:
                     check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, stream()))
                     off = 0
@@ -602,12 +607,19 @@ class _Pass(object):
             if kind == "din":
                 _, gy, gx, lo, lvl, n_in, n_out, book, side, flags, p_w, pt, flg, res, tmp = op
                 g = books[book][side]
+                last_din = None
                 if res is None:
+                    off0 = off
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
                                            n_out, g, p_w, pt, flags, flg == F_BF16)
+                    if self._lw >= 64 and flg != F_BF16 and off > off0:
+                        last_din = (gx, off0, self._lw, n_out)
                 elif V[lvl] and self.wide_rows(n_in, n_out, V[lo], V[lvl], g.vol):
+                    off0 = off
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
                                            n_out, g, p_w, pt, flags, False, 0, AD[res[0]][res[1]])
+                    if self._lw >= 64 and off > off0:
+                        last_din = (gx, off0, self._lw, n_out)
                 else:                    # not a wide launch: d_in into the spare buffer, then the sum
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[tmp[0]][tmp[1]], V[lvl],
                                            n_out, g, p_w, pt, flags, False)
@@ -623,17 +635,35 @@ class _Pass(object):
             elif kind == "bn":
                 _, x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b, res = op
                 if V[lvl]:
-                    pack(buf, off, K_BNB, flg, planes, 0, 0, 0, 0, 0, 0.0, 0.0, leak, 0.0, V[lvl], 0, 0, 0,
+                    parts, nparts, ld = 0, 0, last_din
+                    if (conv_bn_bwd_stats and ld is not None and ld[0] == gy and ld[3] == planes and not flg
+                            and leak >= 0.0):
+                        # the BatchNorm's d_out was written by the wide-kernel input-gradient launch right before it (the
+                        # weight-gradient record in between runs on the second stream): that launch's write-out forms the
+                        # backward statistics (record i32[5] = 1, p6 stats, p7.. the BatchNorm's input and coefficients)
+                        nparts = (V[lvl] + ld[2] - 1) // ld[2]
+                        if bstat is None:
+                            bstat = _hip.workspace("conv_bwd_stats", (max(V) // 64 + 1) * 2 * t.max_planes,
+                                                   torch.float64, self.dev).data_ptr()
+                        parts = bstat
+                        struct.pack_into("<i", buf, ld[1] + 8 + 5 * 4, 1)                                   # i32[5]
+                        struct.pack_into("<f", buf, ld[1] + 32, leak)                                       # f32[0]
+                        struct.pack_into("<6Q", buf, ld[1] + 80 + 6 * 8, bstat, A[x], sbase + st * 4,
+                                         sbase + (st + planes) * 4, p_w, p_b)                               # p6 .. p11
+                    pack(buf, off, K_BNB, flg, planes, nparts, 0, 0, 0, 0, 0.0, 0.0, leak, 0.0, V[lvl], parts, 0, 0,
                          A[x], AD[gx[0]][gx[1]], A[y], AD[gy[0]][gy[1]], sbase + st * 4, sbase + (st + planes) * 4,
                          p_w, pbase + pw if pw >= 0 else 0, pbase + pb if pb >= 0 else 0, bnws, p_b,
                          AD[res[0]][res[1]] if res is not None else 0)
                     off += 176
+                last_din = None
             elif kind == "add":
                 _, a_, b_, s, lvl, planes, flg = op
                 pack(buf, off, K_ADD, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
                      AD[a_[0]][a_[1]], AD[b_[0]][b_[1]], AD[s[0]][s[1]], 0, 0, 0, 0, 0, 0, 0, 0, 0)
                 off += 176
+                last_din = None
             else:
+                last_din = None
                 _, gy, gx, lvl, planes, flg = op
                 pack(buf, off, K_CAST, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
                      AD[gy[0]][gy[1]], AD[gx[0]][gx[1]], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)

@@ -402,3 +402,79 @@ def test_wide_x3_split_is_fp32_accurate(nIn, nOut, npts, form):
     finally:
         for k in ("CONV_X3", "CONV_WIDE", "X3_FORM"):
             _hip.set_knob(k, None)
+
+
+@pytest.mark.parametrize("nIn,nOut,npts,use_res,leak,affine", [(64, 64, 3000, False, 0.0, True), (128, 128, 2500, True, 0.2, True),
+                                                               (128, 64, 900, False, 0.0, False)])
+def test_wide_write_out_backward_statistics_feed_batchnorm_backward(force_wide, nIn, nOut, npts, use_res, leak, affine):
+    """aabr_conv_forward_wide_bwd_stats (the input-gradient launch of the layer that consumed a BatchNorm's output):
+    its per-tile partial sums equal numpy's fp64 sums of the masked d_out it stores, and aabr_bn_backward_parts fed
+    with them gives the d_in / d_weight / d_bias of aabr_bn_backward_add (own statistics pass) to the last bits of the
+    fp64 sums (SCN/CPU/BatchNormalization.cpp:66-106)."""
+    import _hip
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(nIn + 9 * nOut + npts)
+    coords, _ = _scene(rng, npts, (12, 11, 5), 2, 1)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    T = lib.aabr_conv_wide_tile_rows(nIn, nOut, V, V, vol)
+    assert T >= 64
+    ntile = (V + T - 1) // T
+    # the conv launch: g [V, nIn] -> d_out [V, nOut] (any wide launch will do; the transposed flags are exercised elsewhere)
+    W = _t((rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32))
+    wp = torch.empty(lib.aabr_conv_wpack_floats(vol, nIn, nOut), device=DEV)
+    check(lib.aabr_conv_pack_weights(ptr(W), vol, nIn, nOut, 0, ptr(wp), stream()))
+    g = _t(rng.standard_normal((V, nIn)).astype(np.float32))
+    res = _t(rng.standard_normal((V, nOut)).astype(np.float32)) if use_res else None
+    # the BatchNorm whose output the layer consumed: input xb, saved statistics, affine parameters
+    xb = _t((rng.standard_normal((V, nOut)) * 1.3 + 0.2).astype(np.float32))
+    gam = _t(rng.uniform(0.5, 1.5, nOut).astype(np.float32)) if affine else None
+    bet = _t(rng.standard_normal(nOut).astype(np.float32)) if affine else None
+    ws = torch.empty(int(lib.aabr_bn_scratch_floats(nOut)), device=DEV)
+    y = torch.empty_like(xb)
+    sm, si, rm, rv = (torch.zeros(nOut, device=DEV) for _ in range(4))
+    _hip.set_knob("BN_SMALL", 0)
+    try:
+        check(lib.aabr_bn_forward(ptr(xb), ptr(y), V, nOut, ptr(sm), ptr(si), ptr(rm), ptr(rv), ptr(gam) if affine else None,
+                                  ptr(bet) if affine else None, 1e-4, 0.9, 1, leak, ptr(ws), stream()))
+        d_out = torch.empty((V, nOut), device=DEV)
+        d_out0 = torch.empty_like(d_out)
+        stats = torch.full((ntile, 2, nOut), float("nan"), dtype=torch.float64, device=DEV)
+        blocks = ga.blocks_wide(T)
+        a = (ptr(g), nIn, V, None, nOut, V, ptr(blocks), T, vol, None, 0, ptr(wp), ptr(res) if use_res else None)
+        check(lib.aabr_conv_forward_wide_bwd_stats(*a[:3], ptr(d_out), *a[4:], ptr(stats), ptr(xb), ptr(sm), ptr(si),
+                                                   ptr(gam) if affine else None, ptr(bet) if affine else None, leak, stream()))
+        check(lib.aabr_conv_forward_wide_res(*a[:3], ptr(d_out0), *a[4:], stream()))
+        assert torch.equal(d_out, d_out0)
+        # numpy fp64 sums of the masked gradient per tile
+        d32 = d_out.cpu().numpy()
+        mask = (y.cpu().numpy() > 0)
+        dm = np.where(mask, d32, d32 * np.float32(leak)).astype(np.float64)     # the mask multiply is an fp32 operation
+        xc = (xb.cpu().numpy().astype(np.float32) - sm.cpu().numpy().astype(np.float32)).astype(np.float64)
+        st = stats.cpu().numpy()
+        for j in range(ntile):
+            sl = slice(j * T, (j + 1) * T)
+            np.testing.assert_allclose(st[j, 0], dm[sl].sum(0), rtol=1e-12, atol=1e-11)
+            np.testing.assert_allclose(st[j, 1], (xc[sl] * dm[sl]).sum(0), rtol=1e-12, atol=1e-11)
+        radd = _t(rng.standard_normal((V, nOut)).astype(np.float32))
+
+        def run(parts):
+            d_in = torch.empty_like(xb)
+            dw, db = torch.zeros(nOut, device=DEV), torch.zeros(nOut, device=DEV)
+            common = (ptr(xb), ptr(d_in), ptr(y), ptr(d_out), V, nOut, ptr(sm), ptr(si), ptr(gam) if affine else None,
+                      ptr(bet) if affine else None, ptr(dw), ptr(db), leak)
+            if parts:
+                check(lib.aabr_bn_backward_parts(*common, ptr(stats), ntile, ptr(ws), ptr(radd), stream()))
+            else:
+                check(lib.aabr_bn_backward_add(*common, ptr(ws), ptr(radd), stream()))
+            return d_in.cpu().numpy(), dw.cpu().numpy(), db.cpu().numpy()
+
+        got, want = run(True), run(False)
+        np.testing.assert_allclose(got[2], want[2], rtol=3e-7, atol=1e-6)
+        np.testing.assert_allclose(got[1], want[1], rtol=3e-7, atol=1e-6)
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-6, atol=1e-6)
+    finally:
+        _hip.set_knob("BN_SMALL", None)
