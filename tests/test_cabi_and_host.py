@@ -218,3 +218,35 @@ def test_metadata_incremental_input_is_host_bookkeeping_like_the_reference():
     assert md.getNActive(torch.LongTensor([8, 8, 8])) == 4
     md.setInputSpatialLocations(feats, torch.LongTensor([[7, 7, 7, 2]]), torch.FloatTensor([[8, 80]]), False)
     assert feats.shape == (5, 2) and md._inb["nsamples"] == 3
+
+
+def test_bench_roofline_traffic_lookup_matches_the_committed_pmc_profile():
+    """bench.pmc_traffic: the (kernel, grid) instance named by aabr_conv_last_variant() is found in the committed PMC
+    profile although the profiler prints every template argument; a different grid or kernel gives (None, reason),
+    never another instance's number."""
+    import importlib
+    import json
+    bench = importlib.import_module("bench")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                        "r03_pmc_fetch_write_per_kernel.json")
+    pm = json.load(open(path))["kernels"]
+    key = "k_conv_cs<4,0,1,false,1,2,false>|grid=336384"
+    assert key in pm
+    want = int((2.0 * pm[key]["FETCH_SIZE_KB_avg"] + pm[key]["WRITE_SIZE_KB_avg"]) * 1024)
+    got, src = bench.pmc_traffic("k_conv_cs<4,0,1>", 336384)
+    assert got == want and key in src
+    assert bench.pmc_traffic("k_conv_cs<4,0,1>", 12345)[0] is None
+    assert bench.pmc_traffic("k_conv_cs<9,9,9>", 336384)[0] is None
+    assert bench.pmc_traffic("k_conv_cs<2,0,1,bf16,x128>", 336384)[0] is None      # no bf16 pass in the fp32 profile
+
+
+def test_knob_registry_rejects_unknown_names_and_takes_known_ones():
+    """aabr_set_knob: the tuning knobs are a closed list read once per process (never getenv on a launch path)"""
+    import _hip
+    lib = _hip.load()
+    assert lib.aabr_set_knob(b"NO_SUCH_KNOB", 1, 0) != 0
+    assert b"unknown knob" in lib.aabr_last_error()
+    for name in ("CONV_WIDE", "WIDE_NBUF", "BN_SMALL", "CONV_X3", "X3_FORM", "WIDE_PRIO", "PLAN_SIDE_BATCH",
+                 "PLAN_SIDE_PRIO", "VOXEL_MEAN", "WIDE_NCB", "CONV_RS"):
+        assert lib.aabr_set_knob(name.encode(), 1, 0) == 0
+        assert lib.aabr_set_knob(name.encode(), 0, 1) == 0                       # back to "unset"

@@ -583,3 +583,37 @@ def test_output_layer_and_incremental_input_match_oracle():
     ref = scn.InputLayer(3, [16, 16, 8], mode=1)([_t(coords), _t(feats)])
     torch.testing.assert_close(y.features, conv(ref).features, rtol=0, atol=0)
     np.testing.assert_array_equal(xin.get_spatial_locations().numpy(), il1["coords"])
+
+
+def test_prefetched_geometry_is_parked_with_one_event_and_reaped():
+    """SCN.Metadata_3.hand_over: geometry built on another stream and consumed on the current one is kept until its
+    Metadata dies, then parked with ONE event on the consumer stream and dropped once that event has passed
+    (replaces tensor.record_stream per tensor: ~200 marker packets per pass)."""
+    import gc
+    import sparseconvnet as scn
+    from sparseconvnet import SCN
+    rng = np.random.default_rng(3)
+    coords = np.stack([rng.integers(0, 30, 3000), rng.integers(0, 30, 3000), rng.integers(0, 8, 3000),
+                       np.zeros(3000, np.int64)], 1).astype(np.int64)
+    feats = rng.standard_normal((3000, 4)).astype(np.float32)
+    layer = scn.InputLayer(3, [32, 32, 8], mode=4)
+    conv = scn.SubmanifoldConvolution(3, 4, 8, 3, False).to(DEV)
+    c = _t(coords)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    SCN._reap_handed_over()
+    n0 = len(SCN._parked)
+    layer.prepare(c, torch.device(DEV), side)
+    x = layer([c, _t(feats)])
+    md = x.metadata
+    assert getattr(md, "_handed_over", None) is not None and md._handed_over[0] == torch.cuda.current_stream()
+    with torch.no_grad():                              # (an autograd graph would keep the Metadata alive through its nodes)
+        y = conv(x).features.clone()
+    assert len(SCN._parked) == n0                      # alive: nothing parked yet
+    del x, md
+    gc.collect()
+    assert len(SCN._parked) == n0 + 1                  # parked with one event
+    torch.cuda.synchronize()
+    SCN._reap_handed_over()
+    assert len(SCN._parked) == n0                      # the consumer stream has passed it
+    assert torch.isfinite(y).all()
