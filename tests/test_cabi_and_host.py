@@ -237,7 +237,12 @@ def test_bench_roofline_traffic_lookup_matches_the_committed_pmc_profile():
     assert got == want and key in src
     assert bench.pmc_traffic("k_conv_cs<4,0,1>", 12345)[0] is None
     assert bench.pmc_traffic("k_conv_cs<9,9,9>", 336384)[0] is None
-    assert bench.pmc_traffic("k_conv_cs<2,0,1,bf16,x128>", 336384)[0] is None      # no bf16 pass in the fp32 profile
+    # the bf16-storage instance of the same rule book (64-row tiles x 128-column slabs: the same grid size) is a
+    # different entry (template argument `true`, slab argument 2), merged in from the `--dtype bf16` passes
+    kb = "k_conv_cs<2,0,1,true,2,2,false>|grid=336384"
+    got_b, src_b = bench.pmc_traffic("k_conv_cs<2,0,1,bf16,x128>", 336384)
+    assert kb in pm and kb in src_b and got_b != got
+    assert bench.pmc_traffic("k_conv_cs<2,0,1,bf16>", 336384)[0] is None           # 64-column slabs: not this instance
 
 
 def test_knob_registry_rejects_unknown_names_and_takes_known_ones():

@@ -27,6 +27,26 @@ def agg(pat, counter=None):
     return d
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "merge-bf16":
+    # instances of the `--dtype bf16` passes (tools/tools_pmc_bf16.sh) that the fp32 profile does not have
+    path = "profiles/%s_pmc_fetch_write_per_kernel.json" % TAG
+    doc = json.load(open(path))
+    fb = agg("gpurun_out/pmcbf_FETCH_SIZE/**/*counter_collection.csv")
+    wb = agg("gpurun_out/pmcbf_WRITE_SIZE/**/*counter_collection.csv")
+    added = 0
+    for k, v in fb.items():
+        if k in doc["kernels"]:
+            continue
+        wv = wb.get(k, [0.0])
+        doc["kernels"][k] = {"launches": len(v), "FETCH_SIZE_KB_avg": round(sum(v) / len(v), 1),
+                             "WRITE_SIZE_KB_avg": round(sum(wv) / len(wv), 1), "from": "bench.py --dtype bf16"}
+        added += 1
+    doc["note"] += "  Entries marked `from: bench.py --dtype bf16` come from the same passes over the bf16-storage line."
+    json.dump(doc, open(path, "w"), indent=1)
+    print("added", added, "instances")
+    for k, v in sorted(((k, v) for k, v in doc["kernels"].items() if v.get("from")), key=lambda kv: -kv[1]["FETCH_SIZE_KB_avg"] * kv[1]["launches"])[:6]:
+        print(k[:80], v)
+    sys.exit(0)
 f = agg("gpurun_out/pmc_FETCH_SIZE/**/*counter_collection.csv")
 w = agg("gpurun_out/pmc_WRITE_SIZE/**/*counter_collection.csv")
 out = {}
