@@ -120,7 +120,7 @@ _SIGS = {
     "aabr_rpn_decode_maps": (C.c_int, [_i32, _vp, _vp, _vp, _i32p, _i32p, _f32p, _vp, _i32, _f32, _f32p, _f32, _f32,
                                        _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "aabr_rpn_label_generation": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _f32p, _vp, _i32, _f32, _vp, _i32p, _f32p,
-                                            _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+                                            _i32, _i32, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "aabr_rpn_gather_logits": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _i32, _i64, _vp, _vp]),
     "aabr_rpn_proposals_batch": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32p, _i32p, _f32p, _vp, _i32, _f32, _f32p, _f32,
                                            _f32, _f32, _vp, _i64, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _vp, _vp]),

@@ -442,35 +442,77 @@ struct RpnGatherParams {
   int n_maps, nb;
 };
 
-// RPN label generation, fused (reference: RPNLossComputation.match_targets_to_anchors, modeling/rpn/loss_3d.py:91-96:
+// RPN label generation, fused (reference: RPNLossComputation.match_targets_to_anchors, modeling/rpn/loss_3d.py:91-100:
 // `boxlist_iou_3d(target, anchor, aug_thickness, criterion, flag='rpn_label_generation')` over the anchors of ALL maps
-// of an example, then Matcher.__call__'s core, modeling/matcher.py:57-100: best ground truth per anchor and the two
-// thresholds).  One thread per anchor of one example: the anchor is generated from its site (anchor_generator_sparse3d
-// .py:88-104) through the same segment table as k_rpn_decode_maps, the example's ground-truth boxes sit in LDS with the
+// of an example, the |yaw difference| of every pair (utils3d/geometric_torch.py:4-21), then Matcher.__call__ as
+// make_rpn_loss_evaluator builds it, loss_3d.py:338-344 / modeling/matcher.py:50-196: yaw mask, best ground truth
+// per anchor, the two thresholds, set_low_quality_matches_ and its ignore-nearby pass).
+// One thread per anchor of one example: the anchor is generated from its site (anchor_generator_sparse3d.py:88-104)
+// through the same segment table as k_rpn_decode_maps, the example's ground-truth boxes sit in LDS with the
 // target-side thickness clamps applied (rotate_nms_3d_torch.py:59-66), every pair goes through the same
-// iou_eval_entry as aabr_boxes_iou_3d.  The [G, N] matrix is written only when the caller asks for it.
+// iou_eval_entry as aabr_boxes_iou_3d.  The [G, N] matrix is never stored (only when the caller asks for it):
+// set_low_quality_matches_ needs every ground truth's row maximum before any anchor can be labelled, so the pairs are
+// evaluated twice -- PASS 0 reduces the row maxima (wave max -> LDS -> one device atomicMax per row and workgroup, on
+// order-preserving integer keys: max is order-independent, the result is bit-reproducible), PASS 1 re-evaluates the
+// same pairs with the same instructions and labels the anchors.
 struct RpnLabelParams {
   const int32_t *coords[kMaxRpnMaps];
   const float *targets[kMaxRpnBatch];               // [G_b, 7] yx_zb
   int32_t n_targets[kMaxRpnBatch];
+  int32_t gt_begin[kMaxRpnBatch];                   // first row-maximum key of example b
   int32_t seg_begin[kMaxRpnBatch][kMaxRpnMaps + 1]; // in anchors, per example
   int32_t site_begin[kMaxRpnBatch][kMaxRpnMaps];
   int64_t out_begin[kMaxRpnBatch];                  // first anchor of example b in the concatenated outputs
   int64_t iou_begin[kMaxRpnBatch];                  // first float of example b's [G_b, N_b] matrix
   float stride[kMaxRpnMaps][3];
   float aug[4];                                     // target_Y, target_Z, anchor_Y, anchor_Z
-  int n_maps, A, criterion, only_xy;
-  float voxel_scale, fg, bg;
+  int n_maps, A, criterion, only_xy, use_yaw, allow_low;
+  float voxel_scale, fg, bg, yaw_thr;
 };
 constexpr int kLabelTgtChunk = 128;
 
+// order-preserving float -> uint32 key (0 = below every float): the row maxima are reduced with integer atomicMax
+__device__ __forceinline__ uint32_t label_key(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float label_unkey(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// match-quality entry of (ground truth g, this thread's anchor): the IoU of boxlist_iou_3d and, masked, what the
+// Matcher sees (matcher.py:50-55: `match_quality_matrix * (abs(yaw_diff) < yaw_threshold).float()`; yaw_diff =
+// limit_period(target_yaw - anchor_yaw, 0.5, pi) evaluated in fp32 like the torch expression)
+__device__ __forceinline__ float label_pair(const RpnLabelParams &p, const float *t5, float t0, float t1,
+                                            const float *a5, float az0, float az1, float *raw) {
+  float v = iou_eval_entry(t5, a5, p.criterion);
+  if (!p.only_xy) {
+    const float overlap = fminf(az1, t1) - fmaxf(az0, t0);
+    const float common = fmaxf(az1, t1) - fminf(az0, t0);
+    v = v * (overlap / common);
+  }
+  *raw = v;
+  if (p.use_yaw) {
+    const float kPi = 3.14159274101257324f;           // (float)math.pi
+    const float dif = t5[4] - a5[4];
+    const float wrapped = dif - floorf(dif / kPi + 0.5f) * kPi;
+    v = v * (fabsf(wrapped) < p.yaw_thr ? 1.0f : 0.0f);
+  }
+  return v;
+}
+
+template <int PASS>
 __global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const float *__restrict__ base_anchors,
                                                         int64_t *__restrict__ matched_idx,
-                                                        float *__restrict__ matched_val, float *__restrict__ iou_out) {
+                                                        float *__restrict__ matched_val, float *__restrict__ iou_out,
+                                                        uint32_t *__restrict__ gt_best) {
   __shared__ float s_t5[kLabelTgtChunk][5];
   __shared__ float s_tz[kLabelTgtChunk][2];
+  __shared__ uint32_t s_key[kLabelTgtChunk];        // PASS 0: this workgroup's row maxima
+  __shared__ float s_hi[kLabelTgtChunk][2];         // PASS 1: row maximum, ignore threshold
   const int b = blockIdx.y;
   const int64_t N = p.seg_begin[b][p.n_maps];
+  if ((int64_t)blockIdx.x * blockDim.x >= N) return;   // grid.x is sized for the largest example
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int G = p.n_targets[b];
   float a5[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, az0 = 0.f, az1 = 0.f;
@@ -496,6 +538,7 @@ __global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const 
   }
   float best = -__builtin_inff();
   int best_g = 0;
+  bool tie = false, near = false;
   for (int g0 = 0; g0 < G; g0 += kLabelTgtChunk) {
     const int gn = G - g0 < kLabelTgtChunk ? G - g0 : kLabelTgtChunk;
     __syncthreads();
@@ -506,30 +549,54 @@ __global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const 
       s_t5[threadIdx.x][0] = tb[0]; s_t5[threadIdx.x][1] = tb[1]; s_t5[threadIdx.x][2] = th;
       s_t5[threadIdx.x][3] = tb[4]; s_t5[threadIdx.x][4] = tb[6];
       s_tz[threadIdx.x][0] = tb[2]; s_tz[threadIdx.x][1] = tb[2] + h;
-    }
-    __syncthreads();
-    if (t < N) {
-      for (int g = 0; g < gn; ++g) {
-        float t5[5];
-#pragma unroll
-        for (int d = 0; d < 5; ++d) t5[d] = s_t5[g][d];
-        float v = iou_eval_entry(t5, a5, p.criterion);
-        if (!p.only_xy) {
-          const float t0 = s_tz[g][0], t1 = s_tz[g][1];
-          const float overlap = fminf(az1, t1) - fmaxf(az0, t0);
-          const float common = fmaxf(az1, t1) - fminf(az0, t0);
-          v = v * (overlap / common);
-        }
-        if (iou_out) iou_out[p.iou_begin[b] + (int64_t)(g0 + g) * N + t] = v;
-        if (v > best) { best = v; best_g = g0 + g; }   // first maximum, like torch.max(dim=0)
+      if (PASS == 0) s_key[threadIdx.x] = 0u;
+      if (PASS == 1 && p.allow_low) {
+        const float hi = label_unkey(gt_best[p.gt_begin[b] + g0 + threadIdx.x]);
+        const float thr = hi - 0.05f;                 // matcher.py:166-167
+        s_hi[threadIdx.x][0] = hi;
+        s_hi[threadIdx.x][1] = 0.02f > thr ? 0.02f : thr;
       }
     }
+    __syncthreads();
+    for (int g = 0; g < gn; ++g) {
+      float t5[5];
+#pragma unroll
+      for (int d = 0; d < 5; ++d) t5[d] = s_t5[g][d];
+      float raw;
+      const float v = label_pair(p, t5, s_tz[g][0], s_tz[g][1], a5, az0, az1, &raw);
+      if (PASS == 0) {
+        uint32_t k = t < N ? label_key(v) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const uint32_t q = (uint32_t)__shfl_xor((int)k, o, 64);
+          k = q > k ? q : k;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_key[g], k);
+      } else if (t < N) {
+        if (iou_out) iou_out[p.iou_begin[b] + (int64_t)(g0 + g) * N + t] = raw;
+        if (v > best) { best = v; best_g = g0 + g; }   // first maximum, like torch.max(dim=0) on the host
+        if (p.allow_low) {
+          tie = tie || (v == s_hi[g][0]);              // matcher.py:126-128 (== : -0 ties with +0, as in torch)
+          near = near || (v > s_hi[g][1]);             // :168
+        }
+      }
+    }
+    if (PASS == 0) {
+      __syncthreads();
+      if ((int)threadIdx.x < gn && s_key[threadIdx.x])
+        atomicMax(gt_best + p.gt_begin[b] + g0 + threadIdx.x, s_key[threadIdx.x]);
+    }
   }
-  if (t < N) {
+  if (PASS == 1 && t < N) {
     const int64_t o = p.out_begin[b] + t;
     if (G == 0) { matched_idx[o] = -1; matched_val[o] = 0.f; return; }
     matched_val[o] = best;
-    matched_idx[o] = best < p.bg ? -1 : (best < p.fg ? -2 : best_g);   // BELOW_LOW_THRESHOLD / BETWEEN_THRESHOLDS
+    int64_t mi = best < p.bg ? -1 : (best < p.fg ? -2 : best_g);   // BELOW_LOW_THRESHOLD / BETWEEN_THRESHOLDS
+    if (p.allow_low) {
+      if (tie) mi = best_g;                            // matches[pred_inds_to_update] = all_matches[...]
+      if (mi == -1 && near) mi = -2;                   // IGNORE_HIGHEST_MATCH_NEARBY
+    }
+    matched_idx[o] = mi;
   }
 }
 
@@ -600,8 +667,9 @@ extern "C" int aabr_rpn_label_generation(int n_maps, const void *const *coords_p
                                          const float *strides_host, const float *base_anchors, int num_anchors,
                                          float voxel_scale, const void *const *target_ptrs,
                                          const int32_t *n_targets_host, const float *aug_host, int criterion,
-                                         int only_xy, float fg_iou, float bg_iou, int64_t *matched_idx,
-                                         float *matched_val, float *iou_out, void *stream_) {
+                                         int only_xy, float fg_iou, float bg_iou, float yaw_threshold,
+                                         int allow_low_quality_matches, int64_t *matched_idx, float *matched_val,
+                                         float *iou_out, uint32_t *row_max_scratch, void *stream_) {
   AABR_CHECK_ARG(n_maps >= 1 && n_maps <= kMaxRpnMaps && nb >= 0 && nb <= kMaxRpnBatch && num_anchors > 0 &&
                      voxel_scale > 0, "bad arguments (<= 8 maps, <= 16 examples)");
   AABR_CHECK_ARG(coords_ptrs && seg_begin_host && site_begin_host && strides_host && target_ptrs && n_targets_host &&
@@ -613,6 +681,7 @@ extern "C" int aabr_rpn_label_generation(int n_maps, const void *const *coords_p
     for (int d = 0; d < 3; ++d) p.stride[m][d] = m < n_maps ? strides_host[3 * m + d] : 0.f;
   }
   int64_t out = 0, mat = 0, nmax = 0;
+  int32_t gts = 0;
   for (int b = 0; b < kMaxRpnBatch; ++b) {
     const bool on = b < nb;
     for (int m = 0; m <= kMaxRpnMaps; ++m)
@@ -622,6 +691,8 @@ extern "C" int aabr_rpn_label_generation(int n_maps, const void *const *coords_p
     p.n_targets[b] = on ? n_targets_host[b] : 0;
     p.out_begin[b] = out;
     p.iou_begin[b] = mat;
+    p.gt_begin[b] = gts;
+    if (on) gts += p.n_targets[b];
     if (on) {
       AABR_CHECK_ARG(p.n_targets[b] >= 0 && (p.n_targets[b] == 0 || p.targets[b]), "null target list");
       for (int m = 0; m < n_maps; ++m) {
@@ -639,8 +710,20 @@ extern "C" int aabr_rpn_label_generation(int n_maps, const void *const *coords_p
   for (int d = 0; d < 4; ++d) p.aug[d] = aug_host[d];
   p.n_maps = n_maps; p.A = num_anchors; p.criterion = criterion; p.only_xy = only_xy;
   p.voxel_scale = voxel_scale; p.fg = fg_iou; p.bg = bg_iou;
-  hipLaunchKernelGGL(k_rpn_label_maps, dim3((unsigned)ceil_div(nmax, 256), (unsigned)nb), dim3(256), 0,
-                     (hipStream_t)stream_, p, base_anchors, matched_idx, matched_val, iou_out);
+  // Matcher.yaw_diff_constrain: no mask when the threshold exceeds 1.58 (matcher.py:51-52)
+  p.use_yaw = yaw_threshold > 1.58f ? 0 : 1;
+  p.yaw_thr = yaw_threshold;
+  p.allow_low = allow_low_quality_matches ? 1 : 0;
+  const dim3 grid((unsigned)ceil_div(nmax, 256), (unsigned)nb);
+  if (p.allow_low && gts > 0) {
+    AABR_CHECK_ARG(row_max_scratch, "allow_low_quality_matches needs the row-maximum scratch (sum of n_targets words)");
+    AABR_CHECK_HIP(hipMemsetAsync(row_max_scratch, 0, sizeof(uint32_t) * (size_t)gts, (hipStream_t)stream_));
+    hipLaunchKernelGGL(k_rpn_label_maps<0>, grid, dim3(256), 0, (hipStream_t)stream_, p, base_anchors, matched_idx,
+                       matched_val, iou_out, row_max_scratch);
+    AABR_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_rpn_label_maps<1>, grid, dim3(256), 0, (hipStream_t)stream_, p, base_anchors, matched_idx,
+                     matched_val, iou_out, row_max_scratch);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

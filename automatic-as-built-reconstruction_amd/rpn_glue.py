@@ -204,14 +204,19 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
 
 
 def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thickness, criterion=6,
-                      fg_iou=0.55, bg_iou=0.2, batch_size=None, return_matrix=False):
+                      fg_iou=0.55, bg_iou=0.2, batch_size=None, return_matrix=False, yaw_threshold=0.7,
+                      allow_low_quality_matches=True):
     """The label-generation half of the RPN's training step on the device: per example the IoU of its ground-truth
     boxes against the anchors of ALL maps, `boxlist_iou_3d(target, anchor, aug_thickness, criterion,
-    flag='rpn_label_generation')` (RPNLossComputation.match_targets_to_anchors, modeling/rpn/loss_3d.py:91-96;
-    criterion = cfg.MODEL.IOU_CRITERIA = 6, config/defaults.py:44), followed by the core of `Matcher.__call__`
-    (modeling/matcher.py:57-100): best ground truth per anchor, BELOW_LOW_THRESHOLD (-1) / BETWEEN_THRESHOLDS (-2)
-    by the two IoU thresholds (defaults.py:147,151).  The matcher's yaw / centre-distance refinements, the
-    sampler and the losses are plain torch in the reference and are not part of this path.
+    flag='rpn_label_generation')` (RPNLossComputation.match_targets_to_anchors, modeling/rpn/loss_3d.py:91-100;
+    criterion = cfg.MODEL.IOU_CRITERIA = 6, config/defaults.py:44), followed by `Matcher.__call__` as
+    make_rpn_loss_evaluator builds it (loss_3d.py:338-344, modeling/matcher.py:50-196): entries whose |yaw
+    difference| is not below `yaw_threshold` (cfg.MODEL.RPN.YAW_THRESHOLD = 0.7, defaults.py:153; > 1.58 = no mask)
+    are zeroed, best ground truth per anchor, BELOW_LOW_THRESHOLD (-1) / BETWEEN_THRESHOLDS (-2) by the two IoU
+    thresholds (defaults.py:147,151), then -- `allow_low_quality_matches`, True for the RPN -- set_low_quality_matches_
+    and its ignore-nearby pass.  The `cendis` argument the reference also passes is dead there (`if cendis is None or
+    True`, matcher.py:130).  The sampler and the losses are plain torch in the reference and are not part of this path.
+    `matched_vals` / the returned matrix: the masked maximum / the UNMASKED `boxlist_iou_3d` matrix.
 
     maps / base_anchors / strides as in `rpn_proposals`; targets[b] = [G_b, 7] yx_zb boxes of example b (device).
     ONE library call for the whole batch (`aabr_rpn_label_generation`): anchors are generated inside the kernel from
@@ -255,11 +260,14 @@ def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thi
                           device=dev) if return_matrix else None
         aug = (aug_thickness["target_Y"], aug_thickness["target_Z"], aug_thickness["anchor_Y"],
                aug_thickness["anchor_Z"])
+        n_gt = sum(int(t.shape[0]) for t in tg)
+        rowmax = torch.empty(max(n_gt, 1), dtype=torch.int32, device=dev) if allow_low_quality_matches else None
         check(lib.aabr_rpn_label_generation(
             n_maps, _hip.ptrs([g.coords for g in grids]), b1 - b0, _hip.i32xn(seg), _hip.i32xn(site),
             _hip.f32xn([v for st in strides for v in st]), ptr(ba), A, float(voxel_scale), _hip.ptrs(tg),
             _hip.i32xn([int(t.shape[0]) for t in tg]), _hip.f32x4(aug), int(criterion), int(bool(R.DEBUG)),
-            float(fg_iou), float(bg_iou), ptr(midx), ptr(mval), ptr(mat), stream()))
+            float(fg_iou), float(bg_iou), float(yaw_threshold), int(bool(allow_low_quality_matches)), ptr(midx),
+            ptr(mval), ptr(mat), ptr(rowmax), stream()))
         o = mo = 0
         for n, t in zip(n_anch, tg):
             G = int(t.shape[0])

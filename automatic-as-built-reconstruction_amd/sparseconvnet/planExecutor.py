@@ -73,6 +73,9 @@ conv_bn_bwd_stats = os.environ.get("AABR_PLAN_CONV_BN_BWD_STATS", "1") != "0"
 # makes the caller's stream wait for the weight gradients issued so far on the library's second stream.
 grad_segments = 0
 on_grads_ready = None
+# tests: a list here receives every _Pass that runs (its arena holds every activation of the pass --
+# `_Pass.bn_outputs()`); None in production
+debug_passes = None
 
 
 class Unsupported(Exception):
@@ -470,6 +473,7 @@ class _Pass(object):
         self.arena = torch.empty(max(total, 1), dtype=torch.uint8, device=self.dev)
         self.stat = torch.empty(max(t.stat_floats, 1), dtype=torch.float32, device=self.dev)
         base, sbase = self.arena.data_ptr(), self.stat.data_ptr()
+        self.offs = offs
         A = self.A = [base + o for o in offs]
         A[0] = self.x.data_ptr()
         bnws = _hip.workspace("bn", t.bn_floats, torch.float32, self.dev).data_ptr() if t.bn_floats else 0
@@ -538,6 +542,16 @@ class _Pass(object):
             n = V[lvl] * planes * _es(dt)
             res.append(self.arena[offs[b]:offs[b] + n].view(dt).view(V[lvl], planes))
         return res
+
+    def buffer(self, b):
+        """forward buffer `b` of this pass as a tensor view into the arena (tests)"""
+        lvl, planes, dt = self.t.fbufs[b]
+        n = self.V[lvl] * planes * _es(dt)
+        return self.arena[self.offs[b]:self.offs[b] + n].view(dt).view(self.V[lvl], planes)
+
+    def bn_outputs(self):
+        """{BatchNorm module: its output matrix of this pass} (tests: the compiled graph runs no module hooks)"""
+        return {op[-1]: self.buffer(op[2]) for op in self.t.fops if op[0] == "bn" and self.V[op[3]]}
 
     @staticmethod
     def _pinv(bw, byte_off):
@@ -788,6 +802,8 @@ def run_fpn(net, net1):
         return None
     train = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in tpl.params))
     ps = _Pass(tpl, net1.metadata, x)
+    if debug_passes is not None:
+        debug_passes.append(ps)
     if SCN.count_macs:
         for book, w in tpl.macs:
             sparseconvnet.forward_pass_multiplyAdd_count += SCN._macs(ps.books[book][2], w)

@@ -523,16 +523,23 @@ int aabr_boxes_iou_3d(const float *targets, int64_t M, const float *anchors, int
  * seg_begin_host [nb][n_maps+1] and site_begin_host [nb][n_maps] per example): the IoU with every ground-truth box of
  * the example -- boxlist_iou_3d(target, anchor, aug_thickness, criterion, flag='rpn_label_generation'),
  * modeling/rpn/loss_3d.py:91-96, i.e. aabr_boxes_iou_3d on the anchors of anchor_generator_sparse3d.py:88-104 --
- * and the core of Matcher.__call__ (modeling/matcher.py:57-100): matched_val = best IoU, matched_idx = its
- * ground-truth index, or -1 below bg_iou / -2 below fg_iou (all -1 for an example without ground truth).
- * Outputs are concatenated over the examples in order (sum_b N_b entries); iou_out (optional, may be NULL) receives
- * the [G_b, N_b] matrices back to back.  target_ptrs[b] = device [G_b, 7] yx_zb boxes; aug_host[4] = {target_Y,
- * target_Z, anchor_Y, anchor_Z}.                                                                              */
+ * and Matcher.__call__ as make_rpn_loss_evaluator builds and calls it (modeling/rpn/loss_3d.py:96-100,338-344;
+ * modeling/matcher.py:50-196): the entries whose |yaw difference| (utils3d/geometric_torch.py:4-21, target - anchor
+ * wrapped to [-pi/2, pi/2)) is not below yaw_threshold are zeroed (no mask when yaw_threshold > 1.58, matcher.py:51);
+ * matched_val = best masked value over the ground truths, matched_idx = its index (first maximum), or -1 below
+ * bg_iou / -2 below fg_iou; with allow_low_quality_matches != 0 (the RPN's setting) set_low_quality_matches_
+ * follows: an anchor that ties with the row maximum of any ground truth gets its best index back, and an anchor
+ * still at -1 with an entry above max(0.02, row maximum - 0.05) of any ground truth becomes -2.  All -1 for an
+ * example without ground truth.  Outputs are concatenated over the examples in order (sum_b N_b entries); iou_out
+ * (optional, may be NULL) receives the UNMASKED [G_b, N_b] IoU matrices back to back.  target_ptrs[b] = device
+ * [G_b, 7] yx_zb boxes; aug_host[4] = {target_Y, target_Z, anchor_Y, anchor_Z}; row_max_scratch = device words,
+ * sum_b G_b of them (needed with allow_low_quality_matches; the call clears them itself).                      */
 int aabr_rpn_label_generation(int n_maps, const void *const *coords_ptrs, int nb, const int32_t *seg_begin_host,
                               const int32_t *site_begin_host, const float *strides_host, const float *base_anchors,
                               int num_anchors, float voxel_scale, const void *const *target_ptrs,
                               const int32_t *n_targets_host, const float *aug_host, int criterion, int only_xy,
-                              float fg_iou, float bg_iou, int64_t *matched_idx, float *matched_val, float *iou_out,
+                              float fg_iou, float bg_iou, float yaw_threshold, int allow_low_quality_matches,
+                              int64_t *matched_idx, float *matched_val, float *iou_out, uint32_t *row_max_scratch,
                               void *stream);
 /* RPN glue: anchors of the selected flat indices t = site*A + yaw, generated from
  * the sparse site coordinates (modeling/rpn/anchor_generator_sparse3d.py:88-104:

@@ -100,3 +100,43 @@ def rpn_proposals(site_coords, objectness, box_regression, base_anchors, strides
         keep = nms_from_matrix(iou, np.arange(k, dtype=np.int32), nms_thresh)[:post_nms_top_n]
         out.append((dec[keep], score[idx][keep], idx[keep]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RPN label generation: |yaw difference| + Matcher (pinned by tests/golden/matcher_golden.npz, which
+# tests/golden/gen_matcher_golden.py produced by importing the reference's maskrcnn_benchmark/modeling/matcher.py and
+# utils3d/geometric_torch.py; tests/test_oracle_golden.py::test_matcher_*)
+def angle_dif(val0, val1):
+    """utils3d/geometric_torch.py:12-21 with aim_scope_id 0: (val1 - val0) wrapped into [-pi/2, pi/2)"""
+    return limit_period((np.asarray(val1, F) - np.asarray(val0, F)).astype(F), 0.5, PI)
+
+
+BELOW_LOW_THRESHOLD, BETWEEN_THRESHOLDS = -1, -2
+
+
+def matcher(match_quality_matrix, yaw_diff, high_threshold, low_threshold, allow_low_quality_matches=True,
+            yaw_threshold=0.7):
+    """Matcher.__call__ (maskrcnn_benchmark/modeling/matcher.py:57-100) as the RPN loss builds and calls it
+    (rpn/loss_3d.py:91-100,338-344): yaw mask (:50-55), best ground truth per anchor with the first maximum
+    (torch.max(dim=0) on the host), the two thresholds (:88-94), then set_low_quality_matches_ (:104-196) with the
+    module flags as committed upstream (ENALE_SECOND_THIRD_MAX__ONLY_HIGHEST_IOU_TARGET False,
+    IGNORE_HIGHEST_MATCH_NEARBY True, `cendis` unused: `if cendis is None or True`).
+    match_quality_matrix [G, N] fp32, yaw_diff [G, N] fp32 or None -> (matches int64 [N], matched_vals fp32 [N])"""
+    mq = np.asarray(match_quality_matrix, F)
+    if yaw_diff is not None and not (yaw_threshold > 1.58):
+        mq = (mq * (np.abs(np.asarray(yaw_diff, F)) < F(yaw_threshold)).astype(F)).astype(F)
+    vals = mq.max(0)
+    matches = mq.argmax(0).astype(np.int64)            # first maximum
+    all_matches = matches.copy()
+    below = vals < F(low_threshold)
+    between = (vals >= F(low_threshold)) & (vals < F(high_threshold))
+    matches[below] = BELOW_LOW_THRESHOLD
+    matches[between] = BETWEEN_THRESHOLDS
+    if allow_low_quality_matches:
+        highest = mq.max(1)                            # per ground truth, over the anchors
+        upd = (mq == highest[:, None]).any(0)          # every anchor that ties with a row maximum (matcher.py:126-128)
+        matches[upd] = all_matches[upd]
+        thr = np.maximum(F(0.02), (highest - F(0.05)).astype(F))            # :166-167
+        ign = (mq > thr[:, None]).any(0) & (matches == BELOW_LOW_THRESHOLD)  # :168-172
+        matches[ign] = BETWEEN_THRESHOLDS
+    return matches, vals

@@ -46,14 +46,30 @@ def two_stage_backward(c, g_out, W1, W2, W3, bn1, bn2):
 # :140-152 forward, :168-203 forward_fpn).  A tiny reverse-mode tape records the oracle calls of the
 # forward pass and replays their hand-written backward counterparts in reverse order.
 # =====================================================================================================
-class _Node(object):
-    __slots__ = ("v", "g", "coords", "spatial")
+def bf16_round(a):
+    """fp32 array rounded to the nearest bf16 value (ties to even), returned as fp32 -- what a bf16 store keeps"""
+    a = np.ascontiguousarray(a, np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    out = r.view(np.float32).reshape(a.shape)
+    nan = np.isnan(a)
+    if nan.any():
+        out = np.where(nan, a, out)
+    return out
 
-    def __init__(self, v, coords, spatial):
+
+class _Node(object):
+    __slots__ = ("v", "g", "coords", "spatial", "rnd")
+
+    def __init__(self, v, coords, spatial, rnd=None):
         self.v, self.g, self.coords, self.spatial = v, None, coords, tuple(int(s) for s in spatial)
+        self.rnd = rnd        # bf16 storage: gradient sums are stored rounded as well
 
     def add_grad(self, g):
-        self.g = g.copy() if self.g is None else self.g + g
+        if self.g is None:
+            self.g = g.copy()
+        else:
+            self.g = self.g + g if self.rnd is None else self.rnd(self.g + g)
 
 
 class FpnOracle(object):
@@ -62,7 +78,16 @@ class FpnOracle(object):
 
     def __init__(self, params, full_scale, down_kernels, down_strides, rpn_map_sizes, fpn_scales_from_top=(4, 3, 2, 1),
                  roi_scales_from_top=(4, 3, 2, 1), rpn_3d_2d_selector=(1, 2, 3, 4, 5, 6), eps=1e-4, momentum=0.95,
-                 leakiness=0.0, train=True):
+                 leakiness=0.0, train=True, storage="f32"):
+        """storage="bf16": the arithmetic model of FPN_Net(feature_dtype=torch.bfloat16) -- an extension the reference
+        does not have (it instantiates <float> only, SCN/sparseconvnet_cuda.cpp:281-310).  Everything the device
+        STORES as bf16 is rounded here at the same places: the 9->32 input convolution stays fp32 and its output is
+        rounded once; from there on every convolution / BatchNorm / add output, every activation gradient and every
+        convolution weight (the packed copies the matrix cores read) is a bf16 value; accumulation, BatchNorm
+        statistics and all parameter gradients stay fp32 (double here)."""
+        assert storage in ("f32", "bf16")
+        self.bf16 = storage == "bf16"
+        self.rnd = bf16_round if self.bf16 else None
         self.P = params
         self.full_scale = tuple(full_scale)
         self.dk, self.ds = down_kernels, down_strides
@@ -123,13 +148,15 @@ class FpnOracle(object):
 
     def subm_conv(self, x, name, size):
         import time
-        W = self.P[name]
+        W0 = self.P[name]
+        q = self.bf16 and name != "layers_in.1"
+        W = bf16_round(W0) if q else W0
         rb = self._subm_rules(x, size)
         t0 = time.perf_counter()
         out, m = O.conv_fwd(x.v, W.reshape(rb.vol, x.v.shape[1], -1), rb, x.v.shape[0])
         self._t("conv", t0)
         self.macs += m
-        y = _Node(out, x.coords, x.spatial)
+        y = _Node(bf16_round(out) if q else out, x.coords, x.spatial, self.rnd if q else None)
 
         def bwd():
             if y.g is None:
@@ -137,20 +164,33 @@ class FpnOracle(object):
             t0 = time.perf_counter()
             d_in, dW, _ = O.conv_bwd(x.v, y.g, W.reshape(rb.vol, x.v.shape[1], -1), rb)
             self._t("conv", t0)
-            self.grads[name] = dW.reshape(W.shape)
-            x.add_grad(d_in)
+            self.grads[name] = dW.reshape(W0.shape)
+            x.add_grad(bf16_round(d_in) if q else d_in)
+        self.tape.append(bwd)
+        return y
+
+    def to_storage(self, x):
+        """the cast behind the input convolution (FPN_Net._cast / the compiled graph's first record)"""
+        if not self.bf16:
+            return x
+        y = _Node(bf16_round(x.v), x.coords, x.spatial, self.rnd)
+
+        def bwd():
+            if y.g is not None:
+                x.add_grad(y.g)          # bf16 -> fp32: exact
         self.tape.append(bwd)
         return y
 
     def conv(self, x, name, size, stride):
         import time
-        W = self.P[name]
+        W0 = self.P[name]
+        W = bf16_round(W0) if self.bf16 else W0
         rb, oc, osz = self._strided_rules(x.coords, x.spatial, size, stride)
         t0 = time.perf_counter()
         out, m = O.conv_fwd(x.v, W.reshape(rb.vol, x.v.shape[1], -1), rb, oc.shape[0])
         self._t("conv", t0)
         self.macs += m
-        y = _Node(out, oc, osz)
+        y = _Node(bf16_round(out) if self.bf16 else out, oc, osz, self.rnd)
 
         def bwd():
             if y.g is None:
@@ -158,15 +198,16 @@ class FpnOracle(object):
             t0 = time.perf_counter()
             d_in, dW, _ = O.conv_bwd(x.v, y.g, W.reshape(rb.vol, x.v.shape[1], -1), rb)
             self._t("conv", t0)
-            self.grads[name] = dW.reshape(W.shape)
-            x.add_grad(d_in)
+            self.grads[name] = dW.reshape(W0.shape)
+            x.add_grad(bf16_round(d_in) if self.bf16 else d_in)
         self.tape.append(bwd)
         return y
 
     def deconv(self, x, name, size, stride, fine_spatial):
         """CPU/Deconvolution.cpp:15-16: rule book of the (fine -> coarse) convolution, columns swapped"""
         import time
-        W = self.P[name]
+        W0 = self.P[name]
+        W = bf16_round(W0) if self.bf16 else W0
         rb, oc, osz = self._strided_rules(self.sites[tuple(fine_spatial)], fine_spatial, size, stride)
         assert osz == x.spatial and oc.shape[0] == x.v.shape[0]
         fine = self.sites[tuple(fine_spatial)]
@@ -174,7 +215,7 @@ class FpnOracle(object):
         out, m = O.conv_fwd(x.v, W.reshape(rb.vol, x.v.shape[1], -1), rb, fine.shape[0], in_col=1)
         self._t("conv", t0)
         self.macs += m
-        y = _Node(out, fine, fine_spatial)
+        y = _Node(bf16_round(out) if self.bf16 else out, fine, fine_spatial, self.rnd)
 
         def bwd():
             if y.g is None:
@@ -182,8 +223,8 @@ class FpnOracle(object):
             t0 = time.perf_counter()
             d_in, dW, _ = O.conv_bwd(x.v, y.g, W.reshape(rb.vol, x.v.shape[1], -1), rb, in_col=1)
             self._t("conv", t0)
-            self.grads[name] = dW.reshape(W.shape)
-            x.add_grad(d_in)
+            self.grads[name] = dW.reshape(W0.shape)
+            x.add_grad(bf16_round(d_in) if self.bf16 else d_in)
         self.tape.append(bwd)
         return y
 
@@ -194,11 +235,13 @@ class FpnOracle(object):
         out, sm, si, rm, rv = O.bn_fwd(x.v, p["weight"], p["bias"], p["running_mean"], p["running_var"], self.eps,
                                        self.momentum, self.train, self.leak)
         self._t("bn", t0)
+        if self.bf16:
+            out = bf16_round(out)
         self.acts[name] = out
         if self.override is not None and name in self.override:
             out = self.override[name]
         p["running_mean_out"], p["running_var_out"] = rm, rv
-        y = _Node(out, x.coords, x.spatial)
+        y = _Node(out, x.coords, x.spatial, self.rnd)
 
         def bwd():
             if y.g is None:
@@ -207,12 +250,12 @@ class FpnOracle(object):
             d_in, dw, db, _ = O.bn_bwd(x.v, y.v, y.g, sm, si, p["weight"], self.leak)
             self._t("bn", t0)
             self.grads[name + ".weight"], self.grads[name + ".bias"] = dw, db
-            x.add_grad(d_in)
+            x.add_grad(bf16_round(d_in) if self.bf16 else d_in)
         self.tape.append(bwd)
         return y
 
     def add(self, a, b):
-        y = _Node(a.v + b.v, a.coords, a.spatial)
+        y = _Node(bf16_round(a.v + b.v) if self.bf16 else a.v + b.v, a.coords, a.spatial, self.rnd)
 
         def bwd():
             if y.g is not None:
@@ -224,7 +267,7 @@ class FpnOracle(object):
     # ---- the network ----
     def forward(self, locs, feats):
         nscale = 1 + len(self.dk)
-        net = self.subm_conv(self.input_layer(locs, feats), "layers_in.1", (3, 3, 3))
+        net = self.to_storage(self.subm_conv(self.input_layer(locs, feats), "layers_in.1", (3, 3, 3)))
         downs = []
         for k in range(nscale):
             if k > 0:
@@ -259,8 +302,9 @@ class FpnOracle(object):
     def backward(self, rpn_grads):
         """rpn_grads: list of arrays (or None) matching self.rpn_maps"""
         for mp, g in zip(self.rpn_maps, rpn_grads):
-            if g is not None:
-                mp.add_grad(np.ascontiguousarray(g, np.float32))
+            if g is not None:      # bf16 storage: the maps are handed out as fp32 copies, their gradient is stored bf16
+                g = np.ascontiguousarray(g, np.float32)
+                mp.add_grad(bf16_round(g) if self.bf16 else g)
         for fn in reversed(self.tape):
             fn()
         return self.grads

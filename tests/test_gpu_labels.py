@@ -64,8 +64,13 @@ def test_label_generation_iou_at_training_size_vs_oracle():
 
 
 def test_rpn_label_matches_vs_oracle_composition():
-    """rpn_glue.rpn_label_matches (anchors of all maps example-major + IoU + best match + threshold labels) on a
-    2-scene batch through the default FPN_Net's six maps, against box_oracle.grid_anchors + the IoU oracle."""
+    """rpn_glue.rpn_label_matches (anchors of all maps example-major + IoU + |yaw difference| mask + Matcher with
+    set_low_quality_matches_, as make_rpn_loss_evaluator builds it: rpn/loss_3d.py:91-100,338-344) on a 2-scene batch
+    through the default FPN_Net's six maps.  Two comparisons: (1) the IoU matrix against box_oracle.grid_anchors + the
+    IoU oracle (2e-5: device sinf / cosf vs libm); (2) the labels against box_oracle.matcher -- pinned to the
+    reference's own Matcher by tests/golden/matcher_golden.npz -- evaluated on the device's matrix: EXACT (integers),
+    for the RPN's setting, for no yaw mask (the s_3c config's YAW_THRESHOLD 3.0) and for the plain two-threshold
+    matcher (allow_low_quality_matches False)."""
     import box_oracle as BO
     import rpn_glue
     from test_cabi_and_host import default_fpn
@@ -79,31 +84,45 @@ def test_rpn_label_matches_vs_oracle_composition():
     base = [torch.tensor([[0.0, 0.0, 0.0] + list(s) + [y] for y in yaws], dtype=torch.float32) for s in sizes]
     strides = [[2.0 ** s] * 3 for s in (5, 6, 7)] + [[2.0 ** s] * 3 for s in (4, 5, 6)]
     targets = [S.make_gt_boxes(25, 8), S.make_gt_boxes(1, 9)]
-    res = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, [_t(t) for t in targets], LABEL_AUG, 6,
-                                     return_matrix=True)
-    lean = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, [_t(t) for t in targets], LABEL_AUG, 6)
-    assert len(res) == 2
+    tg_dev = [_t(t) for t in targets]
     coords = [m.get_spatial_locations().numpy() for m in rpn]
-    for b in range(2):
-        an = np.concatenate([BO.grid_anchors(c[c[:, 3] == b], base[m].numpy(), 20.0, strides[m])
-                             for m, c in enumerate(coords)], 0).astype(np.float32)
-        want = O.boxes_iou_3d(targets[b], an, (0.4, 0.8, 0.0, 0.0), 6, True)
-        idx, vals, iou = [t.cpu().numpy() for t in res[b]]
-        assert lean[b][2] is None and torch.equal(lean[b][0], res[b][0]) and torch.equal(lean[b][1], res[b][1])
-        assert iou.shape == want.shape and an.shape[0] > 1000
-        np.testing.assert_allclose(iou, want, atol=2e-5)
-        np.testing.assert_allclose(vals, want.max(0), atol=2e-5)
-        lab = np.where(want.max(0) < 0.2, -1, np.where(want.max(0) < 0.55, -2, want.argmax(0)))
-        edge = (np.abs(want.max(0) - 0.2) < 1e-4) | (np.abs(want.max(0) - 0.55) < 1e-4)
-        srt = np.sort(want, 0)
-        tie = (srt[-1] - srt[-2] < 1e-4) if want.shape[0] > 1 else np.zeros(want.shape[1], bool)
-        ok = ~(edge | (tie & (lab >= 0)))
-        np.testing.assert_array_equal(idx[ok], lab[ok])
-        assert ok.mean() > 0.99
+    anchors = [np.concatenate([BO.grid_anchors(c[c[:, 3] == b], base[m].numpy(), 20.0, strides[m])
+                               for m, c in enumerate(coords)], 0).astype(np.float32) for b in range(2)]
+    seen = set()
+    for ythr, allow in ((0.7, True), (3.0, True), (0.7, False)):
+        res = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, tg_dev, LABEL_AUG, 6, return_matrix=True,
+                                         yaw_threshold=ythr, allow_low_quality_matches=allow)
+        lean = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, tg_dev, LABEL_AUG, 6, yaw_threshold=ythr,
+                                          allow_low_quality_matches=allow)
+        assert len(res) == 2
+        for b in range(2):
+            an = anchors[b]
+            want = O.boxes_iou_3d(targets[b], an, (0.4, 0.8, 0.0, 0.0), 6, True)
+            idx, vals, iou = [t.cpu().numpy() for t in res[b]]
+            assert lean[b][2] is None and torch.equal(lean[b][0], res[b][0]) and torch.equal(lean[b][1], res[b][1])
+            assert iou.shape == want.shape and an.shape[0] > 1000
+            np.testing.assert_allclose(iou, want, atol=2e-5)                    # (1) the unmasked matrix
+            yd = np.abs(BO.angle_dif(an[:, 6].reshape(1, -1), targets[b][:, 6].reshape(-1, 1)))
+            lab, mv = BO.matcher(iou, yd, 0.55, 0.2, allow, ythr)               # (2) on the device's own matrix
+            np.testing.assert_array_equal(vals, mv)
+            np.testing.assert_array_equal(idx, lab)
+            seen.update(np.unique(np.minimum(idx, 0)).tolist())
+            if ythr == 0.7 and allow and b == 0:
+                # the yaw mask and the low-quality pass both change labels on this input (the old two-threshold core
+                # alone would not pass this test)
+                plain, _ = BO.matcher(iou, None, 0.55, 0.2, False, 3.0)
+                nomask, _ = BO.matcher(iou, yd, 0.55, 0.2, True, 3.0)
+                assert (plain != lab).sum() > 0 and (nomask != lab).sum() > 0
+    assert seen == {-2, -1, 0}
     # an example without ground truth: every anchor is background (loss_3d.py:91-93)
     res0 = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, [_t(targets[0]), torch.zeros((0, 7), device=DEV)],
                                       LABEL_AUG, 6)
     assert (res0[1][0] == -1).all() and res0[1][2] is None and res0[1][0].numel() > 1000
+    # the same call twice: bit-equal (the row maxima are reduced with integer atomics)
+    again = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, tg_dev, LABEL_AUG, 6)
+    first = rpn_glue.rpn_label_matches(rpn, base, strides, 20.0, tg_dev, LABEL_AUG, 6)
+    for x, y in zip(again, first):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
 
 
 def test_boxlist_nms_3d_roi_post():
