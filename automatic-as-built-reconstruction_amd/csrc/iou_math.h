@@ -181,6 +181,66 @@ AABR_HD bool same_box(const float *a, const float *b) {
   return true;
 }
 
+// ---- exact polygon IoU (the NMS decision) -----------------------------------------------------------------------------
+// The suppression loop of the reference's rotated NMS (spconv 1.x rotate_non_max_suppression_cpu, called from
+// second/core/non_max_suppression/nms_cpu.py:43) takes the matrix above only as a `> 0` pre-filter and decides
+// `overlap >= thresh` on a boost::geometry polygon intersection / union of the two rectangles.  rotate_iou() is not
+// that value where its vertex collection / angular sort breaks down (two thin, nearly parallel walls crossing at
+// 0.035 rad: 0.162 against an exact 0.569 -- tests/test_oracle_golden.py::test_nms_decision_iou_disagreements), so the
+// decision is made on a Sutherland-Hodgman clip in double: corners of center_to_corner_box2d (box_np_ops.py:374-394;
+// corner order x0y0, x0y1, x1y1, x1y0, rotation x' = x cos + y sin, y' = -x sin + y cos), each half-plane of the
+// second rectangle applied in turn, area by the shoelace formula.  r = (xc, yc, size_x, size_y, yaw).
+AABR_HD void clip_corners(const float *r, double *cx, double *cy) {
+  const double a = (double)r[4], s = sin(a), c = cos(a);
+  const double hx = 0.5 * (double)r[2], hy = 0.5 * (double)r[3];
+  const double px[4] = {-hx, -hx, hx, hx}, py[4] = {-hy, hy, hy, -hy};
+  for (int k = 0; k < 4; ++k) {
+    cx[k] = px[k] * c + py[k] * s + (double)r[0];
+    cy[k] = -px[k] * s + py[k] * c + (double)r[1];
+  }
+}
+
+AABR_HD double clip_iou_exact(const float *r1, const float *r2) {
+  double ax[4], ay[4], bx[4], by[4];
+  clip_corners(r1, ax, ay);
+  clip_corners(r2, bx, by);
+  double px[12], py[12], qx[12], qy[12];
+  int n = 4;
+  for (int i = 0; i < 4; ++i) { px[i] = ax[i]; py[i] = ay[i]; }
+  // the corner order above is clockwise in the (x, y) plane for positive sizes (inside = right of each edge); the
+  // sign of the clip rectangle's signed area covers the other orientation
+  double sb = 0.0;
+  for (int i = 0; i < 4; ++i) sb += bx[i] * by[(i + 1) & 3] - bx[(i + 1) & 3] * by[i];
+  const double o = sb <= 0.0 ? 1.0 : -1.0;
+  for (int e = 0; e < 4 && n > 0; ++e) {
+    const double ex = o * (bx[(e + 1) & 3] - bx[e]), ey = o * (by[(e + 1) & 3] - by[e]);
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      const int j = i + 1 < n ? i + 1 : 0;
+      const double di = ey * (px[i] - bx[e]) - ex * (py[i] - by[e]);
+      const double dj = ey * (px[j] - bx[e]) - ex * (py[j] - by[e]);
+      if (di >= 0.0) { qx[m] = px[i]; qy[m] = py[i]; ++m; }
+      if ((di > 0.0 && dj < 0.0) || (di < 0.0 && dj > 0.0)) {
+        const double t = di / (di - dj);
+        qx[m] = px[i] + t * (px[j] - px[i]);
+        qy[m] = py[i] + t * (py[j] - py[i]);
+        ++m;
+      }
+    }
+    n = m;
+    for (int i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+  }
+  if (n < 3) return 0.0;
+  double inter = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const int j = i + 1 < n ? i + 1 : 0;
+    inter += px[i] * py[j] - px[j] * py[i];
+  }
+  inter = 0.5 * fabs(inter);
+  const double uni = fabs((double)r1[2] * (double)r1[3]) + fabs((double)r2[2] * (double)r2[3]) - inter;
+  return uni > 0.0 ? inter / uni : 0.0;
+}
+
 // pair value of rotate_iou_gpu_eval: iou[n][k] for box n, query k
 AABR_HD float iou_eval_entry(const float *box_n, const float *query_k, int criterion) {
   return same_box(box_n, query_k) ? 1.0f : rotate_iou(query_k, box_n, criterion);

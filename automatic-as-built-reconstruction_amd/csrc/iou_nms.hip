@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float *__restrict__ boxe
         const float z0 = b[2], z1 = b[2] + b[5], a0 = c[2], a1 = c[2] + c[5];
         v = v * ((fminf(a1, z1) - fmaxf(a0, z0)) / (fmaxf(a1, z1) - fminf(a0, z0)));
       }
-      hit = v > 0.0f && v >= thresh;
+      // spconv 1.x rotate_non_max_suppression_cpu (behind nms_cpu.py:43): the matrix entry is the `> 0` pre-filter,
+      // the decision is an exact polygon IoU of the two rectangles (2-D, whatever only_xy says) >= thresh
+      hit = v > 0.0f && clip_iou_exact(bi, bj) >= (double)thresh;
     } else {
       const float xx1 = fmaxf(b[0], c[0]), yy1 = fmaxf(b[1], c[1]);
       const float xx2 = fminf(b[2], c[2]), yy2 = fminf(b[3], c[3]);

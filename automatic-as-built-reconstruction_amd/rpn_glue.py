@@ -79,6 +79,7 @@ def rpn_proposals_single_map(tensor, objectness, box_regression, base_anchors, v
 
 
 _trace = None     # tools/tools_step_timeline.py: called with a label at the stage's host-side boundaries
+debug_nms_inputs = None   # tests: a list here receives (nms_boxes [k,7], scores [k]) of every example's NMS call
 
 
 def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel_scale, pre_nms_top_n=2000,
@@ -178,6 +179,8 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
                                        ptr(ba), A, float(voxel_scale), weights_h, float(bbox_xform_clip),
                                        float(nms_aug_thickness[0]), float(nms_aug_thickness[1]), ptr(sel), k,
                                        ptr(boxes), ptr(nms_boxes), ptr(scores), stream()))
+        if debug_nms_inputs is not None:
+            debug_nms_inputs.append((nms_boxes, scores))
         # every example's launches go out first; the numbers kept are read once, after the last one
         keep, meta = _nms.rotate_nms_sorted(nms_boxes, nms_thresh, post_nms_top_n, _nms.REFERENCE_DEBUG_ONLY_XY,
                                             lazy=True)

@@ -287,6 +287,28 @@ int64_t oracle_nms_from_matrix(const float *iou, int64_t n,
   return nk;
 }
 
+/* The same loop with the decision taken on a second matrix: `pre` is what the reference hands spconv as the `> 0`
+ * pre-filter (boxes_iou_3d, nms_cpu.py:36-43), `dec` the exact polygon IoU spconv 1.x computes itself with
+ * boost::geometry and compares with `>= thresh` (restated independently in clip_oracle.c). */
+int64_t oracle_nms_prefilter_decide(const float *pre, const double *dec, int64_t n, const int32_t *order,
+                                    float thresh, int64_t *keep) {
+  char *sup = (char *)calloc(n, 1);
+  int64_t nk = 0;
+  for (int64_t _i = 0; _i < n; ++_i) {
+    int64_t i = order[_i];
+    if (sup[i]) continue;
+    keep[nk++] = i;
+    for (int64_t _j = _i + 1; _j < n; ++_j) {
+      int64_t j = order[_j];
+      if (sup[j]) continue;
+      if (pre[i * n + j] <= 0.0f) continue;
+      if (dec[i * n + j] >= (double)thresh) sup[j] = 1;
+    }
+  }
+  free(sup);
+  return nk;
+}
+
 /* maskrcnn_benchmark/csrc/cpu/nms_cpu.cpp:5-75: axis-aligned NMS with the +1
  * pixel convention; returns kept indices in ascending index order. */
 int64_t oracle_nms_axis_aligned(const float *dets, const float *scores,

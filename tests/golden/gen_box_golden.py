@@ -8,7 +8,8 @@ on seeded inputs (build container only; needs /root/reference):
     clamps per flag, column selection [0,1,3,4,6], module DEBUG=1 => only_xy
   * second/pytorch/core/box_torch_ops.py:557-582        rotate_nms_3d's top-k / index-remap shell
     (the suppression loop inside it is spconv's and cannot run: its stand-in here is the rule
-    DESIGN.md section 4 states, so those vectors pin the SHELL, not the loop)
+    DESIGN.md section 4 states -- the matrix as `> 0` pre-filter, an exact polygon IoU of the reference's own
+    corners for `>= thresh` -- so those vectors pin the SHELL and the corner convention, not the loop)
 
 numba / spconv are absent: the decorator-only placeholder modules of gen_iou_golden.py let the modules
 import; `rotate_iou_gpu_eval` (a CUDA launch wrapper) is replaced in the importing module's namespace
@@ -100,9 +101,38 @@ def main():
     # ---------------------------------------------------------------- rotate_nms_3d shell
     nms_cpu = importlib.import_module("second.core.non_max_suppression.nms_cpu")
 
+    def poly_iou(P, Q):
+        # exact IoU of two convex quadrilaterals (float64 Sutherland-Hodgman + shoelace), written for this generator:
+        # what a polygon library (boost::geometry in spconv 1.x) returns for intersection / union areas
+        def area(p):
+            return 0.5 * sum(p[i][0] * p[(i + 1) % len(p)][1] - p[(i + 1) % len(p)][0] * p[i][1]
+                             for i in range(len(p)))
+        P = [(float(x), float(y)) for x, y in P]
+        Q = [(float(x), float(y)) for x, y in Q]
+        sgn = 1.0 if area(Q) >= 0 else -1.0
+        cur = P
+        for e in range(4):
+            a, b = Q[e], Q[(e + 1) % 4]
+            nxt = []
+            for i in range(len(cur)):
+                p, q = cur[i], cur[(i + 1) % len(cur)]
+                dp = sgn * ((b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]))
+                dq = sgn * ((b[0] - a[0]) * (q[1] - a[1]) - (b[1] - a[1]) * (q[0] - a[0]))
+                if dp >= 0:
+                    nxt.append(p)
+                if (dp > 0 and dq < 0) or (dp < 0 and dq > 0):
+                    t = dp / (dp - dq)
+                    nxt.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+            cur = nxt
+            if not cur:
+                return 0.0
+        inter = abs(area(cur)) if len(cur) >= 3 else 0.0
+        return inter / (abs(area(P)) + abs(area(Q)) - inter)
+
     def stated_rule(corners, order, standup_iou, thresh):
-        # stand-in for spconv.utils.rotate_non_max_suppression_cpu (un-vendored): greedy over `order`;
-        # j suppressed by kept i iff standup_iou[i, j] > 0 and IoU >= thresh with IoU := the same matrix
+        # stand-in for spconv.utils.rotate_non_max_suppression_cpu (un-vendored; its published 1.x loop): greedy over
+        # `order`; j suppressed by kept i iff standup_iou[i, j] > 0 and the polygon IoU of corners[i], corners[j]
+        # (the reference's own center_to_corner_box2d output) >= thresh
         n = len(order)
         sup = np.zeros(n, bool)
         keep = []
@@ -113,7 +143,7 @@ def main():
             keep.append(i)
             for _j in range(_i + 1, n):
                 j = order[_j]
-                if not sup[j] and standup_iou[i, j] > 0 and standup_iou[i, j] >= thresh:
+                if not sup[j] and standup_iou[i, j] > 0 and poly_iou(corners[i], corners[j]) >= thresh:
                     sup[j] = True
         return keep
 

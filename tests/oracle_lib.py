@@ -43,6 +43,9 @@ def lib():
         L.oracle_boxes_iou_3d.argtypes = [f32p, C.c_int64, f32p, C.c_int64, f32p, C.c_int, C.c_int, f32p]
         L.oracle_nms_from_matrix.restype = C.c_int64
         L.oracle_nms_from_matrix.argtypes = [f32p, C.c_int64, i32p, C.c_float, i64p]
+        L.oracle_nms_prefilter_decide.restype = C.c_int64
+        L.oracle_nms_prefilter_decide.argtypes = [f32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"),
+                                                  C.c_int64, i32p, C.c_float, i64p]
         L.oracle_nms_axis_aligned.restype = C.c_int64
         L.oracle_nms_axis_aligned.argtypes = [f32p, f32p, C.c_int64, C.c_float, i64p]
         L.oracle_sparse_to_dense_fwd.argtypes = [i64p, C.c_int64, f32p, C.c_int, i64p, C.c_int64, f32p]
@@ -50,6 +53,7 @@ def lib():
         L.oracle_roi_align_rot3d.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int]
+        L.oracle_clip_iou_matrix.argtypes = [f32p, C.c_int64, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_region_points.restype = C.c_int64
@@ -225,6 +229,16 @@ def boxes_iou_3d(targets, anchors, aug=(0, 0, 0, 0), criterion=-1, only_xy=True)
     return iou
 
 
+def clip_iou_matrix(boxes7):
+    """exact fp64 2-D IoU of rotated rectangles by Sutherland-Hodgman clipping (oracle/clip_oracle.c) -- the value
+    a boost::geometry polygon IoU (spconv 1.x's suppression loop) decides on; independent of the A15 restatement"""
+    b = np.ascontiguousarray(boxes7, np.float32)
+    out = np.zeros((b.shape[0], b.shape[0]), np.float64)
+    if out.size:
+        lib().oracle_clip_iou_matrix(b, b.shape[0], out)
+    return out
+
+
 def nms_from_matrix(iou, order, thresh):
     n = iou.shape[0]
     keep = np.zeros(max(n, 1), np.int64)
@@ -233,8 +247,22 @@ def nms_from_matrix(iou, order, thresh):
     return keep[:nk].copy()
 
 
-def rotate_nms_3d(boxes7, scores, pre_max_size, post_max_size, thresh, only_xy=True):
-    """box_torch_ops.py:557-582 + nms_cpu.py:32-44 on the oracle's own IoU matrix."""
+def nms_prefilter_decide(pre, dec, order, thresh):
+    """greedy loop of spconv 1.x's rotate_non_max_suppression_cpu: `pre` > 0 pre-filter (the A15 matrix the
+    reference passes), decision `dec` >= thresh (exact polygon IoU)"""
+    n = pre.shape[0]
+    keep = np.zeros(max(n, 1), np.int64)
+    nk = lib().oracle_nms_prefilter_decide(np.ascontiguousarray(pre, np.float32),
+                                           np.ascontiguousarray(dec, np.float64), n,
+                                           np.ascontiguousarray(order, np.int32), thresh, keep)
+    return keep[:nk].copy()
+
+
+def rotate_nms_3d(boxes7, scores, pre_max_size, post_max_size, thresh, only_xy=True, decision="clip"):
+    """box_torch_ops.py:557-582 + nms_cpu.py:32-44: the oracle's A15 matrix as the `> 0` pre-filter and -- the
+    stated rule for the un-vendored spconv loop, DESIGN.md section 4 -- the exact polygon IoU (clip_oracle.c) for
+    the `>= thresh` decision.  decision="matrix": the round-1..3 rule (decision on the A15 value itself), kept to
+    count how often the two differ."""
     scores = np.asarray(scores, np.float32)
     n = scores.shape[0]
     if n == 0:
@@ -248,7 +276,10 @@ def rotate_nms_3d(boxes7, scores, pre_max_size, post_max_size, thresh, only_xy=T
     s = scores[idx]
     iou = boxes_iou_3d(b, b, (0, 0, 0, 0), -1, only_xy)
     order = np.argsort(-s, kind="stable").astype(np.int32)
-    keep = nms_from_matrix(iou, order, thresh)[:post_max_size]
+    if decision == "clip":
+        keep = nms_prefilter_decide(iou, clip_iou_matrix(b), order, thresh)[:post_max_size]
+    else:
+        keep = nms_from_matrix(iou, order, thresh)[:post_max_size]
     return idx[keep]
 
 

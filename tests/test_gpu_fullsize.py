@@ -162,6 +162,12 @@ def test_bench_path_bf16_matches_bf16_oracle_at_full_size():
     r = _bench_pass(torch.bfloat16)
     net, P, acts = r["net"], r["P"], r["acts"]
     O.set_threads(16)
+    fails = []
+
+    def need(ok, what):
+        if not ok:
+            fails.append(what)
+
     # (b) free-running oracle in the bf16 storage model
     fo = _oracle_net(P, "bf16")
     o_rpn, o_roi = fo.forward(r["locs"], r["feats"])
@@ -170,7 +176,7 @@ def test_bench_path_bf16_matches_bf16_oracle_at_full_size():
         assert d.features.dtype == torch.float32
         np.testing.assert_array_equal(d.get_spatial_locations().numpy(), o.coords)
         free.append(_l2(d.features.detach().cpu().numpy(), o.v))
-        assert free[-1] <= BF16_FREE_L2, (i, free[-1])
+        need(free[-1] <= BF16_FREE_L2, ("free map", i, free[-1]))
     # (a) teacher-forced: the oracle's BatchNorm outputs replaced by the device's
     P2 = {k: (dict(v) if isinstance(v, dict) else v) for k, v in P.items()}
     fo2 = _oracle_net(P2, "bf16")
@@ -181,14 +187,18 @@ def test_bench_path_bf16_matches_bf16_oracle_at_full_size():
         ref = fo2.acts[name]           # computed from teacher-forced inputs, before the override replaced it
         l2, mx = _l2(a, ref), _relerr(a, ref)
         tf_l2, tf_max = max(tf_l2, l2), max(tf_max, mx)
-        assert l2 <= BF16_TF_L2 and mx <= BF16_TF_MAX, (name, l2, mx)
+        need(l2 <= BF16_TF_L2 and mx <= BF16_TF_MAX, ("teacher-forced", name, l2, mx))
     for i, (d, o) in enumerate(zip(r["rpn"] + r["roi"], t_rpn + t_roi)):
         l2, mx = _l2(d.features.detach().cpu().numpy(), o.v), _relerr(d.features.detach().cpu().numpy(), o.v)
         tf_l2, tf_max = max(tf_l2, l2), max(tf_max, mx)
-        assert l2 <= BF16_TF_L2 and mx <= BF16_TF_MAX, (i, l2, mx)
+        need(l2 <= BF16_TF_L2 and mx <= BF16_TF_MAX, ("teacher-forced map", i, l2, mx))
+    rs = 0.0
     for name, m in r["bn_mods"].items():
-        np.testing.assert_allclose(m.running_mean.cpu().numpy(), P2[name]["running_mean_out"], rtol=5e-3, atol=1e-4)
-        np.testing.assert_allclose(m.running_var.cpu().numpy(), P2[name]["running_var_out"], rtol=5e-3, atol=1e-4)
+        for got, want in ((m.running_mean.cpu().numpy(), P2[name]["running_mean_out"]),
+                          (m.running_var.cpu().numpy(), P2[name]["running_var_out"])):
+            e = float(np.max(np.abs(got - want) / (5e-3 * np.abs(want) + 1e-4)))
+            rs = max(rs, e)
+            need(e <= 1.0, ("running statistic", name, e))
     # (c) gradients
     grads = fo2.backward(r["G"])
     names = ref_net.fpn_param_names(net)
@@ -201,12 +211,57 @@ def test_bench_path_bf16_matches_bf16_oracle_at_full_size():
         got = par.grad.detach().cpu().numpy().reshape(grads[key].shape)
         l2, c = _l2(got, grads[key]), _cos(got, grads[key])
         g_l2, g_cos = max(g_l2, l2), min(g_cos, c)
-        assert l2 <= BF16_GRAD_L2 and c >= BF16_GRAD_COS, (key, l2, c)
+        need(l2 <= BF16_GRAD_L2 and c >= BF16_GRAD_COS, ("gradient", key, l2, c))
         checked += 1
     assert checked >= 100
     l2_in, c_in = _l2(r["d_feats"], grads["d_feats"]), _cos(r["d_feats"], grads["d_feats"])
-    assert l2_in <= BF16_GRAD_L2 and c_in >= BF16_GRAD_COS, (l2_in, c_in)
-    print("full-size bf16 vs bf16-model oracle: free-running map L2 %s; teacher-forced worst L2 %.2e (bound %.2e), "
-          "worst max-error %.2e (bound %.2e); parameter gradients worst L2 %.2e (bound %.2e), worst cosine %.5f over "
-          "%d tensors; input gradient L2 %.2e" % (["%.2e" % v for v in free], tf_l2, BF16_TF_L2, tf_max, BF16_TF_MAX,
-                                                   g_l2, BF16_GRAD_L2, g_cos, checked, l2_in))
+    need(l2_in <= BF16_GRAD_L2 and c_in >= BF16_GRAD_COS, ("input gradient", l2_in, c_in))
+    print("full-size bf16 vs bf16-model oracle: free-running map L2 %s (bound %.2e); teacher-forced worst L2 %.2e "
+          "(bound %.2e), worst max-error %.2e (bound %.2e); running statistics worst %.2f of their tolerance; parameter "
+          "gradients worst L2 %.2e (bound %.2e), worst cosine %.5f over %d tensors; input gradient L2 %.2e cosine %.5f"
+          % (["%.2e" % v for v in free], BF16_FREE_L2, tf_l2, BF16_TF_L2, tf_max, BF16_TF_MAX, rs, g_l2, BF16_GRAD_L2,
+             g_cos, checked, l2_in, c_in))
+    assert not fails, fails[:12]
+
+
+def test_bench_proposal_sets_nms_decision_and_survivors():
+    """VERDICT r3 weak #3 on the bench's OWN proposal sets: one step of bench.Workload (fp32), the 4 x 2,000 decoded,
+    clamped boxes that go into the rotated NMS captured on the way.  (1) count the ordered pairs with pre-filter > 0 on
+    different sides of thresh under the A15 IoU and the exact polygon IoU (oracle/clip_oracle.c); (2) the device's
+    survivors (decision on clip_iou_exact, csrc/iou_math.h) equal the oracle's greedy loop with the two matrices, and
+    the count of proposals the old rule (decision on the A15 value) would have changed is reported."""
+    sys.path.insert(0, REPO)
+    import bench
+    import dp
+    import rpn_glue
+    import sparseconvnet as scn
+    import _nms
+    wl = bench.Workload(scn, torch, dp, torch.device(DEV), torch.float32, 0, 1, 1)
+    wl.prefetch_geometry = False
+    rpn_glue.debug_nms_inputs = []
+    try:
+        wl.forward_backward(0)
+        torch.cuda.synchronize()
+        sets = [(b.cpu().numpy(), s.cpu().numpy()) for b, s in rpn_glue.debug_nms_inputs]
+    finally:
+        rpn_glue.debug_nms_inputs = None
+    assert len(sets) == bench.SCENES_PER_STEP
+    O.set_threads(16)
+    total_pre = total_dis = changed = 0
+    for (b7, sc), (boxes, scores) in zip(sets, wl.last[1]):
+        assert b7.shape == (2000, 7) and (np.diff(sc) <= 0).all()          # sorted by descending score
+        a15 = O.boxes_iou_3d(b7, b7, (0, 0, 0, 0), -1, True)
+        ex = O.clip_iou_matrix(b7)
+        pre = a15 > 0
+        np.fill_diagonal(pre, False)
+        total_pre += int(pre.sum())
+        total_dis += int((pre & ((a15 >= 0.5) != (ex >= 0.5))).sum())
+        order = np.arange(2000, dtype=np.int32)
+        want = O.nms_prefilter_decide(a15, ex, order, 0.5)[:1000]
+        old = O.nms_from_matrix(a15, order, 0.5)[:1000]
+        changed += len(set(want.tolist()) ^ set(old.tolist()))
+        got = _nms.rotate_nms_sorted(torch.as_tensor(b7).to(DEV), 0.5, 1000, True).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(scores.cpu().numpy(), sc[want])     # what the step itself kept
+    print("bench proposal sets: %d ordered pairs with pre-filter > 0, %d on different sides of 0.5 under A15 vs exact "
+          "polygon IoU; survivors that differ between the two rules: %d" % (total_pre, total_dis, changed))
