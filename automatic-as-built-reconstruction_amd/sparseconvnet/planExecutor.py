@@ -568,7 +568,9 @@ class _Pass(object):
         gbufs, bops = bw["gbufs"], bw["ops"]
         offs, total = _offsets(gbufs, V)
         garena = torch.empty(max(total, 1), dtype=torch.uint8, device=self.dev)
-        gparams = torch.empty(max(bw["ptotal"], 1), dtype=torch.float32, device=self.dev)
+        # the data-parallel hook all-reduces slices of this buffer, 64-float padding between the slots included
+        hooked = grad_segments > 1 and on_grads_ready is not None
+        gparams = (torch.zeros if hooked else torch.empty)(max(bw["ptotal"], 1), dtype=torch.float32, device=self.dev)
         gbase, pbase, sbase = garena.data_ptr(), gparams.data_ptr(), self.stat.data_ptr()
         AD = (A, [gbase + o for o in offs], [_dp(g) for g in gouts])
         for (b, _), g in zip(t.outs, gouts):

@@ -316,7 +316,11 @@ class Workload(object):
             from sparseconvnet import planExecutor
             planExecutor.grad_segments = self.grad_buckets
             self.flat.begin_bucketed()
-            self.forward_backward(i)
+            try:
+                self.forward_backward(i)
+            except BaseException:
+                self.flat.abort_bucketed()     # never leave the hook armed behind a failed backward
+                raise
             self.flat.finish_bucketed(1e-5, self.world)
         elif self.world > 1:
             # one flat all-reduce, launched asynchronously right after backward; the proposal stage (top-k, decode, NMS:

@@ -106,3 +106,103 @@ def test_bench_without_gpu_fails_loudly_in_every_rank():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     assert r.returncode != 0 and "needs a GPU" in r.stderr and "{" not in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------- bucketed all-reduce
+def _bucket_worker(rank, world, port, q, cheat):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    import importlib
+    importlib.import_module("automatic-as-built-reconstruction_amd")
+    import dp
+    from sparseconvnet import planExecutor
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    fp = dp.FlatParams([net])
+    fp.broadcast(0)
+    w0 = fp.flat.clone()
+    ps = list(net.parameters())           # 6 tensors; the "compiled graph" below owns the last four
+    out = []
+    for step in range(3):
+        fp.zero_grad()
+        net(torch.full((2, 4), float(rank + 1 + step))).sum().backward()
+        local = [p.grad.clone() for p in ps]
+        # what planExecutor's backward does with the hook armed: a zero-initialised gradient buffer with 64-float
+        # slots, handed over in two pieces as they complete
+        fp.begin_bucketed()
+        assert planExecutor.on_grads_ready is not None
+        slots, off = [], 0
+        for p in ps[2:]:
+            slots.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        gbuf = torch.zeros(off)
+        views = [gbuf[o:o + p.numel()].view_as(p) for o, p in zip(slots, ps[2:])]
+        for v, g in zip(views, local[2:]):
+            v.copy_(g)
+        for p, v in zip(ps[2:], views):
+            p.grad = v                     # autograd would store these views
+        cut = slots[2]
+        pieces = [(gbuf[:cut], list(zip(ps[2:4], views[:2]))), (gbuf[cut:], list(zip(ps[4:], views[2:])))]
+        if cheat and rank == 1 and step == 1:
+            pieces = [(gbuf[:], list(zip(ps[2:], views)))]         # this rank's graph "fell back": one piece
+        try:
+            for k, (flat, pairs) in enumerate(pieces):
+                planExecutor.on_grads_ready(k, len(pieces), flat, pairs)
+                # the pass's own buffer is untouched by the collective: p.grad is still the LOCAL gradient here
+                for (p, v), g in zip(pairs, local[2 + 2 * k:]):
+                    assert torch.equal(v, g)
+            n = fp.finish_bucketed(0.1, world)
+        except RuntimeError as e:
+            fp.abort_bucketed()
+            out.append(("error", str(e)[:60]))
+            break
+        assert planExecutor.on_grads_ready is None and n == 3
+        out.append(("ok", [p.grad.numpy().copy() for p in ps], [g.numpy().copy() for g in local],
+                    fp.flat.detach().numpy().copy()))
+    q.put((rank, w0.numpy().copy(), out))     # numpy: plain pickles (torch would share storage with a dying process)
+    if not cheat:
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_bucket(cheat):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 7 + int(cheat)) % 1000
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q, cheat)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def test_two_rank_bucketed_allreduce_leaves_mean_gradients():
+    """the bucketed hook must not all-reduce the pass's gradient buffer in place -- p.grad stays
+    the local gradient while collectives are in flight and is the cross-rank MEAN after finish_bucketed; the update
+    equals mean-gradient SGD; replicas stay in lock-step over several steps (the bucket plan is agreed once)."""
+    import numpy as np
+    (r0, w0, o0), (r1, w1, o1) = _run_bucket(False)
+    assert np.array_equal(w0, w1) and len(o0) == len(o1) == 3
+    w = w0
+    for (s0, g0, l0, f0), (s1, g1, l1, f1) in zip(o0, o1):
+        assert s0 == s1 == "ok"
+        mean = [(a + b) / 2 for a, b in zip(l0, l1)]
+        for a, b, m in zip(g0, g1, mean):
+            np.testing.assert_allclose(a, m, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(b, m, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(f0, w - 0.1 * np.concatenate([m.reshape(-1) for m in mean]), rtol=1e-5, atol=1e-6)
+        assert np.array_equal(f0, f1)
+        w = f0
+
+
+def test_bucket_plan_mismatch_raises_instead_of_hanging():
+    """a rank whose pieces differ from the agreed plan (its graph fell back to the per-module path) raises before it
+    launches a mismatched collective"""
+    res = _run_bucket(True)
+    out1 = res[1][2]
+    assert out1[0][0] == "ok" and out1[-1][0] == "error" and "plan" in out1[-1][1]

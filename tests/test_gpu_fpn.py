@@ -555,3 +555,24 @@ def test_bucketed_gradient_allreduce_equals_flat_update():
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+def test_rccl_world_size_1_bucketed_equals_flat():
+    """the bench's training step under backend `nccl` (RCCL) at world_size 1 with the bucketed
+    gradient all-reduce forced on, bit-equal to the flat update -- RCCL init, async work handles and the real stream
+    ordering between aabr_plan_run's side-stream join, the hook and the collective (tests/nccl_ws1_child.py, a fresh
+    child process; reference: tools/train_net_sparse3d.py:64-69,183-190)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               AABR_BENCH_PIN="0")
+    port = str(29700 + os.getpid() % 200)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "nccl_ws1_child.py"), port], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["backend"] == "nccl" and out["world_size"] == 1
+    assert out["max_param_change"] > 0                      # the steps really moved the parameters
+    assert out["equal"] and out["reproducible"], out
+    assert out["buckets"] == 5 and out["launched_during_backward"] == 3 and out["bucket_bytes"] > 80e6
+    assert out["hook_disarmed"] and out["grads_are_means"]
