@@ -24,15 +24,18 @@ _SIGS = {
     "aabr_set_knob": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "aabr_quantize_points": (C.c_int, [_vp, _i32, _i64, C.c_double, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "aabr_input_layer_status_words": (C.c_int64, [_i64]),
-    "aabr_input_layer_sites": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aabr_input_layer_sites": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aabr_input_layer_pack_bits": (C.c_int, [_i64, _i32p]),
+    "aabr_input_layer_sites_packed": (C.c_int, [_vp, _i64, _i32, _i32p, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                _vp, _vp, _vp, _vp, _vp, _vp]),
     "aabr_input_layer_forward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "aabr_input_layer_backward": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "aabr_input_layer_rule_table": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
-    "aabr_submanifold_table": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32p, _vp, _vp, _vp]),
-    "aabr_convolution_sites": (C.c_int, [_vp, _i64, _i32p, _i32p, _i32p, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "aabr_convolution_tables": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32p, _i32p,
+    "aabr_submanifold_table": (C.c_int, [_vp, _i64, _vp, _i64, _i32p, _vp, _vp, _vp]),
+    "aabr_convolution_sites": (C.c_int, [_vp, _i64, _i32p, _i32p, _i32p, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "aabr_convolution_tables": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32p, _i32p,
                                           _i32p, _vp, _vp, _vp, _vp]),
-    "aabr_convolution_tables2": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32p, _i32p,
+    "aabr_convolution_tables2": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32p, _i32p,
                                            _i32p, _vp, _vp, _vp, _vp, _vp]),
     "aabr_sample_offsets": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "aabr_table_to_rulebook": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),

@@ -68,25 +68,37 @@ struct __align__(16) GridEnt {
 };
 static_assert(sizeof(GridEnt) == 16, "GridEnt is 16 bytes");
 
+// Probe sequence of every grid: linear inside the key's home BLOCK of kGridBlock slots (wrapping at the block's end),
+// and only when all kGridBlock slots of that block have been visited -- the tables are at most half full, so a full
+// block is a > 40 sigma event for mixed keys -- on through the slots behind the block.  Find and insert walk the same
+// sequence.  The block rule is what lets the LDS-binned voxel scatter (voxel_scatter.hip) build one block per
+// workgroup entirely in LDS and write it out with coalesced stores; it also keeps a probe chain inside one 64 KiB
+// window.  Tables smaller than a block are one block.
+constexpr uint32_t kGridBlock = 4096;
+__device__ inline uint64_t grid_next(uint64_t h, uint64_t mask, uint32_t t) {
+  const uint64_t bm = mask < (uint64_t)(kGridBlock - 1) ? mask : (uint64_t)(kGridBlock - 1);
+  return t < bm ? ((h & ~bm) | ((h + 1) & bm)) : (((t == bm ? (h | bm) : h) + 1) & mask);
+}
+
 // read-only probe of a finished table: one 16-byte load per slot visited
 __device__ inline int grid_find(const GridEnt *__restrict__ g, uint64_t mask, uint64_t key) {
   uint64_t h = mix64(key) & mask;
-  for (;;) {
+  for (uint32_t t = 0;; ++t) {
     const uint4 e = *reinterpret_cast<const uint4 *>(g + h);
     const uint64_t k = (uint64_t)e.x | ((uint64_t)e.y << 32);
     if (k == key) return (int)e.w;
     if (k == kEmptyKey) return -1;
-    h = (h + 1) & mask;
+    h = grid_next(h, mask, t);
   }
 }
 
 // insert-or-find; returns the slot
 __device__ inline uint32_t grid_insert(GridEnt *g, uint64_t mask, uint64_t key) {
   uint64_t h = mix64(key) & mask;
-  for (;;) {
+  for (uint32_t t = 0;; ++t) {
     unsigned long long prev = atomicCAS(&g[h].key, (unsigned long long)kEmptyKey, (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) return (uint32_t)h;
-    h = (h + 1) & mask;
+    h = grid_next(h, mask, t);
   }
 }
 

@@ -397,7 +397,7 @@ static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)ceil_div(n >
 using namespace aabr;
 
 extern "C" int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t *keys,
-                                      const int32_t *vals, int64_t cap, const int32_t *fs_host,
+                                      int64_t cap, const int32_t *fs_host,
                                       int32_t *table, int32_t *counts, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(V >= 0 && fs_host && is_pow2(cap), "bad V/filter/cap");
@@ -434,7 +434,7 @@ static int make_geom(const int32_t *size, const int32_t *stride, const int32_t *
 
 extern "C" int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, const int32_t *size_host,
                                       const int32_t *stride_host, const int32_t *out_spatial_host,
-                                      uint64_t *out_keys, int32_t *out_vals, int64_t out_cap,
+                                      uint64_t *out_keys, int64_t out_cap,
                                       int32_t *scratch, int32_t *out_site_coords, int32_t *meta,
                                       void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
@@ -472,26 +472,26 @@ extern "C" int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, co
 }
 
 extern "C" int aabr_convolution_tables2(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
-                                        const int32_t *in_vals, int64_t in_cap, const int32_t *out_coords,
-                                        int64_t V_out, const uint64_t *out_keys, const int32_t *out_vals,
+                                        int64_t in_cap, const int32_t *out_coords,
+                                        int64_t V_out, const uint64_t *out_keys,
                                         int64_t out_cap, const int32_t *size_host, const int32_t *stride_host,
                                         const int32_t *out_spatial_host, int32_t *table_out, int32_t *table_in,
                                         int32_t *counts, int32_t *counts_in, void *stream_);
 
 extern "C" int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
-                                       const int32_t *in_vals, int64_t in_cap, const int32_t *out_coords,
-                                       int64_t V_out, const uint64_t *out_keys, const int32_t *out_vals,
+                                       int64_t in_cap, const int32_t *out_coords,
+                                       int64_t V_out, const uint64_t *out_keys,
                                        int64_t out_cap, const int32_t *size_host, const int32_t *stride_host,
                                        const int32_t *out_spatial_host, int32_t *table_out, int32_t *table_in,
                                        int32_t *counts, void *stream_) {
-  return aabr_convolution_tables2(in_coords, V_in, in_keys, in_vals, in_cap, out_coords, V_out, out_keys, out_vals,
+  return aabr_convolution_tables2(in_coords, V_in, in_keys, in_cap, out_coords, V_out, out_keys,
                                   out_cap, size_host, stride_host, out_spatial_host, table_out, table_in, counts,
                                   nullptr, stream_);
 }
 
 extern "C" int aabr_convolution_tables2(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
-                                        const int32_t *in_vals, int64_t in_cap, const int32_t *out_coords,
-                                        int64_t V_out, const uint64_t *out_keys, const int32_t *out_vals,
+                                        int64_t in_cap, const int32_t *out_coords,
+                                        int64_t V_out, const uint64_t *out_keys,
                                         int64_t out_cap, const int32_t *size_host, const int32_t *stride_host,
                                         const int32_t *out_spatial_host, int32_t *table_out, int32_t *table_in,
                                         int32_t *counts, int32_t *counts_in, void *stream_) {

@@ -340,12 +340,12 @@ extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
     int rc = AABR_OK;
     switch (o.kind) {
     case AABR_GEOM_SUBM_TABLE:
-      rc = aabr_submanifold_table((const int32_t *)p[0], o.i64[0], (const uint64_t *)p[1], nullptr, o.i64[1], &o.i32[0],
+      rc = aabr_submanifold_table((const int32_t *)p[0], o.i64[0], (const uint64_t *)p[1], o.i64[1], &o.i32[0],
                                   (int32_t *)p[2], (int32_t *)p[3], st);
       break;
     case AABR_GEOM_CONV_TABLES:
-      rc = aabr_convolution_tables2((const int32_t *)p[0], o.i64[0], (const uint64_t *)p[1], nullptr, o.i64[1],
-                                    (const int32_t *)p[2], o.i64[2], (const uint64_t *)p[3], nullptr, o.i64[3],
+      rc = aabr_convolution_tables2((const int32_t *)p[0], o.i64[0], (const uint64_t *)p[1], o.i64[1],
+                                    (const int32_t *)p[2], o.i64[2], (const uint64_t *)p[3], o.i64[3],
                                     &o.i32[0], &o.i32[3], &o.i32[6], (int32_t *)p[4], (int32_t *)p[5], (int32_t *)p[6],
                                     (int32_t *)p[7], st);
       break;
@@ -363,7 +363,7 @@ extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
       break;
     case AABR_GEOM_CONV_SITES:
       rc = aabr_convolution_sites((const int32_t *)p[0], o.i64[0], &o.i32[0], &o.i32[3], &o.i32[6], (uint64_t *)p[1],
-                                  nullptr, o.i64[1], (int32_t *)p[2], (int32_t *)p[3], (int32_t *)p[4], st);
+                                  o.i64[1], (int32_t *)p[2], (int32_t *)p[3], (int32_t *)p[4], st);
       break;
     case AABR_GEOM_SAMPLE_OFFSETS:
       rc = aabr_sample_offsets((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st);

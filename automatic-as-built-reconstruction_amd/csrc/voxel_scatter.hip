@@ -20,10 +20,23 @@
 // for first points (K2) + 4 B point_site + the feature row in and out (K3), and three random 4-8 B sectors in the
 // hash / first / vals arrays.  No CSR build, no per-site sort pass, no slot-table scan.
 //
-// Why not a coarse-cell partition with per-bin LDS hashes: on this data the dedup ratio is ~1 (80k points ->
-// 77k voxels at 2 cm), so an LDS pre-aggregation removes almost no global inserts, and the partition itself
-// (histogram + scan + stable scatter of 44-byte records) costs more passes over the points than the whole of the
-// above.  LDS is used where it pays: the chunk scan / look-back of K2.
+// Round 4: three forms of the insert, one numbering kernel (K2) and one mean kernel behind them.
+//   generic (any coordinates up to 65534, any batch index)  : K1 above, two device atomics per point;
+//   packed  (aabr_input_layer_sites_packed, variant 1)      : ONE device atomic per point -- the 64-bit word
+//       (batch | x | y | z | point index), field widths from the layer's spatial size and n, goes through a CAS into an
+//       8-byte side table (same slot sequence as the grid), a point that finds its own voxel's word takes the minimum
+//       with one atomicMin only when it is the smaller one; K2 reads the winner's index from the word and writes the
+//       finished 16-byte grid entry;
+//   binned  (variant 2, the default when the fields fit)    : LDS-staged hash binning with coalesced HBM writes, NO
+//       device atomics on the table -- P1 k_voxel_bin partitions the points' packed words by hash BLOCK (4096 slots =
+//       one 64 KiB window of the grid: LDS histogram per workgroup, one reservation per (workgroup, block), records
+//       written in runs), P2 k_voxel_bin_build builds each block's table in LDS (ds_cmpst / ds_min on 64-bit words),
+//       tells every point its slot and whether it is its voxel's first (one 4-byte store by point index into an array
+//       that fits the L2s) and writes the block's 4096 finished grid entries, empty ones included, with 16-byte
+//       coalesced stores -- the table fill disappears.  Blocks are self-contained because every grid probes inside
+//       its home block (common.h grid_next).
+// The packed / binned forms set meta[5] = 0 when a point does not fit the word (coordinate beyond the spatial size,
+// batch index beyond the bits left) or a block overflows; the caller then runs the generic form.
 #include "common.h"
 #include <stdlib.h>
 
@@ -68,12 +81,16 @@ __device__ inline unsigned long long st_pack(unsigned flag, unsigned v) {
   return ((unsigned long long)flag << 62) | (unsigned long long)v;
 }
 
-template <int kVsItems>
+// MODE 0: generic (slot[i] + grid[slot].first); 1: packed side table (slot[i] + low bits of words[slot]; the first
+// point writes the whole grid entry); 2: binned (slot[i] = slot | first << 31, written by k_voxel_bin_build)
+constexpr int32_t kInfoNone = 0x7fffffff;
+template <int kVsItems, int MODE>
 __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
     const int64_t *__restrict__ coords, int64_t n, int ncols, const int32_t *__restrict__ slot,
     GridEnt *grid, int32_t *__restrict__ site_coords,
     int32_t *__restrict__ first_pt, int32_t *__restrict__ point_site, int32_t *cnt_extra, int32_t *head,
-    int32_t *__restrict__ nxt, unsigned long long *status, int32_t *meta) {
+    int32_t *__restrict__ nxt, unsigned long long *status, int32_t *meta,
+    const unsigned long long *__restrict__ words, unsigned long long imask) {
   constexpr int kVsChunk = kVsThreads * kVsItems;
   __shared__ int s_chunk;
   __shared__ int s_wsum[kVsThreads / 64];
@@ -87,8 +104,17 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
 #pragma unroll
   for (int j = 0; j < kVsItems; ++j) {
     const int64_t i = base + j;
-    s[j] = i < n ? slot[i] : -1;
-    f[j] = (s[j] >= 0 && grid[s[j]].first == (uint32_t)i) ? 1 : 0;
+    if (MODE == 2) {
+      const int32_t v = i < n ? slot[i] : kInfoNone;
+      s[j] = (v & kInfoNone) == kInfoNone ? -1 : (v & kInfoNone);
+      f[j] = (s[j] >= 0 && v < 0) ? 1 : 0;
+    } else {
+      s[j] = i < n ? slot[i] : -1;
+      if (MODE == 1)
+        f[j] = (s[j] >= 0 && (words[s[j]] & imask) == (unsigned long long)i) ? 1 : 0;
+      else
+        f[j] = (s[j] >= 0 && grid[s[j]].first == (uint32_t)i) ? 1 : 0;
+    }
     a += f[j];
   }
   // chunk-exclusive scan of `a`: wave scan + 4 wave totals through LDS
@@ -158,6 +184,11 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
       *reinterpret_cast<int4 *>(site_coords + 4 * (int64_t)v) =
           make_int4((int)cp[0], (int)cp[1], (int)cp[2], ncols == 4 ? (int)cp[3] : 0);
       first_pt[v] = (int32_t)i;
+      if (MODE == 1) {   // the grid entry is created here: key and first index first, the polled word last
+        GridEnt *e = grid + s[j];
+        e->key = pack_key(ncols == 4 ? (int)cp[3] : 0, (int)cp[0], (int)cp[1], (int)cp[2]);
+        e->first = (uint32_t)i;
+      }
       __hip_atomic_store(&grid[s[j]].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // self-contained value
     }
   }
@@ -176,6 +207,189 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
       atomicAdd(&cnt_extra[v], 1);
     }
     point_site[i] = v;
+  }
+}
+
+// ---- packed words --------------------------------------------------------------------------------------------------
+// word = (((batch << xb | x) << yb | y) << zb | z) << ib | point index: for one voxel the smallest word is its first
+// point.  All ones = empty (the batch field is never all ones).
+struct PackSpec {
+  int xb, yb, zb, bb, ib;
+};
+__device__ inline unsigned long long pk_word(const PackSpec &p, int b, int x, int y, int z, unsigned long long i) {
+  unsigned long long k = (unsigned long long)b;
+  k = (k << p.xb) | (unsigned long long)x;
+  k = (k << p.yb) | (unsigned long long)y;
+  k = (k << p.zb) | (unsigned long long)z;
+  return (k << p.ib) | i;
+}
+__device__ inline uint64_t pk_canonical(const PackSpec &p, unsigned long long w) {
+  unsigned long long k = w >> p.ib;
+  const int z = (int)(k & ((1ull << p.zb) - 1)); k >>= p.zb;
+  const int y = (int)(k & ((1ull << p.yb) - 1)); k >>= p.yb;
+  const int x = (int)(k & ((1ull << p.xb) - 1)); k >>= p.xb;
+  return pack_key((int)k, x, y, z);
+}
+// load + validate point i; returns 0 ok, 1 dropped silently, 2 out of the generic range, 3 does not fit the word
+__device__ inline int pk_load(const int64_t *__restrict__ coords, int64_t i, int ncols, const PackSpec &p, int &b,
+                              int &x, int &y, int &z) {
+  const int64_t *c = coords + i * ncols;
+  const int64_t X = c[0], Y = c[1], Z = c[2], B = ncols == 4 ? c[3] : 0;
+  if (X == -1 && Y == -1 && Z == -1) return 1;
+  if (X < 0 || Y < 0 || Z < 0 || B < 0 || X > kMaxCoord || Y > kMaxCoord || Z > kMaxCoord || B > kMaxCoord) return 2;
+  if (X >= (1ll << p.xb) || Y >= (1ll << p.yb) || Z >= (1ll << p.zb) || B >= (1ll << p.bb) - 1) return 3;
+  b = (int)B; x = (int)X; y = (int)Y; z = (int)Z;
+  return 0;
+}
+constexpr int kMetaRedo = 5;                    // meta word: 0 = run the generic form instead
+
+// variant 1: one device atomic per point
+__global__ __launch_bounds__(256) void k_voxel_insert_packed(const int64_t *__restrict__ coords, int64_t n, int ncols,
+                                                             PackSpec sp, unsigned long long *words, uint64_t mask,
+                                                             int32_t *__restrict__ slot,
+                                                             int32_t *__restrict__ cnt_extra, int32_t *__restrict__ head,
+                                                             unsigned long long *__restrict__ status, int64_t nchunks,
+                                                             int32_t *meta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nchunks) status[i] = 0ull;
+  if (i >= n) return;
+  cnt_extra[i] = 0;
+  head[i] = -1;
+  int b, x, y, z;
+  const int rc = pk_load(coords, i, ncols, sp, b, x, y, z);
+  if (rc) {
+    slot[i] = -1;
+    if (rc == 2) atomicAnd(&meta[2], 0);
+    if (rc == 3) atomicAnd(&meta[kMetaRedo], 0);
+    return;
+  }
+  const unsigned long long w = pk_word(sp, b, x, y, z, (unsigned long long)i);
+  uint64_t h = mix64(pack_key(b, x, y, z)) & mask;
+  for (uint32_t t = 0;; ++t) {
+    const unsigned long long prev = atomicCAS(&words[h], ~0ull, w);
+    if (prev == ~0ull) break;                                  // the usual case: ONE atomic
+    if ((prev >> sp.ib) == (w >> sp.ib)) {                     // my voxel: keep the smaller point index
+      if (w < prev) atomicMin(&words[h], w);
+      break;
+    }
+    h = grid_next(h, mask, t);
+  }
+  slot[i] = (int32_t)h;
+}
+
+// variant 2, P1: partition the points' words by hash block.  LDS: [nbins] counts, [nbins] bases.
+template <int ITEMS>
+__global__ __launch_bounds__(256) void k_voxel_bin(const int64_t *__restrict__ coords, int64_t n, int ncols, PackSpec sp,
+                                                   uint64_t mask, int nbins, int capbin,
+                                                   unsigned long long *__restrict__ rec, int32_t *cursor,
+                                                   int32_t *__restrict__ info, int32_t *__restrict__ cnt_extra,
+                                                   int32_t *__restrict__ head, unsigned long long *__restrict__ status,
+                                                   int64_t nchunks, int32_t *meta) {
+  extern __shared__ int32_t s_hist[];
+  for (int q = threadIdx.x; q < nbins; q += 256) s_hist[q] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (256 * ITEMS);
+  unsigned long long w[ITEMS];
+  int bin[ITEMS], rank[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;      // consecutive lanes read consecutive points
+    bin[j] = -1;
+    if (i < nchunks) status[i] = 0ull;
+    if (i >= n) continue;
+    cnt_extra[i] = 0;
+    head[i] = -1;
+    int b, x, y, z;
+    const int rc = pk_load(coords, i, ncols, sp, b, x, y, z);
+    if (rc) {
+      info[i] = kInfoNone;
+      if (rc == 2) atomicAnd(&meta[2], 0);
+      if (rc == 3) atomicAnd(&meta[kMetaRedo], 0);
+      continue;
+    }
+    w[j] = pk_word(sp, b, x, y, z, (unsigned long long)i);
+    bin[j] = (int)((mix64(pack_key(b, x, y, z)) & mask) / kGridBlock);
+    rank[j] = atomicAdd(&s_hist[bin[j]], 1);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < nbins; q += 256) {
+    const int c = s_hist[q];
+    s_hist[nbins + q] = c ? atomicAdd(&cursor[q], c) : 0;      // one reservation per (workgroup, block)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    if (bin[j] < 0) continue;
+    const int pos = s_hist[nbins + bin[j]] + rank[j];
+    if (pos < capbin)
+      rec[(int64_t)bin[j] * capbin + pos] = w[j];
+    else {                                                     // a block with more points than its region holds
+      atomicAnd(&meta[kMetaRedo], 0);
+      info[base + j * 256 + threadIdx.x] = kInfoNone;
+    }
+  }
+}
+
+// variant 2, P2: one workgroup per hash block builds the block's table in LDS and writes the finished grid entries.
+constexpr int kBinRec = 16;                     // records per thread and sweep (256 x 16 = one region)
+__global__ __launch_bounds__(256) void k_voxel_bin_build(const unsigned long long *__restrict__ rec,
+                                                         const int32_t *__restrict__ cursor, int capbin, PackSpec sp,
+                                                         GridEnt *__restrict__ grid, int32_t *__restrict__ info,
+                                                         int32_t *meta) {
+  __shared__ unsigned long long tab[kGridBlock];
+  const int bin = blockIdx.x;
+  int cnt = cursor[bin];
+  cnt = cnt < capbin ? cnt : capbin;
+  for (int q = threadIdx.x; q < (int)kGridBlock; q += 256) tab[q] = ~0ull;
+  __syncthreads();
+  const unsigned long long *r = rec + (int64_t)bin * capbin;
+  const unsigned long long imask = (1ull << sp.ib) - 1;
+  for (int k0 = 0; k0 < cnt; k0 += 256 * kBinRec) {            // one sweep unless the region is larger than 4096
+    unsigned long long w[kBinRec];
+    int sl[kBinRec];
+#pragma unroll
+    for (int q = 0; q < kBinRec; ++q) {
+      const int k = k0 + q * 256 + threadIdx.x;
+      sl[q] = -1;
+      if (k >= cnt) continue;
+      w[q] = r[k];
+      uint32_t h = (uint32_t)(mix64(pk_canonical(sp, w[q])) & (kGridBlock - 1));
+      for (uint32_t t = 0; t < kGridBlock; ++t) {
+        const unsigned long long prev = atomicCAS(&tab[h], ~0ull, w[q]);
+        if (prev == ~0ull) { sl[q] = (int)h; break; }
+        if ((prev >> sp.ib) == (w[q] >> sp.ib)) {
+          if (w[q] < prev) atomicMin(&tab[h], w[q]);
+          sl[q] = (int)h;
+          break;
+        }
+        h = (h + 1) & (kGridBlock - 1);
+      }
+      if (sl[q] < 0) {                                         // the block is full: the generic form copes
+        atomicAnd(&meta[kMetaRedo], 0);
+        info[(int64_t)(w[q] & imask)] = kInfoNone;
+      }
+    }
+    __syncthreads();                                           // every word of the sweep is in: minima are final for
+#pragma unroll                                                 // the records seen so far only if cnt <= one sweep
+    for (int q = 0; q < kBinRec; ++q) {
+      if (sl[q] < 0) continue;
+      const unsigned long long idx = w[q] & imask;
+      const int first = (tab[sl[q]] & imask) == idx ? 1 : 0;
+      info[(int64_t)idx] = (int32_t)(((uint32_t)bin * kGridBlock + (uint32_t)sl[q]) | ((uint32_t)first << 31));
+    }
+    __syncthreads();
+  }
+  GridEnt *g = grid + (int64_t)bin * kGridBlock;
+  for (int q = threadIdx.x; q < (int)kGridBlock; q += 256) {
+    const unsigned long long w = tab[q];
+    uint4 e;
+    if (w == ~0ull) {
+      e = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    } else {
+      const uint64_t key = pk_canonical(sp, w);
+      e = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(w & imask), 0xffffffffu);
+    }
+    *reinterpret_cast<uint4 *>(g + q) = e;
   }
 }
 
@@ -234,11 +448,19 @@ __global__ __launch_bounds__(256) void k_voxel_mean(const float *__restrict__ in
                                                     const int32_t *__restrict__ head,
                                                     const int32_t *__restrict__ nxt, int32_t *__restrict__ last_pt,
                                                     int mode, int32_t *meta) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // a workgroup covers spb = 256 / planes consecutive sites, one thread per (site, plane) (rows wider than 256: one
+  // site, threads stride over the planes): the only division is a 32-bit one of the thread index (the 64-bit
+  // `idx / planes` of round 3 was most of this kernel's time)
+  const bool narrow = planes <= 256;
+  const unsigned spb = narrow ? 256u / (unsigned)planes : 1u;
+  const unsigned sl = narrow ? threadIdx.x / (unsigned)planes : 0u;
+  const int p0 = (int)(threadIdx.x - sl * (unsigned)planes);
+  const int pstep = narrow ? planes : 256;
+  const int64_t v = (int64_t)blockIdx.x * spb + sl;
+  const bool on = sl < spb && v < V;
   int extra = 0;
-  if (idx < V * planes) {
-    const int64_t v = idx / planes;
-    const int p = (int)(idx - v * planes);
+  if (on) for (int p = p0; p < planes; p += pstep) {
+    const int64_t idx = v * planes + p;
     const int first = first_pt[v];
     extra = cnt_extra[v];
     float acc = 0.0f;
@@ -264,7 +486,7 @@ __global__ __launch_bounds__(256) void k_voxel_mean(const float *__restrict__ in
     out[idx] = acc;
   }
   // largest point count of a site (IOLayersRules.h:96-103 maxActive): one atomic per block, only when it grows
-  int m = extra + (idx < V * planes ? 1 : 0);
+  int m = extra + (on ? 1 : 0);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     const int o = __shfl_xor(m, d);
@@ -346,22 +568,23 @@ __global__ __launch_bounds__(256) void k_voxel_backward(float *__restrict__ d_in
                                                         const int32_t *__restrict__ first_pt,
                                                         const int32_t *__restrict__ last_pt,
                                                         const int32_t *__restrict__ cnt_extra, int mode) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n * planes) return;
-  const int64_t i = idx / planes;
-  const int p = (int)(idx - i * planes);
+  const bool narrow = planes <= 256;                        // points per workgroup etc.: see k_voxel_mean
+  const unsigned spb = narrow ? 256u / (unsigned)planes : 1u;
+  const unsigned sl = narrow ? threadIdx.x / (unsigned)planes : 0u;
+  const int p0 = (int)(threadIdx.x - sl * (unsigned)planes);
+  const int pstep = narrow ? planes : 256;
+  const int64_t i = (int64_t)blockIdx.x * spb + sl;
+  if (sl >= spb || i >= n) return;
   const int v = point_site[i];
-  float g = 0.0f;
-  if (v >= 0) {
-    bool take = true;
+  bool take = v >= 0;
+  float mult = 1.0f;
+  if (take) {
     if (mode == 1) take = (first_pt[v] == (int32_t)i);
     if (mode == 2) take = (last_pt[v] == (int32_t)i);
-    if (take) {
-      const float mult = mode == 4 ? __fdiv_rn(1.0f, (float)(cnt_extra[v] + 1)) : 1.0f;
-      g = __fadd_rn(0.0f, __fmul_rn(mult, d_out[(int64_t)v * planes + p]));
-    }
+    if (take && mode == 4) mult = __fdiv_rn(1.0f, (float)(cnt_extra[v] + 1));
   }
-  d_in[idx] = g;
+  for (int p = p0; p < planes; p += pstep)
+    d_in[i * planes + p] = take ? __fadd_rn(0.0f, __fmul_rn(mult, d_out[(int64_t)v * planes + p])) : 0.0f;
 }
 
 // reference-format rule table rules[1] (IOLayersRules.h:112-124): [V, 1+maxActive] = (count, ascending points..)
@@ -395,10 +618,10 @@ extern "C" int64_t aabr_input_layer_status_words(int64_t n) {
   return 2 * ceil_div(n > 0 ? n : 1, (int64_t)kVsThreads * vs_items(n));
 }
 
-extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys, uint32_t *first,
-                                      int32_t *vals, int64_t cap, int32_t *slot, int32_t *point_site,
-                                      int32_t *site_coords, int32_t *first_pt, int32_t *cnt_extra, int32_t *head,
-                                      int32_t *nxt, int32_t *status, int32_t *meta, void *stream_) {
+extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys, int64_t cap,
+                                      int32_t *slot, int32_t *point_site, int32_t *site_coords, int32_t *first_pt,
+                                      int32_t *cnt_extra, int32_t *head, int32_t *nxt, int32_t *status, int32_t *meta,
+                                      void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(n >= 0 && n < (1ll << 31) - 65536 && (ncols == 3 || ncols == 4), "0 <= n < 2^31, ncols in {3,4}");
   AABR_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "cap must be a power of two >= max(64, 2n)");
@@ -407,7 +630,6 @@ extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncol
   AABR_CHECK_ARG(((uintptr_t)status & 7) == 0 && ((uintptr_t)site_coords & 15) == 0 && ((uintptr_t)keys & 15) == 0,
                  "status 8-, site_coords / grid entries 16-byte aligned");
   AABR_CHECK_ARG(n == 0 || coords, "null coords");
-  (void)first; (void)vals;   // round-2 layout (separate arrays); the grid's 16-byte entries hold them now
   GridEnt *grid = reinterpret_cast<GridEnt *>(keys);
   const int items = vs_items(n);
   const int64_t nchunks = ceil_div(n > 0 ? n : 1, (int64_t)kVsThreads * items);
@@ -426,9 +648,87 @@ extern "C" int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncol
   // K1 also clears the chunk status words and the per-site chain heads / counts (consumed by K2 only)
   hipLaunchKernelGGL(k_voxel_insert, grid1(n > nchunks ? n : nchunks, 256), dim3(256), 0, st, coords, n, ncols, grid,
                      (uint64_t)(cap - 1), slot, cnt_extra, head, (unsigned long long *)status, nchunks, meta);
-  hipLaunchKernelGGL(k_voxel_number<4>, dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
+  hipLaunchKernelGGL((k_voxel_number<4, 0>), dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
                      grid, site_coords, first_pt, point_site, cnt_extra, head, nxt,
-                     (unsigned long long *)status, meta);
+                     (unsigned long long *)status, meta, (const unsigned long long *)nullptr, 0ull);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+static int bits_for(int64_t v) {   // bits that hold 0 .. v-1
+  int b = 1;
+  while ((1ll << b) < v) ++b;
+  return b;
+}
+static bool pack_spec(int64_t n, const int32_t *spatial, PackSpec &sp) {
+  for (int d = 0; d < 3; ++d)
+    if (spatial[d] < 1 || spatial[d] > kMaxCoord + 1) return false;
+  sp.xb = bits_for(spatial[0]); sp.yb = bits_for(spatial[1]); sp.zb = bits_for(spatial[2]);
+  sp.ib = bits_for(n > 1 ? n : 2);
+  sp.bb = 64 - sp.xb - sp.yb - sp.zb - sp.ib;
+  if (sp.bb > 16) sp.bb = 16;
+  return sp.bb >= 2;
+}
+
+extern "C" int aabr_input_layer_pack_bits(int64_t n, const int32_t *spatial_host) {
+  PackSpec sp;
+  if (!spatial_host || n < 0 || !pack_spec(n, spatial_host, sp)) return 0;
+  return sp.bb;
+}
+
+extern "C" int aabr_input_layer_sites_packed(const int64_t *coords, int64_t n, int ncols, const int32_t *spatial_host,
+                                             int variant, uint64_t *keys, int64_t cap, uint64_t *words, int32_t *cursor,
+                                             int32_t *slot, int32_t *point_site, int32_t *site_coords, int32_t *first_pt,
+                                             int32_t *cnt_extra, int32_t *head, int32_t *nxt, int32_t *status,
+                                             int32_t *meta, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(n > 0 && n < (1ll << 31) - 65536 && (ncols == 3 || ncols == 4), "0 < n < 2^31, ncols in {3,4}");
+  AABR_CHECK_ARG(is_pow2(cap) && cap >= 2 * n && cap >= 64, "cap must be a power of two >= max(64, 2n)");
+  AABR_CHECK_ARG(variant == 1 || variant == 2, "variant: 1 packed (one atomic per point), 2 LDS-binned");
+  AABR_CHECK_ARG(coords && spatial_host && keys && words && slot && point_site && site_coords && first_pt && cnt_extra &&
+                     head && nxt && status && meta, "null pointer");
+  AABR_CHECK_ARG(((uintptr_t)status & 7) == 0 && ((uintptr_t)site_coords & 15) == 0 && ((uintptr_t)keys & 15) == 0 &&
+                     ((uintptr_t)words & 7) == 0, "status / words 8-, site_coords / grid entries 16-byte aligned");
+  PackSpec sp;
+  AABR_CHECK_ARG(pack_spec(n, spatial_host, sp), "the fields (spatial size, n) do not fit a 64-bit word: use "
+                                                 "aabr_input_layer_sites (aabr_input_layer_pack_bits tells)");
+  GridEnt *grid = reinterpret_cast<GridEnt *>(keys);
+  const int64_t nchunks = ceil_div(n, (int64_t)kVsThreads * vs_items(n));
+  const unsigned long long imask = (1ull << sp.ib) - 1;
+  hipMemsetAsync(meta, 0xFF, AABR_META_WORDS * sizeof(int32_t), st);
+  if (variant == 1) {
+    hipMemsetAsync(grid, 0xFF, cap * sizeof(GridEnt), st);
+    hipMemsetAsync(words, 0xFF, cap * sizeof(uint64_t), st);
+    hipLaunchKernelGGL(k_voxel_insert_packed, grid1(n, 256), dim3(256), 0, st, coords, n, ncols, sp,
+                       (unsigned long long *)words, (uint64_t)(cap - 1), slot, cnt_extra, head,
+                       (unsigned long long *)status, nchunks, meta);
+    hipLaunchKernelGGL((k_voxel_number<4, 1>), dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
+                       grid, site_coords, first_pt, point_site, cnt_extra, head, nxt, (unsigned long long *)status,
+                       meta, (const unsigned long long *)words, imask);
+  } else {
+    const int64_t nbins = cap / kGridBlock;
+    AABR_CHECK_ARG(cap >= (int64_t)kGridBlock && nbins <= 4096 && cursor,
+                   "LDS-binned form: 4096 <= cap <= 2^24 slots and a cursor array of cap/4096 words");
+    hipMemsetAsync(cursor, 0, nbins * sizeof(int32_t), st);
+    // ~8 points per (workgroup, block): few reservations, records written in 64-byte runs
+    int64_t per = 8 * nbins;
+    per = per < 1024 ? 1024 : (per > 8192 ? 8192 : per);
+    const size_t lds = 2 * (size_t)nbins * sizeof(int32_t);
+#define AABR_BIN(ITEMS)                                                                                              \
+  hipLaunchKernelGGL((k_voxel_bin<ITEMS>), grid1(n, 256 * ITEMS), dim3(256), lds, st, coords, n, ncols, sp,          \
+                     (uint64_t)(cap - 1), (int)nbins, (int)kGridBlock, (unsigned long long *)words, cursor, slot,    \
+                     cnt_extra, head, (unsigned long long *)status, nchunks, meta)
+    if (per <= 1024) AABR_BIN(4);
+    else if (per <= 2048) AABR_BIN(8);
+    else if (per <= 4096) AABR_BIN(16);
+    else AABR_BIN(32);
+#undef AABR_BIN
+    hipLaunchKernelGGL(k_voxel_bin_build, dim3((unsigned)nbins), dim3(256), 0, st, (const unsigned long long *)words,
+                       (const int32_t *)cursor, (int)kGridBlock, sp, grid, slot, meta);
+    hipLaunchKernelGGL((k_voxel_number<4, 2>), dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
+                       grid, site_coords, first_pt, point_site, cnt_extra, head, nxt, (unsigned long long *)status,
+                       meta, (const unsigned long long *)nullptr, imask);
+  }
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -446,7 +746,7 @@ extern "C" int aabr_input_layer_forward(const float *in_feats, float *out_feats,
     hipLaunchKernelGGL(k_voxel_mean_row<16>, grid1(V, 256), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats, V,
                        planes, first_pt, cnt_extra, head, nxt, last_pt, mode, meta);
   else
-    hipLaunchKernelGGL(k_voxel_mean, grid1(V * planes, 256), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats,
+    hipLaunchKernelGGL(k_voxel_mean, grid1(V, planes <= 256 ? 256 / planes : 1), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats,
                        V, planes, first_pt, cnt_extra, head, nxt, last_pt, mode, meta);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
@@ -459,7 +759,7 @@ extern "C" int aabr_input_layer_backward(float *d_in_feats, const float *d_out_f
   if (n == 0) return AABR_OK;
   AABR_CHECK_ARG(d_in_feats && d_out_feats && point_site && first_pt && cnt_extra, "null pointer");
   AABR_CHECK_ARG(mode != 2 || last_pt, "mode 2 needs last_pt");
-  hipLaunchKernelGGL(k_voxel_backward, grid1(n * planes, 256), dim3(256), 0, (hipStream_t)stream_, d_in_feats,
+  hipLaunchKernelGGL(k_voxel_backward, grid1(n, planes <= 256 ? 256 / planes : 1), dim3(256), 0, (hipStream_t)stream_, d_in_feats,
                      d_out_feats, n, planes, point_site, first_pt, last_pt, cnt_extra, mode);
   AABR_CHECK_LAUNCH();
   return AABR_OK;

@@ -270,6 +270,13 @@ class _Grid(object):
         return [o[b + 1] - o[b] for b in range(nb)]
 
 
+# voxel-scatter form (csrc/voxel_scatter.hip): 2 LDS-binned (default), 1 one atomic per point, 0 generic; AABR_SCATTER
+# overrides (the A/B of tools/tools_scatter_kernels.py); below SCATTER_MIN_POINTS the generic form's fewer launches win
+import os as _os
+scatter_variant = int(_os.environ.get("AABR_SCATTER", "2"))
+SCATTER_MIN_POINTS = int(_os.environ.get("AABR_SCATTER_MIN_POINTS", "32768"))
+scatter_stats = {"variant0": 0, "variant1": 0, "variant2": 0, "redone": 0}
+
 MAX_SAMPLES = 61     # per-sample offsets that ride along with a grid's site-count read (64-word rows)
 
 
@@ -580,12 +587,24 @@ class Metadata_3(object):
         cap = _hip.next_pow2(2 * n)
         n1 = max(n, 1)
         nst = int(lib.aabr_input_layer_status_words(n))
+        # Which form of the insert (csrc/voxel_scatter.hip): 2 = LDS-binned, 1 = one atomic per point, 0 = generic (two
+        # atomics per point; any coordinates).  The first two need (batch, x, y, z, point index) in one 64-bit word --
+        # widths from the layer's spatial size and n -- and are only worth their extra launch from a few 10^4 points on;
+        # a point that does not fit is reported through meta[5] and the generic form runs instead (inputLayerFinish).
+        sp3 = _hip.i32x3(_key(spatial_size))
+        variant = scatter_variant
+        if variant and (n < SCATTER_MIN_POINTS or lib.aabr_input_layer_pack_bits(n, sp3) < 2):
+            variant = 0
+        if variant == 2 and not (4096 <= cap <= (1 << 24)):
+            variant = 1
         # int32 words, 16-byte aligned pieces; the grid's 16-byte entries {key, first, val} and meta sit back to back
         # so the library clears them with ONE fill:  grid(4*cap) meta(8) | slot(n) point_site(n) nxt(n)
         #                      site_coords(4*n1) first_pt(n1) cnt_extra(n1) head(n1) last_pt(n1) status(nst)
         names = [("keys", 4 * cap), ("meta", _hip.META_WORDS), ("slot", n),
                  ("point_site", n), ("nxt", n), ("site_coords", 4 * n1), ("first_pt", n1), ("cnt_extra", n1),
                  ("head", n1), ("last_pt", n1), ("status", nst)]
+        if variant:      # scratch of the packed forms: cap 8-byte words + one cursor per 4096-slot block
+            names += [("words", 2 * cap), ("cursor", max(cap // 4096, 1))]
         offs, tot = {}, 0
         for name, sz in names:
             offs[name] = tot
@@ -599,9 +618,15 @@ class Metadata_3(object):
         P = lambda name: base + 4 * offs[name]
         host = ev = None
         if n > 0:
-            check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, P("keys"), None, None, cap, P("slot"),
-                                             P("point_site"), P("site_coords"), P("first_pt"), P("cnt_extra"),
-                                             P("head"), P("nxt"), P("status"), P("meta"), stream()))
+            if variant:
+                check(lib.aabr_input_layer_sites_packed(ptr(coords), n, ncols, sp3, variant, P("keys"), cap, P("words"),
+                                                        P("cursor"), P("slot"), P("point_site"), P("site_coords"),
+                                                        P("first_pt"), P("cnt_extra"), P("head"), P("nxt"), P("status"),
+                                                        P("meta"), stream()))
+            else:
+                check(lib.aabr_input_layer_sites(ptr(coords), n, ncols, P("keys"), cap, P("slot"),
+                                                 P("point_site"), P("site_coords"), P("first_pt"), P("cnt_extra"),
+                                                 P("head"), P("nxt"), P("status"), P("meta"), stream()))
             if asynchronous:
                 # pinned read-back buffer + event from a small recycling pool (allocating pinned memory
                 # per scene costs more than the whole enqueue)
@@ -613,7 +638,11 @@ class Metadata_3(object):
             keys.fill_(-1)
             meta.zero_()
         self._pending = dict(host=host, event=ev, meta=meta, site_coords=site_coords, keys=keys, vals=vals,
-                             cap=cap, coords=coords, buf=buf)
+                             cap=cap, coords=coords, buf=buf, variant=variant,
+                             redo=(lambda: check(lib.aabr_input_layer_sites(
+                                 ptr(coords), n, ncols, P("keys"), cap, P("slot"), P("point_site"), P("site_coords"),
+                                 P("first_pt"), P("cnt_extra"), P("head"), P("nxt"), P("status"), P("meta"), stream()))))
+        scatter_stats["variant%d" % variant] += 1
         self.input = dict(point_site=piece["point_site"], first_pt=piece["first_pt"], cnt_extra=piece["cnt_extra"],
                           head=piece["head"], nxt=piece["nxt"], last_pt=piece["last_pt"], meta=meta, n=n, V=None,
                           mode=int(mode), spatial=_key(spatial_size), coords_src=coords_src)
@@ -629,6 +658,11 @@ class Metadata_3(object):
                     _pinned_pool.append((pend["host"], pend["event"]))
             else:
                 m = pend["meta"].tolist()  # synchronous read-back
+            if pend["variant"] and m[5] == 0:
+                # a point did not fit the packed word (or a hash block overflowed): the generic form on the same buffers
+                scatter_stats["redone"] += 1
+                pend["redo"]()
+                m = pend["meta"].tolist()
             self._pending = None
             if m[2]:
                 raise _hip.AabrError("InputLayer: coordinates must lie in [0, 65534] (batch index too)")
@@ -744,7 +778,7 @@ class Metadata_3(object):
             out_coords = torch.empty((max(E, 1), 4), dtype=torch.int32, device=dev)
             meta = torch.empty(_hip.META_WORDS, dtype=torch.int32, device=dev)
             check(lib.aabr_convolution_sites(ptr(gi.coords), gi.V, _hip.i32x3(fs), _hip.i32x3(st),
-                                             _hip.i32x3(osz), ptr(keys), ptr(vals), cap, ptr(scratch),
+                                             _hip.i32x3(osz), ptr(keys), cap, ptr(scratch),
                                              ptr(out_coords), ptr(meta), stream()))
             V_out = meta.tolist()[0]  # host sync: sizes the output feature tensor
             go = _Grid(out_coords[:V_out], keys, vals, cap, V_out)
@@ -753,8 +787,8 @@ class Metadata_3(object):
             t_in = torch.empty((vol, gi.V), dtype=torch.int32, device=dev)
             counts = torch.empty(vol * ((V_out + 255) // 256), dtype=torch.int32, device=dev)
             counts_in = torch.empty(vol * ((gi.V + 255) // 256), dtype=torch.int32, device=dev)
-            check(lib.aabr_convolution_tables2(ptr(gi.coords), gi.V, ptr(gi.keys), ptr(gi.vals), gi.cap,
-                                               ptr(go.coords), V_out, ptr(go.keys), ptr(go.vals), go.cap,
+            check(lib.aabr_convolution_tables2(ptr(gi.coords), gi.V, ptr(gi.keys), gi.cap,
+                                               ptr(go.coords), V_out, ptr(go.keys), go.cap,
                                                _hip.i32x3(fs), _hip.i32x3(st), _hip.i32x3(osz), ptr(t_out),
                                                ptr(t_in), ptr(counts), ptr(counts_in), stream()))
             tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, counts_in, vol, gi.V), vol, V_out, gi.V)

@@ -357,6 +357,28 @@ def hip_time(torch, fn, group, reps):
     return sum(ms) / len(ms) * 1e-3
 
 
+def device_time(torch, fn, group=4, reps=6, block_cycles=6000000):
+    """device-side duration of fn()'s launches with the HOST taken out: a busy-wait kernel holds the stream
+    (torch.cuda._sleep, ~2-3 ms) while `group` calls are enqueued behind it, HIP events bracket the calls -- they run
+    back to back once the wait ends, so the elapsed time has no enqueue gaps in it (hip_time with group 1 measures a
+    short chain of launches at the pace the interpreter issues them).  Returns seconds per call."""
+    fn()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(block_cycles)
+        a.record()
+        for _ in range(group):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        out.append(a.elapsed_time(b) / group)
+    out.sort()
+    out = out[: max(1, len(out) * 3 // 4)]
+    return sum(out) / len(out) * 1e-3
+
+
 def conv_kernel_table(torch, wl, dtype):
     """Every convolution launch of one training step (forward, input-gradient, weight-gradient), grouped by
     (kernel kind, planes, rule book); each distinct instance re-launched alone and timed with HIP events.

@@ -58,9 +58,10 @@ int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale
 
 /* ---- hash grid ---------------------------------------------------------------------------
  * A grid is an open-addressing table of cap 16-byte entries {uint64 key (packed b,x,y,z), uint32 first, int32 val
- * (row of the site)}, handed over through the `keys` parameters (16-byte aligned); the `vals` parameters are the
- * round-2 layout's second array and are ignored (pass NULL).  cap must be a power of two >= 2 * (number of
- * inserted keys).
+ * (row of the site)}, handed over through the `keys` parameters (16-byte aligned).  cap must be a power of two
+ * >= 2 * (number of inserted keys).  Probing is linear inside the key's home block of 4096 slots (csrc/common.h
+ * grid_next): a probe chain stays inside one 64 KiB window and the LDS-binned voxel scatter can build a block per
+ * workgroup.
  * Replaces SparseGrid / SparseGridMap (SCN/Metadata/Metadata.h:24-33).                       */
 
 /* Voxel scatter, geometry half -- replaces Metadata<3>::inputLayer -> inputLayerRules
@@ -70,10 +71,9 @@ int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale
  * the site's chain.
  *   coords       int64 [n, ncols] (ncols 3 or 4; 4th column = batch index)   (API layout)
  *   keys         the hash grid: cap entries of 16 bytes {uint64 key, uint32 first, int32 val}, 16-byte aligned,
- *                contents overwritten (round 3: interleaved so that the insert's CAS, its first-seen minimum and
- *                every later probe of a slot touch one 64-byte sector); first, vals: ignored, pass NULL (round-2
- *                layout of separate arrays, kept in the signature);
- *                laid out back to back and followed by `meta` they are cleared with a single fill
+ *                contents overwritten (interleaved so that the insert's CAS, its first-seen minimum and every
+ *                later probe of a slot touch one 64-byte sector); followed directly by `meta` the two are cleared
+ *                with a single fill
  *   slot         int32 [n]   scratch: hash slot of every point
  *   point_site   int32 [n]   out: output row of every input row (-1: dropped)
  *   site_coords  int32 [n,4] out: first V rows valid, first-seen order
@@ -83,10 +83,29 @@ int aabr_quantize_points(const void *xyz, int is_double, int64_t n, double scale
  *   status       int32 [aabr_input_layer_status_words(n)] scratch (8-byte aligned)
  *   meta         int32 [AABR_META_WORDS] out (device): V, (maxActive: written by aabr_input_layer_forward), error */
 int64_t aabr_input_layer_status_words(int64_t n);
-int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys, uint32_t *first,
-                           int32_t *vals, int64_t cap, int32_t *slot, int32_t *point_site,
-                           int32_t *site_coords, int32_t *first_pt, int32_t *cnt_extra, int32_t *head,
-                           int32_t *nxt, int32_t *status, int32_t *meta, void *stream);
+int aabr_input_layer_sites(const int64_t *coords, int64_t n, int ncols, uint64_t *keys, int64_t cap,
+                           int32_t *slot, int32_t *point_site, int32_t *site_coords, int32_t *first_pt,
+                           int32_t *cnt_extra, int32_t *head, int32_t *nxt, int32_t *status, int32_t *meta,
+                           void *stream);
+/* The same result (site list, first-seen numbering, chains, finished hash grid) by the two forms BASELINE.json's
+ * north_star asks about, for inputs whose (batch, x, y, z, point index) fit ONE 64-bit word -- field widths from the
+ * layer's spatial size (IOLayersRules.h:18-125 receives it as `spatialSize`) and n; aabr_input_layer_pack_bits returns
+ * the bits left for the batch index (0: does not fit, use aabr_input_layer_sites):
+ *   variant 1  one device atomic per point (CAS of the word into an 8-byte side table, atomicMin only for the
+ *              smaller of two points of one voxel) instead of two;
+ *   variant 2  LDS-staged hash binning with coalesced HBM writes and no device atomics on the table: the words are
+ *              partitioned by hash block (4096 slots), every block's table is built in LDS by one workgroup and its
+ *              4096 finished 16-byte entries are written with coalesced stores (no fill of the grid).
+ * words: cap 8-byte words of scratch (side table / record regions); cursor: cap/4096 int32 (variant 2; 4096 <= cap
+ * <= 2^24).  When a point does not fit the word (coordinate >= spatial size, batch index beyond the bits left) or a
+ * block overflows its record region, meta[5] comes back 0 (else -1) and the caller must run aabr_input_layer_sites
+ * on the same buffers instead; the other outputs are then unspecified.  n > 0.                                */
+int aabr_input_layer_pack_bits(int64_t n, const int32_t *spatial_host);
+int aabr_input_layer_sites_packed(const int64_t *coords, int64_t n, int ncols, const int32_t *spatial_host,
+                                  int variant, uint64_t *keys, int64_t cap, uint64_t *words, int32_t *cursor,
+                                  int32_t *slot, int32_t *point_site, int32_t *site_coords, int32_t *first_pt,
+                                  int32_t *cnt_extra, int32_t *head, int32_t *nxt, int32_t *status, int32_t *meta,
+                                  void *stream);
 
 /* Voxel scatter, feature half -- replaces InputLayer_ForwardPass / InputLayer_fp_
  * (SCN/CPU/IOLayers.cpp:11-29, SCN/CUDA/IOLayers.cu:14-41).  mode: 1 keep-first-listed,
@@ -112,7 +131,7 @@ int aabr_input_layer_rule_table(const int32_t *first_pt, const int32_t *last_pt,
  * counts (int32 [vol * ceil(V/256)], optional) receives per-offset, per-256-row-block rule
  * counts (sum over the second index = rules at that offset).                                 */
 int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t *keys,
-                           const int32_t *vals, int64_t cap, const int32_t *filter_size_host,
+                           int64_t cap, const int32_t *filter_size_host,
                            int32_t *table, int32_t *counts, void *stream);
 
 /* Per-sample row offsets of a batch-contiguous site list -- replaces SparseGrid::ctr (Metadata.h:24-33; read by
@@ -126,7 +145,7 @@ int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t
  * Convolution_InputSgToRulesAndOutputSg (Metadata.cpp:484-510, ConvolutionRules.h:11-34,
  * RectangularRegions.h:95-119).  Creates the output grid (sites numbered in first-seen order
  * over input rows ascending, then output-region order) and reports V_out in meta[0].
- *   out_keys: out_cap 16-byte grid entries as in aabr_input_layer_sites (out_vals ignored, pass NULL);
+ *   out_keys: out_cap 16-byte grid entries as in aabr_input_layer_sites;
  *   scratch int32 [E + 4*ceil(E/256) + 16], E = V_in * max_out_per_in,
  *   max_out_per_in = prod(ceil(size/stride)); out_site_coords int32 [E,4].
  * size, stride <= 64 per axis; for size == stride (one output site per input site) up to 65536, so that a chain of
@@ -134,25 +153,25 @@ int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t
  * strides): the site set and its first-seen order are those of the level-by-level construction.          */
 int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, const int32_t *size_host,
                            const int32_t *stride_host, const int32_t *out_spatial_host,
-                           uint64_t *out_keys, int32_t *out_vals, int64_t out_cap,
+                           uint64_t *out_keys, int64_t out_cap,
                            int32_t *scratch, int32_t *out_site_coords, int32_t *meta,
                            void *stream);
 /* counts (optional): int32 [vol * ceil(V_out/256)] per-block rule counts, as above.
  * table_out[k*V_out + o] = input row at offset k of output o's window (or -1);
  * table_in [k*V_in  + u] = output row whose window holds input u at offset k (or -1).       */
 int aabr_convolution_tables(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
-                            const int32_t *in_vals, int64_t in_cap,
+                            int64_t in_cap,
                             const int32_t *out_coords, int64_t V_out, const uint64_t *out_keys,
-                            const int32_t *out_vals, int64_t out_cap, const int32_t *size_host,
+                            int64_t out_cap, const int32_t *size_host,
                             const int32_t *stride_host, const int32_t *out_spatial_host,
                             int32_t *table_out, int32_t *table_in, int32_t *counts,
                             void *stream);
 /* the same with the per-block rule counts of table_in as well (counts_in int32 [vol * ceil(V_in/256)], may be
  * NULL): what the weight-gradient pass of a transposed convolution sizes its chunks with.               */
 int aabr_convolution_tables2(const int32_t *in_coords, int64_t V_in, const uint64_t *in_keys,
-                            const int32_t *in_vals, int64_t in_cap,
+                            int64_t in_cap,
                             const int32_t *out_coords, int64_t V_out, const uint64_t *out_keys,
-                            const int32_t *out_vals, int64_t out_cap, const int32_t *size_host,
+                            int64_t out_cap, const int32_t *size_host,
                             const int32_t *stride_host, const int32_t *out_spatial_host,
                             int32_t *table_out, int32_t *table_in, int32_t *counts,
                              int32_t *counts_in, void *stream);
@@ -454,17 +473,17 @@ typedef struct AabrPlanOp {
 int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *stream);
 /* Geometry plan (extension): the rule-book builders of a pass handed over as ONE list, each record = one of the
  * entry points above called with the record's fields -- nothing is computed differently:
- *   AABR_GEOM_SUBM_TABLE    aabr_submanifold_table(p0 coords, i64[0] V, p1 grid, NULL, i64[1] cap, i32[0..2] filter,
+ *   AABR_GEOM_SUBM_TABLE    aabr_submanifold_table(p0 coords, i64[0] V, p1 grid, i64[1] cap, i32[0..2] filter,
  *                           p2 table, p3 counts)
- *   AABR_GEOM_CONV_TABLES   aabr_convolution_tables2(p0 in_coords, i64[0] V_in, p1 in_grid, NULL, i64[1] in_cap,
- *                           p2 out_coords, i64[2] V_out, p3 out_grid, NULL, i64[3] out_cap, i32[0..2] size,
+ *   AABR_GEOM_CONV_TABLES   aabr_convolution_tables2(p0 in_coords, i64[0] V_in, p1 in_grid, i64[1] in_cap,
+ *                           p2 out_coords, i64[2] V_out, p3 out_grid, i64[3] out_cap, i32[0..2] size,
  *                           i32[3..5] stride, i32[6..8] out_spatial, p4 table_out, p5 table_in, p6 counts, p7 counts_in)
  *   AABR_GEOM_TILE_BLOCKS   aabr_build_tile_blocks(p0 table, i64[0] V, i32[0] vol, p1 blocks)
  *   AABR_GEOM_WIDE_BLOCKS   aabr_build_wide_blocks(p0 table, i64[0] V, i32[0] vol, i32[1] tile_rows, p1 blocks)
  *   AABR_GEOM_OFFSET_PAIRS  aabr_build_offset_pairs(p0 table, p1 block_counts, i64[0] V, i32[0] vol, p2 pairs)
  *   AABR_GEOM_RS            aabr_build_rs(p0 table, i64[0] V, i32[0] vol, i32[1] unit_rows, p1 words)
  *   AABR_GEOM_CONV_SITES    aabr_convolution_sites(p0 in_coords, i64[0] V_in, i32[0..2] size, i32[3..5] stride,
- *                           i32[6..8] out_spatial, p1 out_grid, NULL, i64[1] out_cap, p2 scratch, p3 out_coords, p4 meta)
+ *                           i32[6..8] out_spatial, p1 out_grid, i64[1] out_cap, p2 scratch, p3 out_coords, p4 meta)
  *   AABR_GEOM_SAMPLE_OFFSETS aabr_sample_offsets(p0 coords, p1 meta, i64[0] V_max, i32[0] max_samples, p2 out)
  * Stops at the first failing record and returns its code.                                                      */
 #define AABR_GEOM_SUBM_TABLE 1

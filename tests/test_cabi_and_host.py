@@ -34,7 +34,7 @@ def test_argument_validation_without_gpu():
     """entry points validate before touching the device (no compute happens here)"""
     import _hip
     lib = _hip.load()
-    assert lib.aabr_input_layer_sites(None, -1, 3, None, None, None, 64, None, None, None, None, None, None, None, None,
+    assert lib.aabr_input_layer_sites(None, -1, 3, None, 64, None, None, None, None, None, None, None, None,
                                       None, None) == -1
     assert b"ncols" in lib.aabr_last_error()
     assert lib.aabr_conv_forward(None, 0, 10, None, 4, 10, None, 27, None, None, 0, None, None) == -1

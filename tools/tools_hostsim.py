@@ -20,7 +20,7 @@ class Fake(object):
             return fn
         if name == "aabr_input_layer_sites":
             def sites(*a):
-                meta = a[11]
+                meta = a[13]
                 arr = (ctypes.c_int32 * 8).from_address(meta if isinstance(meta, int) else meta.value)
                 arr[0] = V_FAKE; arr[1] = 6; arr[2] = 0
                 return 0

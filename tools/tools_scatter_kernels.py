@@ -1,5 +1,7 @@
-"""Dev tool: the voxel scatter's kernels one by one (HIP events around each library call) at several sizes.
-usage: tools_scatter_kernels.py"""
+"""Dev tool: A/B of the voxel scatter's three insert forms (AABR_SCATTER 0 generic / 1 one atomic per point / 2
+LDS-binned) at the bench batch (4 x 80k points) and at 1.5 M points, device time with the host taken out
+(bench.device_time: the launches queue up behind a busy-wait kernel and run back to back).
+usage: tools_scatter_kernels.py   (run it under `rocprofv3 --kernel-trace --stats` for the per-kernel split)"""
 import importlib, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -10,27 +12,42 @@ from _hip import ptr, stream, check
 from sparseconvnet import SCN
 lib = _hip.load()
 dev = torch.device("cuda", 0)
-for npts, nsc, ext in ((80000, 4, (16.0, 12.0, 2.7)), (1500000, 1, (40.0, 30.0, 2.7))):
+SP = torch.LongTensor([4096, 4096, 512])
+print("# N points, V sites; algorithmic bytes = N*68 + V*52 (SURVEY 8d); times in us, device side only")
+for npts, nsc, ext, tag in ((80000, 4, (16.0, 12.0, 2.7), "bench batch 4 x S80k"),
+                            (1500000, 1, (16.0, 12.0, 2.7), "1.5 M points, 16 x 12 m (BASELINE configs[4])"),
+                            (1500000, 1, (40.0, 30.0, 2.7), "1.5 M points, 40 x 30 m")):
     L, F = [], []
     for j in range(nsc):
         l, f = S.make_scene(npts, 9000 + j, 50, ext)
         L.append(np.concatenate([l, np.full((l.shape[0], 1), j, np.int64)], 1)); F.append(f)
     locs = torch.as_tensor(np.concatenate(L, 0)).to(dev); feats = torch.as_tensor(np.concatenate(F, 0)).to(dev)
-    keep = []
-    def sites():
-        md = SCN.Metadata_3()
-        md.inputLayerEnqueue(torch.LongTensor([4096, 4096, 512]), locs, 4, dev, asynchronous=False)
-        keep.append(md); del keep[:-4]
-    t_sites = bench.hip_time(torch, sites, 1, 10)
-    md = SCN.Metadata_3()
-    V = md.inputLayer(torch.LongTensor([4096, 4096, 512]), locs, 4, 4, dev)
-    il = md.input
-    out = torch.empty((V, feats.shape[1]), device=dev)
-    def mean():
-        check(lib.aabr_input_layer_forward(ptr(feats), ptr(out), V, feats.shape[1], ptr(il["first_pt"]), ptr(il["cnt_extra"]),
-                                           ptr(il["head"]), ptr(il["nxt"]), ptr(il["last_pt"]), 4, ptr(il["meta"]), stream()))
-    t_mean = bench.hip_time(torch, mean, 1, 10)
     N = locs.shape[0]
-    by = N * 68 + V * 52
-    print("N=%d V=%d: fill+insert+number %.1f us, mean %.1f us, total %.1f us = %.1f GB/s (%.2f %% of 8 TB/s)" % (
-        N, V, t_sites * 1e6, t_mean * 1e6, (t_sites + t_mean) * 1e6, by / (t_sites + t_mean) / 1e9, by / (t_sites + t_mean) / 8e10))
+    for variant in (0, 1, 2):
+        SCN.scatter_variant = variant
+        keep = []
+        def sites():
+            md = SCN.Metadata_3()
+            md.inputLayerEnqueue(SP, locs, 4, dev, asynchronous=False)
+            keep.append(md); del keep[:-6]
+        t_sites = bench.device_time(torch, sites)
+        md = SCN.Metadata_3()
+        V = md.inputLayer(SP, locs, 4, 4, dev)
+        il = md.input
+        out = torch.empty((V, feats.shape[1]), device=dev)
+        def mean():
+            check(lib.aabr_input_layer_forward(ptr(feats), ptr(out), V, feats.shape[1], ptr(il["first_pt"]),
+                                               ptr(il["cnt_extra"]), ptr(il["head"]), ptr(il["nxt"]), ptr(il["last_pt"]), 4,
+                                               ptr(il["meta"]), stream()))
+        t_mean = bench.device_time(torch, mean)
+        g = torch.randn((V, feats.shape[1]), device=dev)
+        d_in = torch.empty_like(feats)
+        def bwd():
+            check(lib.aabr_input_layer_backward(ptr(d_in), ptr(g), N, feats.shape[1], ptr(il["point_site"]),
+                                                ptr(il["first_pt"]), ptr(il["last_pt"]), ptr(il["cnt_extra"]), 4, stream()))
+        t_bwd = bench.device_time(torch, bwd)
+        by = N * 68 + V * 52
+        tot = t_sites + t_mean
+        print("%-48s variant %d: N=%d V=%d  sites %.1f  mean %.1f  total %.1f us = %.0f GB/s (%.2f %% of 8 TB/s)   "
+              "backward %.1f us (%.0f GB/s)" % (tag, variant, N, V, t_sites * 1e6, t_mean * 1e6, tot * 1e6, by / tot / 1e9,
+                                                by / tot / 8e10, t_bwd * 1e6, (N + V) * 4 * feats.shape[1] / t_bwd / 1e9))
