@@ -84,6 +84,7 @@ __device__ inline unsigned long long st_pack(unsigned flag, unsigned v) {
 // MODE 0: generic (slot[i] + grid[slot].first); 1: packed side table (slot[i] + low bits of words[slot]; the first
 // point writes the whole grid entry); 2: binned (slot[i] = slot | first << 31, written by k_voxel_bin_build)
 constexpr int32_t kInfoNone = 0x7fffffff;
+constexpr int32_t kInfoMulti = 0x40000000;      // info bit 30: the point's voxel holds more than one point
 template <int kVsItems, int MODE>
 __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
     const int64_t *__restrict__ coords, int64_t n, int ncols, const int32_t *__restrict__ slot,
@@ -106,8 +107,8 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
     const int64_t i = base + j;
     if (MODE == 2) {
       const int32_t v = i < n ? slot[i] : kInfoNone;
-      s[j] = (v & kInfoNone) == kInfoNone ? -1 : (v & kInfoNone);
-      f[j] = (s[j] >= 0 && v < 0) ? 1 : 0;
+      s[j] = (v & kInfoNone) == kInfoNone ? -1 : (v & (kInfoMulti - 1));
+      f[j] = (s[j] >= 0 && v < 0) ? ((v & kInfoMulti) ? 2 : 1) : 0;
     } else {
       s[j] = i < n ? slot[i] : -1;
       if (MODE == 1)
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
       else
         f[j] = (s[j] >= 0 && grid[s[j]].first == (uint32_t)i) ? 1 : 0;
     }
-    a += f[j];
+    a += f[j] ? 1 : 0;
   }
   // chunk-exclusive scan of `a`: wave scan + 4 wave totals through LDS
   int incl = a;
@@ -184,6 +185,11 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
       *reinterpret_cast<int4 *>(site_coords + 4 * (int64_t)v) =
           make_int4((int)cp[0], (int)cp[1], (int)cp[2], ncols == 4 ? (int)cp[3] : 0);
       first_pt[v] = (int32_t)i;
+      if (MODE == 2 && f[j] == 2) {   // the voxel's chain was linked by k_voxel_bin_build: head and count by slot
+        const unsigned long long e = words[s[j]];
+        head[v] = (int32_t)(uint32_t)e;
+        cnt_extra[v] = (int32_t)(e >> 32);
+      }
       if (MODE == 1) {   // the grid entry is created here: key and first index first, the polled word last
         GridEnt *e = grid + s[j];
         e->key = pack_key(ncols == 4 ? (int)cp[3] : 0, (int)cp[0], (int)cp[1], (int)cp[2]);
@@ -203,8 +209,10 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
         v = __hip_atomic_load(&grid[s[j]].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v < 0) __builtin_amdgcn_s_sleep(1);
       } while (v < 0);
-      nxt[i] = atomicExch(&head[v], (int32_t)i);
-      atomicAdd(&cnt_extra[v], 1);
+      if (MODE != 2) {
+        nxt[i] = atomicExch(&head[v], (int32_t)i);
+        atomicAdd(&cnt_extra[v], 1);
+      }
     }
     point_site[i] = v;
   }
@@ -330,66 +338,86 @@ __global__ __launch_bounds__(256) void k_voxel_bin(const int64_t *__restrict__ c
   }
 }
 
-// variant 2, P2: one workgroup per hash block builds the block's table in LDS and writes the finished grid entries.
-constexpr int kBinRec = 16;                     // records per thread and sweep (256 x 16 = one region)
-__global__ __launch_bounds__(256) void k_voxel_bin_build(const unsigned long long *__restrict__ rec,
+// variant 2, P2: one workgroup per hash block builds the block's table in LDS, links the further points of every
+// voxel into the voxel's chain (LDS exchange: the block sees ALL points of its voxels, so the chain heads and counts
+// need no device atomics either; they go out per SLOT, over the block's own record region, and K2's first points
+// carry them to their site rows) and writes the finished grid entries.
+constexpr int kBinRec = 16;                     // records per thread (256 x 16 = one region = kGridBlock)
+__global__ __launch_bounds__(256) void k_voxel_bin_build(unsigned long long *__restrict__ rec,
                                                          const int32_t *__restrict__ cursor, int capbin, PackSpec sp,
                                                          GridEnt *__restrict__ grid, int32_t *__restrict__ info,
-                                                         int32_t *meta) {
+                                                         int32_t *__restrict__ nxt, int32_t *meta) {
   __shared__ unsigned long long tab[kGridBlock];
+  __shared__ int32_t lhead[kGridBlock];
+  __shared__ int32_t lcnt[kGridBlock];
   const int bin = blockIdx.x;
   int cnt = cursor[bin];
   cnt = cnt < capbin ? cnt : capbin;
-  for (int q = threadIdx.x; q < (int)kGridBlock; q += 256) tab[q] = ~0ull;
+  for (int q = threadIdx.x; q < (int)kGridBlock; q += 256) { tab[q] = ~0ull; lhead[q] = -1; lcnt[q] = 0; }
   __syncthreads();
-  const unsigned long long *r = rec + (int64_t)bin * capbin;
+  unsigned long long *r = rec + (int64_t)bin * capbin;
   const unsigned long long imask = (1ull << sp.ib) - 1;
-  for (int k0 = 0; k0 < cnt; k0 += 256 * kBinRec) {            // one sweep unless the region is larger than 4096
-    unsigned long long w[kBinRec];
-    int sl[kBinRec];
+  unsigned long long w[kBinRec];
+  int sl[kBinRec];
 #pragma unroll
-    for (int q = 0; q < kBinRec; ++q) {
-      const int k = k0 + q * 256 + threadIdx.x;
-      sl[q] = -1;
-      if (k >= cnt) continue;
-      w[q] = r[k];
-      uint32_t h = (uint32_t)(mix64(pk_canonical(sp, w[q])) & (kGridBlock - 1));
-      for (uint32_t t = 0; t < kGridBlock; ++t) {
-        const unsigned long long prev = atomicCAS(&tab[h], ~0ull, w[q]);
-        if (prev == ~0ull) { sl[q] = (int)h; break; }
-        if ((prev >> sp.ib) == (w[q] >> sp.ib)) {
-          if (w[q] < prev) atomicMin(&tab[h], w[q]);
-          sl[q] = (int)h;
-          break;
-        }
-        h = (h + 1) & (kGridBlock - 1);
+  for (int q = 0; q < kBinRec; ++q) {
+    const int k = q * 256 + threadIdx.x;
+    sl[q] = -1;
+    w[q] = k < cnt ? r[k] : ~0ull;
+  }
+#pragma unroll
+  for (int q = 0; q < kBinRec; ++q) {
+    if (w[q] == ~0ull) continue;
+    uint32_t h = (uint32_t)(mix64(pk_canonical(sp, w[q])) & (kGridBlock - 1));
+    for (uint32_t t = 0; t < kGridBlock; ++t) {
+      const unsigned long long prev = atomicCAS(&tab[h], ~0ull, w[q]);
+      if (prev == ~0ull) { sl[q] = (int)h; break; }
+      if ((prev >> sp.ib) == (w[q] >> sp.ib)) {
+        if (w[q] < prev) atomicMin(&tab[h], w[q]);
+        sl[q] = (int)h;
+        break;
       }
-      if (sl[q] < 0) {                                         // the block is full: the generic form copes
-        atomicAnd(&meta[kMetaRedo], 0);
-        info[(int64_t)(w[q] & imask)] = kInfoNone;
-      }
+      h = (h + 1) & (kGridBlock - 1);
     }
-    __syncthreads();                                           // every word of the sweep is in: minima are final for
-#pragma unroll                                                 // the records seen so far only if cnt <= one sweep
-    for (int q = 0; q < kBinRec; ++q) {
-      if (sl[q] < 0) continue;
-      const unsigned long long idx = w[q] & imask;
-      const int first = (tab[sl[q]] & imask) == idx ? 1 : 0;
-      info[(int64_t)idx] = (int32_t)(((uint32_t)bin * kGridBlock + (uint32_t)sl[q]) | ((uint32_t)first << 31));
+    if (sl[q] < 0) {                                           // the block is full: the generic form copes
+      atomicAnd(&meta[kMetaRedo], 0);
+      info[(int64_t)(w[q] & imask)] = kInfoNone;
     }
-    __syncthreads();
+  }
+  __syncthreads();                                             // every word is in: the minima are final
+  int first[kBinRec];
+#pragma unroll
+  for (int q = 0; q < kBinRec; ++q) {
+    first[q] = 0;
+    if (sl[q] < 0) continue;
+    const unsigned long long idx = w[q] & imask;
+    first[q] = (tab[sl[q]] & imask) == idx ? 1 : 0;
+    if (!first[q]) {                                           // a further point of its voxel: push it on the chain
+      nxt[(int64_t)idx] = atomicExch(&lhead[sl[q]], (int32_t)idx);
+      atomicAdd(&lcnt[sl[q]], 1);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kBinRec; ++q) {
+    if (sl[q] < 0) continue;
+    const uint32_t multi = lcnt[sl[q]] > 0 ? (uint32_t)kInfoMulti : 0u;
+    info[(int64_t)(w[q] & imask)] =
+        (int32_t)(((uint32_t)bin * kGridBlock + (uint32_t)sl[q]) | multi | ((uint32_t)first[q] << 31));
   }
   GridEnt *g = grid + (int64_t)bin * kGridBlock;
   for (int q = threadIdx.x; q < (int)kGridBlock; q += 256) {
-    const unsigned long long w = tab[q];
+    const unsigned long long ww = tab[q];
     uint4 e;
-    if (w == ~0ull) {
+    if (ww == ~0ull) {
       e = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     } else {
-      const uint64_t key = pk_canonical(sp, w);
-      e = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(w & imask), 0xffffffffu);
+      const uint64_t key = pk_canonical(sp, ww);
+      e = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(ww & imask), 0xffffffffu);
     }
     *reinterpret_cast<uint4 *>(g + q) = e;
+    // per slot {chain head, further points}: over the block's own record region (every record was read above)
+    r[q] = ((unsigned long long)(uint32_t)lcnt[q] << 32) | (unsigned long long)(uint32_t)lhead[q];
   }
 }
 
@@ -442,51 +470,75 @@ __device__ inline void for_points_ascending(int first, int extra, int hd, const 
 // out[v] = sum_j mult * in[pts[j]] in ascending point order, separate multiply and add (no FMA contraction) so
 // the fp32 result is bit-identical to InputLayer_ForwardPass (CPU/IOLayers.cpp:18-27:
 // `out_f[plane] += multiplier * in_f[plane]`).  Also records the site's last point and the largest point count.
+constexpr int kMeanU = 8;   // sites per thread: the two-hop chain first_pt[v] -> in[first] carries 4 bytes per lane, so
+                            // a wave needs several of them in flight to keep the memory system busy (round 3's one
+                            // site per thread streamed at ~1 TB/s: latency-bound, and its 64-bit idx / planes was most
+                            // of its instructions)
 __global__ __launch_bounds__(256) void k_voxel_mean(const float *__restrict__ in, float *__restrict__ out, int64_t V,
                                                     int planes, const int32_t *__restrict__ first_pt,
                                                     const int32_t *__restrict__ cnt_extra,
                                                     const int32_t *__restrict__ head,
                                                     const int32_t *__restrict__ nxt, int32_t *__restrict__ last_pt,
                                                     int mode, int32_t *meta) {
-  // a workgroup covers spb = 256 / planes consecutive sites, one thread per (site, plane) (rows wider than 256: one
-  // site, threads stride over the planes): the only division is a 32-bit one of the thread index (the 64-bit
-  // `idx / planes` of round 3 was most of this kernel's time)
+  // a workgroup covers kMeanU groups of spb = 256 / planes consecutive sites, one thread per (site, plane) and group
+  // (rows wider than 256: one site per group, threads stride over the planes); the only division is a 32-bit one of
+  // the thread index
   const bool narrow = planes <= 256;
   const unsigned spb = narrow ? 256u / (unsigned)planes : 1u;
   const unsigned sl = narrow ? threadIdx.x / (unsigned)planes : 0u;
   const int p0 = (int)(threadIdx.x - sl * (unsigned)planes);
   const int pstep = narrow ? planes : 256;
-  const int64_t v = (int64_t)blockIdx.x * spb + sl;
-  const bool on = sl < spb && v < V;
-  int extra = 0;
-  if (on) for (int p = p0; p < planes; p += pstep) {
-    const int64_t idx = v * planes + p;
-    const int first = first_pt[v];
-    extra = cnt_extra[v];
-    float acc = 0.0f;
-    if (extra == 0) {
-      acc = __fadd_rn(0.0f, __fmul_rn(1.0f, in[(int64_t)first * planes + p]));
-      if (p == 0 && last_pt) last_pt[v] = first;
-    } else {
-      const int hd = head[v];
-      const float mult = mode == 4 ? __fdiv_rn(1.0f, (float)(extra + 1)) : 1.0f;
-      int last = first;
-      if (mode == 1) {
-        acc = __fadd_rn(0.0f, in[(int64_t)first * planes + p]);
-        for (int q = hd; q >= 0; q = nxt[q]) last = q > last ? q : last;
+  int mx = 0;
+  for (int p = p0; p < planes; p += pstep) {
+    int first[kMeanU], extra[kMeanU], hd0[kMeanU];
+    float x[kMeanU], y[kMeanU];
+#pragma unroll
+    for (int j = 0; j < kMeanU; ++j) {
+      const int64_t v = ((int64_t)blockIdx.x * kMeanU + j) * spb + sl;
+      const bool on = sl < spb && v < V;
+      first[j] = on ? first_pt[v] : -1;
+      extra[j] = on ? cnt_extra[v] : 0;
+      hd0[j] = on ? head[v] : -1;          // -1 unless the site has further points
+    }
+#pragma unroll
+    for (int j = 0; j < kMeanU; ++j) {      // the first point's row and (two-point sites: the bulk of the rest) the second
+      x[j] = first[j] >= 0 ? in[(int64_t)first[j] * planes + p] : 0.0f;
+      y[j] = (extra[j] > 0 && hd0[j] >= 0) ? in[(int64_t)hd0[j] * planes + p] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < kMeanU; ++j) {
+      if (first[j] < 0) continue;
+      const int64_t v = ((int64_t)blockIdx.x * kMeanU + j) * spb + sl;
+      float acc;
+      int last = first[j];
+      if (extra[j] == 0) {
+        acc = __fadd_rn(0.0f, __fmul_rn(1.0f, x[j]));
+      } else if (extra[j] == 1 && mode >= 3) {   // first < head always: the voxel's smallest index numbers it
+        const float mult = mode == 4 ? 0.5f : 1.0f;
+        acc = __fadd_rn(__fadd_rn(0.0f, __fmul_rn(mult, x[j])), __fmul_rn(mult, y[j]));
+        last = hd0[j];
       } else {
-        for_points_ascending(first, extra, hd, nxt, [&](int pt) {
-          last = pt;
-          if (mode != 2) acc = __fadd_rn(acc, __fmul_rn(mult, in[(int64_t)pt * planes + p]));
-        });
-        if (mode == 2) acc = __fadd_rn(0.0f, in[(int64_t)last * planes + p]);
+        const int hd = hd0[j];
+        const float mult = mode == 4 ? __fdiv_rn(1.0f, (float)(extra[j] + 1)) : 1.0f;
+        acc = 0.0f;
+        if (mode == 1) {
+          acc = __fadd_rn(0.0f, x[j]);
+          for (int q = hd; q >= 0; q = nxt[q]) last = q > last ? q : last;
+        } else {
+          for_points_ascending(first[j], extra[j], hd, nxt, [&](int pt) {
+            last = pt;
+            if (mode != 2) acc = __fadd_rn(acc, __fmul_rn(mult, pt == first[j] ? x[j] : in[(int64_t)pt * planes + p]));
+          });
+          if (mode == 2) acc = __fadd_rn(0.0f, in[(int64_t)last * planes + p]);
+        }
       }
       if (p == 0 && last_pt) last_pt[v] = last;
+      out[v * planes + p] = acc;
+      mx = extra[j] + 1 > mx ? extra[j] + 1 : mx;
     }
-    out[idx] = acc;
   }
   // largest point count of a site (IOLayersRules.h:96-103 maxActive): one atomic per block, only when it grows
-  int m = extra + (on ? 1 : 0);
+  int m = mx;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     const int o = __shfl_xor(m, d);
@@ -563,28 +615,45 @@ __global__ __launch_bounds__(256) void k_voxel_mean_row(const float *__restrict_
 }
 
 // d_in[i] = mult * d_out[site(i)] for the points that contributed (InputLayer_BackwardPass, CPU/IOLayers.cpp:30-47)
+constexpr int kBwdU = 4;    // points per thread (see kMeanU)
 __global__ __launch_bounds__(256) void k_voxel_backward(float *__restrict__ d_in, const float *__restrict__ d_out,
                                                         int64_t n, int planes, const int32_t *__restrict__ point_site,
                                                         const int32_t *__restrict__ first_pt,
                                                         const int32_t *__restrict__ last_pt,
                                                         const int32_t *__restrict__ cnt_extra, int mode) {
-  const bool narrow = planes <= 256;                        // points per workgroup etc.: see k_voxel_mean
+  const bool narrow = planes <= 256;                        // points per workgroup and group etc.: see k_voxel_mean
   const unsigned spb = narrow ? 256u / (unsigned)planes : 1u;
   const unsigned sl = narrow ? threadIdx.x / (unsigned)planes : 0u;
   const int p0 = (int)(threadIdx.x - sl * (unsigned)planes);
   const int pstep = narrow ? planes : 256;
-  const int64_t i = (int64_t)blockIdx.x * spb + sl;
-  if (sl >= spb || i >= n) return;
-  const int v = point_site[i];
-  bool take = v >= 0;
-  float mult = 1.0f;
-  if (take) {
-    if (mode == 1) take = (first_pt[v] == (int32_t)i);
-    if (mode == 2) take = (last_pt[v] == (int32_t)i);
-    if (take && mode == 4) mult = __fdiv_rn(1.0f, (float)(cnt_extra[v] + 1));
+  if (sl >= spb) return;
+  int v[kBwdU];
+  float mult[kBwdU];
+#pragma unroll
+  for (int j = 0; j < kBwdU; ++j) {
+    const int64_t i = ((int64_t)blockIdx.x * kBwdU + j) * spb + sl;
+    v[j] = i < n ? point_site[i] : -2;
   }
-  for (int p = p0; p < planes; p += pstep)
-    d_in[i * planes + p] = take ? __fadd_rn(0.0f, __fmul_rn(mult, d_out[(int64_t)v * planes + p])) : 0.0f;
+#pragma unroll
+  for (int j = 0; j < kBwdU; ++j) {
+    const int64_t i = ((int64_t)blockIdx.x * kBwdU + j) * spb + sl;
+    mult[j] = 1.0f;
+    if (v[j] >= 0) {
+      if (mode == 1 && first_pt[v[j]] != (int32_t)i) v[j] = -1;
+      if (mode == 2 && last_pt[v[j]] != (int32_t)i) v[j] = -1;
+      if (mode == 4 && v[j] >= 0) mult[j] = __fdiv_rn(1.0f, (float)(cnt_extra[v[j]] + 1));
+    }
+  }
+  for (int p = p0; p < planes; p += pstep) {
+    float g[kBwdU];
+#pragma unroll
+    for (int j = 0; j < kBwdU; ++j) g[j] = v[j] >= 0 ? d_out[(int64_t)v[j] * planes + p] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < kBwdU; ++j) {
+      const int64_t i = ((int64_t)blockIdx.x * kBwdU + j) * spb + sl;
+      if (v[j] != -2) d_in[i * planes + p] = v[j] >= 0 ? __fadd_rn(0.0f, __fmul_rn(mult[j], g[j])) : 0.0f;
+    }
+  }
 }
 
 // reference-format rule table rules[1] (IOLayersRules.h:112-124): [V, 1+maxActive] = (count, ascending points..)
@@ -723,11 +792,11 @@ extern "C" int aabr_input_layer_sites_packed(const int64_t *coords, int64_t n, i
     else if (per <= 4096) AABR_BIN(16);
     else AABR_BIN(32);
 #undef AABR_BIN
-    hipLaunchKernelGGL(k_voxel_bin_build, dim3((unsigned)nbins), dim3(256), 0, st, (const unsigned long long *)words,
-                       (const int32_t *)cursor, (int)kGridBlock, sp, grid, slot, meta);
+    hipLaunchKernelGGL(k_voxel_bin_build, dim3((unsigned)nbins), dim3(256), 0, st, (unsigned long long *)words,
+                       (const int32_t *)cursor, (int)kGridBlock, sp, grid, slot, nxt, meta);
     hipLaunchKernelGGL((k_voxel_number<4, 2>), dim3((unsigned)nchunks), dim3(kVsThreads), 0, st, coords, n, ncols, slot,
                        grid, site_coords, first_pt, point_site, cnt_extra, head, nxt, (unsigned long long *)status,
-                       meta, (const unsigned long long *)nullptr, imask);
+                       meta, (const unsigned long long *)words, imask);
   }
   AABR_CHECK_LAUNCH();
   return AABR_OK;
@@ -746,7 +815,7 @@ extern "C" int aabr_input_layer_forward(const float *in_feats, float *out_feats,
     hipLaunchKernelGGL(k_voxel_mean_row<16>, grid1(V, 256), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats, V,
                        planes, first_pt, cnt_extra, head, nxt, last_pt, mode, meta);
   else
-    hipLaunchKernelGGL(k_voxel_mean, grid1(V, planes <= 256 ? 256 / planes : 1), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats,
+    hipLaunchKernelGGL(k_voxel_mean, grid1(V, (planes <= 256 ? 256 / planes : 1) * kMeanU), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats,
                        V, planes, first_pt, cnt_extra, head, nxt, last_pt, mode, meta);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
@@ -759,7 +828,7 @@ extern "C" int aabr_input_layer_backward(float *d_in_feats, const float *d_out_f
   if (n == 0) return AABR_OK;
   AABR_CHECK_ARG(d_in_feats && d_out_feats && point_site && first_pt && cnt_extra, "null pointer");
   AABR_CHECK_ARG(mode != 2 || last_pt, "mode 2 needs last_pt");
-  hipLaunchKernelGGL(k_voxel_backward, grid1(n, planes <= 256 ? 256 / planes : 1), dim3(256), 0, (hipStream_t)stream_, d_in_feats,
+  hipLaunchKernelGGL(k_voxel_backward, grid1(n, (planes <= 256 ? 256 / planes : 1) * kBwdU), dim3(256), 0, (hipStream_t)stream_, d_in_feats,
                      d_out_feats, n, planes, point_site, first_pt, last_pt, cnt_extra, mode);
   AABR_CHECK_LAUNCH();
   return AABR_OK;

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd database (the default output of `rocprofv3 --kernel-trace --stats` on ROCm 7.2)
 as a per-kernel CSV (name, calls, total / average / min / max duration in ns, share) -- the same columns as
-rocprofv3's kernel_stats.csv.  usage: rocpd_stats.py results.db [out.csv] [--after-frac F]"""
+rocprofv3's kernel_stats.csv.  usage: rocpd_stats.py results.db [out.csv] [--after-frac F] [--by-grid]
+--by-grid: one row per (kernel, grid size in threads) -- `name|grid=N`, the key bench.py's roofline object and the PMC
+summaries use -- so that the average duration of ONE instance (e.g. the dominant convolution launch) can be read from the
+committed profile instead of from the kernel's average over all its grids."""
 import csv
 import re
 import sqlite3
@@ -9,9 +12,13 @@ import sys
 
 
 def short(name):
+    tail = ""
+    if "|grid=" in name:
+        name, tail = name.rsplit("|", 1)
+        tail = "|" + tail
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*\)$", "", name)
-    return name[:150]
+    return name[:150] + tail
 
 
 def main():
@@ -19,7 +26,21 @@ def main():
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else "kernel_name"
-    rows = list(cur.execute("select %s, start, end from kernels order by start" % namecol))
+    by_grid = "--by-grid" in sys.argv
+    gcols = [c for c in ("grid_size_x", "grid_size_y", "grid_size_z") if c in cols] or \
+            [c for c in ("grid_x", "grid_y", "grid_z") if c in cols]
+    if by_grid and not gcols:
+        sys.stderr.write("no grid-size columns in the kernels view (columns: %s)\n" % ", ".join(cols))
+        by_grid = False
+    if by_grid:
+        rows = []
+        for r in cur.execute("select %s, start, end, %s from kernels order by start" % (namecol, ", ".join(gcols))):
+            g = 1
+            for v in r[3:]:
+                g *= max(int(v or 1), 1)
+            rows.append((r[0] + "|grid=%d" % g, r[1], r[2]))
+    else:
+        rows = list(cur.execute("select %s, start, end from kernels order by start" % namecol))
     frac = 0.0
     if "--after-frac" in sys.argv:
         frac = float(sys.argv[sys.argv.index("--after-frac") + 1])
