@@ -470,75 +470,45 @@ __device__ inline void for_points_ascending(int first, int extra, int hd, const 
 // out[v] = sum_j mult * in[pts[j]] in ascending point order, separate multiply and add (no FMA contraction) so
 // the fp32 result is bit-identical to InputLayer_ForwardPass (CPU/IOLayers.cpp:18-27:
 // `out_f[plane] += multiplier * in_f[plane]`).  Also records the site's last point and the largest point count.
-constexpr int kMeanU = 8;   // sites per thread: the two-hop chain first_pt[v] -> in[first] carries 4 bytes per lane, so
-                            // a wave needs several of them in flight to keep the memory system busy (round 3's one
-                            // site per thread streamed at ~1 TB/s: latency-bound, and its 64-bit idx / planes was most
-                            // of its instructions)
+// (round 4: a 32-bit-index form and an 8-sites-per-thread form of this kernel were measured SLOWER -- 92 and 124 us
+// against 73 us at 1.5 M points -- profiles/r04_scatter_ab.txt; this is the round-3 kernel)
 __global__ __launch_bounds__(256) void k_voxel_mean(const float *__restrict__ in, float *__restrict__ out, int64_t V,
                                                     int planes, const int32_t *__restrict__ first_pt,
                                                     const int32_t *__restrict__ cnt_extra,
                                                     const int32_t *__restrict__ head,
                                                     const int32_t *__restrict__ nxt, int32_t *__restrict__ last_pt,
                                                     int mode, int32_t *meta) {
-  // a workgroup covers kMeanU groups of spb = 256 / planes consecutive sites, one thread per (site, plane) and group
-  // (rows wider than 256: one site per group, threads stride over the planes); the only division is a 32-bit one of
-  // the thread index
-  const bool narrow = planes <= 256;
-  const unsigned spb = narrow ? 256u / (unsigned)planes : 1u;
-  const unsigned sl = narrow ? threadIdx.x / (unsigned)planes : 0u;
-  const int p0 = (int)(threadIdx.x - sl * (unsigned)planes);
-  const int pstep = narrow ? planes : 256;
-  int mx = 0;
-  for (int p = p0; p < planes; p += pstep) {
-    int first[kMeanU], extra[kMeanU], hd0[kMeanU];
-    float x[kMeanU], y[kMeanU];
-#pragma unroll
-    for (int j = 0; j < kMeanU; ++j) {
-      const int64_t v = ((int64_t)blockIdx.x * kMeanU + j) * spb + sl;
-      const bool on = sl < spb && v < V;
-      first[j] = on ? first_pt[v] : -1;
-      extra[j] = on ? cnt_extra[v] : 0;
-      hd0[j] = on ? head[v] : -1;          // -1 unless the site has further points
-    }
-#pragma unroll
-    for (int j = 0; j < kMeanU; ++j) {      // the first point's row and (two-point sites: the bulk of the rest) the second
-      x[j] = first[j] >= 0 ? in[(int64_t)first[j] * planes + p] : 0.0f;
-      y[j] = (extra[j] > 0 && hd0[j] >= 0) ? in[(int64_t)hd0[j] * planes + p] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < kMeanU; ++j) {
-      if (first[j] < 0) continue;
-      const int64_t v = ((int64_t)blockIdx.x * kMeanU + j) * spb + sl;
-      float acc;
-      int last = first[j];
-      if (extra[j] == 0) {
-        acc = __fadd_rn(0.0f, __fmul_rn(1.0f, x[j]));
-      } else if (extra[j] == 1 && mode >= 3) {   // first < head always: the voxel's smallest index numbers it
-        const float mult = mode == 4 ? 0.5f : 1.0f;
-        acc = __fadd_rn(__fadd_rn(0.0f, __fmul_rn(mult, x[j])), __fmul_rn(mult, y[j]));
-        last = hd0[j];
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int extra = 0;
+  if (idx < V * planes) {
+    const int64_t v = idx / planes;
+    const int p = (int)(idx - v * planes);
+    const int first = first_pt[v];
+    extra = cnt_extra[v];
+    float acc = 0.0f;
+    if (extra == 0) {
+      acc = __fadd_rn(0.0f, __fmul_rn(1.0f, in[(int64_t)first * planes + p]));
+      if (p == 0 && last_pt) last_pt[v] = first;
+    } else {
+      const int hd = head[v];
+      const float mult = mode == 4 ? __fdiv_rn(1.0f, (float)(extra + 1)) : 1.0f;
+      int last = first;
+      if (mode == 1) {
+        acc = __fadd_rn(0.0f, in[(int64_t)first * planes + p]);
+        for (int q = hd; q >= 0; q = nxt[q]) last = q > last ? q : last;
       } else {
-        const int hd = hd0[j];
-        const float mult = mode == 4 ? __fdiv_rn(1.0f, (float)(extra[j] + 1)) : 1.0f;
-        acc = 0.0f;
-        if (mode == 1) {
-          acc = __fadd_rn(0.0f, x[j]);
-          for (int q = hd; q >= 0; q = nxt[q]) last = q > last ? q : last;
-        } else {
-          for_points_ascending(first[j], extra[j], hd, nxt, [&](int pt) {
-            last = pt;
-            if (mode != 2) acc = __fadd_rn(acc, __fmul_rn(mult, pt == first[j] ? x[j] : in[(int64_t)pt * planes + p]));
-          });
-          if (mode == 2) acc = __fadd_rn(0.0f, in[(int64_t)last * planes + p]);
-        }
+        for_points_ascending(first, extra, hd, nxt, [&](int pt) {
+          last = pt;
+          if (mode != 2) acc = __fadd_rn(acc, __fmul_rn(mult, in[(int64_t)pt * planes + p]));
+        });
+        if (mode == 2) acc = __fadd_rn(0.0f, in[(int64_t)last * planes + p]);
       }
       if (p == 0 && last_pt) last_pt[v] = last;
-      out[v * planes + p] = acc;
-      mx = extra[j] + 1 > mx ? extra[j] + 1 : mx;
     }
+    out[idx] = acc;
   }
   // largest point count of a site (IOLayersRules.h:96-103 maxActive): one atomic per block, only when it grows
-  int m = mx;
+  int m = extra + (idx < V * planes ? 1 : 0);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     const int o = __shfl_xor(m, d);
@@ -615,7 +585,8 @@ __global__ __launch_bounds__(256) void k_voxel_mean_row(const float *__restrict_
 }
 
 // d_in[i] = mult * d_out[site(i)] for the points that contributed (InputLayer_BackwardPass, CPU/IOLayers.cpp:30-47)
-constexpr int kBwdU = 4;    // points per thread (see kMeanU)
+constexpr int kBwdU = 4;    // points per thread: the two-hop chain point_site[i] -> d_out[site] carries 4 bytes per lane,
+                            // several in flight per thread: 49 -> 35-38 us at 1.5 M points (1.75 -> 2.3-2.7 TB/s)
 __global__ __launch_bounds__(256) void k_voxel_backward(float *__restrict__ d_in, const float *__restrict__ d_out,
                                                         int64_t n, int planes, const int32_t *__restrict__ point_site,
                                                         const int32_t *__restrict__ first_pt,
@@ -815,7 +786,7 @@ extern "C" int aabr_input_layer_forward(const float *in_feats, float *out_feats,
     hipLaunchKernelGGL(k_voxel_mean_row<16>, grid1(V, 256), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats, V,
                        planes, first_pt, cnt_extra, head, nxt, last_pt, mode, meta);
   else
-    hipLaunchKernelGGL(k_voxel_mean, grid1(V, (planes <= 256 ? 256 / planes : 1) * kMeanU), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats,
+    hipLaunchKernelGGL(k_voxel_mean, grid1(V * planes, 256), dim3(256), 0, (hipStream_t)stream_, in_feats, out_feats,
                        V, planes, first_pt, cnt_extra, head, nxt, last_pt, mode, meta);
   AABR_CHECK_LAUNCH();
   return AABR_OK;

@@ -59,6 +59,7 @@ N_GT = 40                       # ground-truth walls per scene (label generation
 # cfg.MODEL.RPN.LABEL_AUG_THICKNESS_{Y,Z}_TAR_ANC (config/defaults.py:161-162; rpn/loss_3d.py:351)
 LABEL_AUG = {"target_Y": 0.4, "anchor_Y": 0.0, "target_Z": 0.8, "anchor_Z": 0.0}
 MIN_TIMED_S = 0.2               # a timed region shorter than this is reported as such (`timed_region_short`)
+PMC_PROFILE = "r04_pmc_fetch_write_per_kernel.json"   # committed --pmc passes of this command (tools/tools_pmc.sh)
 
 # RPN constants of the reference config (defaults.py:127-131,159-181)
 ANCHOR_SIZES_3D = [[0.4, 1.5, 1.5], [1.5, 1.5, 1.0], [4, 4, 1.5], [0.2, 0.5, 3], [0.4, 1.5, 3], [0.6, 2.5, 3]]
@@ -495,7 +496,7 @@ def pmc_traffic(kernel_name, grid_threads):
     """HBM bytes per launch of the (kernel, grid size) instance from the committed PMC passes of THIS command
     (profiles/, separate --pmc runs, tools/tools_pmc.sh; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 note of
     MI355X_MICROARCH.md).  Returns (bytes, source) or (None, reason) -- never a number for a different kernel."""
-    name = "r03_pmc_fetch_write_per_kernel.json"
+    name = PMC_PROFILE
     path = os.path.join(REPO, "profiles", name)
     try:
         pm = json.load(open(path))["kernels"]
@@ -520,6 +521,143 @@ def pmc_traffic(kernel_name, grid_threads):
         return None, "instance %s not in the committed PMC profile (dispatch or workload changed since it was taken)" % key
     return int((2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024), \
         "committed profile profiles/%s, entry %s (%d launches)" % (name, key, v["launches"])
+
+
+def pmc_kernels_traffic(prefixes):
+    """sum over the committed PMC profile's entries whose kernel name starts with one of `prefixes` of the bytes moved
+    per launch (2 x FETCH + WRITE), largest grid of each kernel -- the voxel-scatter stage's HBM traffic; None when
+    the profile is missing"""
+    try:
+        pm = json.load(open(os.path.join(REPO, "profiles", PMC_PROFILE)))["kernels"]
+    except Exception:
+        return None, "no committed PMC profile for this round"
+    best = {}
+    for k, v in pm.items():
+        nm, _, g = k.partition("|grid=")
+        if not any(nm.startswith(p) for p in prefixes):
+            continue
+        if nm not in best or int(g) > best[nm][0]:
+            best[nm] = (int(g), (2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
+    if not best:
+        return None, "no scatter kernels in profiles/%s" % PMC_PROFILE
+    return int(sum(b for _, b in best.values())), "profiles/%s: %s" % (PMC_PROFILE, ", ".join(sorted(best)))
+
+
+def scatter_block(torch, scn, locs, feats, tag):
+    """voxel scatter (A1+A2) on one point list: device time of the geometry half (hash grid + first-seen numbering +
+    chains: csrc/voxel_scatter.hip) and of the feature half (ordered mean), host taken out (device_time); algorithmic
+    bytes N*(32 + 4*C_in) + V*(4*C_in + 16)"""
+    import _hip
+    from _hip import ptr, stream, check
+    from sparseconvnet import SCN
+    lib = _hip.load()
+    dev = locs.device
+    SP = torch.LongTensor([4096, 4096, 512])
+    fdet = feats.detach()
+    keep = []
+
+    def sites():
+        md = SCN.Metadata_3()
+        md.inputLayerEnqueue(SP, locs, 4, dev, asynchronous=False)
+        keep.append(md)
+        del keep[:-6]
+    with torch.no_grad():
+        t_sites = device_time(torch, sites)
+        md = SCN.Metadata_3()
+        V = md.inputLayer(SP, locs, 4, 4, dev)
+        il = md.input
+        out = torch.empty((V, fdet.shape[1]), device=dev)
+
+        def mean():
+            check(lib.aabr_input_layer_forward(ptr(fdet), ptr(out), V, fdet.shape[1], ptr(il["first_pt"]),
+                                               ptr(il["cnt_extra"]), ptr(il["head"]), ptr(il["nxt"]), ptr(il["last_pt"]),
+                                               4, ptr(il["meta"]), stream()))
+        t_mean = device_time(torch, mean)
+        inp = scn.InputLayer(3, [4096, 4096, 512], mode=4)
+        t_call = hip_time(torch, lambda: inp([locs, fdet]), 1, 10)
+    n, c = int(locs.shape[0]), int(fdet.shape[1])
+    by = n * (32 + 4 * c) + V * (4 * c + 16)
+    t = t_sites + t_mean
+    return dict(workload=tag, points=n, sites=int(V), bytes=by, insert_form=int(SCN.scatter_variant),
+                device_seconds=round(t, 7), sites_seconds=round(t_sites, 7), mean_seconds=round(t_mean, 7),
+                device_gbs=round(by / t / 1e9, 2), device_frac_of_hbm_peak=round(by / t / 1e9 / PEAK_HBM_GBS, 5),
+                seconds=round(t_call, 7), achieved_gbs=round(by / t_call / 1e9, 2),
+                frac_of_hbm_peak=round(by / t_call / 1e9 / PEAK_HBM_GBS, 5))
+
+
+def stage_rooflines(torch, scn, wl, table, V0):
+    """SURVEY 8(d)'s per-stage figures beside the headline: rule-book build (bytes + probes/s), convolution forward /
+    weight gradient (flop-weighted over the step's launches), BatchNorm forward / backward (HBM fraction), rotated NMS
+    (pairs/s).  Each stage is timed alone on this workload's own operands, device side (device_time)."""
+    import _hip
+    import _nms
+    import synth_scenes as S
+    from _hip import ptr, stream, check
+    from sparseconvnet import SCN
+    lib = _hip.load()
+    dev = wl.dev
+    out = {}
+    locs, feats = wl.batches[0]
+    with torch.no_grad():
+        # --- submanifold rule table of the input grid, k = 3: 27 probes per site into the hash grid
+        md = SCN.Metadata_3()
+        V = md.inputLayer(torch.LongTensor([4096, 4096, 512]), locs, 4, 4, dev)
+        g = md.grids[(4096, 4096, 512)]
+        table_ = torch.empty((27, g.V), dtype=torch.int32, device=dev)
+        counts = torch.empty(27 * ((g.V + 255) // 256), dtype=torch.int32, device=dev)
+        fs = _hip.i32x3((3, 3, 3))
+
+        def subm():
+            check(lib.aabr_submanifold_table(ptr(g.coords), g.V, ptr(g.keys), g.cap, fs, ptr(table_), ptr(counts),
+                                             stream()))
+        t = device_time(torch, subm)
+        R = int((table_ >= 0).sum().item())
+        by = 16 * g.V + 4 * 27 * g.V
+        out["rulebook_build"] = dict(what="aabr_submanifold_table, k = 3, input grid", sites=int(g.V), rules=R,
+                                     seconds=round(t, 7), bytes=by, gbs=round(by / t / 1e9, 1),
+                                     frac_of_hbm_peak=round(by / t / 1e9 / PEAK_HBM_GBS, 4),
+                                     probes_per_s=round(27 * g.V / t, 1),
+                                     note="bytes = 16 V (site list) + 4 vol V (gather table written); SURVEY 8d's 2R*4 "
+                                          "pair form is produced from the table by k_fill_offset_pairs")
+        # --- BatchNorm forward / backward on the largest 32- and 128-plane maps of the step
+        bn = {}
+        for rows, planes in ((V0, 32), (max((r["rows_out"] for r in table if r["n_out"] == 128), default=V0 // 4), 128)):
+            x = torch.randn((rows, planes), device=dev)
+            y = torch.empty_like(x)
+            sm, si = torch.empty(planes, device=dev), torch.empty(planes, device=dev)
+            rm, rv = torch.zeros(planes, device=dev), torch.ones(planes, device=dev)
+            w, b = torch.ones(planes, device=dev), torch.zeros(planes, device=dev)
+            t_f = device_time(torch, lambda: SCN.BatchNormalization_updateOutput(x, y, sm, si, rm, rv, w, b, 1e-4, 0.95,
+                                                                               True, 0.0))
+            dy, dx = torch.randn_like(x), torch.empty_like(x)
+            dw, db = torch.empty(planes, device=dev), torch.empty(planes, device=dev)
+            t_b = device_time(torch, lambda: SCN.BatchNormalization_backward(x, dx, y, dy, sm, si, rm, rv, w, b, dw, db,
+                                                                            0.0))
+            bf, bb = 3 * 4 * rows * planes, 5 * 4 * rows * planes
+            bn["%dx%d" % (rows, planes)] = dict(fwd_us=round(t_f * 1e6, 1), fwd_gbs=round(bf / t_f / 1e9, 1),
+                                                fwd_frac_of_hbm_peak=round(bf / t_f / 1e9 / PEAK_HBM_GBS, 4),
+                                                bwd_us=round(t_b * 1e6, 1), bwd_gbs=round(bb / t_b / 1e9, 1),
+                                                bwd_frac_of_hbm_peak=round(bb / t_b / 1e9 / PEAK_HBM_GBS, 4))
+        out["batchnorm"] = dict(bn, note="algorithmic bytes: forward 3 * 4 V C, backward 5 * 4 V C (SURVEY 8d); unfused "
+                                         "entry points, timed alone")
+        # --- rotated NMS of one 2000-box proposal set
+        b7, sc = S.make_nms_boxes(2000, 0)
+        o = (-sc).argsort()
+        bd = torch.as_tensor(b7[o]).to(dev)
+        t_n = device_time(torch, lambda: _nms.rotate_nms_sorted(bd, 0.5, 1000, True, lazy=True), group=2)
+        out["rotated_nms"] = dict(boxes=2000, seconds=round(t_n, 7), pairs=2000 * 1999 // 2,
+                                  pairs_per_s=round(2000 * 1999 / 2 / t_n, 1),
+                                  note="mask (A15 IoU pre-filter + exact clip decision) + greedy scan, device side; "
+                                       "VALU / latency bound, no roofline fraction claimed (SURVEY 8d)")
+    for kind, name in (("fwd", "conv_forward_type"), ("dw", "conv_weight_gradient")):
+        fl = sum(r["flops_per_launch"] * r["calls_per_step"] for r in table if r["kind"] == kind)
+        us = sum(r["step_us"] for r in table if r["kind"] == kind)
+        if us:
+            bf = any("bf16" in r["kernel"] for r in table if r["kind"] == kind)
+            peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
+            out[name] = dict(flop_weighted_tflops=round(fl / us / 1e6, 2), frac_of_mfma_peak=round(fl / us / 1e6 / peak, 4),
+                             step_us=round(us, 1), launches=sum(r["calls_per_step"] for r in table if r["kind"] == kind))
+    return out
 
 
 def roofline_block(torch, wl, dtype, step_us):
@@ -562,8 +700,9 @@ def cpu_baseline(wl, torch, budget_s=25.0):
     O.set_threads(max(1, min(ncpu, int(os.environ.get("AABR_CPU_THREADS", "16")))))
     P = ref_net.fpn_params(wl.net)
     done, t0, stages = 0, time.perf_counter(), {}
+    n_cpu = min(N_POINTS, 80000)      # --config 4: the sample stays S80k scenes of the same network (bounded CPU time)
     while True:
-        l, f = S.make_scene(N_POINTS, 9000 + done, VOXEL_SCALE)
+        l, f = S.make_scene(n_cpu, 9000 + done, VOXEL_SCALE)
         locs = np.concatenate([l, np.zeros((l.shape[0], 1), np.int64)], 1)
         t_s = time.perf_counter()
         fo = ref_net.FpnOracle(P, (4096, 4096, 512), [[2, 2, 2]] * 8, [[2, 2, 2]] * 8,
@@ -776,15 +915,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batches", type=int, default=2, help="distinct resident 4-scene batches per rank, cycled")
+    ap.add_argument("--batches", type=int, default=8,
+                    help="distinct resident batches per rank, cycled (8: the timed region does not keep seeing the same "
+                         "two shapes)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="BASELINE.json configs index: 2 (default, the headline) = 4 x S80k @ 2 cm per GPU and step; "
+                         "4 = one 1.5 M-point scene @ 2 cm per step (the rule-book stress; bf16 storage unless --dtype "
+                         "f32), same network and step")
     ap.add_argument("--min-timed-s", type=float, default=1.0,
                     help="when the --steps region is shorter than this, a second region of at least this many "
                          "seconds is timed right after it and reported as `timing.extended` (0 = off)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the disclosed settle loop before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="feature storage of the HEADLINE loop")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="feature storage of the HEADLINE loop (default: f32 for --config 2, bf16 for --config 4)")
     args = ap.parse_args()
+    global SCENES_PER_STEP, N_POINTS
+    if args.config == 4:
+        SCENES_PER_STEP, N_POINTS = 1, 1500000
+        if args.batches > 2:
+            args.batches = 2
+    if args.dtype is None:
+        args.dtype = "bf16" if args.config == 4 else "f32"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(sys.argv[1:], args.gpus))   # before anything touches the GPU
@@ -837,11 +990,14 @@ def main():
             "unit": "scenes/s", "n_gpus": world, "steps": n_timed, "warmup": args.warmup,
             "ms_per_step": round(el / n_timed * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: 'walls' config = default FPN_Net (21.2 M parameters), "
-                                   "4 x S80k scenes @ 2 cm per GPU and step (%d points -> %d voxels), voxel scatter + "
-                                   "all rule books rebuilt every step, fwd + bwd + SGD, RPN head + label-generation IoU "
-                                   "(criterion 6) + cross-scale top-2000 decode + rotated-3D NMS per scene%s" %
-                                   (n_pts, V0, "" if args.dtype == "f32" else ", bf16 feature storage"),
+            "config": {"workload": "BASELINE.json configs[%d]: %s = default FPN_Net (21.2 M parameters), "
+                                   "%s @ 2 cm per GPU and step (%d points -> %d voxels), voxel scatter + "
+                                   "all rule books rebuilt every step, fwd + bwd + SGD, RPN head + label generation "
+                                   "(criterion-6 IoU + the reference Matcher) + cross-scale top-2000 decode + rotated-3D "
+                                   "NMS per scene%s" %
+                                   (args.config, "'walls' config" if args.config == 2 else "dense whole-building scene",
+                                    "4 x S80k scenes" if args.config == 2 else "1 x S1.5M scene", n_pts, V0,
+                                    "" if args.dtype == "f32" else ", bf16 feature storage"),
                        "global_batch": world * SCENES_PER_STEP, "points_per_scene": N_POINTS,
                        "voxel_scale": VOXEL_SCALE, "parallelism": "dp%d" % world,
                        "proposals_per_scene": n_prop, "label_generation": bool(wl.label_generation),
@@ -872,40 +1028,32 @@ def main():
             fl = sum(r["flops_per_launch"] * r["calls_per_step"] for r in table if r["kind"] == "fwd")
             us = sum(r["step_us"] for r in table if r["kind"] == "fwd")
             line["conv_fwd_flop_weighted_tflops"] = round(fl / us / 1e6, 2) if us else None
-            # voxel scatter (A1+A2): N*(32 + 4*C_in) + V*(4*C_in + 16) algorithmic bytes
+            # voxel scatter (A1+A2): N*(32 + 4*C_in) + V*(4*C_in + 16) algorithmic bytes, on the step's own
+            # batch and on one 1.5 M-point scene (BASELINE configs[4]'s size)
             locs, feats = wl.batches[0]
-            inp = scn.InputLayer(3, [4096, 4096, 512], mode=4)
-            with torch.no_grad():
-                t_sc = hip_time(torch, lambda: inp([locs, feats.detach()]), 1, 10)
-
-                # the device side alone (one fill + k_voxel_insert + k_voxel_number + k_voxel_mean), without the
-                # host read of V that sizes the output tensor: enqueue-only calls bracketed by HIP events
-                from sparseconvnet import SCN as _SCN
-                fdet = feats.detach()
-                outf = torch.empty((V0, fdet.shape[1]), device=dev)
-                lib_ = __import__("_hip").load()
-                from _hip import ptr as _ptr, stream as _stream, check as _check
-                keep = []
-
-                def dev_only():
-                    md = _SCN.Metadata_3()
-                    md.inputLayerEnqueue(torch.LongTensor([4096, 4096, 512]), locs, 4, dev, asynchronous=False)
-                    il = md.input
-                    _check(lib_.aabr_input_layer_forward(_ptr(fdet), _ptr(outf), V0, fdet.shape[1], _ptr(il["first_pt"]),
-                                                         _ptr(il["cnt_extra"]), _ptr(il["head"]), _ptr(il["nxt"]),
-                                                         _ptr(il["last_pt"]), 4, _ptr(il["meta"]), _stream()))
-                    keep.append(md)          # buffers stay alive until the timing has been read
-                    del keep[:-4]
-                t_dev = hip_time(torch, dev_only, 1, 10)
-            sc_bytes = n_pts * (32 + 4 * 9) + V0 * (4 * 9 + 16)
-            line["voxel_scatter"] = dict(bytes=sc_bytes, seconds=round(t_sc, 7),
-                                         achieved_gbs=round(sc_bytes / t_sc / 1e9, 2),
-                                         frac_of_hbm_peak=round(sc_bytes / t_sc / 1e9 / PEAK_HBM_GBS, 5),
-                                         device_seconds=round(t_dev, 7),
-                                         device_gbs=round(sc_bytes / t_dev / 1e9, 2),
-                                         device_frac_of_hbm_peak=round(sc_bytes / t_dev / 1e9 / PEAK_HBM_GBS, 5),
-                                         note="`seconds`: whole InputLayer call on the 4-scene batch incl. the host "
-                                              "read of V; `device_seconds`: fill + 3 kernels, enqueue only")
+            vs = scatter_block(torch, scn, locs, feats, "the step's batch")
+            tr, src = pmc_kernels_traffic(("aabr::k_voxel", "k_voxel"))
+            vs["traffic"], vs["traffic_source"] = tr, src
+            if tr:
+                vs["traffic_over_algorithmic"] = round(tr / vs["bytes"], 2)
+            vs["note"] = ("device_seconds = sites_seconds (fill + insert + numbering) + mean_seconds, launches queued "
+                          "behind a busy-wait kernel so that no host gap is in the figure; `seconds`: the whole "
+                          "InputLayer call incl. its host read of V")
+            line["voxel_scatter"] = vs
+            if N_POINTS < 1000000:
+                try:
+                    import synth_scenes as S_
+                    l15, f15 = S_.make_batch(1, 1500000, 0, VOXEL_SCALE)
+                    line["voxel_scatter_1p5M"] = scatter_block(torch, scn, torch.as_tensor(l15).to(dev),
+                                                               torch.as_tensor(f15).to(dev),
+                                                               "one 1.5 M-point scene @ 2 cm (BASELINE configs[4])")
+                    del l15, f15
+                except Exception as e:  # pragma: no cover
+                    line["voxel_scatter_1p5M"] = {"error": repr(e)[:200]}
+            try:
+                line["stage_rooflines"] = stage_rooflines(torch, scn, wl, table, V0)
+            except Exception as e:  # pragma: no cover
+                line["stage_rooflines"] = {"error": repr(e)[:300]}
             if wl.label_generation:
                 import rpn_glue
                 maps = wl.last[0]
