@@ -187,9 +187,8 @@ AABR_HD bool same_box(const float *a, const float *b) {
 // `overlap >= thresh` on a boost::geometry polygon intersection / union of the two rectangles.  rotate_iou() is not
 // that value where its vertex collection / angular sort breaks down (two thin, nearly parallel walls crossing at
 // 0.035 rad: 0.162 against an exact 0.569 -- tests/test_oracle_golden.py::test_nms_decision_iou_disagreements), so the
-// decision is made on a Sutherland-Hodgman clip in double: corners of center_to_corner_box2d (box_np_ops.py:374-394;
-// corner order x0y0, x0y1, x1y1, x1y0, rotation x' = x cos + y sin, y' = -x sin + y cos), each half-plane of the
-// second rectangle applied in turn, area by the shoelace formula.  r = (xc, yc, size_x, size_y, yaw).
+// decision is made on an exact clip in double: corners of center_to_corner_box2d (box_np_ops.py:374-394; corner order
+// x0y0, x0y1, x1y1, x1y0, rotation x' = x cos + y sin, y' = -x sin + y cos).  r = (xc, yc, size_x, size_y, yaw).
 AABR_HD void clip_corners(const float *r, double *cx, double *cy) {
   const double a = (double)r[4], s = sin(a), c = cos(a);
   const double hx = 0.5 * (double)r[2], hy = 0.5 * (double)r[3];
@@ -200,43 +199,58 @@ AABR_HD void clip_corners(const float *r, double *cx, double *cy) {
   }
 }
 
+// Intersection area by boundary integration instead of polygon construction (no vertex lists, no dynamic indexing:
+// everything stays in registers on the device): the boundary of A n B is made of the pieces of A's edges inside B and
+// the pieces of B's edges inside A; each edge is cut down to its piece inside the other rectangle by the four
+// half-planes (parametric clip), and the shoelace sum over the directed pieces is twice the area.  A piece of
+// boundary the two rectangles SHARE (collinear edges running the same way) is counted once: A's edges are clipped
+// against B closed (d >= 0), the copy on B's side is left out.  Agrees with a Sutherland-Hodgman
+// clip (oracle/clip_oracle.c, tests/test_oracle_golden.py) to 1e-12.
+AABR_HD double clip_edges_inside(const double *ax, const double *ay, const double *bx, const double *by, bool drop_collinear) {
+  double sum = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    const double x0 = ax[i], y0 = ay[i], x1 = ax[(i + 1) & 3], y1 = ay[(i + 1) & 3];
+    double t0 = 0.0, t1 = 1.0;
+    bool out = false;
+    for (int e = 0; e < 4; ++e) {
+      const double ex = bx[(e + 1) & 3] - bx[e], ey = by[(e + 1) & 3] - by[e];
+      const double d0 = ey * (x0 - bx[e]) - ex * (y0 - by[e]);      // >= 0: on the inner side of B's edge e
+      const double d1 = ey * (x1 - bx[e]) - ex * (y1 - by[e]);
+      if (d0 < 0.0 && d1 < 0.0) out = true;
+      // on the line of B's edge e: a shared piece of boundary when the two edges run the same way (interiors on the
+      // same side: counted with the other rectangle's copy), two pieces that cancel when they run against each other
+      // (the rectangles touch from opposite sides)
+      if (drop_collinear && d0 == 0.0 && d1 == 0.0 && (x1 - x0) * ex + (y1 - y0) * ey > 0.0) out = true;
+      if (d0 < 0.0 && d1 >= 0.0) { const double t = d0 / (d0 - d1); t0 = t > t0 ? t : t0; }
+      if (d1 < 0.0 && d0 >= 0.0) { const double t = d0 / (d0 - d1); t1 = t < t1 ? t : t1; }
+    }
+    if (!out && t0 < t1) {
+      const double px = x0 + t0 * (x1 - x0), py = y0 + t0 * (y1 - y0);
+      const double qx = x0 + t1 * (x1 - x0), qy = y0 + t1 * (y1 - y0);
+      sum += px * qy - qx * py;
+    }
+  }
+  return sum;
+}
+
 AABR_HD double clip_iou_exact(const float *r1, const float *r2) {
   double ax[4], ay[4], bx[4], by[4];
   clip_corners(r1, ax, ay);
   clip_corners(r2, bx, by);
-  double px[12], py[12], qx[12], qy[12];
-  int n = 4;
-  for (int i = 0; i < 4; ++i) { px[i] = ax[i]; py[i] = ay[i]; }
-  // the corner order above is clockwise in the (x, y) plane for positive sizes (inside = right of each edge); the
-  // sign of the clip rectangle's signed area covers the other orientation
-  double sb = 0.0;
-  for (int i = 0; i < 4; ++i) sb += bx[i] * by[(i + 1) & 3] - bx[(i + 1) & 3] * by[i];
-  const double o = sb <= 0.0 ? 1.0 : -1.0;
-  for (int e = 0; e < 4 && n > 0; ++e) {
-    const double ex = o * (bx[(e + 1) & 3] - bx[e]), ey = o * (by[(e + 1) & 3] - by[e]);
-    int m = 0;
-    for (int i = 0; i < n; ++i) {
-      const int j = i + 1 < n ? i + 1 : 0;
-      const double di = ey * (px[i] - bx[e]) - ex * (py[i] - by[e]);
-      const double dj = ey * (px[j] - bx[e]) - ex * (py[j] - by[e]);
-      if (di >= 0.0) { qx[m] = px[i]; qy[m] = py[i]; ++m; }
-      if ((di > 0.0 && dj < 0.0) || (di < 0.0 && dj > 0.0)) {
-        const double t = di / (di - dj);
-        qx[m] = px[i] + t * (px[j] - px[i]);
-        qy[m] = py[i] + t * (py[j] - py[i]);
-        ++m;
-      }
-    }
-    n = m;
-    for (int i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+  // the corner order is clockwise for positive sizes (inner side = right of each edge); a rectangle given with a
+  // negative size is turned round so that both run the same way
+  double sa = 0.0, sb = 0.0;
+  for (int i = 0; i < 4; ++i) {
+    sa += ax[i] * ay[(i + 1) & 3] - ax[(i + 1) & 3] * ay[i];
+    sb += bx[i] * by[(i + 1) & 3] - bx[(i + 1) & 3] * by[i];
   }
-  if (n < 3) return 0.0;
-  double inter = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const int j = i + 1 < n ? i + 1 : 0;
-    inter += px[i] * py[j] - px[j] * py[i];
-  }
-  inter = 0.5 * fabs(inter);
+  if (sa > 0.0) { double t = ax[1]; ax[1] = ax[3]; ax[3] = t; t = ay[1]; ay[1] = ay[3]; ay[3] = t; }
+  if (sb > 0.0) { double t = bx[1]; bx[1] = bx[3]; bx[3] = t; t = by[1]; by[1] = by[3]; by[3] = t; }
+  // shift to A's first corner: the shoelace terms lose no digits to the scene's offset
+  const double ox = ax[0], oy = ay[0];
+  for (int i = 0; i < 4; ++i) { ax[i] -= ox; ay[i] -= oy; bx[i] -= ox; by[i] -= oy; }
+  const double twice = clip_edges_inside(ax, ay, bx, by, false) + clip_edges_inside(bx, by, ax, ay, true);
+  const double inter = 0.5 * fabs(twice);
   const double uni = fabs((double)r1[2] * (double)r1[3]) + fabs((double)r2[2] * (double)r2[3]) - inter;
   return uni > 0.0 ? inter / uni : 0.0;
 }

@@ -227,6 +227,7 @@ def test_bench_roofline_traffic_lookup_matches_the_committed_pmc_profile():
     import importlib
     import json
     bench = importlib.import_module("bench")
+    bench.PMC_PROFILE = "r03_pmc_fetch_write_per_kernel.json"     # the lookup logic, on a profile whose keys are known
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
                         "r03_pmc_fetch_write_per_kernel.json")
     pm = json.load(open(path))["kernels"]

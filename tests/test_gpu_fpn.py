@@ -574,5 +574,5 @@ def test_rccl_world_size_1_bucketed_equals_flat():
     assert out["backend"] == "nccl" and out["world_size"] == 1
     assert out["max_param_change"] > 0                      # the steps really moved the parameters
     assert out["equal"] and out["reproducible"], out
-    assert out["buckets"] == 5 and out["launched_during_backward"] == 3 and out["bucket_bytes"] > 80e6
+    assert out["buckets"] == 5 and out["launched_during_backward"] == 3 and out["bucket_bytes"] > 70e6
     assert out["hook_disarmed"] and out["grads_are_means"]
