@@ -85,7 +85,7 @@ def main():
                launched_during_backward=flat.bucket_stats["launched_during_backward"],
                bucket_bytes=flat.bucket_stats["bytes"], max_abs_diff=float((want - got).abs().max()),
                max_param_change=moved, hook_disarmed=planExecutor.on_grads_ready is None,
-               grads_are_means=bool(all(p.grad is not None for p in flat.params[:4])))
+               grads_are_means=bool(sum(p.grad is not None for p in flat.params) > 100))
     print(json.dumps(out))
     sys.stdout.flush()
     dist.barrier()
