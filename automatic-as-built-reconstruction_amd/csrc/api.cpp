@@ -4,7 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
-#include "../../include/aabr_hip.h"
+#include "common.h"
 
 namespace aabr {
 static thread_local char g_err[512] = "";
@@ -15,11 +15,10 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-enum Knob { K_CONV_WLDS, K_CONV_SMALL, K_CONV_NBW, K_CONV_WPB, K_CONV_RS, K_RS_UNIT, K_WIDE_ROWS, K_CONV_WIDE,
-            K_WIDE_NBUF, K_CONV_WIDE_BF16, K_VOXEL_MEAN, K_WIDE_NCB, K_BN_SMALL, K_CONV_X3, K_X3_FORM, K_WIDE_PRIO, K_PLAN_SIDE_BATCH, K_PLAN_SIDE_PRIO, K_COUNT };
-constexpr int kKnobUnset = -2147483647 - 1;
-static const char *const g_knob_names[K_COUNT] = {"CONV_WLDS", "CONV_SMALL", "CONV_NBW", "CONV_WPB", "CONV_RS", "RS_UNIT",
-                                                  "WIDE_ROWS", "CONV_WIDE", "WIDE_NBUF", "CONV_WIDE_BF16", "VOXEL_MEAN", "WIDE_NCB", "BN_SMALL", "CONV_X3", "X3_FORM", "WIDE_PRIO", "PLAN_SIDE_BATCH", "PLAN_SIDE_PRIO"};
+#define AABR_KNOB_NAME(n) #n,
+static const char *const g_knob_names[] = {AABR_KNOB_LIST(AABR_KNOB_NAME)};
+#undef AABR_KNOB_NAME
+static_assert(sizeof(g_knob_names) / sizeof(*g_knob_names) == K_COUNT, "one name per knob");
 static std::atomic<int> g_knob_val[K_COUNT];
 static std::atomic<int> g_knob_state[K_COUNT];   // 0: environment not read yet, 1: value final
 int knob(Knob k) {

@@ -12,8 +12,14 @@ void set_error(const char *fmt, ...);
 // Tuning knobs (experiments and tests only; the defaults are what ships).  Each is read from its environment
 // variable AABR_<NAME> ONCE, at its first use in the process, and can be set explicitly through aabr_set_knob --
 // no entry point calls getenv on its launch path.
-enum Knob { K_CONV_WLDS, K_CONV_SMALL, K_CONV_NBW, K_CONV_WPB, K_CONV_RS, K_RS_UNIT, K_WIDE_ROWS, K_CONV_WIDE,
-            K_WIDE_NBUF, K_CONV_WIDE_BF16, K_VOXEL_MEAN, K_WIDE_NCB, K_BN_SMALL, K_CONV_X3, K_X3_FORM, K_WIDE_PRIO, K_PLAN_SIDE_BATCH, K_PLAN_SIDE_PRIO, K_COUNT };
+// ONE list: the enumerators and the names (api.cpp) are generated from it, so they cannot drift apart.
+#define AABR_KNOB_LIST(X)                                                                                            \
+  X(CONV_WLDS) X(CONV_SMALL) X(CONV_NBW) X(CONV_WPB) X(CONV_RS) X(RS_UNIT) X(WIDE_ROWS) X(CONV_WIDE) X(WIDE_NBUF)     \
+  X(CONV_WIDE_BF16) X(VOXEL_MEAN) X(WIDE_NCB) X(BN_SMALL) X(CONV_X3) X(X3_FORM) X(WIDE_PRIO) X(PLAN_SIDE_BATCH)       \
+  X(PLAN_SIDE_PRIO) X(SMALL_WPB) X(SMALL_MAX) X(WIDE_SPLIT)
+#define AABR_KNOB_ENUM(n) K_##n,
+enum Knob { AABR_KNOB_LIST(AABR_KNOB_ENUM) K_COUNT };
+#undef AABR_KNOB_ENUM
 constexpr int kKnobUnset = -2147483647 - 1;
 int knob(Knob k);            // kKnobUnset when neither the environment nor aabr_set_knob gave a value
 

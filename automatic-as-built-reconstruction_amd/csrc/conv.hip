@@ -1965,13 +1965,25 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
     }
   }
   // tiny rule books with wide layers (coarse FPN scales): (pair, chunk) items over 8 waves x 16-column slabs
-  if (lean && nkc >= 2 && ceil_div(V_out, 64) * nnb < 512) {
-    if (knob(K_CONV_SMALL) != 0) {             // tuning experiments only: 0 disables
-      constexpr int kW = 8;
-      g_last_variant = "k_conv_blocks_mfma_small<8>";
-      hipLaunchKernelGGL((k_conv_blocks_mfma_small<kW>), dim3((unsigned)ceil_div(V_out, 64), (unsigned)nnb),
-                         dim3(64 * kW), (size_t)kW * 64 * 16 * sizeof(float), st, in_feats, n_in, in_bytes, out_feats,
-                         n_out, V_out, blocks, words_bytes, vol, flip & 1, wpack, wp_bytes, bias);
+  {
+    const int smax = knob(K_SMALL_MAX) == kKnobUnset ? 512 : knob(K_SMALL_MAX);
+    if (lean && nkc >= 2 && ceil_div(V_out, 64) * nnb < smax && knob(K_CONV_SMALL) != 0) {   // CONV_SMALL=0 disables
+      // 16 waves per workgroup when the grid alone cannot fill the chip (each wave's chain of dependent (pair,
+      // chunk) items halves; 94 VGPRs: four waves per SIMD fit): SMALL_WPB forces 8 / 16
+      int wpb = ceil_div(V_out, 64) * nnb < 1024 ? 16 : 8;
+      if (knob(K_SMALL_WPB) == 8 || knob(K_SMALL_WPB) == 16) wpb = knob(K_SMALL_WPB);
+      const dim3 grid((unsigned)ceil_div(V_out, 64), (unsigned)nnb);
+      if (wpb == 16) {
+        g_last_variant = "k_conv_blocks_mfma_small<16>";
+        hipLaunchKernelGGL((k_conv_blocks_mfma_small<16>), grid, dim3(64 * 16), (size_t)16 * 64 * 16 * sizeof(float), st,
+                           in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip & 1, wpack,
+                           wp_bytes, bias);
+      } else {
+        g_last_variant = "k_conv_blocks_mfma_small<8>";
+        hipLaunchKernelGGL((k_conv_blocks_mfma_small<8>), grid, dim3(64 * 8), (size_t)8 * 64 * 16 * sizeof(float), st,
+                           in_feats, n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip & 1, wpack,
+                           wp_bytes, bias);
+      }
       AABR_CHECK_LAUNCH();
       return AABR_OK;
     }

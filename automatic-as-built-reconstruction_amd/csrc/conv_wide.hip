@@ -160,16 +160,24 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
   // it gather the same input rows (consecutive sites lie on the same surface), so they hit that XCD's L2 instead of
   // all eight L2s fetching the whole input (round 2: 580 MB of fetches per launch for 91 MB of operands).  Speed
   // only -- which workgroup computes a tile does not change a bit of it.
+  // Offset split (coarse maps: too few (tile, slab) items to fill the chip): grid.y = slabs x P, part p of a (tile, slab)
+  // sweeps the filter offsets [p vol / P, (p + 1) vol / P) only and writes its fp32 partial tile to out + p V_out co;
+  // k_split_reduce adds the parts in part order (bias, residual and the storage rounding happen there).
+  const int nparts = (wflip >> 8) & 0xff;
   int64_t tile;
-  int nb0;
+  int nb0, part = 0;
   {
     const unsigned ny = gridDim.y, total = gridDim.x * ny;
     const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
     const unsigned per = total >> 3, rem = total & 7u, x = lin & 7u;
     const unsigned wi = x * per + (x < rem ? x : rem) + (lin >> 3);
     tile = wi / ny;
-    nb0 = (int)(wi % ny) * (kNB * NCB);
+    unsigned sp = wi % ny;
+    if (nparts > 1) { part = (int)(sp % (unsigned)nparts); sp /= (unsigned)nparts; }
+    nb0 = (int)sp * (kNB * NCB);
   }
+  const int k_lo = nparts > 1 ? part * vol / nparts : 0;
+  const int kend = nparts > 1 ? (part + 1) * vol / nparts : vol;   // offsets >= kend are past the end for this part
   const int64_t row0 = tile * kT2;
   const int64_t ntiles = (V_out + kT2 - 1) / kT2;
   const int maxb = (kT2 / 16) * vol;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
   auto pre_of = [&](int k) { return __builtin_amdgcn_readlane(vpre, k); };
   auto next_offset = [&](int k) {
     ++k;
-    while (k < vol && pre_of(k + 1) == pre_of(k)) ++k;
+    while (k < kend && pre_of(k + 1) == pre_of(k)) ++k;
     return k;
   };
   struct WReg { u32x4 w0[NP][NCB][KG], w1[NP][NCB][KG]; };
@@ -295,9 +303,9 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
   // Software pipeline over the tile's block pairs (pairs never straddle an offset):
   //   entries two pairs ahead (registers), gathered rows one pair ahead (registers -> LDS stage after this pair's
   //   MFMAs), weights one offset ahead.  A gather never waits for an entry load issued in the same iteration.
-  struct Pos { int b, k; };                // k >= vol: past the end
+  struct Pos { int b, k; };                // k >= kend: past the end
   auto adv = [&](Pos q) {
-    if (q.k >= vol) return q;
+    if (q.k >= kend) return q;
     const int kend = pre_of(q.k + 1);
     q.b += 2;
     if (q.b >= kend) { q.b = kend; q.k = next_offset(q.k); }
@@ -314,12 +322,12 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
     // so the workgroup's pace is NSET pairs per gather latency and NSET = 4 nearly doubles it, measured).  Entries run
     // one pair further ahead.  Pair i lives in set i % NSET; the step body exists once per set (static registers).
     Pos pp[NSET + 2];
-    pp[0].k = next_offset(-1);
-    if (pp[0].k >= vol) break;
+    pp[0].k = next_offset(k_lo - 1);
+    if (pp[0].k >= kend) break;
     pp[0].b = pre_of(pp[0].k);
 #pragma unroll
     for (int i = 1; i < NSET + 2; ++i) pp[i] = adv(pp[i - 1]);
-    auto ent_of = [&](const Pos &q) { const bool v = q.k < vol; return load_ent(v ? q.b : pp[0].b, v ? q.k : pp[0].k); };
+    auto ent_of = [&](const Pos &q) { const bool v = q.k < kend; return load_ent(v ? q.b : pp[0].b, v ? q.k : pp[0].k); };
     Ent ee[NSET + 2];
 #pragma unroll
     for (int i = 0; i <= NSET; ++i) ee[i] = ent_of(pp[i]);
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
         accumulate2(e0.ea, accA, e0.eb, accB);
       }
       if (NBUF == 1) wg_barrier();                           // single stage: every wave is done reading it
-      if (pp[1].k < vol) stage_store(g_store, par ^ 1);      // the next pair, gathered NSET - 1 steps ago
+      if (pp[1].k < kend) stage_store(g_store, par ^ 1);     // the next pair, gathered NSET - 1 steps ago
       if (DBG & 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); }
       wg_barrier();
       if (DBG & 4) {
@@ -498,14 +506,14 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
     load_w(wA, k, kg);
     for (;;) {
       int kn = next_offset(k);
-      if (kn < vol) load_w(wB, kn, kg);                      // next offset's weights in flight during this offset
+      if (kn < kend) load_w(wB, kn, kg);                     // next offset's weights in flight during this offset
       while (pp[0].k == k) step2(wA);
-      if (kn >= vol) break;
+      if (kn >= kend) break;
       k = kn;
       kn = next_offset(k);
-      if (kn < vol) load_w(wA, kn, kg);
+      if (kn < kend) load_w(wA, kn, kg);
       while (pp[0].k == k) step2(wB);
-      if (kn >= vol) break;
+      if (kn >= kend) break;
       k = kn;
     }
   }
@@ -523,6 +531,15 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
   // bias / residual, after the bf16 rounding) -- per tile one [2][co] pair of fp64 column sums (x, x^2), combined by the
   // BatchNorm's finalize in tile order, so the result does not depend on which workgroup ran when
   constexpr int QW = 16 * NCB;             // 16-byte columns of the slab; 256 % QW == 0: a thread keeps its column
+  if (nparts > 1) {                        // this part's fp32 partial tile (an empty offset range writes zeros)
+    float *po = out + (int64_t)part * V_out * co;
+    for (int i = threadIdx.x; i < nrows * QW; i += 256) {
+      const int r = i / QW, q = i % QW;
+      *reinterpret_cast<f32x4 *>(po + (row0 + r) * co + nb0 * 16 + q * 4) =
+          *reinterpret_cast<const f32x4 *>(Ct + r * WS + ((q ^ (r & 15)) << 2));
+    }
+    return;
+  }
   double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
   float bmu[4] = {0.f, 0.f, 0.f, 0.f}, bwc[4] = {0.f, 0.f, 0.f, 0.f}, bbc[4] = {0.f, 0.f, 0.f, 0.f};
   if (!BF && stats && bn.x) {              // this thread's four columns of the BatchNorm's forward coefficients
@@ -768,6 +785,116 @@ static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, flo
 #undef AABR_WIDE_CS_N
   }
 #undef AABR_LAUNCH_WIDE
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+// ---- offset split for coarse maps ---------------------------------------------------------------------------------------
+// The coarse FPN scales (49 .. 5,565 rows x 128-256 planes) give the wide kernel 4 .. 180 (tile, slab) items -- a fraction
+// of the chip -- and the 64-row-tile kernels that ran them instead re-fetch every block's weights (8-10 TB/s of L2->CU
+// traffic for 28-35 TFLOP/s).  Split: P parts per (tile, slab), each sweeping vol / P filter offsets with the wide
+// kernel's economy (weights per offset in registers, gathered rows shared through LDS) into its own fp32 partial tile;
+// k_split_reduce sums the parts in part order -- fixed order, bit-reproducible -- and applies bias / residual / the
+// bf16 rounding.  Scratch: P x V_out x n_out floats.
+namespace aabr {
+template <bool BF>
+__global__ __launch_bounds__(256) void k_split_reduce(const float *__restrict__ parts, int nparts, int64_t n4, int co4,
+                                                      const float *__restrict__ bias, const float *__restrict__ res,
+                                                      void *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = reinterpret_cast<const f32x4 *>(parts)[i];
+  for (int p = 1; p < nparts; ++p) {
+    const f32x4 w = reinterpret_cast<const f32x4 *>(parts)[(int64_t)p * n4 + i];
+    v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+  }
+  if (bias) {
+    const float *bb = bias + (i % co4) * 4;
+    v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
+  }
+  if (res) {
+    const f32x4 rr = reinterpret_cast<const f32x4 *>(res)[i];
+    v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+  }
+  if (BF) {
+    bf16x4w o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    reinterpret_cast<bf16x4w *>(out)[i] = o;
+  } else {
+    reinterpret_cast<f32x4 *>(out)[i] = v;
+  }
+}
+} // namespace aabr
+
+// (P << 16) | tile_rows when this launch should go to aabr_conv_forward_wide_split, else 0.  Asked after
+// aabr_conv_wide_tile_rows declined (fewer than 320 (tile, slab) items).
+extern "C" int aabr_conv_wide_split(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
+  if (n_in <= 0 || n_out <= 0 || (n_in & 31) || (n_out & 63) || vol <= 1 || vol > kMaxVol || V_out <= 0) return 0;
+  if (rows_in >= (1ll << 23) || rows_in * n_in * 4 >= (1ll << 31)) return 0;
+  if (n_in < 64 || (n_in > 128 && (n_in & 127))) return 0;
+  if (knob(K_WIDE_SPLIT) == 0) return 0;
+  const int T = 64;
+  const int64_t items = ((V_out + T - 1) / T) * (n_out / 64);
+  if (items >= 320) return 0;
+  int P = (int)((512 + items - 1) / items);
+  if (P > vol) P = vol;
+  if (P > 32) P = 32;
+  {                                                // tuning experiments only
+    const int v = knob(K_WIDE_SPLIT);
+    if (v >= 2 && v <= 32) P = v < vol ? v : vol;
+  }
+  if (P < 2) return 0;
+  if (wide_words(V_out, vol, T) * 4 >= (1ll << 31) || (int64_t)vol * n_in * n_out * 4 >= (1ll << 31)) return 0;
+  return (P << 16) | T;
+}
+
+extern "C" int64_t aabr_conv_wide_split_scratch_floats(int64_t V_out, int n_out, int parts) {
+  return V_out > 0 && n_out > 0 && parts > 0 ? (int64_t)parts * V_out * n_out : 0;
+}
+
+extern "C" int aabr_conv_forward_wide_split(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
+                                            int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                            const float *bias, int flags, const float *wpack, const float *residual,
+                                            int parts, float *scratch, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(parts >= 2 && parts <= 32 && parts <= vol && scratch && ((uintptr_t)scratch & 15) == 0,
+                 "2 <= parts <= min(32, vol) and a 16-byte aligned scratch of parts x V_out x n_out floats");
+  AABR_CHECK_ARG(((uintptr_t)residual & 15) == 0, "residual must be 16-byte aligned");
+  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 31) == 0 && (n_out & 63) == 0, "plane counts: n_in % 32, n_out % 64");
+  AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
+  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
+  if (V_out == 0) return AABR_OK;
+  AABR_CHECK_ARG(in_feats && out_feats && blocks && wpack && rows_in > 0, "null pointer / empty input");
+  AABR_CHECK_ARG(rows_in < (1ll << 23), "too many input rows for the wide block format");
+  const int64_t in_bytes = rows_in * n_in * 4, words_bytes = wide_words(V_out, vol, tile_rows) * 4;
+  AABR_CHECK_ARG(in_bytes < (1ll << 31) && words_bytes < (1ll << 31), "buffers must be < 2 GiB");
+  AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 15) == 0 && ((uintptr_t)wpack & 15) == 0,
+                 "feature / weight pointers must be 16-byte aligned");
+  const int nkc = n_in / 32;
+  const int64_t wp_bytes = (int64_t)vol * nkc * (n_out / 16) * 2048;
+  AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
+  AABR_CHECK_ARG(n_in <= 128 || (n_in & 127) == 0, "n_in above 128 must be a multiple of 128");
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)((n_out / 64) * parts));
+  const int flip = ((flags >> 1) & 1) | (knob(K_WIDE_PRIO) == 0 ? 0 : 2) | (parts << 8);
+  const int kg = nkc >= 4 ? 4 : nkc;
+#define AABR_SPLIT_CS(KG)                                                                                              \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         80 * 1024));                                                                  \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    g_last_variant = "k_conv_cs<" #KG ",0,2,split>";                                                                   \
+    hipLaunchKernelGGL((k_conv_cs<KG, 0, 2>), grid, dim3(256),                                                         \
+                       (size_t)((tile_rows + 1) * kWS + 2 * 2 * 16 * KG * 32) * sizeof(float), st, in_feats, n_in,      \
+                       in_bytes, scratch, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes,                \
+                       (const float *)nullptr, tile_rows, (const float *)nullptr, (double *)nullptr, BnBwdStats{});     \
+  } while (0)
+  if (kg == 2) AABR_SPLIT_CS(2); else if (kg == 3) AABR_SPLIT_CS(3); else AABR_SPLIT_CS(4);
+#undef AABR_SPLIT_CS
+  const int64_t n4 = V_out * n_out / 4;
+  hipLaunchKernelGGL((k_split_reduce<false>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, scratch, parts, n4,
+                     n_out / 4, bias, residual, (void *)out_feats);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

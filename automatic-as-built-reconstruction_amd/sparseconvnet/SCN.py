@@ -982,6 +982,14 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
         check(lib.aabr_conv_forward_wide(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
                                          ptr(gather.blocks_wide(tile_rows)), tile_rows, gather.vol, ptr(_opt(bias)),
                                          flags & 3, ptr(wpack), stream()))
+    elif wide_split(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16):
+        T, P = wide_split(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16)
+        if not (flags & 4):
+            check(lib.aabr_conv_pack_weights(ptr(w), gather.vol, n_in, n_out, flags & 1, ptr(wpack), stream()))
+        scratch = _hip.workspace("wide_split", P * n_rows_out * n_out, torch.float32, inp.device)
+        check(lib.aabr_conv_forward_wide_split(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
+                                               ptr(gather.blocks_wide(T)), T, gather.vol, ptr(_opt(bias)), flags & 3,
+                                               ptr(wpack), None, P, ptr(scratch), stream()))
     else:
         check(conv(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
                    ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
@@ -1060,6 +1068,16 @@ def wide_tile_rows(n_in, n_out, rows_in, rows_out, vol, bf16=False, prepacked=Tr
     return lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, vol)
 
 
+def wide_split(n_in, n_out, rows_in, rows_out, vol, bf16=False):
+    """(tile_rows, parts) when this launch goes to the offset-split form of the wide kernel (coarse maps: too few
+    (tile, slab) items to fill the chip; csrc/conv_wide.hip aabr_conv_forward_wide_split), else None.  Asked after
+    `wide_tile_rows` declined; fp32 storage."""
+    if bf16 or rows_out == 0:
+        return None
+    v = _hip.load().aabr_conv_wide_split(n_in, n_out, rows_in, rows_out, vol)
+    return (v & 0xffff, v >> 16) if v else None
+
+
 def rs_unit_rows(n_in, n_out, rows_in, rows_out, vol, bf16, prepacked=True):
     """rows per unit when this launch goes to the row-stationary bf16 kernel (csrc/conv_rs.hip), else 0 -- asked
     before `wide_tile_rows` by the layer code, the stream pre-builder and the graph executor alike"""
@@ -1092,10 +1110,14 @@ def compile_streams(gather, rows_in, n_in, n_out, dtype, weight_grad=False):
     unit_rows = rs_unit_rows(n_in, n_out, rows_in, gather.rows, gather.vol, dtype == torch.bfloat16)
     tile_rows = 0 if unit_rows else wide_tile_rows(n_in, n_out, rows_in, gather.rows, gather.vol,
                                                    dtype == torch.bfloat16)
+    sp = None if (unit_rows or tile_rows) else wide_split(n_in, n_out, rows_in, gather.rows, gather.vol,
+                                                          dtype == torch.bfloat16)
     if unit_rows:
         gather.rs_stream(unit_rows)
     elif tile_rows:
         gather.blocks_wide(tile_rows)
+    elif sp:
+        gather.blocks_wide(sp[0])
     else:
         gather.blocks()
     if weight_grad:

@@ -39,7 +39,7 @@ from .deconvolution import Deconvolution
 
 _OP = struct.Struct("<ii6i4f4q12Q")          # AabrPlanOp (include/aabr_hip.h)
 assert _OP.size == 176
-K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST, K_RS = 1, 2, 3, 4, 5, 6, 7, 8
+K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST, K_RS, K_WSPLIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 F_BF16, F_TO_BF16, F_SIDE, F_JOIN = 1, 2, 4, 8
 _ALIGN = 256
 BF16 = torch.bfloat16
@@ -444,6 +444,13 @@ class _Pass(object):
             T = self._wide[key] = SCN.wide_tile_rows(n_in, n_out, rows_in, rows_out, vol, bf)
         return T
 
+    def split_of(self, n_in, n_out, rows_in, rows_out, vol, bf=False):
+        key = ("split", n_in, n_out, rows_in, rows_out, vol, bf)
+        v = self._wide.get(key, 0)
+        if v == 0:
+            v = self._wide[key] = SCN.wide_split(n_in, n_out, rows_in, rows_out, vol, bf) or ()
+        return v or None
+
     def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf,
                     xf=0, res=0):
         """the record of the launch SCN._conv_fwd makes for a prepacked weight; returns the new write offset"""
@@ -458,10 +465,16 @@ class _Pass(object):
         T = self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf)
         assert T or not res
         self._lw = T
+        sp = None if T else self.split_of(n_in, n_out, rows_in, rows_out, gather.vol, bf)
         if T:
             pack(buf, off, K_WIDE, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0,
                  0.0, rows_in, rows_out, 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), res, 0, p_pack, 0, 0, 0, 0,
                  0, 0)
+        elif sp:       # coarse map: the wide kernel cut into parts over the filter offsets (fp32 storage)
+            Ts, P = sp
+            ws = _hip.workspace("wide_split%d" % (xf & F_SIDE), P * rows_out * n_out, torch.float32, self.dev).data_ptr()
+            pack(buf, off, K_WSPLIT, xf, n_in, n_out, gather.vol, flags & 3, Ts, P, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
+                 0, 0, src, dst, gather.blocks_wide(Ts).data_ptr(), 0, 0, p_pack, ws, 0, 0, 0, 0, 0)
         else:
             pack(buf, off, K_CONV, (F_BF16 if bf else 0) | xf, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,
                  rows_in, rows_out, 0, 0, src, dst, gather.blocks().data_ptr(), p_w, 0, p_pack, 0, 0, 0, 0, 0, 0)

@@ -380,7 +380,7 @@ def device_time(torch, fn, group=4, reps=6, block_cycles=6000000):
     return sum(out) / len(out) * 1e-3
 
 
-def conv_kernel_table(torch, wl, dtype):
+def conv_kernel_table(torch, wl, dtype, max_rows=None):
     """Every convolution launch of one training step (forward, input-gradient, weight-gradient), grouped by
     (kernel kind, planes, rule book); each distinct instance re-launched alone and timed with HIP events.
     Returns rows sorted by their share of the step."""
@@ -405,6 +405,8 @@ def conv_kernel_table(torch, wl, dtype):
     dev = wl.dev
     for g in groups.values():
         ga, n_in, n_out, rows_in = g["gather"], g["n_in"], g["n_out"], g["rows_in"]
+        if max_rows is not None and ga.rows > max_rows:      # dev tools: the coarse scales only
+            continue
         R = float(sum(ga.rule_counts()))
         bf = g["dtype"] == torch.bfloat16
         fdt = torch.bfloat16 if bf else torch.float32
@@ -459,6 +461,16 @@ def conv_kernel_table(torch, wl, dtype):
                 def fn():
                     check(lib.aabr_conv_forward_wide(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks),
                                                      tile_rows, ga.vol, None, g["flags"] & 3, ptr(wpack), stream()))
+            elif SCN.wide_split(n_in, n_out, rows_in, ga.rows, ga.vol, bf):
+                Ts, P = SCN.wide_split(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
+                blocks = ga.blocks_wide(Ts)
+                scratch = torch.empty(P * ga.rows * n_out, device=dev)
+                check(lib.aabr_conv_pack_weights(ptr(w), ga.vol, n_in, n_out, tr_, ptr(wpack), stream()))
+
+                def fn():
+                    check(lib.aabr_conv_forward_wide_split(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks),
+                                                           Ts, ga.vol, None, g["flags"] & 3, ptr(wpack), None, P,
+                                                           ptr(scratch), stream()))
             else:
                 blocks = ga.blocks()
                 check(conv(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks), ga.vol, ptr(w), None,

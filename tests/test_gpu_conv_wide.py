@@ -478,3 +478,82 @@ def test_wide_write_out_backward_statistics_feed_batchnorm_backward(force_wide, 
         np.testing.assert_allclose(got[0], want[0], rtol=1e-6, atol=1e-6)
     finally:
         _hip.set_knob("BN_SMALL", None)
+
+
+@pytest.mark.parametrize("nIn,nOut,npts,parts", [(128, 128, 700, 0), (256, 256, 300, 0), (128, 64, 60, 0), (64, 128, 1500, 5),
+                                                 (256, 128, 40, 27)])
+def test_wide_offset_split_matches_oracle_and_unsplit(nIn, nOut, npts, parts):
+    """aabr_conv_forward_wide_split (coarse maps: every (tile, slab) item cut into parts over the filter offsets,
+    partial tiles summed in part order): forward, transposed (input-gradient form), with bias and residual, against the
+    oracle (SCN/CPU/Convolution.cpp:117-185) and against the 64-row-tile kernel; the same call twice gives the same
+    bits; the decision function picks it exactly where the wide kernel declines for lack of workgroups."""
+    import _hip
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(nIn * 3 + nOut + npts)
+    coords, _ = _scene(rng, npts, (9, 8, 4), 2, 1)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    assert lib.aabr_conv_wide_tile_rows(nIn, nOut, V, V, vol) == 0          # too few workgroups for the unsplit form
+    v = lib.aabr_conv_wide_split(nIn, nOut, V, V, vol)
+    assert v, "the split form should take this launch"
+    T, P = v & 0xffff, v >> 16
+    assert T == 64 and 2 <= P <= vol and ((V + 63) // 64) * (nOut // 64) * P >= 256
+    if parts:
+        P = parts
+    il = O.input_layer(coords, np.zeros((npts, 1), np.float32), 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    W = (rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32)
+    f = rng.standard_normal((V, nIn)).astype(np.float32)
+    b = rng.standard_normal(nOut).astype(np.float32)
+    r = rng.standard_normal((V, nOut)).astype(np.float32)
+    Wd, fd, bd, rd = _t(W), _t(f), _t(b), _t(r)
+    wp = torch.empty(lib.aabr_conv_wpack_floats(vol, nIn, nOut), device=DEV)
+    check(lib.aabr_conv_pack_weights(ptr(Wd), vol, nIn, nOut, 0, ptr(wp), stream()))
+    scratch = torch.empty(int(lib.aabr_conv_wide_split_scratch_floats(V, nOut, P)), device=DEV)
+    blocks = ga.blocks_wide(T)
+    out = torch.empty((V, nOut), device=DEV)
+    check(lib.aabr_conv_forward_wide_split(ptr(fd), nIn, V, ptr(out), nOut, V, ptr(blocks), T, vol, ptr(bd), 0, ptr(wp),
+                                           ptr(rd), P, ptr(scratch), stream()))
+    ref, _ = O.conv_fwd(f, W.reshape(vol, nIn, nOut), rb, V, b)
+    ref = ref + r
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * np.abs(f).max() * nIn)
+    out2 = torch.empty_like(out)
+    scratch.fill_(float("nan"))                                              # every part writes its whole partial tile
+    check(lib.aabr_conv_forward_wide_split(ptr(fd), nIn, V, ptr(out2), nOut, V, ptr(blocks), T, vol, ptr(bd), 0, ptr(wp),
+                                           ptr(rd), P, ptr(scratch), stream()))
+    assert torch.equal(out, out2)
+    # against the 64-row-tile kernel (other summation order over the offsets: fp32 rounding apart)
+    out3 = torch.empty_like(out)
+    wp3 = torch.empty_like(wp)
+    check(lib.aabr_conv_forward(ptr(fd), nIn, V, ptr(out3), nOut, V, ptr(ga.blocks()), vol, ptr(Wd), ptr(bd), 0, ptr(wp3),
+                                stream()))
+    np.testing.assert_allclose(got, (out3 + rd).cpu().numpy(), rtol=2e-5, atol=1e-5 * np.abs(ref).max())
+    # transposed form: d_in = d_out @ W[k]^T over the mirrored offsets
+    g = rng.standard_normal((V, nOut)).astype(np.float32)
+    wt = torch.empty(lib.aabr_conv_wpack_floats(vol, nOut, nIn), device=DEV)
+    check(lib.aabr_conv_pack_weights(ptr(Wd), vol, nOut, nIn, 1, ptr(wt), stream()))
+    vb = lib.aabr_conv_wide_split(nOut, nIn, V, V, vol)
+    assert vb
+    Tb, Pb = vb & 0xffff, vb >> 16
+    d_in = torch.empty((V, nIn), device=DEV)
+    sc2 = torch.empty(int(lib.aabr_conv_wide_split_scratch_floats(V, nIn, Pb)), device=DEV)
+    check(lib.aabr_conv_forward_wide_split(ptr(_t(g)), nOut, V, ptr(d_in), nIn, V, ptr(ga.blocks_wide(Tb)), Tb, vol, None, 3,
+                                           ptr(wt), None, Pb, ptr(sc2), stream()))
+    want, _, _ = O.conv_bwd(f, g, W.reshape(vol, nIn, nOut), rb)
+    np.testing.assert_allclose(d_in.cpu().numpy(), want, rtol=1e-4, atol=2e-6 * np.abs(g).max() * nOut)
+    # through the layer: the module dispatches the split form here
+    conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, False).to(DEV)
+    conv.weight.data.copy_(Wd)
+    xs = scn.SparseConvNetTensor()
+    xs.metadata, xs.spatial_size = x.metadata, x.spatial_size
+    xs.features = fd.clone().requires_grad_(True)
+    y = conv(xs)
+    assert lib.aabr_conv_last_variant().decode().endswith("split>")
+    ref0, _ = O.conv_fwd(f, W.reshape(vol, nIn, nOut), rb, V)
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref0, rtol=1e-4, atol=2e-6 * np.abs(f).max() * nIn)
+    y.features.backward(_t(g))
+    np.testing.assert_allclose(xs.features.grad.cpu().numpy(), want, rtol=1e-4, atol=2e-6 * np.abs(g).max() * nOut)

@@ -9,7 +9,8 @@ dt = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.
 wl = bench.Workload(scn, torch, dp, dev, dt, 0, 1, 1)
 for i in range(2):
     wl.step(i)
-rows = bench.conv_kernel_table(torch, wl, dt)
+mr = int(os.environ["AABR_TABLE_MAX_ROWS"]) if os.environ.get("AABR_TABLE_MAX_ROWS") else None   # coarse scales only
+rows = bench.conv_kernel_table(torch, wl, dt, mr)
 tot = sum(r["step_us"] for r in rows)
 print("total conv us/step %.0f over %d instances" % (tot, len(rows)))
 for r in rows:
