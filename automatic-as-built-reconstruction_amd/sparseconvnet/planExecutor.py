@@ -436,6 +436,7 @@ class _Pass(object):
             bk.append((tb.out, tb.inn if tb.inn is not None else tb.out, tb))
         self.books = bk
         self._wide = {}
+        self._tmp = []
 
     def wide_rows(self, n_in, n_out, rows_in, rows_out, vol, bf=False):
         key = (n_in, n_out, rows_in, rows_out, vol, bf)
@@ -472,7 +473,12 @@ class _Pass(object):
                  0, 0)
         elif sp:       # coarse map: the wide kernel cut into parts over the filter offsets (fp32 storage)
             Ts, P = sp
-            ws = _hip.workspace("wide_split%d" % (xf & F_SIDE), P * rows_out * n_out, torch.float32, self.dev).data_ptr()
+            # its own scratch per record: the list is launched later in ONE call, so a shared grow-only workspace could
+            # be reallocated under records already written (the allocator frees it in stream order once the pass's
+            # next list is built)
+            tmp = torch.empty(P * rows_out * n_out, dtype=torch.float32, device=self.dev)
+            self._tmp.append(tmp)
+            ws = tmp.data_ptr()
             pack(buf, off, K_WSPLIT, xf, n_in, n_out, gather.vol, flags & 3, Ts, P, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
                  0, 0, src, dst, gather.blocks_wide(Ts).data_ptr(), 0, 0, p_pack, ws, 0, 0, 0, 0, 0)
         else:
@@ -482,6 +488,7 @@ class _Pass(object):
 
     def forward(self):
         t, V = self.t, self.V
+        self._tmp = []
         offs, total = _offsets(t.fbufs, V, 1)
         self.arena = torch.empty(max(total, 1), dtype=torch.uint8, device=self.dev)
         self.stat = torch.empty(max(t.stat_floats, 1), dtype=torch.float32, device=self.dev)
@@ -576,6 +583,7 @@ class _Pass(object):
 
     def backward(self, gouts, need_dx):
         t, V, A = self.t, self.V, self.A
+        self._tmp = []
         gouts = [g.contiguous() if g is not None else None for g in gouts]
         bw = t.backward(tuple(g is not None for g in gouts), need_dx)
         gbufs, bops = bw["gbufs"], bw["ops"]

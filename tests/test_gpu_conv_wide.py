@@ -500,7 +500,7 @@ def test_wide_offset_split_matches_oracle_and_unsplit(nIn, nOut, npts, parts):
     v = lib.aabr_conv_wide_split(nIn, nOut, V, V, vol)
     assert v, "the split form should take this launch"
     T, P = v & 0xffff, v >> 16
-    assert T == 64 and 2 <= P <= vol and ((V + 63) // 64) * (nOut // 64) * P >= 256
+    assert T == 64 and 2 <= P <= vol and (P == vol or ((V + 63) // 64) * (nOut // 64) * P >= 256)
     if parts:
         P = parts
     il = O.input_layer(coords, np.zeros((npts, 1), np.float32), 4)
