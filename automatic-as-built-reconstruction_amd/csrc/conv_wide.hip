@@ -795,7 +795,9 @@ static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, flo
 // traffic for 28-35 TFLOP/s).  Split: P parts per (tile, slab), each sweeping vol / P filter offsets with the wide
 // kernel's economy (weights per offset in registers, gathered rows shared through LDS) into its own fp32 partial tile;
 // k_split_reduce sums the parts in part order -- fixed order, bit-reproducible -- and applies bias / residual / the
-// bf16 rounding.  Scratch: P x V_out x n_out floats.
+// bf16 rounding.  Scratch: P x V_out x n_out floats.  Measured on the bench's coarse rule books (profiles/r04_conv_split_ab.txt):
+// 128->128 at 5,565 rows 62 -> 53 us, 256->256 at 1,382 rows 83 -> 62 us, at 332 rows 47 -> 28 us; single stage buffer (three
+// workgroups per CU) over the double one: -10 %; below 8 (tile, slab) items the 16-column item kernel stays ahead.
 namespace aabr {
 template <bool BF>
 __global__ __launch_bounds__(256) void k_split_reduce(const float *__restrict__ parts, int nparts, int64_t n4, int co4,
@@ -835,7 +837,10 @@ extern "C" int aabr_conv_wide_split(int n_in, int n_out, int64_t rows_in, int64_
   const int T = 64;
   const int64_t items = ((V_out + T - 1) / T) * (n_out / 64);
   if (items >= 320) return 0;
-  int P = (int)((512 + items - 1) / items);
+  const int min_items = knob(K_SPLIT_MIN_ITEMS) == kKnobUnset ? 8 : knob(K_SPLIT_MIN_ITEMS);   // below: the 16-column item kernel wins
+  if (items < min_items) return 0;
+  const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 1024 : knob(K_SPLIT_TARGET);   // workgroups aimed at (measured 512 / 1024 / 1536)
+  int P = (int)((target + items - 1) / items);
   if (P > vol) P = vol;
   if (P > 32) P = 32;
   {                                                // tuning experiments only
@@ -876,22 +881,25 @@ extern "C" int aabr_conv_forward_wide_split(const float *in_feats, int n_in, int
   dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)((n_out / 64) * parts));
   const int flip = ((flags >> 1) & 1) | (knob(K_WIDE_PRIO) == 0 ? 0 : 2) | (parts << 8);
   const int kg = nkc >= 4 ? 4 : nkc;
-#define AABR_SPLIT_CS(KG)                                                                                              \
+  const int nbuf = knob(K_SPLIT_NBUF) == 2 ? 2 : 1;   // single stage buffer: three workgroups per CU (latency-bound launches)
+#define AABR_SPLIT_CS_N(KG, NB)                                                                                        \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          80 * 1024));                                                                  \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    g_last_variant = "k_conv_cs<" #KG ",0,2,split>";                                                                   \
-    hipLaunchKernelGGL((k_conv_cs<KG, 0, 2>), grid, dim3(256),                                                         \
-                       (size_t)((tile_rows + 1) * kWS + 2 * 2 * 16 * KG * 32) * sizeof(float), st, in_feats, n_in,      \
+    g_last_variant = "k_conv_cs<" #KG ",0," #NB ",split>";                                                             \
+    hipLaunchKernelGGL((k_conv_cs<KG, 0, NB>), grid, dim3(256),                                                        \
+                       (size_t)((tile_rows + 1) * kWS + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_feats, n_in,     \
                        in_bytes, scratch, n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes,                \
                        (const float *)nullptr, tile_rows, (const float *)nullptr, (double *)nullptr, BnBwdStats{});     \
   } while (0)
+#define AABR_SPLIT_CS(KG) do { if (nbuf == 1) AABR_SPLIT_CS_N(KG, 1); else AABR_SPLIT_CS_N(KG, 2); } while (0)
   if (kg == 2) AABR_SPLIT_CS(2); else if (kg == 3) AABR_SPLIT_CS(3); else AABR_SPLIT_CS(4);
 #undef AABR_SPLIT_CS
+#undef AABR_SPLIT_CS_N
   const int64_t n4 = V_out * n_out / 4;
   hipLaunchKernelGGL((k_split_reduce<false>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, scratch, parts, n4,
                      n_out / 4, bias, residual, (void *)out_feats);
