@@ -233,10 +233,11 @@ AABR_HD double clip_edges_inside(const double *ax, const double *ay, const doubl
   return sum;
 }
 
-AABR_HD double clip_iou_exact(const float *r1, const float *r2) {
+// the same on corners computed ahead (clip_corners): the NMS mask kernel computes a box's corners once per workgroup
+AABR_HD double clip_iou_corners(const double *ax0, const double *ay0, const double *bx0, const double *by0, double area_a,
+                                double area_b) {
   double ax[4], ay[4], bx[4], by[4];
-  clip_corners(r1, ax, ay);
-  clip_corners(r2, bx, by);
+  for (int i = 0; i < 4; ++i) { ax[i] = ax0[i]; ay[i] = ay0[i]; bx[i] = bx0[i]; by[i] = by0[i]; }
   // the corner order is clockwise for positive sizes (inner side = right of each edge); a rectangle given with a
   // negative size is turned round so that both run the same way
   double sa = 0.0, sb = 0.0;
@@ -251,8 +252,15 @@ AABR_HD double clip_iou_exact(const float *r1, const float *r2) {
   for (int i = 0; i < 4; ++i) { ax[i] -= ox; ay[i] -= oy; bx[i] -= ox; by[i] -= oy; }
   const double twice = clip_edges_inside(ax, ay, bx, by, false) + clip_edges_inside(bx, by, ax, ay, true);
   const double inter = 0.5 * fabs(twice);
-  const double uni = fabs((double)r1[2] * (double)r1[3]) + fabs((double)r2[2] * (double)r2[3]) - inter;
+  const double uni = area_a + area_b - inter;
   return uni > 0.0 ? inter / uni : 0.0;
+}
+
+AABR_HD double clip_iou_exact(const float *r1, const float *r2) {
+  double ax[4], ay[4], bx[4], by[4];
+  clip_corners(r1, ax, ay);
+  clip_corners(r2, bx, by);
+  return clip_iou_corners(ax, ay, bx, by, fabs((double)r1[2] * (double)r1[3]), fabs((double)r2[2] * (double)r2[3]));
 }
 
 // pair value of rotate_iou_gpu_eval: iou[n][k] for box n, query k

@@ -223,6 +223,81 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float *__restrict__ boxe
   if (lane == 0) mask[i * colblocks + cb] = bits;
 }
 
+// Rotated boxes, round 4.  The decision of the reference's loop is `pre-filter matrix > 0 and exact polygon IoU >=
+// thresh` (spconv 1.x behind nms_cpu.py:43); evaluated in that order every overlapping pair pays both the numba-style
+// IoU (vertex collection + sort, ~4x the cost of the clip) and the clip.  Here: a workgroup owns 16 rows x 64 columns;
+// the corners of its 80 boxes are computed ONCE (fp64 sin / cos per box instead of per pair) and shared through LDS;
+// per pair: circumscribed circles apart -> no hit; else the exact clip (registers only); only a pair that WOULD suppress
+// (clip >= thresh: a few per cent) evaluates the pre-filter value.  Same verdicts as the order above.
+constexpr int kNmsRows = 16;
+__global__ __launch_bounds__(256) void k_nms_mask_rot(const float *__restrict__ boxes, int64_t n, float thresh,
+                                                      int only_xy, int colblocks,
+                                                      unsigned long long *__restrict__ mask) {
+  __shared__ double s_cx[64 + kNmsRows][4], s_cy[64 + kNmsRows][4];
+  __shared__ float s_b[64 + kNmsRows][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cb = blockIdx.y;
+  const int64_t i0 = (int64_t)blockIdx.x * kNmsRows;
+  if (cb < (int)(i0 >> 6)) {                           // wholly below the diagonal: a lower-scored box suppresses nothing
+    if (threadIdx.x < kNmsRows && i0 + threadIdx.x < n) mask[(i0 + threadIdx.x) * colblocks + cb] = 0ull;
+    return;
+  }
+  if (threadIdx.x < 64 + kNmsRows) {                   // slots 0..63: the column boxes; 64..79: the row boxes
+    const int64_t q = threadIdx.x < 64 ? (int64_t)cb * 64 + threadIdx.x : i0 + (threadIdx.x - 64);
+    float b7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (q < n)
+#pragma unroll
+      for (int d = 0; d < 7; ++d) b7[d] = boxes[q * 7 + d];
+    const float r5[5] = {b7[0], b7[1], b7[3], b7[4], b7[6]};
+    double cx[4], cy[4];
+    clip_corners(r5, cx, cy);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s_cx[threadIdx.x][k] = cx[k]; s_cy[threadIdx.x][k] = cy[k]; }
+#pragma unroll
+    for (int d = 0; d < 7; ++d) s_b[threadIdx.x][d] = b7[d];
+  }
+  __syncthreads();
+  const int64_t j = (int64_t)cb * 64 + lane;
+  float c[7];
+#pragma unroll
+  for (int d = 0; d < 7; ++d) c[d] = s_b[lane][d];
+  double jx[4], jy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { jx[k] = s_cx[lane][k]; jy[k] = s_cy[lane][k]; }
+  const double area_j = fabs((double)c[3] * (double)c[4]);
+  const float rj = 0.5f * sqrtf(c[3] * c[3] + c[4] * c[4]);
+  for (int t = 0; t < kNmsRows / 4; ++t) {
+    const int rs = wave * (kNmsRows / 4) + t;
+    const int64_t i = i0 + rs;
+    if (i >= n) break;                                 // wave-uniform
+    bool hit = false;
+    if (cb >= (int)(i >> 6) && j < n && j > i) {
+      const float *b = s_b[64 + rs];
+      const float dx = b[0] - c[0], dy = b[1] - c[1];
+      const float ri = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
+      const float rr = (ri + rj) * 1.0001f + 1e-6f;    // conservative: never rejects a pair the clip would count
+      if (dx * dx + dy * dy <= rr * rr) {
+        double ix[4], iy[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ix[k] = s_cx[64 + rs][k]; iy[k] = s_cy[64 + rs][k]; }
+        const double e = clip_iou_corners(ix, iy, jx, jy, fabs((double)b[3] * (double)b[4]), area_j);
+        if (e >= (double)thresh) {
+          const float bi[5] = {b[0], b[1], b[3], b[4], b[6]};
+          const float bj[5] = {c[0], c[1], c[3], c[4], c[6]};
+          float v = iou_eval_entry(bi, bj, -1);        // matrix entry [i][j] of boxes_iou_3d(dets, dets)
+          if (!only_xy) {
+            const float z0 = b[2], z1 = b[2] + b[5], a0 = c[2], a1 = c[2] + c[5];
+            v = v * ((fminf(a1, z1) - fmaxf(a0, z0)) / (fmaxf(a1, z1) - fminf(a0, z0)));
+          }
+          hit = v > 0.0f;
+        }
+      }
+    }
+    const unsigned long long bits = __ballot(hit);
+    if (lane == 0) mask[i * colblocks + cb] = bits;
+  }
+}
+
 // Greedy scan.  remv words live in LDS (colblocks <= 8192 -> n <= 524288).
 __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long *__restrict__ mask, int64_t n,
                                                   int colblocks, int64_t post_max,
@@ -408,6 +483,10 @@ static int nms_sorted_impl(const float *boxes, int64_t n, float thresh, int only
   if (!boxes || !mask || !keep) { set_error("%s: null pointer", fn); return AABR_EINVAL; }
   int64_t colblocks = ceil_div(n, 64);
   if (colblocks > 8192) { set_error("%s: n too large (max 524288)", fn); return AABR_EINVAL; }
+  if constexpr (KIND == 0)
+    hipLaunchKernelGGL(k_nms_mask_rot, dim3((unsigned)ceil_div(n, kNmsRows), (unsigned)colblocks), dim3(256), 0, st,
+                       boxes, n, thresh, only_xy, (int)colblocks, reinterpret_cast<unsigned long long *>(mask));
+  else
   hipLaunchKernelGGL((k_nms_mask<KIND>), dim3((unsigned)ceil_div(n, 4), (unsigned)colblocks), dim3(256), 0, st,
                      boxes, n, thresh, only_xy, (int)colblocks, (unsigned long long *)mask);
   hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), (size_t)colblocks * 8, st,
