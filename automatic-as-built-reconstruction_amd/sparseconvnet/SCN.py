@@ -277,6 +277,13 @@ scatter_variant = int(_os.environ.get("AABR_SCATTER", "2"))
 SCATTER_MIN_POINTS = int(_os.environ.get("AABR_SCATTER_MIN_POINTS", "32768"))
 scatter_stats = {"variant0": 0, "variant1": 0, "variant2": 0, "redone": 0}
 
+def derived_cap(E):
+    """slots of a derived (strided-level) grid that receives at most E keys: 1.5 E rounded up to a power of two --
+    worst-case load 2/3, typical 0.15-0.35 (a level keeps a half to a sixth of the sites it is derived from).  Round 3
+    used 2 E: every derived grid of a pass was as large as its base grid and was cleared every step."""
+    return _hip.next_pow2(max(64, E + (E + 1) // 2))
+
+
 MAX_SAMPLES = 61     # per-sample offsets that ride along with a grid's site-count read (64-word rows)
 
 
@@ -709,7 +716,7 @@ class Metadata_3(object):
         gi = self.grids[_key(in_spatial)]
         dev = gi.keys.device
         E = gi.V
-        cap = _hip.next_pow2(2 * E)
+        cap = derived_cap(E)
         nblk = (max(E, 1) + 255) // 256
         metas = torch.empty((max(len(specs), 1), _hip.META_WORDS), dtype=torch.int32, device=dev)
         ext = torch.empty((max(len(specs), 1), MAX_SAMPLES + 3), dtype=torch.int32, device=dev)
@@ -770,7 +777,7 @@ class Metadata_3(object):
             for a, b in zip(fs, st):
                 maxout *= (a + b - 1) // b
             E = gi.V * maxout
-            cap = _hip.next_pow2(2 * E)
+            cap = derived_cap(E)
             nblk = (max(E, 1) + 255) // 256
             keys = torch.empty(2 * cap, dtype=torch.int64, device=dev)   # cap 16-byte entries {key, first, val}
             vals = None

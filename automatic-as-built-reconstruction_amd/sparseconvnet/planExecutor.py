@@ -76,6 +76,9 @@ on_grads_ready = None
 # tests: a list here receives every _Pass that runs (its arena holds every activation of the pass --
 # `_Pass.bn_outputs()`); None in production
 debug_passes = None
+# a pass that will not be differentiated packs its activations by liveness (AABR_PLAN_PACK_ARENA=0: one slot each, as
+# the training pass needs them)
+pack_inference_arena = os.environ.get("AABR_PLAN_PACK_ARENA", "1") != "0"
 
 
 class Unsupported(Exception):
@@ -486,10 +489,80 @@ class _Pass(object):
                  rows_in, rows_out, 0, 0, src, dst, gather.blocks().data_ptr(), p_w, 0, p_pack, 0, 0, 0, 0, 0, 0)
         return off + 176
 
-    def forward(self):
+    def _live_offsets(self):
+        """arena offsets for a pass nobody will differentiate (torch.no_grad): a buffer's bytes are handed on once its
+        last reader has been recorded -- first fit over a free list, in record order (one stream) -- instead of every
+        activation of the network living until the pass object dies.  Returns (offsets, total, total without reuse)."""
+        t, V = self.t, self.V
+        fbufs, books, fuse = t.fbufs, self.books, t.fuse
+        steps, skip = [], set()            # (buffers read, buffer written) per emitted record
+        for op, xf in t.emit:
+            if xf & F_SIDE:
+                return None
+            kind = op[0]
+            if kind == "conv":
+                x, y, lvl, lo, n_in, n_out, book, side = op[1:9]
+                fz = fuse.get(id(op))
+                if fz is not None and V[lo] and self.wide_rows(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
+                    add_op, other = fz
+                    skip.add(id(add_op))
+                    steps.append(((x, other), add_op[3]))
+                else:
+                    steps.append(((x,), y))
+            elif kind == "add":
+                if id(op) not in skip:
+                    steps.append(((op[1], op[2]), op[3]))
+            else:
+                steps.append(((op[1],), op[2]))
+        last = {}
+        for i, (rd, _) in enumerate(steps):
+            for b in rd:
+                last[b] = i
+        for b, _ in t.outs:
+            last[b] = len(steps)
+        size = lambda b: (V[fbufs[b][0]] * fbufs[b][1] * _es(fbufs[b][2]) + _ALIGN - 1) // _ALIGN * _ALIGN
+        offs, free, top = [0] * len(fbufs), [], 0      # free: [offset, bytes], sorted by offset
+        dying = {}
+        for b, i in last.items():
+            dying.setdefault(i, []).append(b)
+        for i, (rd, wr) in enumerate(steps):
+            need = size(wr)
+            for f in free:                               # first fit
+                if f[1] >= need:
+                    offs[wr] = f[0]
+                    f[0] += need
+                    f[1] -= need
+                    break
+            else:
+                offs[wr] = top
+                top += need
+            free = [f for f in free if f[1] > 0]
+            if wr not in last:                           # written, never read, not an output: free at once
+                dying.setdefault(i, []).append(wr)
+            for b in dying.get(i, ()):                   # read for the last time by this record
+                if b == 0:
+                    continue                             # the graph input is not in the arena
+                free.append([offs[b], size(b)])
+            free.sort()
+            merged = []
+            for f in free:                               # coalesce neighbours
+                if merged and merged[-1][0] + merged[-1][1] == f[0]:
+                    merged[-1][1] += f[1]
+                else:
+                    merged.append(f)
+            free = merged
+        return offs, top, sum(size(b) for b in range(1, len(fbufs)))
+
+    def forward(self, keep=True):
+        """`keep` False (no autograd): the arena is packed by liveness (`_live_offsets`)"""
         t, V = self.t, self.V
         self._tmp = []
-        offs, total = _offsets(t.fbufs, V, 1)
+        packed = None if keep else self._live_offsets()
+        if packed is not None:
+            offs, total, flat = packed
+            stats["arena_bytes_packed"], stats["arena_bytes_flat"] = total, flat
+        else:
+            offs, total = _offsets(t.fbufs, V, 1)
         self.arena = torch.empty(max(total, 1), dtype=torch.uint8, device=self.dev)
         self.stat = torch.empty(max(t.stat_floats, 1), dtype=torch.float32, device=self.dev)
         base, sbase = self.arena.data_ptr(), self.stat.data_ptr()
@@ -834,7 +907,7 @@ def run_fpn(net, net1):
     if train:
         feats = _GraphFunction.apply(ps, x, *tpl.params)
     else:
-        feats = ps.forward()
+        feats = ps.forward(keep=not pack_inference_arena)
     stats["passes"] += 1
     res = []
     for (b, sp), f in zip(tpl.outs, feats):

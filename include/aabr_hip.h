@@ -145,7 +145,7 @@ int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t
  * Convolution_InputSgToRulesAndOutputSg (Metadata.cpp:484-510, ConvolutionRules.h:11-34,
  * RectangularRegions.h:95-119).  Creates the output grid (sites numbered in first-seen order
  * over input rows ascending, then output-region order) and reports V_out in meta[0].
- *   out_keys: out_cap 16-byte grid entries as in aabr_input_layer_sites;
+ *   out_keys: out_cap 16-byte grid entries as in aabr_input_layer_sites, out_cap a power of two >= 1.5 E;
  *   scratch int32 [E + 4*ceil(E/256) + 16], E = V_in * max_out_per_in,
  *   max_out_per_in = prod(ceil(size/stride)); out_site_coords int32 [E,4].
  * size, stride <= 64 per axis; for size == stride (one output site per input site) up to 65536, so that a chain of

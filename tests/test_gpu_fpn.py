@@ -576,3 +576,34 @@ def test_rccl_world_size_1_bucketed_equals_flat():
     assert out["equal"] and out["reproducible"], out
     assert out["buckets"] == 5 and out["launched_during_backward"] == 3 and out["bucket_bytes"] > 70e6
     assert out["hook_disarmed"] and out["grads_are_means"]
+
+
+def test_inference_pass_packs_its_arena_by_liveness():
+    """VERDICT r3 housekeeping: a pass nobody differentiates (torch.no_grad) hands a buffer's bytes on after its last
+    reader instead of keeping every activation of the network; same bits as the unpacked pass, a fraction of the bytes"""
+    from sparseconvnet import planExecutor
+    for fdt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(12)
+        net = _fpn(feature_dtype=fdt).to(DEV)
+        net.compiled_graph = True
+        net.eval()
+        locs, feats = S.make_batch(2, 30000, 51, 20)
+        l, f = _t(locs), _t(feats)
+        outs = {}
+        for packed in (False, True):
+            planExecutor.pack_inference_arena = packed
+            planExecutor.stats.pop("arena_bytes_packed", None)
+            try:
+                with torch.no_grad():
+                    rpn, roi = net([l, f])
+                    torch.cuda.synchronize()
+                    outs[packed] = [m.features.clone() for m in rpn + roi]
+            finally:
+                planExecutor.pack_inference_arena = True
+            if packed:
+                pk, fl = planExecutor.stats["arena_bytes_packed"], planExecutor.stats["arena_bytes_flat"]
+                assert 0 < pk < 0.35 * fl, (pk, fl)
+            else:
+                assert "arena_bytes_packed" not in planExecutor.stats
+        for a, b in zip(outs[False], outs[True]):
+            assert torch.equal(a, b)
