@@ -482,7 +482,7 @@ def test_wide_write_out_backward_statistics_feed_batchnorm_backward(force_wide, 
 
 @pytest.mark.parametrize("nIn,nOut,npts,parts", [(128, 128, 700, 0), (256, 256, 600, 0), (128, 64, 600, 0), (64, 128, 1500, 5),
                                                  (256, 128, 700, 27)])
-def test_wide_offset_split_matches_oracle_and_unsplit(nIn, nOut, npts, parts):
+def test_wide_offset_split_matches_oracle_and_unsplit(request, nIn, nOut, npts, parts):
     """aabr_conv_forward_wide_split (coarse maps: every (tile, slab) item cut into parts over the filter offsets,
     partial tiles summed in part order): forward, transposed (input-gradient form), with bias and residual, against the
     oracle (SCN/CPU/Convolution.cpp:117-185) and against the 64-row-tile kernel; the same call twice gives the same
@@ -497,6 +497,8 @@ def test_wide_offset_split_matches_oracle_and_unsplit(nIn, nOut, npts, parts):
     tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
     ga, V, vol = tb.out, tb.V_out, tb.vol
     assert lib.aabr_conv_wide_tile_rows(nIn, nOut, V, V, vol) == 0          # too few workgroups for the unsplit form
+    _hip.set_knob("SPLIT_MIN_ITEMS", 1)       # (below 8 (tile, slab) items the dispatch prefers the 16-column item kernel)
+    request.addfinalizer(lambda: _hip.set_knob("SPLIT_MIN_ITEMS", None))
     v = lib.aabr_conv_wide_split(nIn, nOut, V, V, vol)
     assert v, "the split form should take this launch"
     T, P = v & 0xffff, v >> 16
