@@ -271,6 +271,15 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
     if (n_pending) hipStreamSynchronize(g_side.stream);
     return rc;
   };
+  // the caller's stream waits for everything issued on the second stream so far; every error leaves through fail()
+  auto join_side = [&]() -> int {
+    hipEvent_t e = g_side.get(n_events++);
+    if (e == nullptr) { aabr::set_error("aabr_plan_run: event creation failed"); return AABR_ELAUNCH; }
+    hipError_t he = hipEventRecord(e, g_side.stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(main_stream, e, 0);
+    if (he != hipSuccess) { aabr::set_error("aabr_plan_run: HIP error %s", hipGetErrorString(he)); return AABR_ELAUNCH; }
+    return AABR_OK;
+  };
   auto flush = [&]() -> int {
     if (deferred.empty()) return AABR_OK;
     if (!g_side.stream) {
@@ -301,10 +310,8 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
       const int rc = flush();
       if (rc != AABR_OK) return fail(rc);
       if (n_pending) {
-        hipEvent_t e = g_side.get(n_events++);
-        AABR_CHECK_ARG(e != nullptr, "event creation failed");
-        AABR_CHECK_HIP(hipEventRecord(e, g_side.stream));
-        AABR_CHECK_HIP(hipStreamWaitEvent(main_stream, e, 0));
+        const int jr = join_side();
+        if (jr != AABR_OK) return fail(jr);
         n_pending = 0;
       }
     }
@@ -324,10 +331,8 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
     if (rc != AABR_OK) return fail(rc);
   }
   if (n_pending) {
-    hipEvent_t e = g_side.get(n_events++);
-    AABR_CHECK_ARG(e != nullptr, "event creation failed");
-    AABR_CHECK_HIP(hipEventRecord(e, g_side.stream));
-    AABR_CHECK_HIP(hipStreamWaitEvent(main_stream, e, 0));
+    const int jr = join_side();
+    if (jr != AABR_OK) return fail(jr);
   }
   return AABR_OK;
 }
@@ -404,23 +409,46 @@ __global__ void k_mailbox_post(const uint32_t *__restrict__ src, int words, uint
 }
 } // namespace aabr
 
+// capacity of every live mailbox: aabr_mailbox_post refuses a payload larger than what aabr_mailbox_create allocated
+// (the posting kernel writes into host memory: an oversized post would run past the block)
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_mb_mu;
+static std::unordered_map<void *, int64_t> g_mb_cap;
+
 extern "C" int aabr_mailbox_create(int64_t payload_bytes, void **box) {
   AABR_CHECK_ARG(box && payload_bytes > 0 && payload_bytes <= (1 << 20) && (payload_bytes & 3) == 0, "payload: 4..1 MiB, % 4");
   void *p = nullptr;
   AABR_CHECK_HIP(hipHostMalloc(&p, (size_t)payload_bytes + 8, hipHostMallocCoherent | hipHostMallocMapped));
   memset(p, 0, (size_t)payload_bytes + 8);
+  {
+    std::lock_guard<std::mutex> lk(g_mb_mu);
+    g_mb_cap[p] = payload_bytes;
+  }
   *box = p;
   return AABR_OK;
 }
 
 extern "C" int aabr_mailbox_destroy(void *box) {
-  if (box) AABR_CHECK_HIP(hipHostFree(box));
+  if (box) {
+    {
+      std::lock_guard<std::mutex> lk(g_mb_mu);
+      g_mb_cap.erase(box);
+    }
+    AABR_CHECK_HIP(hipHostFree(box));
+  }
   return AABR_OK;
 }
 
 extern "C" int aabr_mailbox_post(const void *src, int64_t bytes, void *box, uint32_t seq, void *stream_) {
   AABR_CHECK_ARG(src && box && bytes > 0 && (bytes & 3) == 0 && ((uintptr_t)src & 3) == 0, "payload");
   AABR_CHECK_ARG(seq != 0, "sequence numbers start at 1 (a fresh mailbox reads 0)");
+  {
+    std::lock_guard<std::mutex> lk(g_mb_mu);
+    auto it = g_mb_cap.find(box);
+    AABR_CHECK_ARG(it != g_mb_cap.end(), "not a mailbox of aabr_mailbox_create (or already destroyed)");
+    AABR_CHECK_ARG(bytes <= it->second, "payload larger than the mailbox was created for");
+  }
   void *dbox = nullptr;
   AABR_CHECK_HIP(hipHostGetDevicePointer(&dbox, box, 0));
   hipLaunchKernelGGL(k_mailbox_post, dim3(1), dim3(256), 0, (hipStream_t)stream_, (const uint32_t *)src, (int)(bytes / 4),

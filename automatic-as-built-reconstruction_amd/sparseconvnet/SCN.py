@@ -462,7 +462,11 @@ class Metadata_3(object):
         event on the consumer stream for each of the ~200 geometry tensors of a pass -- 200 marker packets between two
         training steps, measured as 1.07 ms of idle main stream per 14.4 ms step (tools/tools_step_timeline.py,
         profiles/r03_step_timeline.txt).  Instead the tensors are kept until this object dies, then parked with ONE
-        event recorded on the consumer stream and dropped when that event has passed (`_reap_handed_over`)."""
+        event recorded on the consumer stream and dropped when that event has passed (`_reap_handed_over`).
+        Everything that enqueues reads of this geometry on `consumer` holds THIS object until it has enqueued them --
+        the SparseConvNetTensors of the pass, the compiled `_Pass` (planExecutor: `ps.md`, kept by the autograd node
+        until its backward list is out) and every per-layer Function ctx (`ctx.input_metadata`) -- so the parking event
+        recorded in __del__ lies behind the last such read."""
         self._handed_over = (consumer, self.device_tensors())
 
     def __del__(self):

@@ -293,6 +293,7 @@ class FPN_Net(torch.nn.Module):
         inp_layer.prepare(coords, dev, stream)
         src, ver, c64, md = inp_layer._prepared[-1]
         from . import SCN
+        SCN._reap_handed_over()      # geometry of earlier passes whose parking event has passed (also reaped by forward)
         with torch.cuda.stream(stream):
             md.inputLayerFinish()
             stub = scn.SparseConvNetTensor(None, md, inp_layer.spatial_size)
