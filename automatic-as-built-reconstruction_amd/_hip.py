@@ -20,6 +20,7 @@ _f32p = C.POINTER(C.c_float)
 
 _SIGS = {
     "aabr_version": (C.c_int, []),
+    "aabr_build_flags": (C.c_int, []),
     "aabr_last_error": (C.c_char_p, []),
     "aabr_set_knob": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "aabr_quantize_points": (C.c_int, [_vp, _i32, _i64, C.c_double, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),

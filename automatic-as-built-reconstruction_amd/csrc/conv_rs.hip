@@ -55,6 +55,7 @@ static inline int64_t rs_words(int64_t V, int vol, int U) {
   return nu * (kRsHdr + U + (int64_t)vol * 4 * kRsSI * 16);
 }
 
+#ifdef AABR_DEV   // the row-stationary kernels are an A/B experiment (measured slower): `make DEV=1` builds only
 __global__ __launch_bounds__(256) void k_build_rs(const int32_t *__restrict__ table, int64_t V, int vol, int U,
                                                   int32_t *__restrict__ words) {
   __shared__ unsigned long long s_key[kRsMaxU];
@@ -386,12 +387,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_rsq(
   }
 }
 
+#endif  // AABR_DEV
 } // namespace aabr
 using namespace aabr;
 
 extern "C" int64_t aabr_rs_words(int64_t V, int vol, int unit_rows) { return rs_words(V, vol, unit_rows); }
 
 extern "C" int aabr_build_rs(const int32_t *table, int64_t V, int vol, int unit_rows, int32_t *words, void *stream_) {
+#ifndef AABR_DEV
+  (void)table; (void)V; (void)vol; (void)unit_rows; (void)words; (void)stream_;
+  aabr::set_error("aabr_build_rs: the row-stationary kernels exist in a `make DEV=1` build only (aabr_build_flags)");
+  return AABR_EINVAL;
+#else
   AABR_CHECK_ARG(V >= 0 && vol > 0 && vol <= kRsMaxVol, "bad sizes (vol <= 32)");
   AABR_CHECK_ARG(unit_rows >= 16 && unit_rows <= kRsMaxU && (unit_rows & 15) == 0, "unit_rows: multiple of 16, <= 256");
   if (V == 0) return AABR_OK;
@@ -400,10 +407,12 @@ extern "C" int aabr_build_rs(const int32_t *table, int64_t V, int vol, int unit_
   hipLaunchKernelGGL(k_build_rs, dim3(nu), dim3(256), 0, (hipStream_t)stream_, table, V, vol, unit_rows, words);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
+#endif
 }
 
 // unit size for V_out rows: the number of units is a multiple of the workgroups the chip runs at once (one per
 // CU and slab), so every workgroup gets the same number of units; a unit holds at most 256 rows (16 groups)
+#ifdef AABR_DEV
 static int rs_unit(int64_t V_out, int slabs, int umax) {
   const int64_t wgs = 256 / slabs > 0 ? 256 / slabs : 1;
   int64_t n = (V_out + umax - 1) / umax;
@@ -412,9 +421,14 @@ static int rs_unit(int64_t V_out, int slabs, int umax) {
   u = (u + 15) & ~15ll;
   return (int)(u < 32 ? 32 : u);
 }
+#endif
 
 // 0: not for this launch; otherwise the unit size (rows) of the stream aabr_conv_forward_rs_bf16 wants
 extern "C" int aabr_conv_rs_unit_rows(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
+#ifndef AABR_DEV
+  (void)n_in; (void)n_out; (void)rows_in; (void)V_out; (void)vol;
+  return 0;                                  // never dispatched: the kernels are not in this build
+#else
   if ((n_in != 64 && n_in != 128) || n_out <= 0 || (n_out & 63) || vol <= 0 || vol >= kRsHdr) return 0;
   if (rows_in <= 0 || V_out <= 0 || rows_in * n_in * 2 >= (1ll << 31) - 4096) return 0;
   if ((int64_t)vol * n_in * n_out * 2 >= (1ll << 31)) return 0;
@@ -434,11 +448,18 @@ extern "C" int aabr_conv_rs_unit_rows(int n_in, int n_out, int64_t rows_in, int6
   // for the LDS-tile kernel -- one wave per SIMD and role with a barrier per step serialises gather latency, LDS
   // reads, weight loads and MFMAs instead of overlapping them.  Kept behind AABR_CONV_RS=1 for the A/B and the tests.
   return U;
+#endif
 }
 
 extern "C" int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
                                          int n_out, int64_t V_out, const int32_t *rs_stream, int unit_rows, int vol,
                                          const float *bias, int flags, const uint16_t *wpack, void *stream_) {
+#ifndef AABR_DEV
+  (void)in_feats; (void)n_in; (void)rows_in; (void)out_feats; (void)n_out; (void)V_out; (void)rs_stream; (void)unit_rows;
+  (void)vol; (void)bias; (void)flags; (void)wpack; (void)stream_;
+  aabr::set_error("aabr_conv_forward_rs_bf16: the row-stationary kernels exist in a `make DEV=1` build only");
+  return AABR_EINVAL;
+#else
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG((n_in == 64 || n_in == 128) && n_out > 0 && (n_out & 63) == 0, "plane counts: n_in 64|128, n_out % 64");
   AABR_CHECK_ARG(vol > 0 && vol < kRsHdr && V_out >= 0 && rows_in >= 0, "bad sizes (vol <= 31)");
@@ -478,4 +499,5 @@ extern "C" int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int
 #undef AABR_RS_LAUNCH
   AABR_CHECK_LAUNCH();
   return AABR_OK;
+#endif
 }

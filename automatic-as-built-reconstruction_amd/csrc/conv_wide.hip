@@ -132,8 +132,11 @@ struct BnBwdStats {
 // are <= 2^-25 |a w|, below the rounding of an fp32 FMA chain) with v_mfma_f32_16x16x32_bf16: 6 x 16 cycles per 16 x 16
 // x 32 block instead of 8 x 32 cycles of v_mfma_f32_16x16x4_f32 -- 2.7x the matrix rate at fp32 accuracy.  KG counts
 // 64-channel chunks as for BF; rows are gathered and written in fp32.
-template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2, bool X3 = false>
-__global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
+// RING (fp32, experiment behind the WIDE_OCC4 knob): the B operands of a pair leave LDS one 32-channel chunk ahead of
+// their MFMAs through a two-slot register ring instead of all at once (16 registers instead of 64), so that the kernel
+// fits 128 registers = FOUR waves per SIMD; with 80-row tiles (37 KiB of LDS) four workgroups share a CU.
+template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2, bool X3 = false, bool RING = false>
+__global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
@@ -401,6 +404,37 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
                                                                      __builtin_bit_cast(bf16x8w, b1[TA[t]][c]), accB[cb], 0, 0, 0);
                 }
           }
+        } else if constexpr (RING) {
+          u32x4 ra[2][2];
+          auto ld = [&](int sidx, int slot) {
+            const float *base = sidx < KG ? sa : sb;
+            const int c = sidx < KG ? sidx : sidx - KG;
+            ra[slot][0] = *reinterpret_cast<const u32x4 *>(base + (((c * 8 + g * 2) ^ (c16 & SWZ)) << 2));
+            ra[slot][1] = *reinterpret_cast<const u32x4 *>(base + (((c * 8 + g * 2 + 1) ^ (c16 & SWZ)) << 2));
+          };
+          ld(0, 0);
+#pragma unroll
+          for (int sidx = 0; sidx < 2 * KG; ++sidx) {
+            if (sidx + 1 < 2 * KG) ld(sidx + 1, (sidx + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int c = sidx < KG ? sidx : sidx - KG;
+            if (sidx < KG) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[0][0][c][t]), bcf_(ra[sidx & 1][0][t]), accA[0], 0, 0, 0);
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[0][0][c][t]), bcf_(ra[sidx & 1][1][t]), accA[0], 0, 0, 0);
+            } else if (e0.hb) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                accB[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[0][0][c][t]), bcf_(ra[sidx & 1][0][t]), accB[0], 0, 0, 0);
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                accB[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[0][0][c][t]), bcf_(ra[sidx & 1][1][t]), accB[0], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         } else {
         // all of the pair's B operands leave LDS before the first MFMA (counted lgkmcnt waits follow)
         u32x4 a0[KG], a1[KG], b0[KG], b1[KG];
@@ -501,9 +535,20 @@ __global__ __launch_bounds__(256, (NBUF == 2 || X3) ? 2 : 3) void k_conv_cs(cons
       }
       gs = gs + 1 == NSET ? 0 : gs + 1;
     };
-    WReg wA, wB;
+    WReg wA;
     int k = pp[0].k;
     load_w(wA, k, kg);
+    if constexpr (RING) {                  // one weight register set: the next offset's slice is requested when this one is done
+      for (;;) {
+        const int kn = next_offset(k);
+        while (pp[0].k == k) step2(wA);
+        if (kn >= kend) break;
+        k = kn;
+        load_w(wA, k, kg);
+      }
+      continue;
+    }
+    WReg wB;
     for (;;) {
       int kn = next_offset(k);
       if (kn < kend) load_w(wB, kn, kg);                     // next offset's weights in flight during this offset
@@ -767,6 +812,15 @@ static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, flo
   do {                                                                                                    \
     if (nbuf == 1) AABR_WIDE_CS_N(KG, D, 1); else AABR_WIDE_CS_N(KG, D, 2);                               \
   } while (0)
+#ifdef AABR_DEV   // measured slower (profiles/r04_conv_occ4_ab.txt): in `make DEV=1` builds only
+  if (kg == 4 && nbuf == 1 && !(dbg & 7) && knob(K_WIDE_OCC4) == 1 && tile_rows <= 80) {   // experiment: four workgroups per CU
+    AABR_LAUNCH_WIDE((k_conv_cs<4, 0, 1, false, 1, 2, false, true>), "k_conv_cs<4,0,1,ring>",
+                     (size_t)((tile_rows + 1) * kWS + 2 * 16 * 4 * 32) * sizeof(float), in_feats, n_in, in_bytes, out_feats,
+                     n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows, residual, stats, bn);
+    AABR_CHECK_LAUNCH();
+    return AABR_OK;
+  }
+#endif
 #ifdef AABR_DEV
     if (dbg & 7) { // timing experiments (tools/, `make DEV=1`): only the 128-channel-group instance carries the debug variants
       AABR_CHECK_ARG(kg == 4, "debug variants exist for n_in >= 128 only");
@@ -1056,7 +1110,7 @@ extern "C" int64_t aabr_conv_wpack_x3_elems(int vol, int n_in, int n_out) {
 
 // form of the launch: 1 = 64-channel groups x 128-column slabs, 2 = 128-channel groups x 64-column slabs,
 // 3 = 64-channel groups x 64-column slabs; 0 = not supported
-static int x3_form(int n_in, int n_out) {
+[[maybe_unused]] static int x3_form(int n_in, int n_out) {
   if (n_in <= 0 || n_out <= 0 || (n_in & 63) || (n_out & 63)) return 0;
   const int v = knob(K_X3_FORM);
   if (v == 2 && (n_in & 127) == 0) return 2;
@@ -1071,6 +1125,10 @@ extern "C" int aabr_conv_wide_tile_rows_x3(int n_in, int n_out, int64_t rows_in,
   // channels or 64 columns: three term planes of weights do not fit the registers otherwise) and the split at the stage
   // store costs more than the MFMAs saved -- 322-338 us against 326 us of the fp32-MFMA kernel on the dominant
   // instance.  Off unless the CONV_X3 knob is 1 (tests, tools).
+#ifndef AABR_DEV
+  (void)n_in; (void)n_out; (void)rows_in; (void)V_out; (void)vol;
+  return 0;                                  // the three-term kernels are in `make DEV=1` builds only
+#else
   if (vol <= 0 || vol > kMaxVol || knob(K_CONV_X3) != 1) return 0;
   const int form = x3_form(n_in, n_out);
   if (!form) return 0;
@@ -1083,12 +1141,20 @@ extern "C" int aabr_conv_wide_tile_rows_x3(int n_in, int n_out, int64_t rows_in,
   if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
   if ((int64_t)vol * n_in * n_out * 6 >= (1ll << 31)) return 0;
   return T;
+#endif
 }
 
 extern "C" int aabr_conv_forward_wide_x3(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
                                          int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
                                          int flags, const uint16_t *wpack, const float *residual, double *stats,
                                          void *stream_) {
+#ifndef AABR_DEV
+  (void)in_feats; (void)n_in; (void)rows_in; (void)out_feats; (void)n_out; (void)V_out; (void)blocks; (void)tile_rows;
+  (void)vol; (void)bias; (void)flags; (void)wpack; (void)residual; (void)stats; (void)stream_;
+  aabr::set_error("aabr_conv_forward_wide_x3: measured no faster than the fp32-MFMA kernel (profiles/r03_conv_x3_ab.txt); "
+                  "in `make DEV=1` builds only");
+  return AABR_EINVAL;
+#else
   hipStream_t st = (hipStream_t)stream_;
   const int form = x3_form(n_in, n_out);
   AABR_CHECK_ARG(form != 0, "plane counts: n_in % 64, n_out % 64");
@@ -1144,4 +1210,5 @@ extern "C" int aabr_conv_forward_wide_x3(const float *in_feats, int n_in, int64_
 #undef AABR_X3
   AABR_CHECK_LAUNCH();
   return AABR_OK;
+#endif
 }

@@ -39,6 +39,10 @@ int aabr_version(void);
  * read ONCE at its first use in the process; aabr_set_knob overrides it (unset != 0: back to "no value").  No entry
  * point reads the environment on its launch path.                                                              */
 int aabr_set_knob(const char *name, int value, int unset);
+/* bit 0: a `make DEV=1` build -- it additionally carries the A/B kernels that were measured slower and are never
+ * dispatched (aabr_conv_forward_rs_bf16 / aabr_build_rs, aabr_conv_forward_wide_x3, the phase-clock variants); in a
+ * release build those entry points return an error and their decision functions return 0.                      */
+int aabr_build_flags(void);
 /* number of int32 words of the `meta` block written by the geometry builders */
 #define AABR_META_WORDS 8
 /* meta[0] = number of active sites, meta[1] = max points per site (input layer only),

@@ -322,6 +322,10 @@ def test_wide_x3_split_is_fp32_accurate(nIn, nOut, npts, form):
     pipe.  Against the oracle at the SAME tolerance as the fp32-MFMA kernel, against an fp64 evaluation of the same
     sums (its error must not exceed 2x the fp32-MFMA kernel's own -- both are fp32-accumulation errors), forward
     form with bias + residual + BatchNorm statistics and input-gradient form, all three launch forms."""
+    import _hip as _h
+    if not (_h.load().aabr_build_flags() & 1):
+        assert _h.load().aabr_conv_wide_tile_rows_x3(nIn, nOut, 1000, 1000, 27) == 0
+        pytest.skip("release build: the three-term kernels are compiled into `make DEV=1` builds only")
     import _hip
     from _hip import ptr, stream, check
     scn = _scn()
