@@ -546,7 +546,7 @@ def pmc_kernels_traffic(prefixes):
     best = {}
     for k, v in pm.items():
         nm, _, g = k.partition("|grid=")
-        if not any(nm.startswith(p) for p in prefixes):
+        if not any(nm.startswith(p) for p in prefixes) or "backward" in nm:
             continue
         if nm not in best or int(g) > best[nm][0]:
             best[nm] = (int(g), (2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)

@@ -246,6 +246,25 @@ def test_bench_roofline_traffic_lookup_matches_the_committed_pmc_profile():
     assert bench.pmc_traffic("k_conv_cs<2,0,1,bf16>", 336384)[0] is None           # 64-column slabs: not this instance
 
 
+def test_bench_pmc_lookups_resolve_in_this_rounds_profile():
+    """the profile bench.py names for THIS round is committed and both lookups resolve in it: the dominant convolution
+    instance (fp32 and bf16 storage) by (kernel, grid) and the voxel-scatter stage's kernels by name"""
+    import importlib
+    import json
+    bench = importlib.import_module("bench")
+    bench.PMC_PROFILE = "r04_pmc_fetch_write_per_kernel.json"
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", bench.PMC_PROFILE)
+    pm = json.load(open(path))["kernels"]
+    grids = sorted(int(k.split("|grid=")[1]) for k in pm if k.startswith("k_conv_cs<4,0,1,false,1,2,false,false>"))
+    assert grids
+    got, src = bench.pmc_traffic("k_conv_cs<4,0,1>", 336384)
+    assert got and got > 50e6 and "336384" in src
+    got_b, src_b = bench.pmc_traffic("k_conv_cs<2,0,1,bf16,x128>", 336384)
+    assert got_b and got_b != got and ",true,2," in src_b
+    tr, names = bench.pmc_kernels_traffic(("aabr::k_voxel", "k_voxel"))
+    assert tr and 50e6 < tr < 400e6 and "k_voxel_bin_build" in names and "backward" not in names
+
+
 def test_knob_registry_rejects_unknown_names_and_takes_known_ones():
     """aabr_set_knob: the tuning knobs are a closed list read once per process (never getenv on a launch path)"""
     import _hip
