@@ -1044,7 +1044,8 @@ def main():
             # batch and on one 1.5 M-point scene (BASELINE configs[4]'s size)
             locs, feats = wl.batches[0]
             vs = scatter_block(torch, scn, locs, feats, "the step's batch")
-            tr, src = pmc_kernels_traffic(("aabr::k_voxel", "k_voxel"))
+            tr, src = pmc_kernels_traffic(("aabr::k_voxel", "k_voxel")) if args.config == 2 else \
+                (None, "the committed PMC passes are over the --config 2 command")
             vs["traffic"], vs["traffic_source"] = tr, src
             if tr:
                 vs["traffic_over_algorithmic"] = round(tr / vs["bytes"], 2)
