@@ -679,11 +679,14 @@ extern "C" int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, in
   // CU): then its time is the longest workgroup, so take the smallest tile (>= 64 rows) that still fits one round
   // (measured, profiles/r02_conv_wide_ab.txt: 22k rows x 2 slabs, 128 -> 96 rows: 184 -> 133 us; with several rounds
   // smaller tiles only lower the block fill: 84k rows 385 -> 400 us)
-  int T = 128;
+  // up to 64 input channels (channel groups of 32 / 64: 8 KiB of stage, ~100 registers) 112-row tiles with a single
+  // stage buffer fit FOUR workgroups per CU (36.9 KiB each): 64->64 at 200k rows 204 -> 190 us, at 282k rows 180 -> 171
+  // (round 4, measured with AABR_WIDE_NBUF / AABR_WIDE_ROWS); 128-channel groups stay at 128 rows / three per CU
+  int T = n_in <= 64 ? 112 : 128;
   {
     const int64_t slabs = n_out / 64;
-    if (((V_out + 127) / 128) * slabs <= 512)
-      for (int t = 64; t < 128; t += 16)
+    if (((V_out + T - 1) / T) * slabs <= 512)
+      for (int t = 64; t < T; t += 16)
         if (((V_out + t - 1) / t) * slabs <= 512) { T = t; break; }
   }
   {                                                // tuning experiments only
@@ -788,7 +791,7 @@ static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, flo
   // LDS stage buffers: with 128-channel groups the double-buffered stage (32 KiB) allows two workgroups per CU, a
   // single buffer three (49 KiB each) at the price of a second barrier per pair: measured +4...+10 % (128->128 at 84k
   // rows 380 -> 367 us, 256->256 1366 -> 1272 us); narrower groups fit three workgroups with the double buffer
-  int nbuf = kg == 4 ? 1 : 2;
+  int nbuf = (kg == 4 || kg <= 2) ? 1 : 2;   // kg <= 2: single buffer + 112-row tiles = four workgroups per CU (above)
   {                                                // tuning experiments only
     const int v = knob(K_WIDE_NBUF);
     if (v == 1 || v == 2) nbuf = v;
