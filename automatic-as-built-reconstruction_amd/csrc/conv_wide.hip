@@ -1104,6 +1104,81 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
 }
 
 
+// ---- offset split, bf16 storage ---------------------------------------------------------------------------------------
+// the coarse scales of a bf16-storage pass (round 4: 50 launches of k_conv_blocks_mfma_bf16 per step, 8 % of the bf16
+// step's kernel time): the same cut over the filter offsets; the parts are fp32 (the kernel's LDS tile is), the reduce
+// kernel rounds once to bf16 -- the same single rounding per stored value as the unsplit kernels.
+extern "C" int aabr_conv_wide_split_bf16(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
+  if (n_in <= 0 || n_out <= 0 || (n_in & 63) || (n_out & 63) || vol <= 1 || vol > kMaxVol || V_out <= 0) return 0;
+  if (rows_in >= (1ll << 23) || rows_in * n_in * 2 >= (1ll << 31)) return 0;
+  if (n_in > 256 && (n_in & 255)) return 0;
+  if (knob(K_WIDE_SPLIT) == 0 || knob(K_CONV_WIDE_BF16) == 0) return 0;
+  const int T = 64;
+  const int64_t items = ((V_out + T - 1) / T) * (n_out / 64);
+  if (items >= 320) return 0;
+  const int min_items = knob(K_SPLIT_MIN_ITEMS) == kKnobUnset ? 8 : knob(K_SPLIT_MIN_ITEMS);
+  if (items < min_items) return 0;
+  const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 1024 : knob(K_SPLIT_TARGET);
+  int P = (int)((target + items - 1) / items);
+  if (P > vol) P = vol;
+  if (P > 32) P = 32;
+  {
+    const int v = knob(K_WIDE_SPLIT);
+    if (v >= 2 && v <= 32) P = v < vol ? v : vol;
+  }
+  if (P < 2) return 0;
+  if (wide_words(V_out, vol, T) * 4 >= (1ll << 31) || (int64_t)vol * n_in * n_out * 2 >= (1ll << 31)) return 0;
+  return (P << 16) | T;
+}
+
+extern "C" int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
+                                                 int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                                 const float *bias, int flags, const uint16_t *wpack, int parts,
+                                                 float *scratch, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(parts >= 2 && parts <= 32 && parts <= vol && scratch && ((uintptr_t)scratch & 15) == 0,
+                 "2 <= parts <= min(32, vol) and a 16-byte aligned scratch of parts x V_out x n_out floats");
+  AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 63) == 0 && (n_out & 63) == 0, "plane counts: n_in % 64, n_out % 64");
+  AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
+  AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
+  if (V_out == 0) return AABR_OK;
+  AABR_CHECK_ARG(in_feats && out_feats && blocks && wpack && rows_in > 0, "null pointer / empty input");
+  AABR_CHECK_ARG(rows_in < (1ll << 23), "too many input rows for the wide block format");
+  const int64_t in_bytes = rows_in * n_in * 2, words_bytes = wide_words(V_out, vol, tile_rows) * 4;
+  AABR_CHECK_ARG(in_bytes < (1ll << 31) && words_bytes < (1ll << 31), "buffers must be < 2 GiB");
+  AABR_CHECK_ARG(((uintptr_t)in_feats & 15) == 0 && ((uintptr_t)out_feats & 15) == 0 && ((uintptr_t)wpack & 15) == 0,
+                 "feature / weight pointers must be 16-byte aligned");
+  const int nkc = n_in / 64;
+  const int64_t wp_bytes = (int64_t)vol * (n_in / 32) * (n_out / 16) * 1024;
+  AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
+  AABR_CHECK_ARG(n_in <= 256 || (n_in & 255) == 0, "n_in above 256 must be a multiple of 256");
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)((n_out / 64) * parts));
+  const int flip = ((flags >> 1) & 1) | (parts << 8);
+  const int kg = nkc >= 4 ? 4 : nkc;
+  const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
+#define AABR_SPLIT_BF(KG)                                                                                              \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, 1, true, 1, 2>),                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                      \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    g_last_variant = "k_conv_cs<" #KG ",0,1,bf16,split>";                                                              \
+    hipLaunchKernelGGL((k_conv_cs<KG, 0, 1, true, 1, 2>), grid, dim3(256),                                             \
+                       (size_t)((tile_rows + 1) * kWS + 2 * 16 * KG * 32) * sizeof(float), st, in_f, n_in, in_bytes,    \
+                       scratch, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, (const float *)nullptr,   \
+                       tile_rows, (const float *)nullptr, (double *)nullptr, BnBwdStats{});                            \
+  } while (0)
+  if (kg == 1) AABR_SPLIT_BF(1); else if (kg == 2) AABR_SPLIT_BF(2); else if (kg == 3) AABR_SPLIT_BF(3); else AABR_SPLIT_BF(4);
+#undef AABR_SPLIT_BF
+  const int64_t n4 = V_out * n_out / 4;
+  hipLaunchKernelGGL((k_split_reduce<true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, scratch, parts, n4,
+                     n_out / 4, bias, (const float *)nullptr, (void *)out_feats);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
 // ---- fp32 storage on the bf16 matrix pipe (three-term split, k_conv_cs<.., X3>) -------------------------------------
 // weight pack: three bf16 term planes, each in the layout of aabr_conv_pack_weights2_bf16 (plane p at p * plane bytes)
 extern "C" int64_t aabr_conv_wpack_x3_elems(int vol, int n_in, int n_out) {

@@ -186,10 +186,12 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
                                            (const float *)p[5], (const float *)p[3], (double *)p[6], st);
     break;
   case AABR_PLAN_CONV_WIDE_SPLIT:
-    AABR_CHECK_ARG(!bf, "AABR_PLAN_CONV_WIDE_SPLIT exists for fp32 storage only");
-    rc = aabr_conv_forward_wide_split((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
-                                      (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
-                                      (const float *)p[5], (const float *)p[3], o.i32[5], (float *)p[6], st);
+    rc = bf ? aabr_conv_forward_wide_split_bf16((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
+                                                o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4],
+                                                o.i32[3], (const uint16_t *)p[5], o.i32[5], (float *)p[6], st)
+            : aabr_conv_forward_wide_split((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
+                                           (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
+                                           (const float *)p[5], (const float *)p[3], o.i32[5], (float *)p[6], st);
     break;
   case AABR_PLAN_CONV_RS:
     AABR_CHECK_ARG(bf, "AABR_PLAN_CONV_RS exists for bf16 storage only");

@@ -994,14 +994,19 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
         check(lib.aabr_conv_forward_wide(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
                                          ptr(gather.blocks_wide(tile_rows)), tile_rows, gather.vol, ptr(_opt(bias)),
                                          flags & 3, ptr(wpack), stream()))
-    elif wide_split(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16):
+    elif (not bf16 or (flags & 4)) and wide_split(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16):
         T, P = wide_split(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16)
-        if not (flags & 4):
-            check(lib.aabr_conv_pack_weights(ptr(w), gather.vol, n_in, n_out, flags & 1, ptr(wpack), stream()))
         scratch = _hip.workspace("wide_split", P * n_rows_out * n_out, torch.float32, inp.device)
-        check(lib.aabr_conv_forward_wide_split(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
-                                               ptr(gather.blocks_wide(T)), T, gather.vol, ptr(_opt(bias)), flags & 3,
-                                               ptr(wpack), None, P, ptr(scratch), stream()))
+        if bf16:
+            check(lib.aabr_conv_forward_wide_split_bf16(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
+                                                        ptr(gather.blocks_wide(T)), T, gather.vol, ptr(_opt(bias)),
+                                                        flags & 3, ptr(wpack), P, ptr(scratch), stream()))
+        else:
+            if not (flags & 4):
+                check(lib.aabr_conv_pack_weights(ptr(w), gather.vol, n_in, n_out, flags & 1, ptr(wpack), stream()))
+            check(lib.aabr_conv_forward_wide_split(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
+                                                   ptr(gather.blocks_wide(T)), T, gather.vol, ptr(_opt(bias)), flags & 3,
+                                                   ptr(wpack), None, P, ptr(scratch), stream()))
     else:
         check(conv(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out, ptr(gather.blocks()), gather.vol,
                    ptr(w), ptr(_opt(bias)), flags, ptr(wpack), stream()))
@@ -1100,10 +1105,11 @@ def wide_tile_rows(n_in, n_out, rows_in, rows_out, vol, bf16=False, prepacked=Tr
 def wide_split(n_in, n_out, rows_in, rows_out, vol, bf16=False):
     """(tile_rows, parts) when this launch goes to the offset-split form of the wide kernel (coarse maps: too few
     (tile, slab) items to fill the chip; csrc/conv_wide.hip aabr_conv_forward_wide_split), else None.  Asked after
-    `wide_tile_rows` declined; fp32 storage."""
-    if bf16 or rows_out == 0:
+    `wide_tile_rows` declined; bf16 storage: with a prepacked weight only (as for the wide kernel)."""
+    if rows_out == 0:
         return None
-    v = _hip.load().aabr_conv_wide_split(n_in, n_out, rows_in, rows_out, vol)
+    lib = _hip.load()
+    v = (lib.aabr_conv_wide_split_bf16 if bf16 else lib.aabr_conv_wide_split)(n_in, n_out, rows_in, rows_out, vol)
     return (v & 0xffff, v >> 16) if v else None
 
 

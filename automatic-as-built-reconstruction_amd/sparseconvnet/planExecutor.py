@@ -482,7 +482,7 @@ class _Pass(object):
             tmp = torch.empty(P * rows_out * n_out, dtype=torch.float32, device=self.dev)
             self._tmp.append(tmp)
             ws = tmp.data_ptr()
-            pack(buf, off, K_WSPLIT, xf, n_in, n_out, gather.vol, flags & 3, Ts, P, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
+            pack(buf, off, K_WSPLIT, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, Ts, P, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
                  0, 0, src, dst, gather.blocks_wide(Ts).data_ptr(), 0, 0, p_pack, ws, 0, 0, 0, 0, 0)
         else:
             pack(buf, off, K_CONV, (F_BF16 if bf else 0) | xf, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,

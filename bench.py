@@ -465,12 +465,22 @@ def conv_kernel_table(torch, wl, dtype, max_rows=None):
                 Ts, P = SCN.wide_split(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
                 blocks = ga.blocks_wide(Ts)
                 scratch = torch.empty(P * ga.rows * n_out, device=dev)
-                check(lib.aabr_conv_pack_weights(ptr(w), ga.vol, n_in, n_out, tr_, ptr(wpack), stream()))
+                if bf:
+                    wt = torch.empty_like(wpack)
+                    a_, b_ = (wt, wpack) if tr_ else (wpack, wt)   # the input-gradient launch reads the transposed pack
+                    check(lib.aabr_conv_pack_weights2_bf16(ptr(w), ga.vol, w.size(2), w.size(3), ptr(a_), ptr(b_), stream()))
 
-                def fn():
-                    check(lib.aabr_conv_forward_wide_split(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks),
-                                                           Ts, ga.vol, None, g["flags"] & 3, ptr(wpack), None, P,
-                                                           ptr(scratch), stream()))
+                    def fn():
+                        check(lib.aabr_conv_forward_wide_split_bf16(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows,
+                                                                    ptr(blocks), Ts, ga.vol, None, g["flags"] & 3,
+                                                                    ptr(wpack), P, ptr(scratch), stream()))
+                else:
+                    check(lib.aabr_conv_pack_weights(ptr(w), ga.vol, n_in, n_out, tr_, ptr(wpack), stream()))
+
+                    def fn():
+                        check(lib.aabr_conv_forward_wide_split(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows,
+                                                               ptr(blocks), Ts, ga.vol, None, g["flags"] & 3, ptr(wpack),
+                                                               None, P, ptr(scratch), stream()))
             else:
                 blocks = ga.blocks()
                 check(conv(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(blocks), ga.vol, ptr(w), None,

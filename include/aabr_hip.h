@@ -442,6 +442,12 @@ int aabr_conv_forward_wide_split(const float *in_feats, int n_in, int64_t rows_i
                                  int flags, const float *wpack, const float *residual, int parts, float *scratch,
                                  void *stream);
 
+/* the same for bf16 feature storage (in / out / wpack bf16, parts fp32, one rounding in the second stage; no residual) */
+int aabr_conv_wide_split_bf16(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
+int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
+                                      int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                                      int flags, const uint16_t *wpack, int parts, float *scratch, void *stream);
+
 /* ---- compiled launch plans (extension) --------------------------------------------------------
  * The reference enters its library once per layer and direction from Python (SCN/pybind.cpp:134-221 behind
  * sparseconvnet/ layer modules).  A host that has compiled the static part of a network into a list of launches hands
@@ -476,9 +482,9 @@ int aabr_conv_forward_wide_split(const float *in_feats, int n_in, int64_t rows_i
 #define AABR_PLAN_CAST 7
 #define AABR_PLAN_CONV_RS 8 /* aabr_conv_forward_rs_bf16(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 rs_stream,
                                i32[4] unit_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack); bf16 storage only */
-#define AABR_PLAN_CONV_WIDE_SPLIT 9 /* aabr_conv_forward_wide_split(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
-                                       i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual,
-                                       i32[5] parts, p6 scratch) */
+#define AABR_PLAN_CONV_WIDE_SPLIT 9 /* aabr_conv_forward_wide_split[_bf16](p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
+                                       i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual (fp32
+                                       storage only), i32[5] parts, p6 scratch) */
 #define AABR_PLAN_BF16 1
 #define AABR_PLAN_TO_BF16 2
 #define AABR_PLAN_JOIN 8 /* the caller's stream waits for the second stream in front of this record */

@@ -563,3 +563,82 @@ def test_wide_offset_split_matches_oracle_and_unsplit(request, nIn, nOut, npts, 
     np.testing.assert_allclose(y.features.detach().cpu().numpy(), ref0, rtol=1e-4, atol=2e-6 * np.abs(f).max() * nIn)
     y.features.backward(_t(g))
     np.testing.assert_allclose(xs.features.grad.cpu().numpy(), want, rtol=1e-4, atol=2e-6 * np.abs(g).max() * nOut)
+
+
+@pytest.mark.parametrize("nIn,nOut,npts,parts", [(128, 128, 700, 0), (256, 256, 600, 0), (128, 64, 600, 0),
+                                                 (64, 128, 1500, 5), (256, 128, 700, 27), (512, 64, 400, 0)])
+def test_wide_offset_split_bf16_storage(request, nIn, nOut, npts, parts):
+    """aabr_conv_forward_wide_split_bf16 (the offset split for a bf16-storage pass's coarse scales): forward and
+    input-gradient form against the oracle (SCN/CPU/Convolution.cpp:117-185) on the SAME bf16-rounded features and
+    weights -- products exact in fp32, differences = accumulation order + ONE rounding to bf16 in the reduce kernel
+    (tolerance 2^-7 of the largest term, as for the unsplit bf16 kernel); same call twice gives the same bits; the
+    layer under `.to(bfloat16)` dispatches it."""
+    import _hip
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(nIn * 5 + nOut + npts)
+    coords, _ = _scene(rng, npts, (9, 8, 4), 2, 1)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    assert lib.aabr_conv_wide_tile_rows_bf16(nIn, nOut, V, V, vol) == 0
+    _hip.set_knob("SPLIT_MIN_ITEMS", 1)
+    request.addfinalizer(lambda: _hip.set_knob("SPLIT_MIN_ITEMS", None))
+    v = lib.aabr_conv_wide_split_bf16(nIn, nOut, V, V, vol)
+    assert v, "the split form should take this launch"
+    T, P = v & 0xffff, v >> 16
+    assert T == 64 and 2 <= P <= vol
+    if parts:
+        P = parts
+    il = O.input_layer(coords, np.zeros((npts, 1), np.float32), 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    W = (rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32)
+    Wd = _t(W)
+    n = int(lib.aabr_conv_wpack_bf16_elems(vol, nIn, nOut))
+    pf = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    pt = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    check(lib.aabr_conv_pack_weights2_bf16(ptr(Wd), vol, nIn, nOut, ptr(pf), ptr(pt), stream()))
+    Wr = Wd.bfloat16().float().cpu().numpy().reshape(vol, nIn, nOut)
+    f = torch.as_tensor(rng.standard_normal((V, nIn)).astype(np.float32)).to(DEV).bfloat16()
+    b = rng.standard_normal(nOut).astype(np.float32)
+    out = torch.empty((V, nOut), dtype=torch.bfloat16, device=DEV)
+    scratch = torch.full((int(lib.aabr_conv_wide_split_scratch_floats(V, nOut, P)),), float("nan"), device=DEV)
+    blocks = ga.blocks_wide(T)
+    check(lib.aabr_conv_forward_wide_split_bf16(ptr(f), nIn, V, ptr(out), nOut, V, ptr(blocks), T, vol, ptr(_t(b)), 0,
+                                                ptr(pf), P, ptr(scratch), stream()))
+    assert _variant().endswith("bf16,split>"), _variant()
+    ref, _ = O.conv_fwd(f.float().cpu().numpy(), Wr, rb, V, b)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2 ** -7, atol=2 ** -7 * np.abs(ref).max())
+    out2 = torch.empty_like(out)
+    check(lib.aabr_conv_forward_wide_split_bf16(ptr(f), nIn, V, ptr(out2), nOut, V, ptr(blocks), T, vol, ptr(_t(b)), 0,
+                                                ptr(pf), P, ptr(scratch), stream()))
+    assert torch.equal(out, out2)
+    # input-gradient form
+    g = torch.as_tensor(rng.standard_normal((V, nOut)).astype(np.float32)).to(DEV).bfloat16()
+    vb = lib.aabr_conv_wide_split_bf16(nOut, nIn, V, V, vol)
+    assert vb
+    Tb, Pb = vb & 0xffff, vb >> 16
+    d_in = torch.empty((V, nIn), dtype=torch.bfloat16, device=DEV)
+    sc2 = torch.empty(int(lib.aabr_conv_wide_split_scratch_floats(V, nIn, Pb)), device=DEV)
+    check(lib.aabr_conv_forward_wide_split_bf16(ptr(g), nOut, V, ptr(d_in), nIn, V, ptr(ga.blocks_wide(Tb)), Tb, vol, None,
+                                                3, ptr(pt), Pb, ptr(sc2), stream()))
+    dref, _, _ = O.conv_bwd(np.zeros((V, nIn), np.float32), g.float().cpu().numpy(), Wr, rb, want_bias=False)
+    np.testing.assert_allclose(d_in.float().cpu().numpy(), dref, rtol=2 ** -7, atol=2 ** -7 * np.abs(dref).max())
+    # through the layer in bf16 storage
+    conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, False).to(DEV)
+    conv.weight.data.copy_(Wd)
+    xs = scn.SparseConvNetTensor()
+    xs.metadata, xs.spatial_size = x.metadata, x.spatial_size
+    xs.features = f.clone().requires_grad_(True)
+    y = conv(xs)
+    assert y.features.dtype == torch.bfloat16
+    if _variant().endswith("bf16,split>"):            # (the layer prepacks in bf16 storage; otherwise the item kernel ran)
+        ref0, _ = O.conv_fwd(f.float().cpu().numpy(), Wr, rb, V)
+        np.testing.assert_allclose(y.features.detach().float().cpu().numpy(), ref0, rtol=2 ** -7,
+                                   atol=2 ** -7 * np.abs(ref0).max())
+        y.features.backward(g)
+        np.testing.assert_allclose(xs.features.grad.float().cpu().numpy(), dref, rtol=2 ** -7,
+                                   atol=2 ** -7 * np.abs(dref).max())
+    else:
+        pytest.fail("the bf16 layer did not dispatch the split form: " + _variant())
