@@ -63,6 +63,9 @@ _SIGS = {
                                                _vp, _vp]),
     "aabr_conv_forward_wide_bf16_stats": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp,
                                                     _vp, _vp]),
+    "aabr_conv_forward_wide_bf16_bwd_stats": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp,
+                                                        _vp, _vp, _vp, _vp, _f32, _vp]),
+    "aabr_bn_backward_parts_bf16": (C.c_int, [_vp] * 4 + [_i64, _i32] + [_vp] * 6 + [_f32, _vp, _i32, _vp, _vp]),
     "aabr_conv_forward_wide_bwd_stats": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp,
                                                    _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp]),
     "aabr_bn_backward_parts": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32,

@@ -555,7 +555,8 @@ static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int
   int nparts = bn_parts(rows, planes, v4 ? 4 : 1);
   const double *fin_part = part;
   if (pre_part) {   // the statistics' partial sums came with the write-out of the convolution that produced d_out
-    AABR_CHECK_ARG(pre_nparts > 0 && recompute, "precomputed backward statistics: fp32 storage, leakiness >= 0");
+    AABR_CHECK_ARG(pre_nparts > 0 && (recompute || sizeof(T) == 2),
+                   "precomputed backward statistics: leakiness >= 0 in fp32 storage (the sign is recomputed from x)");
     fin_part = pre_part;
     nparts = pre_nparts;
   } else if (v4)
@@ -636,6 +637,18 @@ extern "C" int aabr_bn_backward_parts(const float *in, float *d_in, const float 
   AABR_CHECK_ARG(parts && nparts > 0, "partials");
   return bn_backward_t<float>(in, d_in, out, d_out, rows, planes, save_mean, save_invstd, weight, bias, d_weight,
                               d_bias, leakiness, scratch, stream_, d_in_add, parts, nparts);
+}
+
+extern "C" int aabr_bn_backward_parts_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out, const uint16_t *d_out,
+                                           int64_t rows, int planes, const float *save_mean, const float *save_invstd,
+                                           const float *weight, const float *bias, float *d_weight, float *d_bias,
+                                           float leakiness, const double *parts, int nparts, float *scratch,
+                                           void *stream_) {
+  AABR_CHECK_ARG(parts && nparts > 0, "partials");
+  return bn_backward_t<__bf16>(reinterpret_cast<const __bf16 *>(in), reinterpret_cast<__bf16 *>(d_in),
+                               reinterpret_cast<const __bf16 *>(out), reinterpret_cast<const __bf16 *>(d_out), rows,
+                               planes, save_mean, save_invstd, weight, bias, d_weight, d_bias, leakiness, scratch,
+                               stream_, nullptr, parts, nparts);
 }
 
 // bf16 feature storage (extension; statistics in fp64, affine maths in fp32, parameters fp32)

@@ -120,9 +120,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // consumed in the forward pass; with `x` set the write-out forms that BatchNorm's BACKWARD statistics instead of the
 // forward ones -- per tile [2][co] fp64 sums of d and (x - mean) * d, d = d_out masked by the sign of the forward
 // activation recomputed from x exactly as k_bn_partials<1> does (same floats, same operations)
+// bf16 storage: the sign comes from the STORED (rounded) activation `out` as in k_bn_partials<1, .., bf16> (x, out bf16)
 struct BnBwdStats {
   const float *x, *mean, *invstd, *weight, *bias;   // x == nullptr: forward statistics (or none)
   float leak;
+  const float *out;                                 // bf16 storage only
 };
 
 // X3 (fp32 storage, fp32-equivalent arithmetic on the bf16 matrix pipe): every fp32 operand is split into three bf16
@@ -587,13 +589,15 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
   }
   double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
   float bmu[4] = {0.f, 0.f, 0.f, 0.f}, bwc[4] = {0.f, 0.f, 0.f, 0.f}, bbc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (!BF && stats && bn.x) {              // this thread's four columns of the BatchNorm's forward coefficients
+  if (stats && bn.x) {                     // this thread's four columns of the BatchNorm's forward coefficients
     const int p0 = nb0 * 16 + (threadIdx.x % QW) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bmu[j] = bn.mean[p0 + j];
-      bwc[j] = bn.invstd[p0 + j] * (bn.weight ? bn.weight[p0 + j] : 1.0f);
-      bbc[j] = -bmu[j] * bwc[j] + (bn.bias ? bn.bias[p0 + j] : 0.0f);
+      if (!BF) {
+        bwc[j] = bn.invstd[p0 + j] * (bn.weight ? bn.weight[p0 + j] : 1.0f);
+        bbc[j] = -bmu[j] * bwc[j] + (bn.bias ? bn.bias[p0 + j] : 0.0f);
+      }
     }
   }
 #pragma unroll 4
@@ -616,7 +620,17 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
       *reinterpret_cast<f32x4 *>(out + (row0 + r) * co + nb0 * 16 + q * 4) = v;
     }
     if (stats) {
-      if (!BF && bn.x) {                   // backward statistics of the BatchNorm whose d_out this tile is
+      if (BF && bn.x) {                    // (v holds the rounded, stored d_out here)
+        const int64_t at = (row0 + r) * co + nb0 * 16 + q * 4;
+        const bf16x4w xv = *reinterpret_cast<const bf16x4w *>(reinterpret_cast<const __bf16 *>(bn.x) + at);
+        const bf16x4w ov = *reinterpret_cast<const bf16x4w *>(reinterpret_cast<const __bf16 *>(bn.out) + at);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = ((float)ov[j] > 0.0f) ? v[j] : v[j] * bn.leak;
+          sa[j] += (double)d;
+          sb[j] += (double)((float)xv[j] - bmu[j]) * (double)d;
+        }
+      } else if (bn.x) {                   // backward statistics of the BatchNorm whose d_out this tile is
         const f32x4 xv = *reinterpret_cast<const f32x4 *>(bn.x + (row0 + r) * co + nb0 * 16 + q * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1017,10 +1031,35 @@ extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, i
                                            flags, wpack, nullptr, stream_);
 }
 
+static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
+                            int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias, int flags,
+                            const uint16_t *wpack, double *stats, BnBwdStats bn, void *stream_);
+
 extern "C" int aabr_conv_forward_wide_bf16_stats(const uint16_t *in_feats, int n_in, int64_t rows_in,
                                                  uint16_t *out_feats, int n_out, int64_t V_out, const int32_t *blocks,
                                                  int tile_rows, int vol, const float *bias, int flags,
                                                  const uint16_t *wpack, double *stats, void *stream_) {
+  return wide_launch_bf16(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias, flags, wpack,
+                          stats, BnBwdStats{}, stream_);
+}
+
+extern "C" int aabr_conv_forward_wide_bf16_bwd_stats(const uint16_t *in_feats, int n_in, int64_t rows_in,
+                                                     uint16_t *out_feats, int n_out, int64_t V_out,
+                                                     const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                                                     int flags, const uint16_t *wpack, double *stats,
+                                                     const uint16_t *bn_in, const uint16_t *bn_out,
+                                                     const float *save_mean, float leakiness, void *stream_) {
+  AABR_CHECK_ARG(stats && bn_in && bn_out && save_mean, "null pointer");
+  AABR_CHECK_ARG((((uintptr_t)bn_in | (uintptr_t)bn_out) & 7) == 0, "the BatchNorm's input / output must be 8-byte aligned");
+  BnBwdStats bn{reinterpret_cast<const float *>(bn_in), save_mean, nullptr, nullptr, nullptr, leakiness,
+                reinterpret_cast<const float *>(bn_out)};
+  return wide_launch_bf16(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias, flags, wpack,
+                          stats, bn, stream_);
+}
+
+static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
+                            int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias, int flags,
+                            const uint16_t *wpack, double *stats, BnBwdStats bn, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(!stats || (tile_rows >= 64 && ((uintptr_t)stats & 7) == 0), "statistics need tiles of >= 64 rows");
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 63) == 0 && (n_out & 63) == 0, "plane counts: n_in % 64, n_out % 64");
@@ -1057,7 +1096,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
     hipLaunchKernelGGL((k_conv_cs<KG, D, NB, true, NCB, kBfSets>), grid, dim3(256),                                \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr, stats, BnBwdStats{});                                                      \
+                       tile_rows, (const float *)nullptr, stats, bn);                                                      \
   } while (0)
 #define AABR_WIDE_BF_S(KG, NB, NCB, NS)                                                                                  \
   do {                                                                                                             \
@@ -1071,7 +1110,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
     hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS>), grid, dim3(256),                                         \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr, stats, BnBwdStats{});                                                      \
+                       tile_rows, (const float *)nullptr, stats, bn);                                                      \
   } while (0)
 #define AABR_WIDE_BF_K(KG)                                                                                         \
   do {                                                                                                             \

@@ -170,7 +170,13 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
     break;
   case AABR_PLAN_CONV_WIDE:
     if (o.i32[5] == 1) { // the write-out forms the BACKWARD statistics of the BatchNorm whose d_out it produces
-      AABR_CHECK_ARG(!bf, "backward statistics from the write-out: fp32 storage only");
+      if (bf) {          // p7 the BatchNorm's input, p9 its stored output (the sign), p8 save_mean
+        rc = aabr_conv_forward_wide_bf16_bwd_stats((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
+                                                   o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4],
+                                                   o.i32[3], (const uint16_t *)p[5], (double *)p[6], (const uint16_t *)p[7],
+                                                   (const uint16_t *)p[9], (const float *)p[8], o.f32[0], st);
+        break;
+      }
       rc = aabr_conv_forward_wide_bwd_stats((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
                                             (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
                                             (const float *)p[5], (const float *)p[3], (double *)p[6],
@@ -229,7 +235,13 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
     break;
   case AABR_PLAN_BN_BWD:
     if (o.i64[1]) { // the statistics' partial sums came with the producing convolution (i64[1] = address, i32[1] of them)
-      AABR_CHECK_ARG(!bf, "precomputed backward statistics: fp32 storage only");
+      if (bf) {
+        rc = aabr_bn_backward_parts_bf16((const uint16_t *)p[0], (uint16_t *)p[1], (const uint16_t *)p[2],
+                                         (const uint16_t *)p[3], o.i64[0], o.i32[0], (const float *)p[4], (const float *)p[5],
+                                         (const float *)p[6], (const float *)p[10], (float *)p[7], (float *)p[8], o.f32[2],
+                                         (const double *)(uintptr_t)o.i64[1], o.i32[1], (float *)p[9], st);
+        break;
+      }
       rc = aabr_bn_backward_parts((const float *)p[0], (float *)p[1], (const float *)p[2], (const float *)p[3], o.i64[0],
                                   o.i32[0], (const float *)p[4], (const float *)p[5], (const float *)p[6],
                                   (const float *)p[10], (float *)p[7], (float *)p[8], o.f32[2],

@@ -60,7 +60,7 @@ fuse_adds = os.environ.get("AABR_PLAN_FUSE_ADDS", "1") != "0"
 # convolution's write-out (aabr_conv_forward_wide_stats -> aabr_bn_forward_parts): one pass over the matrix less
 conv_bn_stats = os.environ.get("AABR_PLAN_CONV_BN_STATS", "1") != "0"
 # ... and a BatchNorm backward right behind the wide-kernel input-gradient launch that produced its d_out takes its
-# statistics from that launch's write-out (aabr_conv_forward_wide_bwd_stats -> aabr_bn_backward_parts; fp32 storage)
+# statistics from that launch's write-out (aabr_conv_forward_wide[_bf16]_bwd_stats -> aabr_bn_backward_parts[_bf16])
 conv_bn_bwd_stats = os.environ.get("AABR_PLAN_CONV_BN_BWD_STATS", "1") != "0"
 
 
@@ -722,7 +722,7 @@ class _Pass(object):
                     off0 = off
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
                                            n_out, g, p_w, pt, flags, flg == F_BF16)
-                    if self._lw >= 64 and flg != F_BF16 and off > off0:
+                    if self._lw >= 64 and off > off0:
                         last_din = (gx, off0, self._lw, n_out)
                 elif V[lvl] and self.wide_rows(n_in, n_out, V[lo], V[lvl], g.vol):
                     off0 = off
@@ -746,8 +746,8 @@ class _Pass(object):
                 _, x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b, res = op
                 if V[lvl]:
                     parts, nparts, ld = 0, 0, last_din
-                    if (conv_bn_bwd_stats and ld is not None and ld[0] == gy and ld[3] == planes and not flg
-                            and leak >= 0.0):
+                    if (conv_bn_bwd_stats and ld is not None and ld[0] == gy and ld[3] == planes
+                            and (flg == F_BF16 or (not flg and leak >= 0.0))):
                         # the BatchNorm's d_out was written by the wide-kernel input-gradient launch right before it (the
                         # weight-gradient record in between runs on the second stream): that launch's write-out forms the
                         # backward statistics (record i32[5] = 1, p6 stats, p7.. the BatchNorm's input and coefficients)
@@ -759,7 +759,7 @@ class _Pass(object):
                         struct.pack_into("<i", buf, ld[1] + 8 + 5 * 4, 1)                                   # i32[5]
                         struct.pack_into("<f", buf, ld[1] + 32, leak)                                       # f32[0]
                         struct.pack_into("<6Q", buf, ld[1] + 80 + 6 * 8, bstat, A[x], sbase + st * 4,
-                                         sbase + (st + planes) * 4, p_w, p_b)                               # p6 .. p11
+                                         A[y] if flg == F_BF16 else sbase + (st + planes) * 4, p_w, p_b)    # p6 .. p11
                     pack(buf, off, K_BNB, flg, planes, nparts, 0, 0, 0, 0, 0.0, 0.0, leak, 0.0, V[lvl], parts, 0, 0,
                          A[x], AD[gx[0]][gx[1]], A[y], AD[gy[0]][gy[1]], sbase + st * 4, sbase + (st + planes) * 4,
                          p_w, pbase + pw if pw >= 0 else 0, pbase + pb if pb >= 0 else 0, bnws, p_b,

@@ -260,6 +260,17 @@ int aabr_bn_backward_parts(const float *in, float *d_in, const float *out, const
                            const float *save_mean, const float *save_invstd, const float *weight, const float *bias,
                            float *d_weight, float *d_bias, float leakiness, const double *parts, int nparts,
                            float *scratch, const float *d_in_add, void *stream);
+/* bf16 storage of the two: the sign comes from the BatchNorm's STORED output `bn_out` (as aabr_bn_backward_bf16 reads
+ * it), x and d are the stored (rounded) values, sums in fp64 -- the same terms k_bn_partials forms.               */
+int aabr_conv_forward_wide_bf16_bwd_stats(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
+                                          int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                          const float *bias, int flags, const uint16_t *wpack, double *stats,
+                                          const uint16_t *bn_in, const uint16_t *bn_out, const float *save_mean,
+                                          float leakiness, void *stream);
+int aabr_bn_backward_parts_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out, const uint16_t *d_out,
+                                int64_t rows, int planes, const float *save_mean, const float *save_invstd,
+                                const float *weight, const float *bias, float *d_weight, float *d_bias, float leakiness,
+                                const double *parts, int nparts, float *scratch, void *stream);
 /* BatchNormalization forward in training mode with the statistics' partial sums given (layout above; any producer
  * that writes [nparts][2][planes] fp64 sums of x and x^2 will do): everything else as aabr_bn_forward[_bf16].   */
 int aabr_bn_forward_parts(const float *in, float *out, int64_t rows, int planes, float *save_mean,
@@ -458,7 +469,9 @@ int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_
  *        AABR_PLAN_CONV_WIDE  aabr_conv_forward_wide_stats(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
  *                             i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual, p6 stats);
  *                             i32[5] == 1: aabr_conv_forward_wide_bwd_stats(..., p6 stats, p7 bn_in, p8 save_mean,
- *                             p9 save_invstd, p10 bn_weight, p11 bn_bias, f32[0] leakiness)
+ *                             p9 save_invstd, p10 bn_weight, p11 bn_bias, f32[0] leakiness); bf16 storage:
+ *                             aabr_conv_forward_wide_bf16_bwd_stats(..., p6 stats, p7 bn_in, p9 bn_out, p8 save_mean,
+ *                             f32[0] leakiness)
  *        AABR_PLAN_CONV_DW    aabr_conv_backward_weight[_bf16](p0 in, i32[0] n_in, p1 d_out, i32[1] n_out,
  *                             i64[0] V_out, p2 pairs, i32[2] vol, i64[1] max_chunks, p3 dW, p4 d_bias, p5 scratch)
  *        AABR_PLAN_BN_FWD     aabr_bn_forward[_bf16](p0 in, p1 out, i64[0] rows, i32[0] planes, p2 save_mean,
@@ -468,7 +481,8 @@ int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_
  *        AABR_PLAN_BN_BWD     aabr_bn_backward[_bf16](p0 in, p1 d_in, p2 out, p3 d_out, i64[0] rows, i32[0] planes,
  *                             p4 save_mean, p5 save_invstd, p6 weight, p10 bias, p7 d_weight, p8 d_bias,
  *                             f32[2] leakiness, p9 scratch); fp32 with p11 != NULL: aabr_bn_backward_add(..., p11);
- *                             i64[1] != 0: aabr_bn_backward_parts(..., parts = (double *)i64[1], i32[1] nparts, p9, p11)
+ *                             i64[1] != 0: aabr_bn_backward_parts[_bf16](..., parts = (double *)i64[1], i32[1] nparts,
+ *                             p9[, p11 in fp32 storage])
  *        AABR_PLAN_ADD        aabr_add(p0 a, p1 b, p2 out, i64[0] n)
  *        AABR_PLAN_CAST       aabr_cast_storage(p0 in, p1 out, i64[0] n, flags & AABR_PLAN_TO_BF16)
  *   flags & AABR_PLAN_BF16 selects the bf16-storage entry point.  Stops at the first failing record and returns

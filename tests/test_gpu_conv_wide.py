@@ -642,3 +642,79 @@ def test_wide_offset_split_bf16_storage(request, nIn, nOut, npts, parts):
                                    atol=2 ** -7 * np.abs(dref).max())
     else:
         pytest.fail("the bf16 layer did not dispatch the split form: " + _variant())
+
+
+@pytest.mark.parametrize("nIn,nOut,npts,leak", [(64, 64, 3000, 0.0), (128, 128, 2500, 0.2), (128, 64, 900, 0.0),
+                                                (64, 128, 2500, 0.0)])
+def test_wide_bf16_write_out_backward_statistics_feed_batchnorm_backward(nIn, nOut, npts, leak):
+    """aabr_conv_forward_wide_bf16_bwd_stats: per-tile fp64 sums of the STORED (bf16) masked d_out and of (x - mean) *
+    d, the mask from the BatchNorm's stored output (SCN/CPU/BatchNormalization.cpp:66-84 on the bf16-storage model);
+    aabr_bn_backward_parts_bf16 fed with them returns what aabr_bn_backward_bf16 (own statistics pass) returns."""
+    import _hip
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(nIn + 11 * nOut + npts)
+    coords, _ = _scene(rng, npts, (12, 11, 5), 2, 1)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    _hip.set_knob("CONV_WIDE_BF16", 1)
+    _hip.set_knob("BN_SMALL", 0)
+    try:
+        T = lib.aabr_conv_wide_tile_rows_bf16(nIn, nOut, V, V, vol)
+        assert T >= 64
+        ntile = (V + T - 1) // T
+        W = _t((rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32))
+        n = int(lib.aabr_conv_wpack_bf16_elems(vol, nIn, nOut))
+        pf = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        pt = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        check(lib.aabr_conv_pack_weights2_bf16(ptr(W), vol, nIn, nOut, ptr(pf), ptr(pt), stream()))
+        g = _t(rng.standard_normal((V, nIn)).astype(np.float32)).bfloat16()
+        xb = _t((rng.standard_normal((V, nOut)) * 1.3 + 0.2).astype(np.float32)).bfloat16()
+        gam = _t(rng.uniform(0.5, 1.5, nOut).astype(np.float32))
+        bet = _t(rng.standard_normal(nOut).astype(np.float32))
+        ws = torch.empty(int(lib.aabr_bn_scratch_floats(nOut)), device=DEV)
+        y = torch.empty_like(xb)
+        sm, si, rm, rv = (torch.zeros(nOut, device=DEV) for _ in range(4))
+        check(lib.aabr_bn_forward_bf16(ptr(xb), ptr(y), V, nOut, ptr(sm), ptr(si), ptr(rm), ptr(rv), ptr(gam), ptr(bet),
+                                       1e-4, 0.9, 1, leak, ptr(ws), stream()))
+        d_out = torch.empty((V, nOut), dtype=torch.bfloat16, device=DEV)
+        d_out0 = torch.empty_like(d_out)
+        stats = torch.full((ntile, 2, nOut), float("nan"), dtype=torch.float64, device=DEV)
+        blocks = ga.blocks_wide(T)
+        a = (ptr(g), nIn, V, None, nOut, V, ptr(blocks), T, vol, None, 0, ptr(pf))
+        check(lib.aabr_conv_forward_wide_bf16_bwd_stats(*a[:3], ptr(d_out), *a[4:], ptr(stats), ptr(xb), ptr(y), ptr(sm),
+                                                        leak, stream()))
+        check(lib.aabr_conv_forward_wide_bf16(*a[:3], ptr(d_out0), *a[4:], stream()))
+        assert torch.equal(d_out, d_out0)
+        d32 = d_out.float().cpu().numpy()
+        mask = y.float().cpu().numpy() > 0
+        dm = np.where(mask, d32, d32 * np.float32(leak)).astype(np.float64)
+        xc = (xb.float().cpu().numpy() - sm.cpu().numpy().astype(np.float32)).astype(np.float64)
+        st = stats.cpu().numpy()
+        for j in range(ntile):
+            sl = slice(j * T, (j + 1) * T)
+            np.testing.assert_allclose(st[j, 0], dm[sl].sum(0), rtol=1e-12, atol=1e-11)
+            np.testing.assert_allclose(st[j, 1], (xc[sl] * dm[sl]).sum(0), rtol=1e-12, atol=1e-11)
+
+        def run(parts):
+            d_in = torch.empty_like(xb)
+            dw, db = torch.zeros(nOut, device=DEV), torch.zeros(nOut, device=DEV)
+            common = (ptr(xb), ptr(d_in), ptr(y), ptr(d_out), V, nOut, ptr(sm), ptr(si), ptr(gam), ptr(bet), ptr(dw),
+                      ptr(db), leak)
+            if parts:
+                check(lib.aabr_bn_backward_parts_bf16(*common, ptr(stats), ntile, ptr(ws), stream()))
+            else:
+                check(lib.aabr_bn_backward_bf16(*common, ptr(ws), stream()))
+            return d_in.float().cpu().numpy(), dw.cpu().numpy(), db.cpu().numpy()
+
+        got, want = run(True), run(False)
+        np.testing.assert_allclose(got[2], want[2], rtol=3e-7, atol=1e-6)
+        np.testing.assert_allclose(got[1], want[1], rtol=3e-7, atol=1e-6)
+        # d_in is stored in bf16: the fp64 sums agree to ~1e-16, so a stored value differs by at most one bf16 step, rarely
+        diff = np.abs(got[0] - want[0])
+        assert (diff > 0).mean() < 1e-3 and np.all(diff <= 2 ** -7 * np.abs(want[0]) + 1e-30)
+    finally:
+        _hip.set_knob("BN_SMALL", None)
+        _hip.set_knob("CONV_WIDE_BF16", None)
