@@ -93,6 +93,9 @@ _SIGS = {
     "aabr_conv_pack_weights2": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "aabr_conv_pack_weights2_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "aabr_plan_run": (C.c_int, [_vp, _i32, _vp]),
+    "aabr_plan_submit": (C.c_int, [_vp, _i32, _vp, _i32]),
+    "aabr_plan_drain": (C.c_int, []),
+    "aabr_plan_launcher_stats": (None, [_vp, _vp, _vp]),
     "aabr_geom_run": (C.c_int, [_vp, _i32, _vp]),
     "aabr_add": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "aabr_cast_storage": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),

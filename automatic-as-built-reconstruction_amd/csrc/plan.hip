@@ -13,6 +13,12 @@
 // fp32 <-> bf16 storage casts (round-to-nearest-even, as torch's `.to(torch.bfloat16)`).
 #include "common.h"
 #include <string.h>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace aabr {
@@ -141,6 +147,7 @@ static_assert(sizeof(AabrPlanOp) == 176, "AabrPlanOp layout is part of the C ABI
 namespace {
 struct SideStream {
   hipStream_t stream = nullptr;
+  size_t pending = 0;                      // side launches a held part (plan_run_part(.., hold)) left unjoined
   std::vector<hipEvent_t> events;
   hipEvent_t get(size_t k) {
     while (events.size() <= k) {
@@ -270,10 +277,13 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
   return rc;
 }
 
-extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
+// `hold`: this list is a PART of a pass whose next part follows on the same thread -- the side stream is left unjoined at
+// the end (its launches keep running beside the next part's); the part that ends the pass (hold = 0) joins.
+static int plan_run_part(const AabrPlanOp *ops, int n_ops, void *st_, int hold) {
   AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
   hipStream_t main_stream = (hipStream_t)st_;
-  size_t n_events = 0, n_pending = 0;   // events used by this call / side launches not yet joined
+  size_t n_events = 0, n_pending = g_side.pending;   // events used by this call / side launches not yet joined
+  g_side.pending = 0;
   // AABR_PLAN_SIDE records can be handed to the second stream in BATCHES (PLAN_SIDE_BATCH knob): one event on the
   // caller's stream per batch instead of one per record (an event is a marker packet in the queue, ~5 us of it).
   // Measured on the bench step: 13.47 ms with an event per record, 13.60 in batches of 4, 13.68 of 8 -- starting the
@@ -344,11 +354,114 @@ extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
     const int rc = flush();
     if (rc != AABR_OK) return fail(rc);
   }
+  if (hold) {
+    g_side.pending = n_pending;
+    return AABR_OK;
+  }
   if (n_pending) {
     const int jr = join_side();
     if (jr != AABR_OK) return fail(jr);
   }
   return AABR_OK;
+}
+
+extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) { return plan_run_part(ops, n_ops, st_, 0); }
+
+// ---- pipelined submission ---------------------------------------------------------------------------------------------
+// A pass's list costs the host twice: the caller fills the records (interpreter time) and this library issues their
+// launches (3.4 us per launch and 10 us per cross-stream event pair on this stack, tools/dev/launch_cost.hip: 1.7 ms
+// per training step, ~450 launches).  aabr_plan_submit hands a PART of the list to a launcher thread and returns; the
+// caller fills the next part meanwhile.  Parts are issued strictly in submission order, each with the semantics of
+// aabr_plan_run except that only the LAST part (hold_side = 0) joins the second stream.  aabr_plan_drain returns when
+// every submitted part has been issued (not when the device has run it) with the first failing part's code: call it
+// before anything else is enqueued on the streams involved.  One launcher per process; the records are copied.
+namespace {
+struct Launcher {
+  struct Job { std::vector<AabrPlanOp> ops; void *st; int hold; int dev; };
+  std::mutex m;
+  std::condition_variable cv_work, cv_idle;
+  std::deque<Job> q;
+  bool busy = false, started = false;
+  int rc = AABR_OK;
+  std::string err;
+  long long busy_ns = 0, jobs = 0, sleeps = 0;   // (tools: time spent issuing, parts issued, times the queue ran dry)
+  void run() {
+    int cur_dev = -1;
+    for (;;) {
+      Job j;
+      {
+        std::unique_lock<std::mutex> l(m);
+        if (q.empty()) ++sleeps;
+        cv_work.wait(l, [&] { return !q.empty(); });
+        j = std::move(q.front());
+        q.pop_front();
+        busy = true;
+      }
+      int r = AABR_OK;
+      bool skip;
+      const auto t0 = std::chrono::steady_clock::now();
+      { std::lock_guard<std::mutex> l(m); skip = rc != AABR_OK; }   // after a failure the rest of the pass is dropped
+      if (!skip) {
+        if (j.dev != cur_dev) { hipSetDevice(j.dev); cur_dev = j.dev; }
+        r = plan_run_part(j.ops.data(), (int)j.ops.size(), j.st, j.hold);
+      } else if (!j.hold && g_side.pending) {                        // ... but its side stream is never left unjoined
+        hipStreamSynchronize(g_side.stream);
+        g_side.pending = 0;
+      }
+      {
+        std::lock_guard<std::mutex> l(m);
+        if (r != AABR_OK && rc == AABR_OK) { rc = r; err = aabr_last_error(); }
+        busy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        ++jobs;
+        busy = false;
+        if (q.empty()) cv_idle.notify_all();
+      }
+    }
+  }
+};
+Launcher *g_launcher = nullptr;           // created on first use and never destroyed (its thread outlives static destruction)
+std::once_flag g_launcher_once;
+} // namespace
+
+extern "C" int aabr_plan_submit(const AabrPlanOp *ops, int n_ops, void *st, int hold_side) {
+  AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
+  int dev = 0;
+  AABR_CHECK_HIP(hipGetDevice(&dev));
+  std::call_once(g_launcher_once, [] {
+    g_launcher = new Launcher();
+    std::thread([] { g_launcher->run(); }).detach();
+  });
+  Launcher::Job j;
+  j.ops.assign(ops, ops + n_ops);
+  j.st = st;
+  j.hold = hold_side;
+  j.dev = dev;
+  {
+    std::lock_guard<std::mutex> l(g_launcher->m);
+    g_launcher->q.push_back(std::move(j));
+  }
+  g_launcher->cv_work.notify_one();
+  return AABR_OK;
+}
+
+extern "C" void aabr_plan_launcher_stats(int64_t *busy_ns, int64_t *parts, int64_t *sleeps) {
+  *busy_ns = *parts = *sleeps = 0;
+  if (!g_launcher) return;
+  std::lock_guard<std::mutex> l(g_launcher->m);
+  *busy_ns = g_launcher->busy_ns; *parts = g_launcher->jobs; *sleeps = g_launcher->sleeps;
+}
+
+extern "C" int aabr_plan_drain(void) {
+  if (!g_launcher) return AABR_OK;
+  std::unique_lock<std::mutex> l(g_launcher->m);
+  g_launcher->cv_idle.wait(l, [&] { return g_launcher->q.empty() && !g_launcher->busy; });
+  const int rc = g_launcher->rc;
+  if (rc != AABR_OK) {
+    aabr::set_error("%s", g_launcher->err.c_str());
+    g_launcher->rc = AABR_OK;
+    g_launcher->err.clear();
+  }
+  return rc;
 }
 
 // ---- geometry plan: the rule-book builders of a pass as one list ------------------------------------------------

@@ -73,6 +73,15 @@ conv_bn_bwd_stats = os.environ.get("AABR_PLAN_CONV_BN_BWD_STATS", "1") != "0"
 # makes the caller's stream wait for the weight gradients issued so far on the library's second stream.
 grad_segments = 0
 on_grads_ready = None
+# Pipelined hand-over (aabr_plan_submit / aabr_plan_drain; option): every `pipeline_records` records the part of the list
+# that is final goes to the library's launcher thread, which issues its launches while this thread fills the next part --
+# the two halves of a pass's host cost (filling records, issuing launches) overlap instead of adding up, and the device
+# starts the pass one part in instead of after the whole list.  Same records in the same order, bit-equal results
+# (tests/test_gpu_fpn.py).  Measured on the bench step (round 4, tools/tools_host_breakdown.py): the two passes' host time
+# 2.50 -> 2.00 ms (the launcher needs 1.37 ms per step to issue ~450 launches either way, and the pass must be drained
+# before torch's next launch), step time unchanged within noise in fp32 (device-bound) and bf16 (7.88 vs 7.90 ms: the
+# device's chain of small launches is as long as the host's) -- so the default is 0 = one call per pass.
+pipeline_records = int(os.environ.get("AABR_PLAN_PIPELINE", "0"))
 # tests: a list here receives every _Pass that runs (its arena holds every activation of the pass --
 # `_Pass.bn_outputs()`); None in production
 debug_passes = None
@@ -555,6 +564,13 @@ class _Pass(object):
 
     def forward(self, keep=True):
         """`keep` False (no autograd): the arena is packed by liveness (`_live_offsets`)"""
+        try:
+            return self._forward(keep)
+        except BaseException:
+            self.lib.aabr_plan_drain()     # never leave parts of a failed pass in the launcher's queue
+            raise
+
+    def _forward(self, keep):
         t, V = self.t, self.V
         self._tmp = []
         packed = None if keep else self._live_offsets()
@@ -580,7 +596,18 @@ class _Pass(object):
         # that launch (record p6 -> BatchNorm p9) and skips its own statistics pass over the matrix
         last = {0: None, F_SIDE: None}     # per stream: (buffer index written, record offset, tile rows, planes)
         cstat = {}
+        part, start, strm = pipeline_records * 176, 0, stream()
         for op, xf in t.emit:
+            if part and off - start >= part:
+                # records up to `safe` are final (a convolution record stays open while the BatchNorm behind it may
+                # still claim its write-out for the statistics)
+                safe = off
+                for lw in last.values():
+                    if lw is not None and lw[1] < safe:
+                        safe = lw[1]
+                if safe > start:
+                    check(self.lib.aabr_plan_submit(bytes(buf[start:safe]), (safe - start) // 176, strm, 1))
+                    start = safe
             kind = op[0]
             sk = xf & F_SIDE
             if kind == "conv":
@@ -627,8 +654,11 @@ class _Pass(object):
                      A[x], A[y], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
                 off += 176
             last[sk] = None
-        if off:
-            check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, stream()))
+        if part:
+            check(self.lib.aabr_plan_submit(bytes(buf[start:off]), (off - start) // 176, strm, 0))
+            check(self.lib.aabr_plan_drain())      # everything issued: the caller's next launches queue behind the pass
+        elif off:
+            check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, strm))
         res = []
         for b, _ in t.outs:
             lvl, planes, dt = fbufs[b]
@@ -655,6 +685,13 @@ class _Pass(object):
         return inv[byte_off]
 
     def backward(self, gouts, need_dx):
+        try:
+            return self._backward(gouts, need_dx)
+        except BaseException:
+            self.lib.aabr_plan_drain()
+            raise
+
+    def _backward(self, gouts, need_dx):
         t, V, A = self.t, self.V, self.A
         self._tmp = []
         gouts = [g.contiguous() if g is not None else None for g in gouts]
@@ -692,7 +729,13 @@ class _Pass(object):
         inv = sorted((o, i) for i, o in bw["poff"].items()) if nseg > 1 else []
         done_floats, seg_no, next_inv = 0, 0, 0
         last_din, bstat = None, None     # the last wide input-gradient record of the main stream / statistics workspace
+        part, start, strm = (pipeline_records * 176 if nseg == 1 else 0), 0, stream()
         for op_no, op in enumerate(bops):
+            if part and off - start >= part:
+                safe = last_din[1] if last_din is not None else off    # (that record may still get the statistics)
+                if safe > start:
+                    check(self.lib.aabr_plan_submit(bytes(buf[start:safe]), (safe - start) // 176, strm, 1))
+                    start = safe
             if nseg > 1 and seg_no < nseg - 1 and op_no == cut[seg_no]:
                 last_din = None          # its record has been handed over
                 if off:
@@ -778,7 +821,10 @@ class _Pass(object):
                 pack(buf, off, K_CAST, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * planes, 0, 0, 0,
                      AD[gy[0]][gy[1]], AD[gx[0]][gx[1]], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
                 off += 176
-        if off:
+        if part:
+            check(self.lib.aabr_plan_submit(bytes(buf[start:off]), (off - start) // 176, strm, 0))
+            check(self.lib.aabr_plan_drain())
+        elif off:
             check(self.lib.aabr_plan_run(bytes(buf[:off]), off // 176, stream()))
         if nseg > 1:                      # the last piece's gradients
             pairs = []

@@ -512,6 +512,18 @@ typedef struct AabrPlanOp {
   void *p[12];
 } AabrPlanOp; /* 176 bytes, no padding */
 int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *stream);
+/* Pipelined form (extension): a pass's list handed over in PARTS.  aabr_plan_submit copies the records, queues them for the
+ * library's launcher thread and returns at once -- the caller fills the next part while this one's launches go out
+ * (issuing ~450 launches costs the host 1.7 ms per training step, filling their records about as much).  Parts are
+ * issued strictly in submission order with the semantics of aabr_plan_run; with hold_side != 0 the part leaves the
+ * second stream unjoined for the part that follows (the last part of a pass passes 0).  aabr_plan_drain blocks until
+ * every submitted part has been ISSUED and returns the first failing part's code (aabr_last_error() holds its
+ * message; the parts behind a failed one are dropped): call it before enqueuing anything else on the streams used. */
+int aabr_plan_submit(const AabrPlanOp *ops, int n_ops, void *stream, int hold_side);
+int aabr_plan_drain(void);
+/* (tools) the launcher's counters since process start: time spent issuing parts, parts issued, times it found its
+ * queue empty */
+void aabr_plan_launcher_stats(int64_t *busy_ns, int64_t *parts, int64_t *sleeps);
 /* Geometry plan (extension): the rule-book builders of a pass handed over as ONE list, each record = one of the
  * entry points above called with the record's fields -- nothing is computed differently:
  *   AABR_GEOM_SUBM_TABLE    aabr_submanifold_table(p0 coords, i64[0] V, p1 grid, i64[1] cap, i32[0..2] filter,

@@ -373,6 +373,49 @@ def test_fpn_weights_packed_once_per_version_is_bit_identical():
 
 
 @pytest.mark.gpu
+def test_compiled_graph_pipelined_hand_over_is_bit_equal_to_one_call():
+    """planExecutor.pipeline_records (the pass's list handed to the launcher thread in parts while the next part is
+    filled): outputs, input gradient, parameter gradients and running statistics are the bits of the one-call form,
+    for part sizes from one record up; fp32 and bf16 storage."""
+    from sparseconvnet import planExecutor
+    keep = planExecutor.pipeline_records
+    try:
+        for fdt in (torch.float32, torch.bfloat16):
+            torch.manual_seed(8)
+            net = _fpn(feature_dtype=fdt).to(DEV)
+            net.compiled_graph = True
+            state = {k: v.clone() for k, v in net.state_dict().items()}
+            locs, feats = S.make_batch(2, 20000, 43, 20)
+            l = _t(locs)
+
+            def run(parts):
+                planExecutor.pipeline_records = parts
+                net.load_state_dict(state)
+                net.train(True)
+                f = _t(feats).requires_grad_(True)
+                net.zero_grad()
+                rpn, roi = net([l, f])
+                outs = [m.features.detach().clone() for m in rpn + roi]
+                sum(m.features.float().square().mean() for m in rpn + roi).backward()
+                torch.cuda.synchronize()
+                return (outs, f.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                        {k: v.clone() for k, v in net.state_dict().items() if "running" in k})
+
+            ref = run(0)
+            for parts in (1, 7, 32, 1000):
+                got = run(parts)
+                for x, y in zip(ref[0], got[0]):
+                    assert torch.equal(x, y)
+                assert torch.equal(ref[1], got[1])
+                assert ref[2].keys() == got[2].keys()
+                for n in ref[2]:
+                    assert torch.equal(ref[2][n], got[2][n]), (parts, n)
+                for k in ref[3]:
+                    assert torch.equal(ref[3][k], got[3][k]), (parts, k)
+    finally:
+        planExecutor.pipeline_records = keep
+
+
 def test_fpn_compiled_graph_matches_module_path():
     """FPN_Net.compiled_graph (sparseconvnet/planExecutor.py: every layer between the input layer and the returned
     maps as one launch list per pass, one autograd node) against the module path on the same net and input:

@@ -82,6 +82,47 @@ def test_plan_run_records_side_stream_join_and_error_path():
     assert b"aligned" in lib.aabr_last_error()
 
 
+def test_plan_submit_parts_hold_the_side_stream_and_drain_reports_errors():
+    """aabr_plan_submit / aabr_plan_drain (the launcher thread): a list handed over in parts -- the first part leaves
+    its second-stream record unjoined (hold_side = 1), the last part's JOIN record waits for it -- gives the result of
+    the one-call form; an empty closing part joins what is held; a failing part's code and message come out of
+    aabr_plan_drain, the parts behind it are dropped, and the launcher is usable afterwards."""
+    _hip, lib = _lib()
+    n = 1 << 20
+    a, b = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+    s1, s2, s3 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    r1 = _rec(6, 4, i64=(n,), ps=(a.data_ptr(), b.data_ptr(), s1.data_ptr()))         # second stream
+    r2 = _rec(6, 0, i64=(n,), ps=(a.data_ptr(), a.data_ptr(), s2.data_ptr()))
+    r3 = _rec(6, 8, i64=(n,), ps=(s1.data_ptr(), s2.data_ptr(), s3.data_ptr()))         # joins first
+    st = _hip.stream()
+    for _ in range(20):
+        s3.zero_()
+        _hip.check(lib.aabr_plan_submit(r1, 1, st, 1))
+        _hip.check(lib.aabr_plan_submit(r2, 1, st, 1))
+        _hip.check(lib.aabr_plan_submit(r3, 1, st, 0))
+        _hip.check(lib.aabr_plan_drain())
+        assert torch.equal(s3, (a + b) + (a + a))          # (torch's launch queues behind the issued parts)
+    # held side work joined by an empty closing part: the caller's stream sees s1
+    s1.zero_()
+    _hip.check(lib.aabr_plan_submit(r1, 1, st, 1))
+    _hip.check(lib.aabr_plan_submit(b"", 0, st, 0))
+    _hip.check(lib.aabr_plan_drain())
+    assert torch.equal(s1 + 0, a + b)
+    # error path: the failing part's message, nothing issued behind it
+    s2.zero_()
+    torch.cuda.synchronize()
+    _hip.check(lib.aabr_plan_submit(_rec(99, 0), 1, st, 1))
+    _hip.check(lib.aabr_plan_submit(r2, 1, st, 0))
+    assert lib.aabr_plan_drain() != 0
+    assert b"unknown kind" in lib.aabr_last_error()
+    torch.cuda.synchronize()
+    assert float(s2.abs().max()) == 0.0
+    _hip.check(lib.aabr_plan_drain())                      # the error was consumed
+    _hip.check(lib.aabr_plan_submit(r2, 1, st, 0))
+    _hip.check(lib.aabr_plan_drain())
+    assert torch.equal(s2, a + a)
+
+
 def test_strided_grids_in_rounds_equal_level_by_level():
     """FPN_Net.grids_from_input (Metadata.buildGridsFromInput: every grid of a round of four levels straight from
     the round's base grid, one host read per round) against the level-by-level construction: every grid's site

@@ -43,7 +43,7 @@ class LibProxy(object):
         c = self._c.get(k)
         if c is None:
             f = getattr(self._l, k)
-            if k in ("aabr_plan_run", "aabr_geom_run"):
+            if k in ("aabr_plan_run", "aabr_geom_run", "aabr_plan_submit", "aabr_plan_drain"):
                 def c(*a, _f=f, _k=k):
                     t = time.perf_counter()
                     r = _f(*a)
@@ -91,5 +91,9 @@ for i in range(n):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print("host loop %.3f ms/step (%d steps, %s)" % ((t1 - t0) / n * 1e3, n, dtype))
+import ctypes
+st3 = (ctypes.c_int64 * 3)()
+lib.aabr_plan_launcher_stats(ctypes.byref(st3, 0), ctypes.byref(st3, 8), ctypes.byref(st3, 16))
+print("launcher thread since start: busy %.3f ms, %d parts, %d sleeps (%d steps in total)" % (st3[0] / 1e6, st3[1], st3[2], n + 6))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print("  %-36s %7.3f ms/step  %6.1f calls/step" % (k, v / n * 1e3, cnt[k] / n))
