@@ -137,7 +137,13 @@ struct BnBwdStats {
 // RING (fp32, experiment behind the WIDE_OCC4 knob): the B operands of a pair leave LDS one 32-channel chunk ahead of
 // their MFMAs through a two-slot register ring instead of all at once (16 registers instead of 64), so that the kernel
 // fits 128 registers = FOUR waves per SIMD; with 80-row tiles (37 KiB of LDS) four workgroups share a CU.
-template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2, bool X3 = false, bool RING = false>
+// DEFER (bf16 storage): the LDS tile rows a pair's results go to are read TOGETHER with the pair's operands (one LDS
+// round trip) and are the MFMA chains' starting accumulators; the stage barrier follows the reads at once, and the stage
+// store of the next pair, the MFMAs and the write-back of the rows all sit between the two barriers -- instead of
+// MFMAs | read .. add .. write | barrier | stage store | barrier in series.  The sum of a tile element is formed as
+// ((tile + p1) + p2) + .. instead of tile + ((p1 + p2) + ..): fp32 rounding apart, and fixed (run-to-run identical).
+template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2, bool X3 = false, bool RING = false,
+          bool DEFER = false>
 __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
                                                     const float *__restrict__ bias, int kT2,
                                                     const float *__restrict__ res, double *__restrict__ stats,
                                                     BnBwdStats bn) {
+  static_assert(!DEFER || (BF && !X3 && !RING && DBG == 0), "DEFER exists for the plain bf16-storage form");
   constexpr int RG = KG * 8;               // 16-byte granules per staged row
   constexpr int RF = KG * 32;              // floats per staged row
   constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
@@ -362,8 +369,9 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
         const float *sa = St + (NBUF == 2 ? par : 0) * STAGE + c16 * RF;
         const float *sb = sa + 16 * RF;
         f32x4 accA[NCB], accB[NCB];
+        f32x4 *da[NCB], *db[NCB];                              // DEFER: the tile rows the accumulators came from
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) { accA[cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[cb] = accA[cb]; }
+        for (int cb = 0; cb < NCB; ++cb) { accA[cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[cb] = accA[cb]; da[cb] = db[cb] = nullptr; }
         if (wflip & 2) __builtin_amdgcn_s_setprio(3);          // experiment (WIDE_PRIO knob): matrix phase at raised priority
         if constexpr (X3) {
           // term planes of the staged rows: plane pl at sa + pl * STAGE.  Products in the order small -> large:
@@ -451,6 +459,18 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
           a1[c] = *reinterpret_cast<const u32x4 *>(sa + q1);
           b1[c] = *reinterpret_cast<const u32x4 *>(sb + q1);
         }
+        if constexpr (DEFER) {
+          const int ra = e0.ea >= 0 ? (e0.ea & 255) : kT2, rb = e0.eb >= 0 ? (e0.eb & 255) : kT2;
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) {
+            da[cb] = reinterpret_cast<f32x4 *>(Ct + ra * WS + ((((wave * NCB + cb) * 4 + g) ^ (ra & 15)) << 2));
+            db[cb] = reinterpret_cast<f32x4 *>(Ct + rb * WS + ((((wave * NCB + cb) * 4 + g) ^ (rb & 15)) << 2));
+            accA[cb] = *da[cb];                                // (a padding entry: the dummy row, whatever it holds)
+            accB[cb] = *db[cb];
+          }
+          if (NBUF == 1) wg_barrier();                         // every wave holds its operands: the stage is free
+          if (pp[1].k < kend) stage_store(g_store, par ^ 1);   // the next pair, gathered NSET - 1 steps ago
+        }
         if (DBG & 1) { // timing experiments: operands consumed, no MFMAs
 #pragma unroll
           for (int c = 0; c < KG; ++c) {
@@ -509,10 +529,17 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
         }
         if (DBG & 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(accA[0]), "v"(accB[0])); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         if (wflip & 2) __builtin_amdgcn_s_setprio(0);
-        accumulate2(e0.ea, accA, e0.eb, accB);
+        if constexpr (DEFER) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) { *da[cb] = accA[cb]; *db[cb] = accB[cb]; }
+        } else {
+          accumulate2(e0.ea, accA, e0.eb, accB);
+        }
       }
-      if (NBUF == 1) wg_barrier();                           // single stage: every wave is done reading it
-      if (pp[1].k < kend) stage_store(g_store, par ^ 1);     // the next pair, gathered NSET - 1 steps ago
+      if constexpr (!DEFER) {
+        if (NBUF == 1) wg_barrier();                         // single stage: every wave is done reading it
+        if (pp[1].k < kend) stage_store(g_store, par ^ 1);   // the next pair, gathered NSET - 1 steps ago
+      }
       if (DBG & 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t3 = __builtin_amdgcn_s_memtime(); }
       wg_barrier();
       if (DBG & 4) {
@@ -1085,6 +1112,12 @@ static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in,
     const int v = knob(K_WIDE_NBUF);
     if (v == 1 || v == 2) nbuf = v;
   }
+  // DEV builds, WIDE_DEFER knob: the tile rows as the MFMA chains' starting accumulators (k_conv_cs DEFER; 256-channel
+  // groups would spill 73 registers).  Measured on the bench's rule books (round 4): 128->128 at 84 k rows 99.1 -> 97.7 us,
+  // 64->64 at 200 k rows 82.6 -> 79.7 -- the read-add-write is not the exposed latency of a step (the stage store's wait
+  // for the gathered rows is), and the form changes the fp32 summation order, so it is not dispatched.
+  const bool defer = knob(K_WIDE_DEFER) == 1 && kg <= 3;
+  (void)defer;
   const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
   float *out_f = reinterpret_cast<float *>(out_feats);
 constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: measured slower, 100 -> 112 us)
@@ -1098,19 +1131,28 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
                        tile_rows, (const float *)nullptr, stats, bn);                                                      \
   } while (0)
-#define AABR_WIDE_BF_S(KG, NB, NCB, NS)                                                                                  \
+#ifdef AABR_DEV
+#define AABR_WIDE_BF_S(KG, NB, NCB, NS)                                                                             \
+  do {                                                                                                             \
+    if (defer) AABR_WIDE_BF_L(KG, NB, NCB, NS, true);                                                              \
+    else AABR_WIDE_BF_L(KG, NB, NCB, NS, false);                                                                   \
+  } while (0)
+#else
+#define AABR_WIDE_BF_S(KG, NB, NCB, NS) AABR_WIDE_BF_L(KG, NB, NCB, NS, false)
+#endif
+#define AABR_WIDE_BF_L(KG, NB, NCB, NS, DF)                                                                        \
   do {                                                                                                             \
     static bool attr = false;                                                                                      \
     if (!attr) {                                                                                                   \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB, true, NCB, NS>),                          \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB, true, NCB, NS, false, false, DF>),    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                  \
       attr = true;                                                                                                 \
     }                                                                                                              \
     g_last_variant = NCB == 2 ? "k_conv_cs<" #KG ",0," #NB ",bf16,x128>" : "k_conv_cs<" #KG ",0," #NB ",bf16>";    \
-    hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS>), grid, dim3(256),                                         \
+    hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS, false, false, DF>), grid, dim3(256),                   \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr, stats, bn);                                                      \
+                       tile_rows, (const float *)nullptr, stats, bn);                                              \
   } while (0)
 #define AABR_WIDE_BF_K(KG)                                                                                         \
   do {                                                                                                             \
@@ -1137,6 +1179,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
 #undef AABR_WIDE_BF_K
 #undef AABR_WIDE_BF
 #undef AABR_WIDE_BF_S
+#undef AABR_WIDE_BF_L
 #undef AABR_WIDE_BF_D
   AABR_CHECK_LAUNCH();
   return AABR_OK;
