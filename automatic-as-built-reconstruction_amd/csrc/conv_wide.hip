@@ -142,9 +142,13 @@ struct BnBwdStats {
 // store of the next pair, the MFMAs and the write-back of the rows all sit between the two barriers -- instead of
 // MFMAs | read .. add .. write | barrier | stage store | barrier in series.  The sum of a tile element is formed as
 // ((tile + p1) + p2) + .. instead of tile + ((p1 + p2) + ..): fp32 rounding apart, and fixed (run-to-run identical).
+// NW = waves per workgroup (bf16 storage: 8).  At 64-row tiles every wave re-loads its 8 KiB slice of W[k] for about ONE
+// pair step, and the CU's vector-memory path (64 B / clock) is busy ~175 of every ~160 cycles a wave-step may take with 12
+// waves resident: the weights, 3/4 of those bytes, set the pace.  Eight waves x 16 columns share a 128-row x 128-column
+// tile: half the weight bytes per output row, the same gathered bytes, 16 waves per CU (two workgroups) to hide latency.
 template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2, bool X3 = false, bool RING = false,
-          bool DEFER = false>
-__global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
+          bool DEFER = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3))) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
@@ -152,20 +156,24 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
                                                     const float *__restrict__ res, double *__restrict__ stats,
                                                     BnBwdStats bn) {
   static_assert(!DEFER || (BF && !X3 && !RING && DBG == 0), "DEFER exists for the plain bf16-storage form");
+  static_assert(NW == 4 || (NW == 8 && BF && !X3 && !RING && DBG == 0 && (KG & 1) == 0),
+                "eight waves: plain bf16-storage form, rows of 16 x 16-byte granules or a multiple");
+  constexpr int NT = 64 * NW;              // threads
+  constexpr int LPR = NT / 32;             // lanes per gathered pair row (8 or 16)
   constexpr int RG = KG * 8;               // 16-byte granules per staged row
   constexpr int RF = KG * 32;              // floats per staged row
   constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
   constexpr int STAGE = 2 * 16 * RF;       // floats per stage buffer (two blocks)
   constexpr bool BFM = BF || X3;           // bf16 operands in the stage and the weight pack
   constexpr int NP = X3 ? 3 : 1;           // bf16 terms per operand
-  constexpr int NGL = X3 ? 2 * KG : KG;    // 16-byte gather loads per lane and pair (X3: fp32 rows, 32 channels per 128 B)
+  constexpr int NGL = (X3 ? 2 * KG : KG) * 8 / LPR; // 16-byte gather loads per lane and pair (X3: fp32 rows, 32 channels per 128 B)
   extern __shared__ __align__(16) float smem[];
   float *Ct = smem;                        // [kT2 + 1][64] floats, granule-swizzled; the last row swallows padding entries
-  constexpr int WS = kWS * NCB;            // tile row stride in floats = slab width
+  constexpr int WS = 16 * NW * NCB;        // tile row stride in floats = slab width
   float *St = smem + (kT2 + 1) * WS;       // [2][2][16][RF]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
-  const int pr = wave * 8 + (lane >> 3), seg = lane & 7; // gather role: pair row 0..31, 16-byte segment
+  const int pr = wave * (64 / LPR) + lane / LPR, seg = lane % LPR; // gather role: pair row 0..31, 16-byte segment
   const int nkc = BFM ? ci >> 6 : ci >> 5, nnb = co >> 4;  // chunks per row (64 channels with bf16 operands, else 32)
   // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own 4 MiB L2.  Give every XCD a
   // CONTIGUOUS range of (tile, slab) work items instead of every eighth one: the slabs of a tile and the tiles next to
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
     tile = wi / ny;
     unsigned sp = wi % ny;
     if (nparts > 1) { part = (int)(sp % (unsigned)nparts); sp /= (unsigned)nparts; }
-    nb0 = (int)sp * (kNB * NCB);
+    nb0 = (int)sp * (NW * NCB);
   }
   const int k_lo = nparts > 1 ? part * vol / nparts : 0;
   const int kend = nparts > 1 ? (part + 1) * vol / nparts : vol;   // offsets >= kend are past the end for this part
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
   {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 *c4 = reinterpret_cast<f32x4 *>(Ct);
-    for (int i = threadIdx.x; i < (kT2 + 1) * WS / 4; i += 256) c4[i] = z;
+    for (int i = threadIdx.x; i < (kT2 + 1) * WS / 4; i += NT) c4[i] = z;
   }
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
     const unsigned va = (((unsigned)eg & 0x7fffffffu) >> 8) * rowbytes + (unsigned)seg * 16u;
 #pragma unroll
     for (int i = 0; i < NGL; ++i) { // granule seg + 8 i of the row's current channel group
-      const unsigned so = (unsigned)(kg * NGL + i) * 128u;
+      const unsigned so = (unsigned)(kg * NGL + i) * (unsigned)(LPR * 16);
       if (DBG & 2) q.v[i] = (u32x4){(unsigned)eg, 0u, 0u, 0u}; // timing experiments: no global gathers
       else q.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, va, so, 0);
     }
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
       // bf16 granule G >> 1 of the three term planes
 #pragma unroll
       for (int i = 0; i < NGL; ++i) {
-        const int G = seg + 8 * i;
+        const int G = seg + LPR * i;
         float r[4];
         u32x2 t[3];
 #pragma unroll
@@ -294,8 +302,8 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
       return;
     }
 #pragma unroll
-    for (int i = 0; i < KG; ++i)
-      *reinterpret_cast<u32x4 *>(rowp + (((seg + 8 * i) ^ (pr & SWZ)) << 2)) = q.v[i];
+    for (int i = 0; i < NGL; ++i)
+      *reinterpret_cast<u32x4 *>(rowp + (((seg + LPR * i) ^ (pr & SWZ)) << 2)) = q.v[i];
   };
   // branch-free: a padding entry (bit 31) lands in the dummy row; the two blocks of a pair never share a real row,
   // so both reads go out before either write
@@ -604,10 +612,10 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
   // `stats`: the following BatchNorm's statistics from the values this tile writes (exactly the stored values: after
   // bias / residual, after the bf16 rounding) -- per tile one [2][co] pair of fp64 column sums (x, x^2), combined by the
   // BatchNorm's finalize in tile order, so the result does not depend on which workgroup ran when
-  constexpr int QW = 16 * NCB;             // 16-byte columns of the slab; 256 % QW == 0: a thread keeps its column
+  constexpr int QW = 4 * NW * NCB;         // 16-byte columns of the slab; NT % QW == 0: a thread keeps its column
   if (nparts > 1) {                        // this part's fp32 partial tile (an empty offset range writes zeros)
     float *po = out + (int64_t)part * V_out * co;
-    for (int i = threadIdx.x; i < nrows * QW; i += 256) {
+    for (int i = threadIdx.x; i < nrows * QW; i += NT) {
       const int r = i / QW, q = i % QW;
       *reinterpret_cast<f32x4 *>(po + (row0 + r) * co + nb0 * 16 + q * 4) =
           *reinterpret_cast<const f32x4 *>(Ct + r * WS + ((q ^ (r & 15)) << 2));
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
     }
   }
 #pragma unroll 4
-  for (int i = threadIdx.x; i < nrows * QW; i += 256) {
+  for (int i = threadIdx.x; i < nrows * QW; i += NT) {
     const int r = i / QW, q = i % QW;
     f32x4 v = *reinterpret_cast<const f32x4 *>(Ct + r * WS + ((q ^ (r & 15)) << 2));
     if (bias) {
@@ -674,15 +682,15 @@ __global__ __launch_bounds__(256, RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3)) void k
   }
   if (stats) {
     __syncthreads();                       // every read of the tile is done: its LDS holds the partial sums now
-    double *red = reinterpret_cast<double *>(smem); // [256][8] = 16 KiB <= (kT2 + 1) * WS * 4 for kT2 >= 64
+    double *red = reinterpret_cast<double *>(smem); // [NT][8] = 16 / 32 KiB <= (kT2 + 1) * WS * 4 for kT2 >= 64
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[threadIdx.x * 8 + j] = sa[j]; red[threadIdx.x * 8 + 4 + j] = sb[j]; }
     __syncthreads();
-    if (threadIdx.x < 64 * NCB) {
+    if (threadIdx.x < 16 * NW * NCB) {
       const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
       double a = 0.0, b = 0.0;
 #pragma unroll
-      for (int t = 0; t < 256 / QW; ++t) { a += red[(t * QW + q) * 8 + j]; b += red[(t * QW + q) * 8 + 4 + j]; }
+      for (int t = 0; t < NT / QW; ++t) { a += red[(t * QW + q) * 8 + j]; b += red[(t * QW + q) * 8 + 4 + j]; }
       stats[(tile * 2 + 0) * co + nb0 * 16 + threadIdx.x] = a;
       stats[(tile * 2 + 1) * co + nb0 * 16 + threadIdx.x] = b;
     }
@@ -1026,6 +1034,14 @@ extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_i
   // three workgroups per CU; 64-column slabs keep the 96-row tiles of round 2.
   const int ncb = wide_bf16_ncb(n_in, n_out);
   int T = ncb == 2 ? 64 : 96;
+#ifdef AABR_DEV
+  // DEV builds, WIDE_NW8 = 1: eight-wave workgroups (128 input channels, 128-column slabs) on 128-row tiles when that still
+  // leaves more than one round of the 512 resident workgroups (two per CU).  Measured on the bench's rule books (round 4,
+  // profiles/r04_conv_bf16_w8_ab.txt): 84 k rows 99 -> 111 us, 200 k rows 191 -> 199, 282 k rows 169 -> 178, only the
+  // sparsest book (310 k rows, 1.5 rules per row) gains, 138 -> 121 -- half the weight bytes per output row do not pay for
+  // twice the operand reads from the stage and an eight-wave barrier; not dispatched.
+  if (ncb == 2 && n_in == 128 && knob(K_WIDE_NW8) == 1 && ((V_out + 127) / 128) * (n_out / 128) >= 600) T = 128;
+#endif
   {
     const int64_t slabs = n_out / (64 * ncb);
     if (((V_out + T - 1) / T) * slabs <= 512)
@@ -1120,6 +1136,23 @@ static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in,
   (void)defer;
   const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
   float *out_f = reinterpret_cast<float *>(out_feats);
+#ifdef AABR_DEV
+  if (kg == 2 && ncb == 2 && tile_rows >= 128 && knob(K_WIDE_NW8) == 1) {   // eight waves x 16 columns on a 128-column slab
+    static bool attr8 = false;
+    if (!attr8) {
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<2, 0, 1, true, 1, 2, false, false, false, 8>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      attr8 = true;
+    }
+    g_last_variant = "k_conv_cs<2,0,1,bf16,x128,w8>";
+    hipLaunchKernelGGL((k_conv_cs<2, 0, 1, true, 1, 2, false, false, false, 8>), grid, dim3(512),
+                       (size_t)((tile_rows + 1) * 128 + 2 * 16 * 2 * 32) * sizeof(float), st, in_f, n_in, in_bytes, out_f,
+                       n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias, tile_rows,
+                       (const float *)nullptr, stats, bn);
+    AABR_CHECK_LAUNCH();
+    return AABR_OK;
+  }
+#endif
 constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: measured slower, 100 -> 112 us)
 #define AABR_WIDE_BF(KG, NB, NCB) AABR_WIDE_BF_S(KG, NB, NCB, ((KG) <= 2 ? kBfSets : 2))
 #define AABR_WIDE_BF_D(KG, NB, NCB, D)                                                                              \
