@@ -255,7 +255,7 @@ def test_bench_pmc_lookups_resolve_in_this_rounds_profile():
     bench.PMC_PROFILE = "r04_pmc_fetch_write_per_kernel.json"
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", bench.PMC_PROFILE)
     pm = json.load(open(path))["kernels"]
-    grids = sorted(int(k.split("|grid=")[1]) for k in pm if k.startswith("k_conv_cs<4,0,1,false,1,2,false,false>"))
+    grids = sorted(int(k.split("|grid=")[1]) for k in pm if k.startswith("k_conv_cs<4,0,1,false,1,2,false,false"))
     assert grids
     got, src = bench.pmc_traffic("k_conv_cs<4,0,1>", 336384)
     assert got and got > 50e6 and "336384" in src
