@@ -49,6 +49,9 @@ _SIGS = {
     "aabr_conv_forward_wide": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "aabr_conv_wide_split": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
     "aabr_conv_wide_split_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),
+    "aabr_conv_narrow_ok": (C.c_int, [_i32, _i32, _i64, _i64, _i32, _i32]),
+    "aabr_conv_forward_narrow": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "aabr_conv_forward_narrow_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp]),
     "aabr_conv_wide_split_bf16": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
     "aabr_conv_forward_wide_split_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp,
                                                     _i32, _vp, _vp]),

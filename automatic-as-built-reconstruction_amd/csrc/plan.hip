@@ -206,6 +206,13 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
                                            (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
                                            (const float *)p[5], (const float *)p[3], o.i32[5], (float *)p[6], st);
     break;
+  case AABR_PLAN_CONV_NARROW:
+    rc = bf ? aabr_conv_forward_narrow_bf16((const uint16_t *)p[0], o.i64[0], (uint16_t *)p[1], o.i64[1],
+                                            (const int32_t *)p[2], o.i32[2], (const float *)p[3], (const float *)p[4],
+                                            o.i32[3], st)
+            : aabr_conv_forward_narrow((const float *)p[0], o.i64[0], (float *)p[1], o.i64[1], (const int32_t *)p[2],
+                                       o.i32[2], (const float *)p[3], (const float *)p[4], o.i32[3], st);
+    break;
   case AABR_PLAN_CONV_RS:
     AABR_CHECK_ARG(bf, "AABR_PLAN_CONV_RS exists for bf16 storage only");
     rc = aabr_conv_forward_rs_bf16((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1], o.i64[1],

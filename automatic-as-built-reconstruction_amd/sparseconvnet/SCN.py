@@ -949,6 +949,15 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
     if w.dtype != torch.float32:
         raise TypeError("convolution weights are fp32 master parameters, got %s" % w.dtype)
     bf16 = inp.dtype == torch.bfloat16
+    if narrow_ok(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16):
+        # 32 -> 32 planes: all offsets' weights in LDS, 16 output rows per wave in registers, straight from the gather
+        # table (csrc/conv_narrow.hip) -- no weight pack, no block stream
+        fn = lib.aabr_conv_forward_narrow_bf16 if bf16 else lib.aabr_conv_forward_narrow
+        check(fn(ptr(inp), inp.size(0), ptr(out), n_rows_out, ptr(gather.table), gather.vol, ptr(w), ptr(_opt(bias)),
+                 flags & 3, stream()))
+        if trace is not None:
+            trace.append(("fwd", n_in, n_out, gather, inp.size(0), flags & 3, inp.dtype))
+        return n_out
     if bf16:
         elems, name, dt = lib.aabr_conv_wpack_bf16_elems(gather.vol, w.size(2), w.size(3)), "wpack16", torch.bfloat16
         conv, pack2 = lib.aabr_conv_forward_bf16, lib.aabr_conv_pack_weights2_bf16
@@ -1102,6 +1111,14 @@ def wide_tile_rows(n_in, n_out, rows_in, rows_out, vol, bf16=False, prepacked=Tr
     return lib.aabr_conv_wide_tile_rows(n_in, n_out, rows_in, rows_out, vol)
 
 
+def narrow_ok(n_in, n_out, rows_in, rows_out, vol, bf16):
+    """True when this launch goes to the 32 -> 32 kernel (csrc/conv_narrow.hip); asked FIRST by the layer code, the stream
+    pre-builder and the graph executor alike"""
+    if rows_out == 0:
+        return False
+    return bool(_hip.load().aabr_conv_narrow_ok(n_in, n_out, rows_in, rows_out, vol, 1 if bf16 else 0))
+
+
 def wide_split(n_in, n_out, rows_in, rows_out, vol, bf16=False):
     """(tile_rows, parts) when this launch goes to the offset-split form of the wide kernel (coarse maps: too few
     (tile, slab) items to fill the chip; csrc/conv_wide.hip aabr_conv_forward_wide_split), else None.  Asked after
@@ -1152,6 +1169,10 @@ def compile_streams(gather, rows_in, n_in, n_out, dtype, weight_grad=False):
     """Build, ahead of their first use, the block stream the forward-form launch (n_in -> n_out over `gather`) will
     read -- the same choice `_conv_fwd` makes -- and, with `weight_grad`, the offset-pair lists of the dW kernel."""
     if gather is None or gather.rows == 0:
+        return
+    if narrow_ok(n_in, n_out, rows_in, gather.rows, gather.vol, dtype == torch.bfloat16):   # reads the gather table itself
+        if weight_grad:
+            gather.pairs()
         return
     unit_rows = rs_unit_rows(n_in, n_out, rows_in, gather.rows, gather.vol, dtype == torch.bfloat16)
     tile_rows = 0 if unit_rows else wide_tile_rows(n_in, n_out, rows_in, gather.rows, gather.vol,

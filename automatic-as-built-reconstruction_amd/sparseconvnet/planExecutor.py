@@ -39,7 +39,7 @@ from .deconvolution import Deconvolution
 
 _OP = struct.Struct("<ii6i4f4q12Q")          # AabrPlanOp (include/aabr_hip.h)
 assert _OP.size == 176
-K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST, K_RS, K_WSPLIT = 1, 2, 3, 4, 5, 6, 7, 8, 9
+K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST, K_RS, K_WSPLIT, K_NARROW = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 F_BF16, F_TO_BF16, F_SIDE, F_JOIN = 1, 2, 4, 8
 _ALIGN = 256
 BF16 = torch.bfloat16
@@ -470,6 +470,11 @@ class _Pass(object):
         self._lw = 0      # tile rows when the record is a K_WIDE one (its write-out can form BatchNorm statistics)
         if rows_out == 0:
             return off
+        if not res and SCN.narrow_ok(n_in, n_out, rows_in, rows_out, gather.vol, bf):
+            # 32 -> 32 planes from the gather table, raw weights (csrc/conv_narrow.hip): the choice SCN._conv_fwd makes first
+            pack(buf, off, K_NARROW, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, 0, 0, 0.0, 0.0, 0.0,
+                 0.0, rows_in, rows_out, 0, 0, src, dst, gather.table.data_ptr(), p_w, 0, 0, 0, 0, 0, 0, 0, 0)
+            return off + 176
         U = SCN.rs_unit_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf) if not res else 0
         if U:     # bf16 storage, row-stationary form (csrc/conv_rs.hip): the same choice SCN._conv_fwd makes
             pack(buf, off, K_RS, xf | F_BF16, n_in, n_out, gather.vol, flags & 3, U, 0, 0.0, 0.0, 0.0, 0.0, rows_in,

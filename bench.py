@@ -422,9 +422,16 @@ def conv_kernel_table(torch, wl, dtype, max_rows=None):
             else:
                 wpack = torch.empty(lib.aabr_conv_wpack_floats(ga.vol, w.size(2), w.size(3)), device=dev)
                 conv = lib.aabr_conv_forward
-            unit_rows = SCN.rs_unit_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)   # the dispatch of SCN._conv_fwd
-            tile_rows = 0 if unit_rows else SCN.wide_tile_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
-            if unit_rows:
+            narrow = SCN.narrow_ok(n_in, n_out, rows_in, ga.rows, ga.vol, bf)        # the dispatch of SCN._conv_fwd
+            unit_rows = 0 if narrow else SCN.rs_unit_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
+            tile_rows = 0 if (unit_rows or narrow) else SCN.wide_tile_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
+            if narrow:
+                nfn = lib.aabr_conv_forward_narrow_bf16 if bf else lib.aabr_conv_forward_narrow
+
+                def fn():
+                    check(nfn(ptr(inp), rows_in, ptr(out), ga.rows, ptr(ga.table), ga.vol, ptr(w), None, g["flags"] & 3,
+                              stream()))
+            elif unit_rows:
                 words = ga.rs_stream(unit_rows)
                 wt = torch.empty_like(wpack)
                 if tr_:     # w is the layer's own weight; the input-gradient launch reads its transposed pack

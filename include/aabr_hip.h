@@ -459,6 +459,18 @@ int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_
                                       int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
                                       int flags, const uint16_t *wpack, int parts, float *scratch, void *stream);
 
+/* 32 -> 32 plane layers (the finest scales; csrc/conv_narrow.hip): the same sum as aabr_conv_forward (Convolution.cpp:
+ * 117-185), read from the GATHER TABLE `table` [vol][V_out] (input row of output row o at offset k, or -1 -- what
+ * aabr_submanifold_table / aabr_convolution_tables leave behind) instead of a block stream, with the fp32 master weights
+ * W [vol][32][32] staged in LDS by the launch itself (no pack call).  flags: bit 0 transposed weights, bit 1 mirrored
+ * offsets (the submanifold input-gradient form).  aabr_conv_narrow_ok: 1 when the dispatch hands a launch to it (bf16
+ * storage from 400,000 output rows on: where the tile kernels' per-block weight stream stops fitting the L2s).       */
+int aabr_conv_narrow_ok(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol, int bf16);
+int aabr_conv_forward_narrow(const float *in_feats, int64_t rows_in, float *out_feats, int64_t V_out, const int32_t *table,
+                             int vol, const float *W, const float *bias, int flags, void *stream);
+int aabr_conv_forward_narrow_bf16(const uint16_t *in_feats, int64_t rows_in, uint16_t *out_feats, int64_t V_out,
+                                  const int32_t *table, int vol, const float *W, const float *bias, int flags, void *stream);
+
 /* ---- compiled launch plans (extension) --------------------------------------------------------
  * The reference enters its library once per layer and direction from Python (SCN/pybind.cpp:134-221 behind
  * sparseconvnet/ layer modules).  A host that has compiled the static part of a network into a list of launches hands
@@ -499,6 +511,8 @@ int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_
 #define AABR_PLAN_CONV_WIDE_SPLIT 9 /* aabr_conv_forward_wide_split[_bf16](p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
                                        i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual (fp32
                                        storage only), i32[5] parts, p6 scratch) */
+#define AABR_PLAN_CONV_NARROW 10 /* aabr_conv_forward_narrow[_bf16](p0 in, i64[0] rows_in, p1 out, i64[1] V_out, p2 table,
+                                   i32[2] vol, p3 W, p4 bias, i32[3] flags) */
 #define AABR_PLAN_BF16 1
 #define AABR_PLAN_TO_BF16 2
 #define AABR_PLAN_JOIN 8 /* the caller's stream waits for the second stream in front of this record */
