@@ -52,6 +52,10 @@ _SIGS = {
     "aabr_conv_narrow_ok": (C.c_int, [_i32, _i32, _i64, _i64, _i32, _i32]),
     "aabr_conv_forward_narrow": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp]),
     "aabr_conv_forward_narrow_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "aabr_conv_narrow_parts": (C.c_int, [_i64]),
+    "aabr_conv_forward_narrow_bf16_stats": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "aabr_conv_forward_narrow_bf16_bwd_stats": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp,
+                                                          _vp, _f32, _vp]),
     "aabr_conv_wide_split_bf16": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
     "aabr_conv_forward_wide_split_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp,
                                                     _i32, _vp, _vp]),

@@ -40,12 +40,25 @@ constexpr int kNarrowThreads = 1024;
 // fp32 (eight v_mfma_f32_16x16x4_f32, MFMA t takes K slots {channel 8g' + t : g' = 0..3}): the same 8 channels, value t
 // used by MFMA t -- the gathered row is loaded in exactly that grouping, so any channel order inside a lane is a
 // consistent relabelling of K.
-template <bool BF>
+// STATS (bf16 storage; the BatchNorm around the layer takes its statistics from this launch's write-out as it does from
+// k_conv_cs'): 1 = forward sums (v, v^2) of the STORED values; 2 = backward sums of the BatchNorm whose d_out this launch
+// writes: (d, (x - mean) d), d = stored value masked by the sign of that BatchNorm's stored output (the terms of
+// k_bn_partials<1, ., bf16>).  One [2][32] fp64 pair per WORKGROUP (parts[blockIdx.x]): rows summed over a wave's 16 lanes,
+// then over its groups, then over the 16 waves in wave order -- fixed, whatever ran when.
+struct NarrowStats {
+  double *parts;
+  const __bf16 *x, *y;      // STATS == 2: the BatchNorm's input and stored output
+  const float *mean;
+  float leak;
+};
+
+template <bool BF, int STATS = 0>
 __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *__restrict__ in_, int64_t rows_in,
                                                                    void *__restrict__ out_, int64_t V_out,
                                                                    const int32_t *__restrict__ table, int vol,
                                                                    const float *__restrict__ W, const float *__restrict__ bias,
-                                                                   int flags) {
+                                                                   int flags, NarrowStats ns) {
+  static_assert(STATS == 0 || BF, "write-out statistics: bf16 storage");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   constexpr int ES = BF ? 2 : 4;                 // bytes per stored feature
   constexpr int NB = BF ? 4 : 2;                 // offsets per gather batch (two batches in flight: 32 registers)
@@ -66,6 +79,10 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
       else reinterpret_cast<float *>(smem_raw)[(((k * 2 + cb) * 2 + (t >> 2)) * 64 + ln) * 4 + (t & 3)] = w;  // [half][lane][4]
     }
   }
+  // behind the weights: [16 waves][2][32] fp64 statistics accumulators
+  double *sacc = reinterpret_cast<double *>(smem_raw + (size_t)vol * 2 * 64 * (BF ? 16 : 32));
+  if (STATS)
+    for (int i = threadIdx.x; i < 16 * 2 * kNarrowC; i += kNarrowThreads) sacc[i] = 0.0;
   __syncthreads();
   // gathers through a buffer descriptor (32-bit offsets, bounds-checked)
   const unsigned rowbytes = kNarrowC * ES;
@@ -141,22 +158,64 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
       consume(b);
     }
     // lane (c16, g) holds, per column block, columns cb * 16 + 4 g .. + 3 of output row `row`
-    if (live) {
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < 2; ++cb) {
+      const int n0 = cb * 16 + g * 4;
+      double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+      if (live) {
         f32x4 v = acc[cb];
-        const int n0 = cb * 16 + g * 4;
         if (bias) { v[0] += bias[n0]; v[1] += bias[n0 + 1]; v[2] += bias[n0 + 2]; v[3] += bias[n0 + 3]; }
         if (BF) {
           const bf16x4n o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
           *reinterpret_cast<bf16x4n *>(reinterpret_cast<__bf16 *>(out_) + row * kNarrowC + n0) = o;
+          if (STATS == 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float sv = (float)o[t];
+              s1[t] = (double)sv;
+              s2[t] = (double)sv * (double)sv;
+            }
+          } else if (STATS == 2) {
+            const bf16x4n xv = *reinterpret_cast<const bf16x4n *>(ns.x + row * kNarrowC + n0);
+            const bf16x4n yv = *reinterpret_cast<const bf16x4n *>(ns.y + row * kNarrowC + n0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float sv = (float)o[t];
+              const float d = ((float)yv[t] > 0.0f) ? sv : sv * ns.leak;
+              s1[t] = (double)d;
+              s2[t] = (double)((float)xv[t] - ns.mean[n0 + t]) * (double)d;
+            }
+          }
         } else {
           *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(out_) + row * kNarrowC + n0) = v;
+        }
+      }
+      if (STATS) {   // the 16 rows of the group (lanes of equal g), then this wave's accumulators
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+          for (int sh = 1; sh < 16; sh <<= 1) {
+            s1[t] += __shfl_xor(s1[t], sh);
+            s2[t] += __shfl_xor(s2[t], sh);
+          }
+          if (c16 == 0) {
+            sacc[(wave * 2 + 0) * kNarrowC + n0 + t] += s1[t];
+            sacc[(wave * 2 + 1) * kNarrowC + n0 + t] += s2[t];
+          }
         }
       }
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) ent[k] = nxt[k];
+  }
+  if (STATS) {
+    __syncthreads();
+    if (threadIdx.x < 2 * kNarrowC) {
+      const int sidx = threadIdx.x >> 5, col = threadIdx.x & 31;
+      double a = 0.0;
+      for (int w = 0; w < 16; ++w) a += sacc[(w * 2 + sidx) * kNarrowC + col];
+      ns.parts[((int64_t)blockIdx.x * 2 + sidx) * kNarrowC + col] = a;
+    }
   }
 }
 
@@ -178,28 +237,35 @@ extern "C" int aabr_conv_narrow_ok(int n_in, int n_out, int64_t rows_in, int64_t
   return (bf16 && V_out >= 400000) ? 1 : 0;
 }
 
-template <bool BF>
+static unsigned narrow_grid(int64_t V_out) {
+  const int64_t ngroups = (V_out + 15) / 16;
+  const int64_t want = (ngroups + 15) / 16;
+  return (unsigned)(want < 256 ? want : 256);
+}
+
+// workgroups (= statistics parts) of the launch over V_out rows
+extern "C" int aabr_conv_narrow_parts(int64_t V_out) { return V_out > 0 ? (int)narrow_grid(V_out) : 0; }
+
+template <bool BF, int STATS>
 static int conv_narrow_launch(const void *in, int64_t rows_in, void *out, int64_t V_out, const int32_t *table, int vol,
-                              const float *W, const float *bias, int flags, void *stream_) {
+                              const float *W, const float *bias, int flags, NarrowStats ns, void *stream_) {
   AABR_CHECK_ARG(vol > 0 && vol <= kNarrowVol && V_out >= 0 && rows_in >= 0, "bad sizes (vol <= 28)");
   if (V_out == 0) return AABR_OK;
   AABR_CHECK_ARG(in && out && table && W && rows_in > 0, "null pointer / empty input");
   AABR_CHECK_ARG(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "feature pointers must be 16-byte aligned");
   AABR_CHECK_ARG((flags & ~3) == 0, "flags: bit 0 transposed weights, bit 1 mirrored offsets");
   AABR_CHECK_ARG(rows_in * kNarrowC * (BF ? 2 : 4) < (1ll << 31), "input matrix must be < 2 GiB");
-  const size_t lds = (size_t)vol * 2 * 64 * (BF ? 16 : 32);
+  const size_t lds = (size_t)vol * 2 * 64 * (BF ? 16 : 32) + (STATS ? 16 * 2 * kNarrowC * sizeof(double) : 0);
   static bool attr = false;
   if (!attr) {
-    AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_narrow<BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kNarrowVol * 2 * 64 * 32));
+    AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_narrow<BF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kNarrowVol * 2 * 64 * 32 + 16 * 2 * kNarrowC * (int)sizeof(double)));
     attr = true;
   }
-  const int64_t ngroups = (V_out + 15) / 16;
-  const int64_t want = (ngroups + 15) / 16;
-  const unsigned grid = (unsigned)(want < 256 ? want : 256);
-  g_last_variant = BF ? "k_conv_narrow<bf16>" : "k_conv_narrow<f32>";
-  hipLaunchKernelGGL((k_conv_narrow<BF>), dim3(grid), dim3(kNarrowThreads), lds, (hipStream_t)stream_, in, rows_in, out,
-                     V_out, table, vol, W, bias, flags);
+  g_last_variant = BF ? (STATS == 2 ? "k_conv_narrow<bf16,bwd_stats>" : STATS == 1 ? "k_conv_narrow<bf16,stats>" : "k_conv_narrow<bf16>")
+                      : "k_conv_narrow<f32>";
+  hipLaunchKernelGGL((k_conv_narrow<BF, STATS>), dim3(narrow_grid(V_out)), dim3(kNarrowThreads), lds, (hipStream_t)stream_, in,
+                     rows_in, out, V_out, table, vol, W, bias, flags, ns);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -207,11 +273,34 @@ static int conv_narrow_launch(const void *in, int64_t rows_in, void *out, int64_
 extern "C" int aabr_conv_forward_narrow(const float *in_feats, int64_t rows_in, float *out_feats, int64_t V_out,
                                         const int32_t *table, int vol, const float *W, const float *bias, int flags,
                                         void *stream) {
-  return conv_narrow_launch<false>(in_feats, rows_in, out_feats, V_out, table, vol, W, bias, flags, stream);
+  return conv_narrow_launch<false, 0>(in_feats, rows_in, out_feats, V_out, table, vol, W, bias, flags, NarrowStats{}, stream);
 }
 
 extern "C" int aabr_conv_forward_narrow_bf16(const uint16_t *in_feats, int64_t rows_in, uint16_t *out_feats,
                                              int64_t V_out, const int32_t *table, int vol, const float *W,
                                              const float *bias, int flags, void *stream) {
-  return conv_narrow_launch<true>(in_feats, rows_in, out_feats, V_out, table, vol, W, bias, flags, stream);
+  return conv_narrow_launch<true, 0>(in_feats, rows_in, out_feats, V_out, table, vol, W, bias, flags, NarrowStats{}, stream);
+}
+
+// ... with the forward statistics of the stored values: parts [aabr_conv_narrow_parts(V_out)][2][32] fp64 (layout of
+// aabr_conv_forward_wide_bf16_stats, consumer aabr_bn_forward_parts_bf16)
+extern "C" int aabr_conv_forward_narrow_bf16_stats(const uint16_t *in_feats, int64_t rows_in, uint16_t *out_feats,
+                                                   int64_t V_out, const int32_t *table, int vol, const float *W,
+                                                   const float *bias, int flags, double *stats, void *stream) {
+  AABR_CHECK_ARG(stats && ((uintptr_t)stats & 7) == 0, "statistics buffer");
+  NarrowStats ns{stats, nullptr, nullptr, nullptr, 0.0f};
+  return conv_narrow_launch<true, 1>(in_feats, rows_in, out_feats, V_out, table, vol, W, bias, flags, ns, stream);
+}
+
+// ... with the BACKWARD statistics of the BatchNorm whose d_out the launch writes (as aabr_conv_forward_wide_bf16_bwd_stats;
+// consumer aabr_bn_backward_parts_bf16)
+extern "C" int aabr_conv_forward_narrow_bf16_bwd_stats(const uint16_t *in_feats, int64_t rows_in, uint16_t *out_feats,
+                                                       int64_t V_out, const int32_t *table, int vol, const float *W,
+                                                       const float *bias, int flags, double *stats, const uint16_t *bn_in,
+                                                       const uint16_t *bn_out, const float *save_mean, float leakiness,
+                                                       void *stream) {
+  AABR_CHECK_ARG(stats && ((uintptr_t)stats & 7) == 0 && bn_in && bn_out && save_mean, "null pointer");
+  AABR_CHECK_ARG((((uintptr_t)bn_in | (uintptr_t)bn_out) & 7) == 0, "the BatchNorm's input / output must be 8-byte aligned");
+  NarrowStats ns{stats, reinterpret_cast<const __bf16 *>(bn_in), reinterpret_cast<const __bf16 *>(bn_out), save_mean, leakiness};
+  return conv_narrow_launch<true, 2>(in_feats, rows_in, out_feats, V_out, table, vol, W, bias, flags, ns, stream);
 }

@@ -207,6 +207,19 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
                                            (const float *)p[5], (const float *)p[3], o.i32[5], (float *)p[6], st);
     break;
   case AABR_PLAN_CONV_NARROW:
+    if (bf && o.i32[5] == 1) {
+      rc = aabr_conv_forward_narrow_bf16_bwd_stats((const uint16_t *)p[0], o.i64[0], (uint16_t *)p[1], o.i64[1],
+                                                   (const int32_t *)p[2], o.i32[2], (const float *)p[3], (const float *)p[4],
+                                                   o.i32[3], (double *)p[6], (const uint16_t *)p[7], (const uint16_t *)p[9],
+                                                   (const float *)p[8], o.f32[0], st);
+      break;
+    }
+    if (bf && p[6]) {
+      rc = aabr_conv_forward_narrow_bf16_stats((const uint16_t *)p[0], o.i64[0], (uint16_t *)p[1], o.i64[1],
+                                               (const int32_t *)p[2], o.i32[2], (const float *)p[3], (const float *)p[4],
+                                               o.i32[3], (double *)p[6], st);
+      break;
+    }
     rc = bf ? aabr_conv_forward_narrow_bf16((const uint16_t *)p[0], o.i64[0], (uint16_t *)p[1], o.i64[1],
                                             (const int32_t *)p[2], o.i32[2], (const float *)p[3], (const float *)p[4],
                                             o.i32[3], st)

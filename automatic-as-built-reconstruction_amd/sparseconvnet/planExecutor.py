@@ -62,6 +62,11 @@ conv_bn_stats = os.environ.get("AABR_PLAN_CONV_BN_STATS", "1") != "0"
 # ... and a BatchNorm backward right behind the wide-kernel input-gradient launch that produced its d_out takes its
 # statistics from that launch's write-out (aabr_conv_forward_wide[_bf16]_bwd_stats -> aabr_bn_backward_parts[_bf16])
 conv_bn_bwd_stats = os.environ.get("AABR_PLAN_CONV_BN_BWD_STATS", "1") != "0"
+# ... the same two from the write-out of the 32 -> 32 kernel (csrc/conv_narrow.hip; bf16 storage).  Measured on the config-4
+# step, same box, two runs each: narrow kernel off 10.22 / 10.18 ms, on 10.02 / 10.01, on with these statistics 10.13 / 10.13 --
+# the wave-level reductions (16 x 8 fp64 values per 16-row group) cost the launch more than the BatchNorm's own HBM-bound
+# statistics passes; off by default.
+narrow_stats = os.environ.get("AABR_PLAN_NARROW_STATS", "0") != "0"
 
 
 # Data-parallel hook (extension; the reference wraps the model in DistributedDataParallel, whose bucketed all-reduce
@@ -474,6 +479,8 @@ class _Pass(object):
             # 32 -> 32 planes from the gather table, raw weights (csrc/conv_narrow.hip): the choice SCN._conv_fwd makes first
             pack(buf, off, K_NARROW, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, 0, 0, 0.0, 0.0, 0.0,
                  0.0, rows_in, rows_out, 0, 0, src, dst, gather.table.data_ptr(), p_w, 0, 0, 0, 0, 0, 0, 0, 0)
+            if bf and narrow_stats:   # its write-out can form BatchNorm statistics too: one part per workgroup (negative = a part COUNT)
+                self._lw = -int(self.lib.aabr_conv_narrow_parts(rows_out))
             return off + 176
         U = SCN.rs_unit_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf) if not res else 0
         if U:     # bf16 storage, row-stationary form (csrc/conv_rs.hip): the same choice SCN._conv_fwd makes
@@ -624,19 +631,19 @@ class _Pass(object):
                     off0 = off
                     off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[add_op[3]], V[lo], n_out,
                                            books[book][side], p_w, pf, 0, False, xf, A[other])
-                    last[sk] = (add_op[3], off0, self._lw, n_out) if self._lw >= 64 else None
+                    last[sk] = (add_op[3], off0, self._lw, n_out) if (self._lw >= 64 or self._lw < 0) else None
                 else:
                     off0 = off
                     off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[y], V[lo], n_out, books[book][side],
                                            p_w, pf, 0, fbufs[x][2] == BF16, xf)
-                    last[sk] = (y, off0, self._lw, n_out) if self._lw >= 64 else None
+                    last[sk] = (y, off0, self._lw, n_out) if (self._lw >= 64 or self._lw < 0) else None
                 continue
             elif kind == "bn":
                 _, x, y, lvl, planes, flg, train, eps, mom, leak, st, p_rm, p_rv, p_w, p_b, m = op
                 if V[lvl]:
                     parts, nparts, lw = 0, 0, last[sk]
                     if conv_bn_stats and train and lw is not None and lw[0] == x and lw[3] == planes:
-                        nparts = (V[lvl] + lw[2] - 1) // lw[2]
+                        nparts = -lw[2] if lw[2] < 0 else (V[lvl] + lw[2] - 1) // lw[2]
                         ws = cstat.get(sk)
                         if ws is None:   # one buffer per stream: written by the convolution, read by the very next record
                             ws = cstat[sk] = _hip.workspace("conv_stats%d" % sk, (max(V) // 64 + 1) * 2 * t.max_planes,
@@ -770,13 +777,13 @@ class _Pass(object):
                     off0 = off
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
                                            n_out, g, p_w, pt, flags, flg == F_BF16)
-                    if self._lw >= 64 and off > off0:
+                    if (self._lw >= 64 or self._lw < 0) and off > off0:
                         last_din = (gx, off0, self._lw, n_out)
                 elif V[lvl] and self.wide_rows(n_in, n_out, V[lo], V[lvl], g.vol):
                     off0 = off
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
                                            n_out, g, p_w, pt, flags, False, 0, AD[res[0]][res[1]])
-                    if self._lw >= 64 and off > off0:
+                    if (self._lw >= 64 or self._lw < 0) and off > off0:
                         last_din = (gx, off0, self._lw, n_out)
                 else:                    # not a wide launch: d_in into the spare buffer, then the sum
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[tmp[0]][tmp[1]], V[lvl],
@@ -799,7 +806,7 @@ class _Pass(object):
                         # the BatchNorm's d_out was written by the wide-kernel input-gradient launch right before it (the
                         # weight-gradient record in between runs on the second stream): that launch's write-out forms the
                         # backward statistics (record i32[5] = 1, p6 stats, p7.. the BatchNorm's input and coefficients)
-                        nparts = (V[lvl] + ld[2] - 1) // ld[2]
+                        nparts = -ld[2] if ld[2] < 0 else (V[lvl] + ld[2] - 1) // ld[2]
                         if bstat is None:
                             bstat = _hip.workspace("conv_bwd_stats", (max(V) // 64 + 1) * 2 * t.max_planes,
                                                    torch.float64, self.dev).data_ptr()

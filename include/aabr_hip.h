@@ -470,6 +470,18 @@ int aabr_conv_forward_narrow(const float *in_feats, int64_t rows_in, float *out_
                              int vol, const float *W, const float *bias, int flags, void *stream);
 int aabr_conv_forward_narrow_bf16(const uint16_t *in_feats, int64_t rows_in, uint16_t *out_feats, int64_t V_out,
                                   const int32_t *table, int vol, const float *W, const float *bias, int flags, void *stream);
+/* ... with the BatchNorm statistics of the write-out, one [2][32] fp64 pair per workgroup of the launch
+ * (aabr_conv_narrow_parts(V_out) of them): forward sums of the stored values (consumer aabr_bn_forward_parts_bf16) /
+ * backward sums of the BatchNorm whose d_out the launch writes (consumer aabr_bn_backward_parts_bf16), as the wide kernel's
+ * aabr_conv_forward_wide_bf16_stats / _bwd_stats form them per tile. */
+int aabr_conv_narrow_parts(int64_t V_out);
+int aabr_conv_forward_narrow_bf16_stats(const uint16_t *in_feats, int64_t rows_in, uint16_t *out_feats, int64_t V_out,
+                                        const int32_t *table, int vol, const float *W, const float *bias, int flags,
+                                        double *stats, void *stream);
+int aabr_conv_forward_narrow_bf16_bwd_stats(const uint16_t *in_feats, int64_t rows_in, uint16_t *out_feats, int64_t V_out,
+                                            const int32_t *table, int vol, const float *W, const float *bias, int flags,
+                                            double *stats, const uint16_t *bn_in, const uint16_t *bn_out,
+                                            const float *save_mean, float leakiness, void *stream);
 
 /* ---- compiled launch plans (extension) --------------------------------------------------------
  * The reference enters its library once per layer and direction from Python (SCN/pybind.cpp:134-221 behind
@@ -512,7 +524,9 @@ int aabr_conv_forward_narrow_bf16(const uint16_t *in_feats, int64_t rows_in, uin
                                        i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual (fp32
                                        storage only), i32[5] parts, p6 scratch) */
 #define AABR_PLAN_CONV_NARROW 10 /* aabr_conv_forward_narrow[_bf16](p0 in, i64[0] rows_in, p1 out, i64[1] V_out, p2 table,
-                                   i32[2] vol, p3 W, p4 bias, i32[3] flags) */
+                                   i32[2] vol, p3 W, p4 bias, i32[3] flags); bf16 storage with p6 != NULL: .._bf16_stats(.., p6
+                                   stats); i32[5] == 1: .._bf16_bwd_stats(.., p6 stats, p7 bn_in, p9 bn_out, p8 save_mean,
+                                   f32[0] leakiness) */
 #define AABR_PLAN_BF16 1
 #define AABR_PLAN_TO_BF16 2
 #define AABR_PLAN_JOIN 8 /* the caller's stream waits for the second stream in front of this record */

@@ -187,3 +187,138 @@ def test_narrow_equals_tile_kernel_at_scene_size(dtype):
     tol = 2 ** -7 if dtype == torch.bfloat16 else 1e-5
     assert float((a - b).abs().max()) <= tol * float(b.abs().max())
     assert float(b.abs().max()) > 0.1
+
+
+def test_narrow_write_out_statistics_feed_batchnorm():
+    """aabr_conv_forward_narrow_bf16_stats / _bwd_stats: the per-workgroup fp64 partial sums add up to numpy's sums over the
+    STORED bf16 values (forward: v, v^2; backward: masked d and (x - mean) d with the sign from the BatchNorm's stored
+    output, SCN/CPU/BatchNormalization.cpp:28-40,66-84 on the bf16-storage model), the outputs are the bits of the plain
+    launch, and aabr_bn_forward_parts_bf16 / aabr_bn_backward_parts_bf16 fed with them agree with the BatchNorm's own
+    statistics passes."""
+    import _hip
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(12)
+    npts = 5000
+    coords, _ = _scene(rng, npts, (14, 13, 6), 2, 1)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    nparts = int(lib.aabr_conv_narrow_parts(V))
+    assert nparts == min(256, ((V + 15) // 16 + 15) // 16) and nparts > 1
+    W = _t((rng.standard_normal((vol, 1, 32, 32)) * 0.1).astype(np.float32))
+    f = _t(rng.standard_normal((V, 32)).astype(np.float32)).bfloat16()
+    leak = 0.2
+    _hip.set_knob("BN_SMALL", 0)
+    try:
+        out0 = torch.empty((V, 32), dtype=torch.bfloat16, device=DEV)
+        check(lib.aabr_conv_forward_narrow_bf16(ptr(f), V, ptr(out0), V, ptr(ga.table), vol, ptr(W), None, 0, stream()))
+        # forward statistics
+        out = torch.empty_like(out0)
+        st = torch.full((nparts, 2, 32), float("nan"), dtype=torch.float64, device=DEV)
+        check(lib.aabr_conv_forward_narrow_bf16_stats(ptr(f), V, ptr(out), V, ptr(ga.table), vol, ptr(W), None, 0, ptr(st),
+                                                      stream()))
+        assert torch.equal(out, out0)
+        o = out.float().cpu().numpy().astype(np.float64)
+        s = st.cpu().numpy().sum(0)
+        np.testing.assert_allclose(s[0], o.sum(0), rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(s[1], (o ** 2).sum(0), rtol=1e-12, atol=1e-10)
+        ws = torch.empty(int(lib.aabr_bn_scratch_floats(32)), device=DEV)
+        gam = _t(rng.uniform(0.5, 1.5, 32).astype(np.float32))
+        bet = _t(rng.standard_normal(32).astype(np.float32))
+
+        def bn_fwd(parts):
+            y = torch.empty_like(out)
+            sm, si, rm, rv = (torch.zeros(32, device=DEV) for _ in range(4))
+            a = (ptr(out), ptr(y), V, 32, ptr(sm), ptr(si), ptr(rm), ptr(rv), ptr(gam), ptr(bet), 1e-4, 0.9)
+            if parts:
+                check(lib.aabr_bn_forward_parts_bf16(*a, leak, ptr(st), nparts, ptr(ws), stream()))
+            else:
+                check(lib.aabr_bn_forward_bf16(*a, 1, leak, ptr(ws), stream()))
+            return y, sm, si
+
+        (y1, sm1, si1), (y0, sm0, si0) = bn_fwd(True), bn_fwd(False)
+        np.testing.assert_allclose(sm1.cpu().numpy(), sm0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(si1.cpu().numpy(), si0.cpu().numpy(), rtol=1e-6)
+        assert float((y1.float() - y0.float()).abs().max()) <= 2 ** -7 * float(y0.float().abs().max())
+        # backward statistics: this launch writes the d_out of the BatchNorm (input xb, stored output yb)
+        xb = _t((rng.standard_normal((V, 32)) * 1.3 + 0.2).astype(np.float32)).bfloat16()
+        yb = torch.empty_like(xb)
+        sm, si, rm, rv = (torch.zeros(32, device=DEV) for _ in range(4))
+        check(lib.aabr_bn_forward_bf16(ptr(xb), ptr(yb), V, 32, ptr(sm), ptr(si), ptr(rm), ptr(rv), ptr(gam), ptr(bet), 1e-4,
+                                       0.9, 1, leak, ptr(ws), stream()))
+        d_out = torch.empty_like(out0)
+        stb = torch.full((nparts, 2, 32), float("nan"), dtype=torch.float64, device=DEV)
+        check(lib.aabr_conv_forward_narrow_bf16_bwd_stats(ptr(f), V, ptr(d_out), V, ptr(ga.table), vol, ptr(W), None, 0,
+                                                          ptr(stb), ptr(xb), ptr(yb), ptr(sm), leak, stream()))
+        assert torch.equal(d_out, out0)
+        d32 = d_out.float().cpu().numpy()
+        dm = np.where(yb.float().cpu().numpy() > 0, d32, d32 * np.float32(leak)).astype(np.float64)
+        xc = (xb.float().cpu().numpy() - sm.cpu().numpy().astype(np.float32)).astype(np.float64)
+        sb = stb.cpu().numpy().sum(0)
+        np.testing.assert_allclose(sb[0], dm.sum(0), rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(sb[1], (xc * dm).sum(0), rtol=1e-12, atol=1e-10)
+
+        def bn_bwd(parts):
+            d_in = torch.empty_like(xb)
+            dw, db = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+            common = (ptr(xb), ptr(d_in), ptr(yb), ptr(d_out), V, 32, ptr(sm), ptr(si), ptr(gam), ptr(bet), ptr(dw), ptr(db),
+                      leak)
+            if parts:
+                check(lib.aabr_bn_backward_parts_bf16(*common, ptr(stb), nparts, ptr(ws), stream()))
+            else:
+                check(lib.aabr_bn_backward_bf16(*common, ptr(ws), stream()))
+            return d_in.float().cpu().numpy(), dw.cpu().numpy(), db.cpu().numpy()
+
+        got, want = bn_bwd(True), bn_bwd(False)
+        np.testing.assert_allclose(got[2], want[2], rtol=3e-7, atol=1e-6)
+        np.testing.assert_allclose(got[1], want[1], rtol=3e-7, atol=1e-6)
+        diff = np.abs(got[0] - want[0])
+        assert (diff > 0).mean() < 1e-3 and np.all(diff <= 2 ** -7 * np.abs(want[0]) + 1e-30)
+    finally:
+        _hip.set_knob("BN_SMALL", None)
+
+
+def test_narrow_in_the_compiled_graph_with_fused_statistics(force_narrow):
+    """FPN_Net in bf16 storage with the narrow kernel forced for its 32 -> 32 layers: the compiled graph (narrow records,
+    BatchNorm statistics from their write-outs) equals the module path (narrow launches, BatchNorm's own statistics) in
+    outputs and input gradient to the bf16 tolerance, and parameter gradients agree"""
+    import synth_scenes as S
+    from test_gpu_fpn import _fpn
+    scn = _scn()
+    from sparseconvnet import planExecutor
+    keep = planExecutor.narrow_stats
+    planExecutor.narrow_stats = True          # (off by default: measured a loss on the step; the wiring stays tested)
+    try:
+        _narrow_compiled_graph_body(scn, S, _fpn)
+    finally:
+        planExecutor.narrow_stats = keep
+
+
+def _narrow_compiled_graph_body(scn, S, _fpn):
+    torch.manual_seed(11)
+    net = _fpn(feature_dtype=torch.bfloat16).to(DEV)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    locs, feats = S.make_batch(2, 20000, 47, 20)
+    l = _t(locs)
+
+    def run(compiled):
+        net.load_state_dict(state)
+        net.train(True)
+        net.compiled_graph = compiled
+        f = _t(feats).requires_grad_(True)
+        net.zero_grad()
+        rpn, roi = net([l, f])
+        outs = [m.features.detach().float().clone() for m in rpn + roi]
+        sum(m.features.float().square().mean() for m in rpn + roi).backward()
+        torch.cuda.synchronize()
+        return outs, f.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    a, b = run(False), run(True)
+    for x, y in zip(a[0], b[0]):
+        assert float((x - y).abs().max()) <= 2 ** -5 * float(x.abs().max())
+    assert float((a[1] - b[1]).abs().max()) <= 2e-2 * float(a[1].abs().max())
+    for n in a[2]:
+        ga, gb = a[2][n].float(), b[2][n].float()
+        assert float((ga - gb).abs().max()) <= 3e-2 * float(ga.abs().max()) + 1e-12, n
