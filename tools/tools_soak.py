@@ -4,7 +4,7 @@ checksum of the parameters + BatchNorm buffers and one of the last step's propos
 atomics, fixed summation orders, stream interleaving never changes a result).
 The proposal checksum may differ between runs when objectness logits tie exactly (bf16 storage produces such
 ties): torch.topk leaves the order of equal values unspecified, as it does in the reference's post-processor.
-usage: tools_soak.py [steps] [f32|bf16]"""
+usage: tools_soak.py [steps] [f32|bf16] [config4]   (config4: one 1.5 M-point scene per step, BASELINE configs[4])"""
 import hashlib, importlib, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -16,6 +16,8 @@ import bench, dp
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 dtype = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 dev = torch.device("cuda", 0)
+if len(sys.argv) > 3 and sys.argv[3] == "config4":
+    bench.SCENES_PER_STEP, bench.N_POINTS = 1, 1500000
 wl = bench.Workload(scn, torch, dp, dev, dtype, 0, 1, 3)
 for i in range(n):
     wl.step(i)
