@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
 using namespace aabr;
 
 // 1: aabr_conv_forward_narrow[_bf16] takes this launch.  Measured on the bench's rule books (round 4, profiles/
-// r04_conv_narrow_ab.txt): bf16 storage 31 us at 310 k rows against 30 us for the 64-row-tile kernel -- and 90 against 156 us
+// r04_conv_narrow_ab.txt): bf16 storage 31 us at 310 k rows against 30 us for the 64-row-tile kernel -- and 107 against 156 us
 // at 890 k rows, where that kernel's per-block weight stream falls out of the L2s; fp32 storage 64 us against 48 at 310 k
 // rows (twice the gathered bytes through the same number of waves).  So: bf16 storage from 400,000 output rows on.
 extern "C" int aabr_conv_narrow_ok(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol, int bf16) {
