@@ -61,14 +61,15 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
   static_assert(STATS == 0 || BF, "write-out statistics: bf16 storage");
   extern __shared__ __align__(16) unsigned char smem_raw[];
   constexpr int ES = BF ? 2 : 4;                 // bytes per stored feature
-  constexpr int NB = BF ? 4 : 2;                 // offsets per gather batch (two batches in flight: 32 registers)
+  constexpr int NB = BF ? 7 : 4;                 // offsets per gather batch (two batches in flight)
   constexpr int NK = 28;                         // entry slots (vol <= 28 here; 28 .. 32 take the tile kernels)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   // ---- weights -> LDS (once per workgroup): W read in its own order (coalesced), scattered into operand order ----
   {
     const int transpose = flags & 1, mirror = (flags >> 1) & 1;
-    const int total = vol * kNarrowC * kNarrowC;
+    const int total = vol * kNarrowC * kNarrowC;              // = vol x 1024: thread t handles element t of every W[kW]
+#pragma unroll 9
     for (int i = threadIdx.x; i < total; i += kNarrowThreads) {
       const int q = i & 31, p = (i >> 5) & 31, kW = i >> 10;      // W[kW][p][q]
       const int k = mirror ? vol - 1 - kW : kW;
@@ -97,9 +98,9 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
     for (int k = 0; k < NK; ++k) e[k] = table[(int64_t)(k < vol ? k : vol - 1) * V_out + rowc];
   };
   int64_t grp = (int64_t)blockIdx.x * 16 + wave;
-  int ent[NK], nxt[NK];
-  if (grp < ngroups) load_entries(ent, grp);
+  int ent[NK];
   for (; grp < ngroups; grp += gstride) {
+    load_entries(ent, grp);
     const int64_t row = grp * 16 + c16;
     const bool live = row < V_out;
     // which offsets ANY of the 16 rows has (wave-uniform): only those are gathered and multiplied
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
       if (!live || k >= vol) ent[k] = -1;
       m |= (__ballot(ent[k] >= 0) != 0ull ? 1u : 0u) << k;
     }
-    if (grp + gstride < ngroups) load_entries(nxt, grp + gstride);   // the next group's entries arrive under this one's work
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     u32x4 a0[2][NB], a1[2][NB];
     // batches of NB offsets, two in flight: batch b + 1 is requested before batch b is multiplied; an offset none of the
@@ -205,8 +205,6 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
         }
       }
     }
-#pragma unroll
-    for (int k = 0; k < NK; ++k) ent[k] = nxt[k];
   }
   if (STATS) {
     __syncthreads();
