@@ -85,7 +85,8 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
   if (STATS)
     for (int i = threadIdx.x; i < 16 * 2 * kNarrowC; i += kNarrowThreads) sacc[i] = 0.0;
   __syncthreads();
-  // gathers through a buffer descriptor (32-bit offsets, bounds-checked)
+  // gathers through a buffer descriptor (32-bit offsets, bounds-checked): an absent neighbour's lane gets an offset past the
+  // end (the matrix is < 2 GiB) -- the hardware returns zeros without touching memory and the load stays unconditional
   const unsigned rowbytes = kNarrowC * ES;
   const __amdgpu_buffer_rsrc_t rin =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(in_), 0, (int)(rows_in * rowbytes), 0x00020000);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(kNarrowThreads, 1) void k_conv_narrow(const void *_
       for (int j = 0; j < NB; ++j) {
         const int k = b * NB + j;
         if (k < NK && ((m >> k) & 1u)) {
-          const unsigned off = ent[k] >= 0 ? (unsigned)ent[k] * rowbytes + (unsigned)g * (8u * ES) : 0xfffffff0u;
+          const unsigned off = ent[k] >= 0 ? (unsigned)ent[k] * rowbytes + (unsigned)g * (8u * ES) : 0x80000000u;
           a0[b & 1][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
           if (!BF) a1[b & 1][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 16, 0);
         }
