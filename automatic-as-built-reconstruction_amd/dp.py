@@ -20,7 +20,11 @@ class FlatParams(object):
     autograd puts them (no zero-fill and no accumulate launches per step); they are packed into
     the flat gradient buffer by a single multi-tensor copy right before the collective."""
 
-    def __init__(self, modules):
+    def __init__(self, modules, grad_dtype=None):
+        """`grad_dtype=torch.bfloat16` (option): the gradient MESSAGE of the flat all-reduce travels in bf16 -- half the
+        bytes over xGMI (85 -> 42 MB for FPN_Net; SURVEY 5: "bf16 grads halve the message") -- the local gradients are
+        rounded once before the collective, the sum is formed by the backend in bf16 and the mean + update in fp32.
+        Default None: the reference's fp32 all-reduce."""
         params = []
         for m in modules:
             params += [p for p in m.parameters() if p.requires_grad]
@@ -29,6 +33,8 @@ class FlatParams(object):
         dev, dt = params[0].device, params[0].dtype
         self.flat = torch.empty(n, device=dev, dtype=dt)
         self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
+        self.grad_dtype = grad_dtype if (grad_dtype is not None and grad_dtype != dt) else None
+        self.msg = torch.zeros(n, device=dev, dtype=self.grad_dtype) if self.grad_dtype is not None else None
         self.grad_views = []
         self.wait_ms = []
         o = 0
@@ -53,7 +59,12 @@ class FlatParams(object):
             world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         if world_size > 1:
             self.pack_grads()
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
+            if self.msg is not None:          # reduced-precision message: round once, sum, widen
+                self.msg.copy_(self.flat_grad)
+                dist.all_reduce(self.msg, op=dist.ReduceOp.SUM, group=group)
+                self.flat_grad.copy_(self.msg)
+            else:
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
             self.flat_grad.mul_(1.0 / world_size)
 
     def start_allreduce(self, group=None):
@@ -63,7 +74,10 @@ class FlatParams(object):
         parameters are used again."""
         assert getattr(self, "_pending", None) is None, "previous all-reduce not finished"
         self.pack_grads()
-        self._pending = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        if self.msg is not None:
+            self.msg.copy_(self.flat_grad)
+        self._pending = dist.all_reduce(self.msg if self.msg is not None else self.flat_grad, op=dist.ReduceOp.SUM,
+                                        group=group, async_op=True)
 
     def finish_update(self, lr, world_size):
         """wait (stream-ordered for nccl) for the pending all-reduce and apply the SGD update with the mean
@@ -77,6 +91,8 @@ class FlatParams(object):
         self.wait_ms.append((time.perf_counter() - t0) * 1e3)
         del self.wait_ms[:-512]
         self._pending = None
+        if self.msg is not None:
+            self.flat_grad.copy_(self.msg)
         self.flat.add_(self.flat_grad, alpha=-lr / world_size)
         return True
 
@@ -101,10 +117,12 @@ class FlatParams(object):
         what autograd stores in `p.grad` stays the LOCAL gradient until `finish_bucketed` replaces it with the mean.
         Call before `backward()`; `finish_bucketed` after it (or `abort_bucketed` when backward raised).
 
-        All ranks must hand over the same pieces: the sizes seen in the first bucketed step are agreed across the
-        ranks (`_agree_plan`, one small all-gather, once) and every later piece is checked against them BEFORE its
-        collective is launched -- a rank whose graph fell back to the per-module path raises instead of hanging the
-        others in a mismatched collective."""
+        All ranks must hand over the same pieces.  In the FIRST bucketed step no plan exists yet, so that step only
+        collects the cloned buckets; `finish_bucketed` agrees the list of sizes across the ranks (`_agree_plan`: two tiny
+        collectives of fixed shape) and launches the data collectives only then.  From the second step on every piece
+        is checked against the agreed plan BEFORE its collective is launched, underneath the backward pass.  Either way
+        a rank whose graph fell back to the per-module path (or cut its list differently) raises on every rank instead
+        of hanging the others in a mismatched collective -- from step 0 on."""
         from sparseconvnet import planExecutor
         self._bk = dict(works=[], params=[], grads=[], bufs=[], group=group, bytes=0, launched_early=0, sizes=[])
         plan = getattr(self, "_bucket_plan", None)
@@ -117,9 +135,10 @@ class FlatParams(object):
             bk["sizes"].append(flat.numel())
             buf = flat.clone()           # main stream; the collective below is ordered behind it
             bk["bufs"].append(buf)
-            bk["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            if plan is not None:         # agreed plan: launch underneath the rest of the backward pass
+                bk["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+                bk["launched_early"] += 1 if piece < n_pieces - 1 else 0
             bk["bytes"] += buf.numel() * buf.element_size()
-            bk["launched_early"] += 1 if piece < n_pieces - 1 else 0
             base = flat.data_ptr()
             for p_, g_ in pairs:
                 o = (g_.data_ptr() - base) // g_.element_size()
@@ -141,16 +160,22 @@ class FlatParams(object):
                     pass
 
     def _agree_plan(self, sizes, group):
-        """once: every rank must have produced the same list of bucket sizes"""
+        """once, BEFORE the first data collective: every rank must have produced the same list of bucket sizes.  Two
+        collectives whose shapes cannot differ between the ranks: the number of buckets (MIN / MAX of one pair), then --
+        only when the counts agree -- the sizes themselves (MIN / MAX of a tensor of that agreed length)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         if world > 1:
-            mine = torch.zeros(64, dtype=torch.int64, device=self.flat.device)
-            mine[0] = len(sizes)
-            mine[1:1 + len(sizes)] = torch.tensor(sizes, dtype=torch.int64)
-            lo, hi = mine.clone(), mine.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-            if not (torch.equal(lo, mine) and torch.equal(hi, mine)):
+            dev = self.flat.device
+            cnt = torch.tensor([len(sizes), -len(sizes)], dtype=torch.int64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MIN, group=group)       # (min count, -max count)
+            lo, hi = int(cnt[0]), -int(cnt[1])
+            if lo != hi:
+                raise RuntimeError("bucketed all-reduce: the ranks disagree on the bucket plan (%d .. %d buckets; mine: "
+                                   "%s)" % (lo, hi, sizes))
+            mine = torch.tensor(list(sizes) + [-v for v in sizes], dtype=torch.int64, device=dev)
+            agreed = mine.clone()
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)    # (min sizes, -max sizes)
+            if not torch.equal(agreed, mine):
                 raise RuntimeError("bucketed all-reduce: the ranks disagree on the bucket plan (mine: %s)" % (sizes,))
         self._bucket_plan = list(sizes)
 
@@ -172,6 +197,15 @@ class FlatParams(object):
         if plan is not None and n != plan[-1]:
             self.abort_bucketed()
             raise RuntimeError("bucketed all-reduce: last bucket has %d elements, the agreed plan says %d" % (n, plan[-1]))
+        if plan is None:
+            # first bucketed step: nothing has been launched yet (`ready` only collected the buckets) -- agree first
+            try:
+                self._agree_plan(bk["sizes"] + [n], bk["group"])
+            except RuntimeError:
+                self.abort_bucketed()
+                raise
+            for buf in bk["bufs"]:
+                bk["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=bk["group"], async_op=True))
         if rest:
             buf = torch.empty(n, device=self.flat.device, dtype=self.flat.dtype)
             views, o = [], 0
@@ -184,8 +218,6 @@ class FlatParams(object):
             bk["bytes"] += n * buf.element_size()
             bk["params"] += rest
             bk["grads"] += views
-        if plan is None:
-            self._agree_plan(bk["sizes"] + [n], bk["group"])
         t0 = time.perf_counter()
         for w in bk["works"]:
             w.wait()
@@ -222,3 +254,56 @@ def shard_scenes(n_scenes, rank, world_size, sizes=None):
         if j < len(chunk):
             mine.append(chunk[j])
     return mine
+
+
+# ---- the two small collectives outside the gradient path ------------------------------------------------------------
+def reduce_loss_dict(loss_dict, group=None):
+    """The scalar losses of a step averaged onto rank 0 for logging -- `reduce_loss_dict`
+    (maskrcnn_benchmark/engine/trainer_sparse3d.py:17-38): keys in sorted order stacked into one tensor, ONE
+    `dist.reduce` to rank 0, divided by the world size there only (the other ranks keep the un-normalised partial the
+    backend left them, as in the reference).  No-op for one process."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world < 2:
+        return loss_dict
+    with torch.no_grad():
+        names = sorted(loss_dict.keys())
+        stacked = torch.stack([torch.as_tensor(loss_dict[k]).detach().reshape(()) for k in names], dim=0)
+        dist.reduce(stacked, dst=0, group=group)
+        if dist.get_rank(group) == 0:
+            stacked /= world
+        return {k: v for k, v in zip(names, stacked)}
+
+
+def gather_predictions(predictions_per_rank, group=None):
+    """Inference-side gather: every rank holds {scene index: prediction} for the scenes of its shard; rank 0 receives
+    the merged list ordered by scene index, the other ranks None -- `_accumulate_predictions_from_multiple_gpus`
+    (maskrcnn_benchmark/engine/inference.py:32-51) over `scatter_gather` (utils/comm.py:89-157).  The reference
+    pickles each rank's dict to a temporary directory announced through a 256-byte broadcast; here the objects travel
+    through `all_gather_object` (RCCL / gloo), no file system in between.  Device tensors inside the predictions are
+    moved to the host first (the reference's `torch.save` does the same implicitly)."""
+    def to_host(o):
+        if torch.is_tensor(o):
+            return o.detach().cpu()
+        if isinstance(o, dict):
+            return {k: to_host(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(to_host(v) for v in o)
+        return o
+
+    mine = to_host(predictions_per_rank)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        parts = [mine]
+    else:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, mine, group=group)
+        if dist.get_rank(group) != 0:
+            return None
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    ids = sorted(merged.keys())
+    if ids and len(ids) != ids[-1] + 1:
+        import logging
+        logging.getLogger("aabr.dp").warning("Number of scenes that were gathered from multiple processes is not a "
+                                             "contiguous set. Some scenes might be missing from the evaluation")
+    return [merged[i] for i in ids]

@@ -146,7 +146,7 @@ def _bucket_worker(rank, world, port, q, cheat):
             p.grad = v                     # autograd would store these views
         cut = slots[2]
         pieces = [(gbuf[:cut], list(zip(ps[2:4], views[:2]))), (gbuf[cut:], list(zip(ps[4:], views[2:])))]
-        if cheat and rank == 1 and step == 1:
+        if cheat and rank == 1 and step == cheat - 1:
             pieces = [(gbuf[:], list(zip(ps[2:], views)))]         # this rank's graph "fell back": one piece
         try:
             for k, (flat, pairs) in enumerate(pieces):
@@ -160,6 +160,8 @@ def _bucket_worker(rank, world, port, q, cheat):
             out.append(("error", str(e)[:60]))
             break
         assert planExecutor.on_grads_ready is None and n == 3
+        # step 0 agrees the plan first and launches nothing early; later steps launch each piece as it arrives
+        assert fp.bucket_stats["launched_during_backward"] == (0 if step == 0 else 1)
         out.append(("ok", [p.grad.numpy().copy() for p in ps], [g.numpy().copy() for g in local],
                     fp.flat.detach().numpy().copy()))
     q.put((rank, w0.numpy().copy(), out))     # numpy: plain pickles (torch would share storage with a dying process)
@@ -171,7 +173,7 @@ def _bucket_worker(rank, world, port, q, cheat):
 def _run_bucket(cheat):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + 7 + int(cheat)) % 1000
+    port = 29500 + (os.getpid() + 7 + 3 * int(cheat)) % 1000
     procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q, cheat)) for r in range(2)]
     for p in procs:
         p.start()
@@ -203,6 +205,91 @@ def test_two_rank_bucketed_allreduce_leaves_mean_gradients():
 def test_bucket_plan_mismatch_raises_instead_of_hanging():
     """a rank whose pieces differ from the agreed plan (its graph fell back to the per-module path) raises before it
     launches a mismatched collective"""
-    res = _run_bucket(True)
+    res = _run_bucket(2)                      # cheats in step 1: the plan of step 0 catches it in the hook
     out1 = res[1][2]
     assert out1[0][0] == "ok" and out1[-1][0] == "error" and "plan" in out1[-1][1]
+
+
+def test_bucket_plan_mismatch_on_the_first_step_raises_on_every_rank():
+    """ADVICE r4 (dp.py:112): in the FIRST bucketed step no plan exists yet -- the buckets must not be all-reduced before
+    the ranks have agreed on their sizes.  Rank 1 hands over one piece instead of two in step 0: both ranks raise from
+    `_agree_plan` (counts 3 vs 2), nobody hangs in a mismatched collective, no parameter has moved."""
+    res = _run_bucket(1)
+    for rank, w0, out in res:
+        assert len(out) == 1 and out[0][0] == "error" and "disagree" in out[0][1], out
+
+
+# ---------------------------------------------------------------------------------------------- small collectives
+def _misc_worker(rank, world, port, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    import importlib
+    importlib.import_module("automatic-as-built-reconstruction_amd")
+    import dp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # scalar losses onto rank 0 (trainer_sparse3d.py:17-38)
+    red = dp.reduce_loss_dict({"loss_rpn_box_reg": torch.tensor(1.0 + rank), "loss_objectness": torch.tensor(10.0 * (rank + 1))})
+    # predictions of this rank's shard (inference.py:32-51): scene index -> anything picklable
+    mine = {i: {"boxes": torch.full((2, 7), float(i)), "scene": "s%d" % i} for i in dp.shard_scenes(5, rank, world)}
+    got = dp.gather_predictions(mine)
+    # bf16 gradient message: half the bytes, the mean within bf16 rounding of the fp32 mean
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 32)
+    fp16 = dp.FlatParams([lin], grad_dtype=torch.bfloat16)
+    fp16.broadcast(0)
+    w0 = fp16.flat.clone()
+    lin(torch.randn(8, 64, generator=torch.Generator().manual_seed(100 + rank))).square().sum().backward()
+    local = torch.cat([p.grad.reshape(-1) for p in fp16.params]).clone()
+    fp16.allreduce_mean(world)
+    mean16 = fp16.flat_grad.clone()
+    fp16.zero_grad()
+    lin(torch.randn(8, 64, generator=torch.Generator().manual_seed(200 + rank))).square().sum().backward()
+    local2 = torch.cat([p.grad.reshape(-1) for p in fp16.params]).clone()
+    fp16.start_allreduce()
+    fp16.finish_update(0.1, world)
+    q.put((rank, {k: float(v) for k, v in red.items()},
+           None if got is None else [(g["scene"], g["boxes"].numpy().copy()) for g in got],
+           local.numpy().copy(), mean16.numpy().copy(), fp16.msg.element_size(), w0.numpy().copy(),
+           local2.numpy().copy(), fp16.flat.detach().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_loss_reduce_prediction_gather_and_bf16_gradient_message():
+    """`reduce_loss_dict` (one dist.reduce onto rank 0, averaged there only), `gather_predictions`
+    (rank 0 gets the merged list in scene order, the others None) and the bf16 gradient-message option of FlatParams."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 23) % 1000
+    procs = [ctx.Process(target=_misc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, red0, got0, l0, m0, es0, w0, k0, f0), (_, red1, got1, l1, m1, es1, w1, k1, f1) = res
+    assert red0 == {"loss_objectness": 15.0, "loss_rpn_box_reg": 1.5}        # rank 0: the mean
+    assert got1 is None and [s for s, _ in got0] == ["s0", "s1", "s2", "s3", "s4"]
+    assert all((b == float(i)).all() and b.shape == (2, 7) for i, (_, b) in enumerate(got0))
+    assert es0 == es1 == 2                                                    # the message really is 2 bytes per element
+    mean = (l0 + l1) / 2
+    scale = np.abs(mean).max()
+    assert np.abs(m0 - mean).max() <= 2.0 ** -7 * scale and np.array_equal(m0, m1)
+    assert np.abs(m0 - mean).max() > 0                                        # ... and really went through bf16
+    mean2 = (k0 + k1) / 2
+    assert np.abs(f0 - (w0 - 0.1 * mean2)).max() <= 0.1 * 2.0 ** -7 * np.abs(mean2).max() + 1e-7
+    assert np.array_equal(f0, f1)                                             # replicas stay in lock-step
+
+
+def test_single_process_small_collectives_are_no_ops():
+    sys.path.insert(0, os.path.dirname(HERE))
+    import importlib
+    importlib.import_module("automatic-as-built-reconstruction_amd")
+    import dp
+    d = {"a": torch.tensor(2.0)}
+    assert dp.reduce_loss_dict(d) is d
+    assert dp.gather_predictions({1: "b", 0: "a"}) == ["a", "b"]
