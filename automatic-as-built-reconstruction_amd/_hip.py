@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaabr_hip.so")
 
 _lib = None
-META_WORDS = 8
+META_WORDS = 16
+ABI_VERSION = 500      # include/aabr_hip.h AABR_ABI_VERSION this binding (_SIGS) was written for
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 _i32p = C.POINTER(C.c_int32)
@@ -39,6 +40,14 @@ _SIGS = {
     "aabr_convolution_tables2": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32p, _i32p,
                                            _i32p, _vp, _vp, _vp, _vp, _vp]),
     "aabr_sample_offsets": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "aabr_brick_scratch_words": (C.c_int64, [_i64, _i64]),
+    "aabr_brick_build": (C.c_int, [_vp, _i64, _vp, _i32p, _i32p, _i32p, _i32p, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
+                                   _vp]),
+    "aabr_brick_renumber": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
+                                      _vp, _vp]),
+    "aabr_brick_submanifold_table": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _i32p, _vp, _vp, _vp]),
+    "aabr_brick_convolution_tables": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _i64, _i32p, _vp, _vp, _i32p, _i32p,
+                                                _i32p, _vp, _vp, _vp, _vp, _vp]),
     "aabr_table_to_rulebook": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "aabr_spatial_locations": (C.c_int, [_vp, _i64, _vp, _vp]),
     "aabr_conv_last_variant": (C.c_char_p, []),
@@ -171,6 +180,10 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
+        if lib.aabr_version() != ABI_VERSION:     # a stale .so would take shifted arguments into kernels that write
+            raise AabrError("%s reports ABI version %d, this binding was written for %d: rebuild it "
+                            "(`python -c \"import __graft_entry__ as g; g.build()\"`)"
+                            % (LIB_PATH, lib.aabr_version(), ABI_VERSION))
         _lib = lib
     return _lib
 

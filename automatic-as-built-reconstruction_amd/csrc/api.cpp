@@ -46,7 +46,7 @@ extern "C" int aabr_set_knob(const char *name, int value, int unset) {
 }
 
 extern "C" const char *aabr_last_error(void) { return aabr::g_err; }
-extern "C" int aabr_version(void) { return 100; }
+extern "C" int aabr_version(void) { return AABR_ABI_VERSION; }
 // bit 0: built with `make DEV=1` -- the timing-experiment variants and the measured-slower A/B kernels (row-stationary
 // bf16 convolution, fp32 on the bf16 pipe by a three-term split, the four-waves-per-SIMD form of k_conv_cs) are in
 extern "C" int aabr_build_flags(void) {

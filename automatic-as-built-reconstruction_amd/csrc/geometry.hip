@@ -12,7 +12,7 @@
 //   strided conv : first-seen order over input rows ascending, then output-region order
 //                  (the reference's order is dense_hash_map iteration order, an artefact;
 //                   parity there is modulo a per-sample permutation)
-#include "common.h"
+#include "geom.h"
 
 namespace aabr {
 
@@ -95,32 +95,6 @@ __global__ __launch_bounds__(1024) void k_scan_blockprefix(const int32_t *__rest
     meta[3] = cb;
     if (site_off) site_off[ca] = cb; // CSR terminator: offsets[V] = number of valid points
   }
-}
-
-struct ConvGeom {
-  int size[3], stride[3], out_sp[3];
-  int maxout;
-};
-
-// l-th point (region order, z fastest) of the output region of input point p
-// (OutputRegionCalculator, RectangularRegions.h:109-119).  Returns false if l is past the end.
-__device__ inline bool output_region_lth(const ConvGeom &g, const int p[3], int l, int j[3]) {
-  int lb[3], n[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    int num = p[i] - g.size[i] + g.stride[i];
-    int q = num / g.stride[i]; // C division (toward zero), then clamp at 0 like std::max(0L, ..)
-    lb[i] = q > 0 ? q : 0;
-    int ub = p[i] / g.stride[i];
-    if (ub > g.out_sp[i] - 1) ub = g.out_sp[i] - 1;
-    n[i] = ub - lb[i] + 1;
-    if (n[i] <= 0) return false;
-  }
-  if (l >= n[0] * n[1] * n[2]) return false;
-  j[2] = lb[2] + l % n[2]; l /= n[2];
-  j[1] = lb[1] + l % n[1]; l /= n[1];
-  j[0] = lb[0] + l;
-  return true;
 }
 
 // MODE 0: input layer (items = points); MODE 1: strided-conv output sites (items = encounters)
@@ -206,41 +180,6 @@ __global__ __launch_bounds__(kScanThreads) void k_assign_sites(
 }
 
 // ------------------------------------------------------------------ rule tables
-struct Filter3 { int size[3]; };
-
-// counts[k * gridDim.x + blockIdx.x] = number of hits in this block (plain store: 27 hot
-// addresses hammered by one atomic per wave cost more than the whole table build)
-__device__ inline void block_count_store(int hit, int32_t *__restrict__ counts, int k) {
-  __shared__ int wc[4];
-  unsigned long long m = __ballot(hit);
-  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (int)__popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) counts[(int64_t)k * gridDim.x + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
-}
-
-__global__ __launch_bounds__(256) void k_submanifold_table(const int32_t *__restrict__ site_coords,
-                                                           int64_t V, const GridEnt *__restrict__ keys,
-                                                           uint64_t mask,
-                                                           Filter3 fs, int32_t *__restrict__ table,
-                                                           int32_t *__restrict__ counts) {
-  const int k = blockIdx.y;
-  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int hit = 0;
-  if (v < V) {
-    int dz = k % fs.size[2], t = k / fs.size[2];
-    int dy = t % fs.size[1], dx = t / fs.size[1];
-    int4 c = *reinterpret_cast<const int4 *>(site_coords + 4 * v);
-    // InputRegionCalculator_Submanifold: lb = p - size/2
-    int x = c.x + dx - fs.size[0] / 2, y = c.y + dy - fs.size[1] / 2, z = c.z + dz - fs.size[2] / 2;
-    int r = -1;
-    if (coord_in_range(x) && coord_in_range(y) && coord_in_range(z))
-      r = grid_find(keys, mask, pack_key(c.w, x, y, z));
-    table[(int64_t)k * V + v] = r;
-    hit = r >= 0;
-  }
-  if (counts) block_count_store(hit, counts, k);
-}
-
 __global__ __launch_bounds__(256) void k_conv_insert_sites(const int32_t *__restrict__ in_coords,
                                                            int64_t V_in, ConvGeom g, GridEnt *keys,
                                                            uint64_t mask, int32_t *__restrict__ slot) {
@@ -258,63 +197,6 @@ __global__ __launch_bounds__(256) void k_conv_insert_sites(const int32_t *__rest
       slot[e] = -1;
     }
   }
-}
-
-// table_out[k][o]: input row at o*stride + koff (InputRegionCalculator, :95-105)
-__global__ __launch_bounds__(256) void k_conv_table_out(const int32_t *__restrict__ out_coords,
-                                                        int64_t V_out, const GridEnt *__restrict__ in_keys,
-                                                        uint64_t in_mask, ConvGeom g,
-                                                        int32_t *__restrict__ table,
-                                                        int32_t *__restrict__ counts) {
-  const int k = blockIdx.y;
-  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int hit = 0;
-  if (o < V_out) {
-    int dz = k % g.size[2], t = k / g.size[2];
-    int dy = t % g.size[1], dx = t / g.size[1];
-    int4 c = *reinterpret_cast<const int4 *>(out_coords + 4 * o);
-    int x = c.x * g.stride[0] + dx, y = c.y * g.stride[1] + dy, z = c.z * g.stride[2] + dz;
-    int r = -1;
-    if (coord_in_range(x) && coord_in_range(y) && coord_in_range(z))
-      r = grid_find(in_keys, in_mask, pack_key(c.w, x, y, z));
-    table[(int64_t)k * V_out + o] = r;
-    hit = r >= 0;
-  }
-  if (counts) block_count_store(hit, counts, k);
-}
-
-// table_in[k][u]: the output row whose window holds input u at offset k, if that output cell
-// is inside [0, out_spatial) (OutputRegionCalculator clamps, :109-119)
-__global__ __launch_bounds__(256) void k_conv_table_in(const int32_t *__restrict__ in_coords, int64_t V_in,
-                                                       const GridEnt *__restrict__ out_keys,
-                                                       uint64_t out_mask, ConvGeom g,
-                                                       int32_t *__restrict__ table,
-                                                       int32_t *__restrict__ counts) {
-  const int k = blockIdx.y;
-  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int hit = 0;
-  if (u < V_in) {
-    int d[3];
-    d[2] = k % g.size[2];
-    int t = k / g.size[2];
-    d[1] = t % g.size[1];
-    d[0] = t / g.size[1];
-    int4 c = *reinterpret_cast<const int4 *>(in_coords + 4 * u);
-    int p[3] = {c.x, c.y, c.z}, j[3];
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      int q = p[i] - d[i];
-      if (q < 0 || q % g.stride[i] != 0) { ok = false; break; }
-      j[i] = q / g.stride[i];
-      if (j[i] > g.out_sp[i] - 1) { ok = false; break; }
-    }
-    int r = -1;
-    if (ok) r = grid_find(out_keys, out_mask, pack_key(c.w, j[0], j[1], j[2]));
-    table[(int64_t)k * V_in + u] = r;
-    hit = r >= 0;
-  }
-  if (counts) block_count_store(hit, counts, k);   // per 256-row block and offset, like k_conv_table_out
 }
 
 // one block per filter offset: ordered compaction of the table row into (entry, row) pairs
@@ -390,8 +272,6 @@ __global__ __launch_bounds__(64) void k_sample_offsets(const int32_t *__restrict
   if (threadIdx.x == 0) out[0] = (int32_t)V;
 }
 
-static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)ceil_div(n > 0 ? n : 1, bs)); }
-
 } // namespace aabr
 
 using namespace aabr;
@@ -411,25 +291,11 @@ extern "C" int aabr_submanifold_table(const int32_t *site_coords, int64_t V, con
   AABR_CHECK_ARG(vol <= 65535, "filter volume too large");
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(site_coords && keys && table && ((uintptr_t)keys & 15) == 0, "null / misaligned pointer");
-  hipLaunchKernelGGL(k_submanifold_table, dim3((unsigned)ceil_div(V, 256), (unsigned)vol), dim3(256), 0, st,
-                     site_coords, V, reinterpret_cast<const GridEnt *>(keys), (uint64_t)(cap - 1), fs, table, counts);
+  hipLaunchKernelGGL(k_submanifold_table<HashFinder>, dim3((unsigned)ceil_div(V, 256), (unsigned)vol), dim3(256), 0, st,
+                     site_coords, V, HashFinder{reinterpret_cast<const GridEnt *>(keys), (uint64_t)(cap - 1)}, fs, table,
+                     counts);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
-}
-
-// sites_only: output-grid construction alone also accepts the composition of several non-overlapping levels
-// (size == stride up to 65536: exactly one output site per input site), see aabr_convolution_sites
-static int make_geom(const int32_t *size, const int32_t *stride, const int32_t *out_sp, ConvGeom &g,
-                     bool sites_only = false) {
-  g.maxout = 1;
-  for (int i = 0; i < 3; ++i) {
-    const bool composed = sites_only && size[i] == stride[i] && size[i] >= 1 && size[i] <= 65536;
-    if (!composed && (size[i] < 1 || size[i] > 64 || stride[i] < 1 || stride[i] > 64)) return -1;
-    if (out_sp[i] < 1) return -1;
-    g.size[i] = size[i]; g.stride[i] = stride[i]; g.out_sp[i] = out_sp[i];
-    g.maxout *= (size[i] + stride[i] - 1) / stride[i];
-  }
-  return 0;
 }
 
 extern "C" int aabr_convolution_sites(const int32_t *in_coords, int64_t V_in, const int32_t *size_host,
@@ -506,15 +372,16 @@ extern "C" int aabr_convolution_tables2(const int32_t *in_coords, int64_t V_in, 
   int vol = g.size[0] * g.size[1] * g.size[2];
   if (V_out > 0 && table_out) {
     AABR_CHECK_ARG(out_coords && in_keys && ((uintptr_t)in_keys & 15) == 0, "null / misaligned pointer");
-    hipLaunchKernelGGL(k_conv_table_out, dim3((unsigned)ceil_div(V_out, 256), (unsigned)vol), dim3(256), 0, st,
-                       out_coords, V_out, reinterpret_cast<const GridEnt *>(in_keys), (uint64_t)(in_cap - 1), g,
-                       table_out, counts);
+    hipLaunchKernelGGL(k_conv_table_out<HashFinder>, dim3((unsigned)ceil_div(V_out, 256), (unsigned)vol), dim3(256), 0,
+                       st, out_coords, V_out,
+                       HashFinder{reinterpret_cast<const GridEnt *>(in_keys), (uint64_t)(in_cap - 1)}, g, table_out,
+                       counts);
   }
   if (V_in > 0 && table_in) {
     AABR_CHECK_ARG(in_coords && out_keys && ((uintptr_t)out_keys & 15) == 0, "null / misaligned pointer");
-    hipLaunchKernelGGL(k_conv_table_in, dim3((unsigned)ceil_div(V_in, 256), (unsigned)vol), dim3(256), 0, st,
-                       in_coords, V_in, reinterpret_cast<const GridEnt *>(out_keys), (uint64_t)(out_cap - 1), g,
-                       table_in, counts_in);
+    hipLaunchKernelGGL(k_conv_table_in<HashFinder>, dim3((unsigned)ceil_div(V_in, 256), (unsigned)vol), dim3(256), 0, st,
+                       in_coords, V_in, HashFinder{reinterpret_cast<const GridEnt *>(out_keys), (uint64_t)(out_cap - 1)},
+                       g, table_in, counts_in);
   }
   AABR_CHECK_LAUNCH();
   return AABR_OK;

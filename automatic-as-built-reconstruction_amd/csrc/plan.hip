@@ -490,6 +490,12 @@ extern "C" int aabr_plan_drain(void) {
 // one of the builders declared in include/aabr_hip.h and carries its arguments; nothing is computed differently.
 static_assert(sizeof(AabrGeomOp) == 144, "AabrGeomOp layout is part of the C ABI");
 
+// brick levels in a record: dims packed sbx | sby << 16 | sbz << 32 | nb << 48; one allocation = directory, then bricks
+static inline void unpack_dims(int64_t v, int32_t dims[4]) {
+  for (int i = 0; i < 4; ++i) dims[i] = (int32_t)(((uint64_t)v >> (16 * i)) & 0xffffu);
+}
+static inline int64_t dir_bytes(const int32_t dims[4]) { return (int64_t)dims[0] * dims[1] * dims[2] * dims[3] * 16; }
+
 extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
   AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
   for (int j = 0; j < n_ops; ++j) {
@@ -526,6 +532,33 @@ extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
     case AABR_GEOM_SAMPLE_OFFSETS:
       rc = aabr_sample_offsets((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st);
       break;
+    case AABR_GEOM_BRICK_BUILD: {
+      int32_t dims[4];
+      unpack_dims(o.i64[1], dims);
+      char *lvl = (char *)p[2];
+      rc = aabr_brick_build((const int32_t *)p[0], o.i64[0], (const int32_t *)p[1], &o.i32[0], &o.i32[3], &o.i32[6], dims,
+                            lvl, lvl + dir_bytes(dims), o.i64[2], (int32_t *)p[3], (int32_t *)p[4], o.i64[3],
+                            (int32_t *)p[5], (int32_t *)p[6], st);
+      break;
+    }
+    case AABR_GEOM_BRICK_SUBM: {
+      int32_t dims[4];
+      unpack_dims(o.i64[1], dims);
+      const char *lvl = (const char *)p[1];
+      rc = aabr_brick_submanifold_table((const int32_t *)p[0], o.i64[0], dims, lvl, lvl + dir_bytes(dims), &o.i32[0],
+                                        (int32_t *)p[2], (int32_t *)p[3], st);
+      break;
+    }
+    case AABR_GEOM_BRICK_TABLES: {
+      int32_t di[4], dout[4];
+      unpack_dims(o.i64[2], di);
+      unpack_dims(o.i64[3], dout);
+      const char *li = (const char *)p[1], *lo = (const char *)p[3];
+      rc = aabr_brick_convolution_tables((const int32_t *)p[0], o.i64[0], di, li, li + dir_bytes(di), (const int32_t *)p[2],
+                                         o.i64[1], dout, lo, lo + dir_bytes(dout), &o.i32[0], &o.i32[3], &o.i32[6],
+                                         (int32_t *)p[4], (int32_t *)p[5], (int32_t *)p[6], (int32_t *)p[7], st);
+      break;
+    }
     default:
       aabr::set_error("aabr_geom_run: op %d has unknown kind %d", j, o.kind);
       return AABR_EINVAL;

@@ -48,6 +48,7 @@ constexpr int kVsThreads = 256;
 // size (more workgroups for the dependent first[slot] reads; the look-back is not the cost).
 static inline int vs_items(int64_t) { return 4; }
 constexpr int kMetaTicket = 4;                  // meta word used as the chunk ticket counter
+constexpr int kMetaExtent = 8;                  // meta[8..11]: largest x, y, z, batch index over the valid points
 
 __global__ __launch_bounds__(256) void k_voxel_insert(const int64_t *__restrict__ coords, int64_t n, int ncols,
                                                       GridEnt *keys, uint64_t mask,
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
   __syncthreads();
   int site_next = (int)s_excl + ex_in_chunk;
   int mysite[kVsItems];
+  int ext[4] = {-1, -1, -1, -1};       // largest x, y, z, batch index of this thread's first points
 #pragma unroll
   for (int j = 0; j < kVsItems; ++j) {
     mysite[j] = -1;
@@ -182,8 +184,10 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
       const int v = site_next++;
       mysite[j] = v;
       const int64_t *cp = coords + i * ncols;
-      *reinterpret_cast<int4 *>(site_coords + 4 * (int64_t)v) =
-          make_int4((int)cp[0], (int)cp[1], (int)cp[2], ncols == 4 ? (int)cp[3] : 0);
+      const int4 sc = make_int4((int)cp[0], (int)cp[1], (int)cp[2], ncols == 4 ? (int)cp[3] : 0);
+      *reinterpret_cast<int4 *>(site_coords + 4 * (int64_t)v) = sc;
+      ext[0] = sc.x > ext[0] ? sc.x : ext[0]; ext[1] = sc.y > ext[1] ? sc.y : ext[1];
+      ext[2] = sc.z > ext[2] ? sc.z : ext[2]; ext[3] = sc.w > ext[3] ? sc.w : ext[3];
       first_pt[v] = (int32_t)i;
       if (MODE == 2 && f[j] == 2) {   // the voxel's chain was linked by k_voxel_bin_build: head and count by slot
         const unsigned long long e = words[s[j]];
@@ -197,6 +201,18 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
       }
       __hip_atomic_store(&grid[s[j]].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // self-contained value
     }
+  }
+  // the scene's extent (meta[8..11], counting up from the fill's -1): what a brick grid's directory is sized by.
+  // One atomic per wave and axis, and none when the running maximum already covers it.
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int m = ext[q];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const int o = __shfl_xor(m, d);
+      m = o > m ? o : m;
+    }
+    if (lane == 0 && m > __builtin_nontemporal_load(&meta[kMetaExtent + q])) atomicMax(&meta[kMetaExtent + q], m);
   }
   // the other points of a voxel: their first point lies in this or an earlier (already running) chunk
 #pragma unroll

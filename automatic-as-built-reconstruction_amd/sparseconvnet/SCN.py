@@ -169,7 +169,8 @@ import struct as _struct
 
 _GEOM = _struct.Struct("<ii10i4q8Q")
 assert _GEOM.size == 144
-G_SUBM, G_TABLES, G_TILE, G_WIDE, G_PAIRS, G_RS, G_SITES, G_SOFF = 1, 2, 3, 4, 5, 6, 7, 8
+G_SUBM, G_TABLES, G_TILE, G_WIDE, G_PAIRS, G_RS, G_SITES, G_SOFF, G_BK_BUILD, G_BK_SUBM, G_BK_TABLES = \
+    1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 import threading as _threading
 
 
@@ -252,12 +253,59 @@ def _reap_handed_over():
             _parked.pop(0)
 
 
-class _Grid(object):
-    """one scale of the scene: site list + hash table (replaces SparseGrids, Metadata.h:24-34)"""
-    __slots__ = ("coords", "keys", "vals", "cap", "V", "batch_size", "sample_off")
+class _Brick(object):
+    """brick form of one scale (csrc/brick.hip, csrc/geom.h BrickLevel): ONE allocation = dense directory (one 16-byte
+    entry per super-brick of the extent) followed by the occupied bricks; `ext` = the extent (largest coordinate + 1 per
+    axis) the directory covers, `dims` = (super-bricks per axis x3, samples)."""
+    __slots__ = ("level", "dims", "packed", "nw", "nb_cap", "v_cap", "bcoord", "meta", "ext", "coords_full")
 
-    def __init__(self, coords, keys, vals, cap, V, sample_off=None):
+    def __init__(self, ext, nsamples, nb_bound, v_bound, device, meta):
+        self.ext = tuple(int(e) for e in ext)
+        self.dims = tuple(max((e + 15) // 16, 1) for e in self.ext) + (max(int(nsamples), 1),)
+        assert all(d <= 4096 for d in self.dims[:3]) and self.dims[3] <= 65535
+        self.packed = self.dims[0] | (self.dims[1] << 16) | (self.dims[2] << 32) | (self.dims[3] << 48)
+        self.nw = self.dims[0] * self.dims[1] * self.dims[2] * self.dims[3]
+        self.v_cap = max(min(int(v_bound), self.nw * 4096), 1)
+        self.nb_cap = max(min(int(nb_bound), self.v_cap, self.nw * 64), 1)
+        self.level = torch.empty(4 * (self.nw + self.nb_cap), dtype=torch.int32, device=device)
+        self.bcoord = torch.empty((self.nb_cap, 4), dtype=torch.int32, device=device)
+        self.coords_full = torch.empty((self.v_cap, 4), dtype=torch.int32, device=device)
+        self.meta = meta
+
+    def dims_c(self):
+        return _hip.i32xn(self.dims)
+
+    def dir_ptr(self):
+        return self.level.data_ptr()
+
+    def bricks_ptr(self):
+        return self.level.data_ptr() + 16 * self.nw
+
+    def tensors(self):
+        return [self.level, self.bcoord, self.coords_full, self.meta]
+
+
+def _brick_build(src_coords, vin_bound, vin_count_ptr, size, stride, out_sp, bk):
+    """record / launch aabr_brick_build of level `bk` from the sites `src_coords`"""
+    lib = _hip.load()
+    scratch = torch.empty(int(lib.aabr_brick_scratch_words(bk.nw, bk.nb_cap)) + 2, dtype=torch.int32,
+                          device=bk.level.device)
+    so = (-scratch.data_ptr() // 4) % 2          # 8-byte aligned status words
+    _geom(G_BK_BUILD, tuple(size) + tuple(stride) + tuple(out_sp), (vin_bound, bk.packed, bk.nb_cap, bk.v_cap),
+          (_p(src_coords), vin_count_ptr, bk.level.data_ptr(), bk.bcoord.data_ptr(), bk.coords_full.data_ptr(),
+           bk.meta.data_ptr(), scratch.data_ptr() + 4 * so))
+    _keep(scratch)
+    return scratch
+
+
+class _Grid(object):
+    """one scale of the scene: site list + hash table (replaces SparseGrids, Metadata.h:24-34); with
+    Metadata_3(site_order="brick") the hash table is replaced by a brick level (`brick`, keys None)"""
+    __slots__ = ("coords", "keys", "vals", "cap", "V", "batch_size", "sample_off", "brick")
+
+    def __init__(self, coords, keys, vals, cap, V, sample_off=None, brick=None):
         self.coords, self.keys, self.vals, self.cap, self.V = coords, keys, vals, cap, V
+        self.brick = brick
         # host list: first row of sample b (SparseGrid::ctr, Metadata.h:24-33) for b = 0 .. MAX_SAMPLES, or None
         # when the grid was built without the ride-along read
         self.sample_off = sample_off
@@ -285,6 +333,19 @@ def derived_cap(E):
 
 
 MAX_SAMPLES = 61     # per-sample offsets that ride along with a grid's site-count read (64-word rows)
+BRICK_MAX_DIR_WORDS = 1 << 25   # 512 MiB of directory for the input level; above it a scene keeps its hash grids
+brick_stats = {"built": 0, "declined": 0}
+
+
+def _brick_dir_words(extent):
+    w = max(extent[3] + 1, 1)
+    for e in extent[:3]:
+        w *= max((e + 16) // 16, 1)
+    return w
+
+
+_BK_MAX_LEVELS = 48  # brick levels of one Metadata (input + strided levels); one read-back row each:
+_BK_ROW = 64 + 16    # [V, per-sample offsets .. (64 words) | the level's meta block (16 words)]
 
 
 class _Gather(object):
@@ -431,7 +492,13 @@ class Metadata_3(object):
 
     dimension = 3
 
-    def __init__(self):
+    def __init__(self, site_order="first_seen"):
+        """`site_order` (extension): "first_seen" = the reference's numbering of the input sites (IOLayersRules.h:86-91,
+        exact) over hash grids; "brick" = every level numbered brick by brick (csrc/brick.hip): the same sites, rule
+        books and features up to a per-sample permutation of the rows, spatial neighbours adjacent in
+        memory, no hash tables -- what FPN_Net(site_order="brick") / bench.py run on."""
+        assert site_order in ("first_seen", "brick")
+        self.site_order = site_order
         self.clear()
 
     def clear(self):
@@ -441,6 +508,7 @@ class Metadata_3(object):
         self.input = None  # dict(point_site, first_pt, cnt_extra, head, nxt, last_pt, meta, n, V, mode, spatial)
         self.device = None
         self._pregrids = set()
+        self._brick_rows, self._brick_nrows, self._brick_keep = None, 0, []
 
     # ---- reference-visible queries ----------------------------------------------------
     def getSpatialLocations(self, spatial_size):
@@ -488,7 +556,8 @@ class Metadata_3(object):
         if pend is not None:
             ts += [pend["buf"]]
         for g in self.grids.values():
-            ts += [g.coords, g.keys]
+            ts += [g.coords] + ([g.keys] if g.keys is not None else []) + (g.brick.tensors() if g.brick is not None else [])
+        ts += list(self._brick_keep)
         if self.input is not None:
             ts += [self.input["point_site"]]
         for tb in list(self.submanifold.values()) + list(self.rulebooks.values()):
@@ -679,10 +748,101 @@ class Metadata_3(object):
                 raise _hip.AabrError("InputLayer: coordinates must lie in [0, 65534] (batch index too)")
             V = m[0]
             key = self.input["spatial"]
-            self.grids[key] = _Grid(pend["site_coords"][:V], pend["keys"], pend["vals"], pend["cap"], V)
+            if self.site_order == "brick" and V > 0 and _brick_dir_words(m[8:12]) > BRICK_MAX_DIR_WORDS:
+                # a few sites spread over a huge extent: the dense directory would not pay -- hash grids for this scene
+                self.site_order = "first_seen"
+                brick_stats["declined"] += 1
+            if self.site_order == "brick" and V > 0:
+                brick_stats["built"] += 1
+                self.grids[key] = self._brickify_input(pend, V, m[8:12])
+            else:
+                self.grids[key] = _Grid(pend["site_coords"][:V], pend["keys"], pend["vals"], pend["cap"], V)
             self.input["V"] = V   # maxActive (meta[1]) is produced by the forward kernel: read lazily (max_active())
             self.input_spatial = key
         return self.input["V"]
+
+    # ---- brick-major site order (extension; csrc/brick.hip) -------------------------------------------------------------
+    def _brickify_input(self, pend, V, extent):
+        """The voxel scatter has numbered the V input sites in first-seen order and the host knows V and the scene's extent
+        (meta[8..11]).  Build the input level's brick grid from those sites, renumber them brick by brick and carry the
+        input layer's per-site arrays (first point, further-point chain, point -> site) over to the new rows.  Nothing is
+        read back here; the level's error flag rides with the next read (`buildBrickPyramid` / `getRuleBook`)."""
+        lib = _hip.load()
+        il = self.input
+        dev = pend["buf"].device
+        n = il["n"]
+        ext = [e + 1 for e in extent[:3]]
+        nsamples = extent[3] + 1
+        rows = self._brick_rows = torch.empty((_BK_MAX_LEVELS, _BK_ROW), dtype=torch.int32, device=dev)
+        self._brick_nrows = 1
+        bk = _Brick(ext, nsamples, V, V, dev, rows[0, 64:64 + _hip.META_WORDS])
+        old_coords = pend["site_coords"]
+        scratch = _brick_build(old_coords, V, 0, (1, 1, 1), (1, 1, 1), il["spatial"], bk)
+        flush_geom()
+        nb = torch.empty(5 * V + n + 8, dtype=torch.int32, device=dev)
+        new_of_old, old_of_new, first2, extra2, head2 = (nb[i * V:(i + 1) * V] for i in range(5))
+        ps2 = nb[5 * V:5 * V + n]
+        check(lib.aabr_brick_renumber(ptr(old_coords), V, bk.dims_c(), bk.dir_ptr(), bk.bricks_ptr(), ptr(new_of_old),
+                                      ptr(old_of_new), ptr(il["first_pt"]), ptr(il["cnt_extra"]), ptr(il["head"]),
+                                      ptr(first2), ptr(extra2), ptr(head2), ptr(il["point_site"]), n, ptr(ps2),
+                                      bk.meta.data_ptr(), stream()))
+        il.update(point_site=ps2, first_pt=first2, cnt_extra=extra2, head=head2, new_of_old=new_of_old,
+                  old_of_new=old_of_new)
+        self._brick_keep = [nb, rows, scratch]
+        g = _Grid(bk.coords_full[:V], None, None, 0, V, None, bk)
+        return g
+
+    def _brick_read(self):
+        """ONE host read for every brick level enqueued since the last one: [V, per-sample offsets (64 words), meta (16)]
+        per level; checks the error flags"""
+        flush_geom()
+        n = self._brick_nrows
+        rows = _hip.read_back(self._brick_rows[:n].reshape(-1))
+        rows = [rows[i * _BK_ROW:(i + 1) * _BK_ROW] for i in range(n)]
+        for i, r in enumerate(rows):
+            if r[64 + 2]:
+                raise _hip.AabrError("brick grid %d: a site outside the directory's extent or a capacity overflow "
+                                     "(meta %s)" % (i, r[64:64 + 4]))
+        g0 = self.grids[self.input["spatial"]]
+        if rows[0][64] != g0.V:
+            raise _hip.AabrError("brick grid of the input level holds %d sites, the voxel scatter counted %d"
+                                 % (rows[0][64], g0.V))
+        return rows
+
+    def buildBrickPyramid(self, specs):
+        """Extension: the strided levels of a pass as brick grids, each built from its parent LEVEL by device-side counts
+        (aabr_brick_build), all enqueued back to back, ONE host read for all of their site counts and per-sample offsets.
+        specs = [(out_spatial key, source spatial key, size, stride)] in dependency order."""
+        todo = [sp for sp in specs if sp[0] not in self.grids]
+        if not todo:
+            return
+        dev = self._brick_rows.device
+        made = {}
+        first_row = self._brick_nrows
+        for osz, src, size, stride in todo:
+            gs = made.get(src) or self.grids[src]
+            bs = gs.brick
+            ext = [min(o, (e - 1) // st_ + 1) for o, e, st_ in zip(osz, bs.ext, stride)]
+            maxout = 1
+            for a, b in zip(size, stride):
+                maxout *= (a + b - 1) // b
+            row = self._brick_rows[self._brick_nrows]
+            self._brick_nrows += 1
+            assert self._brick_nrows <= _BK_MAX_LEVELS
+            bk = _Brick(ext, bs.dims[3], bs.nb_cap * maxout, bs.v_cap * maxout, dev, row[64:64 + _hip.META_WORDS])
+            _brick_build(bs.coords_full, bs.v_cap, bs.meta.data_ptr(), size, stride, osz, bk)
+            _geom(G_SOFF, (MAX_SAMPLES + 1,), (bk.v_cap,), (_p(bk.coords_full), bk.meta.data_ptr(), row.data_ptr()))
+            made[osz] = _Grid(None, None, None, 0, None, None, bk)
+        rows = self._brick_read()
+        pre = self.__dict__.setdefault("_pregrids", set())
+        for (osz, src, size, stride), r in zip(todo, rows[first_row:]):
+            g = made[osz]
+            V = r[0]
+            off = r[1:64]
+            g.V, g.coords = V, g.brick.coords_full[:V]
+            g.sample_off = off if off[-1] == V else None
+            self.grids[osz] = g
+            pre.add(osz)
 
     def getSubmanifoldRuleBook(self, spatial_size, filter_size):
         """Metadata::getSubmanifoldRuleBook (Metadata.cpp:429-443) -> cached gather table"""
@@ -694,10 +854,12 @@ class Metadata_3(object):
             g = self.grids[_key(spatial_size)]
             fs = _key(filter_size)
             vol = fs[0] * fs[1] * fs[2]
-            dev = g.keys.device
+            dev = g.coords.device
             table = torch.empty((vol, g.V), dtype=torch.int32, device=dev)
             counts = torch.empty(vol * ((g.V + 255) // 256), dtype=torch.int32, device=dev)
-            if g.V > 0:
+            if g.V > 0 and g.brick is not None:
+                _geom(G_BK_SUBM, fs, (g.V, g.brick.packed), (_p(g.coords), g.brick.level.data_ptr(), _p(table), _p(counts)))
+            elif g.V > 0:
                 _geom(G_SUBM, fs, (g.V, g.cap), (_p(g.coords), _p(g.keys), _p(table), _p(counts)))
             # odd filters: the input-gradient gather is the same table read with the mirrored
             # offset (u = v + off_k  <=>  v = u + off_{vol-1-k})
@@ -718,6 +880,8 @@ class Metadata_3(object):
         `getRuleBook` picks the grids up by their spatial size."""
         lib = _hip.load()
         gi = self.grids[_key(in_spatial)]
+        if gi.brick is not None:       # brick grids: each level from the round's base with the composed stride
+            return self.buildBrickPyramid([(_key(o), _key(in_spatial), _key(c), _key(c)) for o, c in specs])
         dev = gi.keys.device
         E = gi.V
         cap = derived_cap(E)
@@ -760,8 +924,17 @@ class Metadata_3(object):
                 self._materialise_input(torch.device("cuda", torch.cuda.current_device()))
             gi = self.grids[_key(in_spatial)]
             fs, st, osz = _key(filter_size), _key(filter_stride), _key(out_spatial)
-            dev = gi.keys.device
+            dev = gi.coords.device
             vol = fs[0] * fs[1] * fs[2]
+            if gi.brick is not None and gi.V > 0 and osz not in self.__dict__.get("_pregrids", ()):
+                self.buildBrickPyramid([(osz, _key(in_spatial), fs, st)])       # (one host read)
+            elif self.site_order == "brick" and gi.V == 0:                      # an empty level under an empty level
+                self.grids[osz] = _Grid(gi.coords[:0], None, None, 0, 0)
+                e = lambda r: torch.empty((vol, 0), dtype=torch.int32, device=dev)
+                tb = _Table(_Gather(e(0), torch.empty(0, dtype=torch.int32, device=dev), vol, 0),
+                            _Gather(e(0), torch.empty(0, dtype=torch.int32, device=dev), vol, 0), vol, 0, 0)
+                self.rulebooks[k] = tb
+                return tb
             go = self.grids.get(osz) if osz in self.__dict__.get("_pregrids", ()) else None
             if go is not None:         # built ahead by buildGridsFromInput
                 self._pregrids.discard(osz)
@@ -770,9 +943,14 @@ class Metadata_3(object):
                 t_in = torch.empty((vol, gi.V), dtype=torch.int32, device=dev)
                 counts = torch.empty(vol * ((V_out + 255) // 256), dtype=torch.int32, device=dev)
                 counts_in = torch.empty(vol * ((gi.V + 255) // 256), dtype=torch.int32, device=dev)
-                _geom(G_TABLES, fs + st + osz, (gi.V, gi.cap, V_out, go.cap),
-                      (_p(gi.coords), _p(gi.keys), _p(go.coords), _p(go.keys), _p(t_out), _p(t_in), _p(counts),
-                       _p(counts_in)))
+                if gi.brick is not None:
+                    _geom(G_BK_TABLES, fs + st + osz, (gi.V, V_out, gi.brick.packed, go.brick.packed),
+                          (_p(gi.coords), gi.brick.level.data_ptr(), _p(go.coords), go.brick.level.data_ptr(), _p(t_out),
+                           _p(t_in), _p(counts), _p(counts_in)))
+                else:
+                    _geom(G_TABLES, fs + st + osz, (gi.V, gi.cap, V_out, go.cap),
+                          (_p(gi.coords), _p(gi.keys), _p(go.coords), _p(go.keys), _p(t_out), _p(t_in), _p(counts),
+                           _p(counts_in)))
                 tb = _Table(_Gather(t_out, counts, vol, V_out), _Gather(t_in, counts_in, vol, gi.V), vol, V_out, gi.V)
                 self.rulebooks[k] = tb
                 return tb

@@ -28,6 +28,7 @@ class FPN_Net(torch.nn.Module):
         self.prepack_weights = True     # extension: see _refresh_weight_packs
         self.grids_from_input = True    # extension: see _grids_from_input
         self.compiled_graph = False     # extension: planExecutor.run_fpn (one launch list per pass)
+        self.site_order = "first_seen"  # extension: "brick" = brick-major rows over brick grids (see set_site_order)
         self.bn_momentum = bn_momentum
         self.track_running_stats = track_running_stats
         self.dimension = dimension
@@ -121,6 +122,17 @@ class FPN_Net(torch.nn.Module):
         self.m_mergeds = m_mergeds
         self.operations_down = operations_down
         self.operations_up = operations_up
+
+    def set_site_order(self, order):
+        """Extension: "brick" numbers the sites of every level brick by brick (SCN.Metadata_3(site_order="brick"),
+        csrc/brick.hip) instead of in the reference's first-seen / insertion order: same sites, same features per site,
+        rows of a sample permuted (the returned maps come with their own `get_spatial_locations`, as always); spatial
+        neighbours are neighbours in memory and no hash table is built or probed."""
+        assert order in ("first_seen", "brick")
+        self.site_order = order
+        self.layers_in[0].site_order = order
+        self.layers_in_0[0].site_order = order
+        return self
 
     @staticmethod
     def _cast(net, dtype):
@@ -225,6 +237,25 @@ class FPN_Net(torch.nn.Module):
             rounds.append((bsz, tuple(int(v) for v in bsz.tolist()), specs))
         return rounds
 
+    def _brick_specs(self, sp):
+        """[(out key, source key, size, stride)] of the pass's strided levels in dependency order (cached per size plan)"""
+        specs = sp.get("brick_specs")
+        if specs is None:
+            from . import SCN
+            key = SCN._key
+            specs = []
+            nscale = len(self.m_downs)
+            for k in range(nscale - 1):
+                ks, st = sp["down"][k]
+                specs.append((key(sp["sizes"][k + 1]), key(sp["sizes"][k]), key(ks), key(st)))
+            for msz, out, ks in sp["rpn"]:
+                # a [1, 1, z] / stride-1 filter that spans the whole z extent: its output sites are the level's (x, y)
+                # columns = the non-overlapping form (1, 1, z) / (1, 1, z); otherwise the overlapping form as it is
+                if key(out) != key(msz):
+                    specs.append((key(out), key(msz), key(ks), key(ks) if key(out)[2] == 1 else (1, 1, 1)))
+            sp["brick_specs"] = specs
+        return specs
+
     def _grids_from_input(self, md, sp):
         """the strided grids of the pass in rounds of four levels when the down-sampling levels do not overlap
         (filter == stride, the reference's default [[2,2,2]]*8): every grid of a round is built straight from the
@@ -232,6 +263,13 @@ class FPN_Net(torch.nn.Module):
         instead of 13.  Not all from level 0: a 49-site level built from 310 k sites is 310 k atomics on 49 words
         (measured: +2 ms); four levels deep the contention stays below ~20 per word on scene data.  The rounds
         themselves are part of the size plan (`_grid_rounds`)."""
+        from . import SCN
+        g0 = md.grids.get(SCN._key(sp["sizes"][0]))
+        if g0 is not None and g0.brick is not None:
+            # brick grids: every level from its PARENT level with device-side counts, the z-collapse grids from their own
+            # level -- ONE host read for the whole pyramid (Metadata_3.buildBrickPyramid)
+            md.buildBrickPyramid(self._brick_specs(sp))
+            return
         if sp["rounds"] is None:
             return
         for bsz, bkey, specs in sp["rounds"]:

@@ -21,6 +21,9 @@ class InputLayer(Module):
         self.spatial_size = toLongTensor(dimension, spatial_size)
         self.mode = mode
         self.device = None
+        # extension (SCN.Metadata_3): "first_seen" = the reference's site numbering (IOLayersRules.h:86-91), "brick" =
+        # brick-major rows over brick grids (same sites and features up to a per-sample permutation of the rows)
+        self.site_order = "first_seen"
 
     def to(self, device):
         self.device = device
@@ -34,7 +37,7 @@ class InputLayer(Module):
         when it is called with the same coordinate tensor."""
         if device is None:
             device = self.device if self.device is not None else coords.device
-        md = Metadata(self.dimension)
+        md = Metadata(self.dimension, self.site_order)
         side = stream if stream is not None else torch.cuda.current_stream()
         c64 = coords if coords.dtype == torch.int64 else coords.long()   # converted ONCE; forward reuses c64
         with torch.cuda.stream(side):
@@ -61,7 +64,7 @@ class InputLayer(Module):
                 cur.wait_stream(md.prepared_on)  # tensors were produced on the side stream
                 md.hand_over(cur)                # ... and their memory stays theirs until `cur` is done with it
             SCN._reap_handed_over()
-        output = SparseConvNetTensor(metadata=md if md is not None else Metadata(self.dimension),
+        output = SparseConvNetTensor(metadata=md if md is not None else Metadata(self.dimension, self.site_order),
                                      spatial_size=self.spatial_size)
         output.features = InputLayerFunction.apply(
             self.dimension, output.metadata, self.spatial_size, c64 if c64 is not None else input[0].long(),

@@ -102,6 +102,9 @@ def spawn_ranks(argv, n, script=None):
     return rc
 
 
+SITE_ORDER_DEFAULT = "first_seen"
+
+
 # ------------------------------------------------------------------------------------------------ workload
 def build_net(scn, torch, dev, dtype):
     torch.manual_seed(0)
@@ -113,6 +116,9 @@ def build_net(scn, torch, dev, dtype):
     # every layer between the input layer and the returned maps as one launch list per pass (planExecutor.py):
     # same kernels, arguments and order as the module path, without its per-layer interpreter time
     net.compiled_graph = os.environ.get("AABR_BENCH_COMPILED_GRAPH", "1") != "0"
+    # site order of every level (FPN_Net.set_site_order): "brick" = brick-major rows over brick grids (csrc/brick.hip),
+    # "first_seen" = the reference's numbering over hash grids; same sites, features and gradients per site either way
+    net.set_site_order(os.environ.get("AABR_BENCH_SITE_ORDER", SITE_ORDER_DEFAULT))
 
     class RpnHead(torch.nn.Module):
         """SingleConvRPNHead_Sparse3D (rpn_sparse3d.py:81-131): 1x1 conv + ReLU, objectness and box heads --

@@ -32,6 +32,9 @@ extern "C" {
 #define AABR_ERANGE (-3)  /* coordinate outside the supported [0, 65534] range */
 
 const char *aabr_last_error(void);
+/* ABI version: bumped whenever a signature, a record layout or AABR_META_WORDS changes; a binding written for one value
+ * must refuse a library that reports another (`_hip.load()` does).  500 = round 5 (16-word meta blocks, brick grids). */
+#define AABR_ABI_VERSION 500
 int aabr_version(void);
 /* Tuning knobs for experiments and tests (no counterpart in the reference; the defaults are what ships): CONV_WIDE,
  * CONV_WIDE_BF16, CONV_RS (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, RS_UNIT, CONV_WLDS,
@@ -44,9 +47,12 @@ int aabr_set_knob(const char *name, int value, int unset);
  * release build those entry points return an error and their decision functions return 0.                      */
 int aabr_build_flags(void);
 /* number of int32 words of the `meta` block written by the geometry builders */
-#define AABR_META_WORDS 8
-/* meta[0] = number of active sites, meta[1] = max points per site (input layer only),
- * meta[2] = error flag (non-zero: coordinate out of range), meta[3] = total of 2nd scan lane */
+#define AABR_META_WORDS 16
+/* meta[0] = number of active sites, meta[1] = max points per site (input layer only; brick levels: number of bricks),
+ * meta[2] = error flag (non-zero: coordinate out of range), meta[3] = total of 2nd scan lane,
+ * meta[4], meta[5] = internal (chunk ticket, redo flag of the packed input-layer forms),
+ * meta[8..11] (input layer) = largest x, y, z and batch index over the valid points, -1 when there is none: the extent
+ * a brick grid's directory is sized by */
 
 /* ---- input pipeline ---------------------------------------------------------------------------
  * Device-side form of the dataset's host quantisation (data3d/suncg_utils/suncg_dataset.py:126-188,
@@ -144,6 +150,48 @@ int aabr_submanifold_table(const int32_t *site_coords, int64_t V, const uint64_t
  * clipped to V_max), out[1 + b] = first row with batch index >= b for b = 0 .. max_samples.                    */
 int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t V_max, int max_samples,
                         int32_t *out, void *stream);
+
+/* ---- brick grids (extension; csrc/brick.hip, csrc/geom.h) -------------------------------------------------------------
+ * A level of the scene stored by WHERE its sites are instead of in a hash table -- what replaces the reference's
+ * per-sample google::dense_hash_map (Metadata.h:24-34) when Metadata_3 is created with site_order="brick":
+ *   dir    [nb * sbx * sby * sbz] 16-byte entries {uint64 word, uint32 prefix, pad}: one entry per super-brick (16^3 voxels)
+ *          of the level's extent, one bit per brick (4^3 voxels), prefix = occupied bricks in front of the word;
+ *   bricks [NB] 16-byte entries {uint64 cell mask, int32 base, pad} in directory order, base = sites in front of the brick;
+ *   row of the site at (b, x, y, z) = base + popcount(mask below cell (x&3)<<4 | (y&3)<<2 | (z&3)).
+ * dims_host = {sbx, sby, sbz, nb}.  Sites are numbered brick by brick, cell by cell: spatial neighbours are neighbours
+ * in memory, a lookup is two dependent 16-byte loads (no hashing), and the row order inside a sample is a permutation
+ * of the reference's first-seen order (parity modulo a per-sample permutation).
+ *
+ * aabr_brick_build: the level that holds, for every input site u < min(vin_bound, *vin_count_dev) (vin_count_dev may
+ * be NULL) and every cell of its output region under (size, stride, out_spatial) (OutputRegionCalculator,
+ * RectangularRegions.h:109-119; size = stride = 1: the level of the input sites themselves; size == stride up to 65536:
+ * the composition of non-overlapping levels as in aabr_convolution_sites), one site -- what
+ * Convolution_InputSgToRulesAndOutputSg creates (ConvolutionRules.h:11-34).  Writes dir, bricks, bcoord [NB] int32x4
+ * brick coordinates, out_coords [V] int32x4 (x, y, z, batch) in row order and meta (meta[0] = V, meta[1] = NB, meta[2] != 0:
+ * a site outside the extent `dims` covers, or more than nb_cap bricks / v_cap sites).  Nothing is read back: a chain of
+ * levels is enqueued back to back with device-side counts.  scratch: aabr_brick_scratch_words(dir words, nb_cap) int32. */
+int64_t aabr_brick_scratch_words(int64_t dir_words, int64_t nb_cap);
+int aabr_brick_build(const int32_t *in_coords, int64_t vin_bound, const int32_t *vin_count_dev, const int32_t *size_host,
+                     const int32_t *stride_host, const int32_t *out_spatial_host, const int32_t *dims_host, void *dir,
+                     void *bricks, int64_t nb_cap, int32_t *bcoord, int32_t *out_coords, int64_t v_cap, int32_t *meta,
+                     int32_t *scratch, void *stream);
+/* Input level: the voxel scatter numbers its sites in first-seen order (IOLayersRules.h:86-91); old_coords [V] are those
+ * sites, (dir, bricks) the brick level built from them.  new_of_old[r] / old_of_new[i] = the permutation; first_pt /
+ * cnt_extra / head re-indexed by the new rows; point_site2[p] = new row of point p's site.                           */
+int aabr_brick_renumber(const int32_t *old_coords, int64_t V, const int32_t *dims_host, const void *dir, const void *bricks,
+                        int32_t *new_of_old, int32_t *old_of_new, const int32_t *first_pt, const int32_t *cnt_extra,
+                        const int32_t *head, int32_t *first_pt2, int32_t *cnt_extra2, int32_t *head2,
+                        const int32_t *point_site, int64_t n, int32_t *point_site2, int32_t *meta, void *stream);
+/* aabr_submanifold_table / aabr_convolution_tables2 over brick levels: same tables, same block counts
+ * (Metadata.cpp:429-443,484-510; SubmanifoldConvolutionRules.h:26-45; ConvolutionRules.h:11-34).                       */
+int aabr_brick_submanifold_table(const int32_t *site_coords, int64_t V, const int32_t *dims_host, const void *dir,
+                                 const void *bricks, const int32_t *filter_size_host, int32_t *table, int32_t *counts,
+                                 void *stream);
+int aabr_brick_convolution_tables(const int32_t *in_coords, int64_t V_in, const int32_t *in_dims_host, const void *in_dir,
+                                  const void *in_bricks, const int32_t *out_coords, int64_t V_out,
+                                  const int32_t *out_dims_host, const void *out_dir, const void *out_bricks,
+                                  const int32_t *size_host, const int32_t *stride_host, const int32_t *out_spatial_host,
+                                  int32_t *table_out, int32_t *table_in, int32_t *counts, int32_t *counts_in, void *stream);
 
 /* Strided convolution geometry -- replaces Metadata<3>::getRuleBook ->
  * Convolution_InputSgToRulesAndOutputSg (Metadata.cpp:484-510, ConvolutionRules.h:11-34,
@@ -575,6 +623,18 @@ void aabr_plan_launcher_stats(int64_t *busy_ns, int64_t *parts, int64_t *sleeps)
 #define AABR_GEOM_RS 6
 #define AABR_GEOM_CONV_SITES 7
 #define AABR_GEOM_SAMPLE_OFFSETS 8
+/* brick grids (one allocation per level: the directory, then the bricks; dims packed sbx | sby << 16 | sbz << 32 | nb << 48):
+ *   AABR_GEOM_BRICK_BUILD   aabr_brick_build(p0 in_coords, i64[0] vin_bound, p1 vin_count_dev, i32[0..2] size, i32[3..5]
+ *                           stride, i32[6..8] out_spatial, i64[1] dims, p2 level, i64[2] nb_cap, p3 bcoord, p4 out_coords,
+ *                           i64[3] v_cap, p5 meta, p6 scratch)
+ *   AABR_GEOM_BRICK_SUBM    aabr_brick_submanifold_table(p0 coords, i64[0] V, i64[1] dims, p1 level, i32[0..2] filter,
+ *                           p2 table, p3 block counts)
+ *   AABR_GEOM_BRICK_TABLES  aabr_brick_convolution_tables(p0 in_coords, i64[0] V_in, i64[2] in dims, p1 in level,
+ *                           p2 out_coords, i64[1] V_out, i64[3] out dims, p3 out level, i32[0..2] size, i32[3..5] stride,
+ *                           i32[6..8] out_spatial, p4 table_out, p5 table_in, p6 counts, p7 counts_in)                  */
+#define AABR_GEOM_BRICK_BUILD 9
+#define AABR_GEOM_BRICK_SUBM 10
+#define AABR_GEOM_BRICK_TABLES 11
 typedef struct AabrGeomOp {
   int32_t kind, pad;
   int32_t i32[10];
