@@ -192,24 +192,28 @@ __global__ __launch_bounds__(kBsThreads) void k_brick_scan(uint4 *arr, int64_t n
   }
 }
 
-// the sites of a finished level, brick by brick, cell by cell: one lane per cell
+// the sites of a finished level, brick by brick, cell by cell.  One thread per brick walks its set cells: on scene data a
+// brick of the fine levels holds 1.5-3 sites (a lane per CELL launched 64 threads for them: 20 M threads at 310 k bricks),
+// and where bricks are full there are few of them.
 __global__ __launch_bounds__(256) void k_brick_expand(const uint4 *__restrict__ bricks, const int4 *__restrict__ bcoord,
                                                       int64_t nb_cap, const int32_t *__restrict__ meta, int64_t v_cap,
                                                       int32_t *__restrict__ site_coords) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t bi = t >> 6;
-  const int c = (int)(t & 63);
+  const int64_t bi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t NB = meta[kBkMetaNB];
   NB = NB < nb_cap ? NB : nb_cap;
   if (bi >= NB) return;
   const uint4 br = bricks[bi];
-  const unsigned long long m = lo64(br);
-  if (!((m >> c) & 1ull)) return;
-  const int64_t row = (int64_t)(int)br.z + __popcll(m & ((1ull << c) - 1ull));
-  if (row >= v_cap) return;
+  unsigned long long m = lo64(br);
   const int4 bc = bcoord[bi];
-  *reinterpret_cast<int4 *>(site_coords + 4 * row) =
-      make_int4(4 * bc.x + (c >> 4), 4 * bc.y + ((c >> 2) & 3), 4 * bc.z + (c & 3), bc.w);
+  int64_t row = (int64_t)(int)br.z;
+  while (m) {
+    const int c = __ffsll((long long)m) - 1;
+    m &= m - 1ull;
+    if (row < v_cap)
+      *reinterpret_cast<int4 *>(site_coords + 4 * row) =
+          make_int4(4 * bc.x + (c >> 4), 4 * bc.y + ((c >> 2) & 3), 4 * bc.z + (c & 3), bc.w);
+    ++row;
+  }
 }
 
 // Input level: the voxel scatter numbered its sites in first-seen order (IOLayersRules.h:86-91); `old_coords` are those
@@ -285,8 +289,12 @@ extern "C" int aabr_brick_build(const int32_t *in_coords, int64_t vin_bound, con
   unsigned long long *status0 = reinterpret_cast<unsigned long long *>(scratch);
   unsigned long long *status1 = status0 + c0;
   int32_t *tickets = reinterpret_cast<int32_t *>(status1 + c1);
-  AABR_CHECK_HIP(hipMemsetAsync(dir, 0, (size_t)nw * 16, st));
-  AABR_CHECK_HIP(hipMemsetAsync(bricks, 0, (size_t)nb_cap * 16, st));
+  if ((char *)bricks == (char *)dir + (size_t)nw * 16)       // one allocation (the layout the Python side uses): ONE fill
+    AABR_CHECK_HIP(hipMemsetAsync(dir, 0, (size_t)(nw + nb_cap) * 16, st));
+  else {
+    AABR_CHECK_HIP(hipMemsetAsync(dir, 0, (size_t)nw * 16, st));
+    AABR_CHECK_HIP(hipMemsetAsync(bricks, 0, (size_t)nb_cap * 16, st));
+  }
   AABR_CHECK_HIP(hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st));
   AABR_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)(2 * (c0 + c1) + 4) * sizeof(int32_t), st));
   if (vin_bound > 0)
@@ -299,7 +307,7 @@ extern "C" int aabr_brick_build(const int32_t *in_coords, int64_t vin_bound, con
                        d, (uint4 *)dir, (uint4 *)bricks, nb_cap, (int4 *)bcoord, meta);
   hipLaunchKernelGGL(k_brick_scan<1>, dim3((unsigned)c1), dim3(kBsThreads), 0, st, (uint4 *)bricks, nb_cap, status1,
                      tickets + 1, meta, v_cap);
-  hipLaunchKernelGGL(k_brick_expand, grid1(nb_cap * 64, 256), dim3(256), 0, st, (const uint4 *)bricks,
+  hipLaunchKernelGGL(k_brick_expand, grid1(nb_cap, 256), dim3(256), 0, st, (const uint4 *)bricks,
                      (const int4 *)bcoord, nb_cap, (const int32_t *)meta, v_cap, out_coords);
   AABR_CHECK_LAUNCH();
   return AABR_OK;

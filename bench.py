@@ -102,7 +102,7 @@ def spawn_ranks(argv, n, script=None):
     return rc
 
 
-SITE_ORDER_DEFAULT = "first_seen"
+SITE_ORDER_DEFAULT = "brick"
 
 
 # ------------------------------------------------------------------------------------------------ workload
@@ -591,6 +591,8 @@ def scatter_block(torch, scn, locs, feats, tag):
     fdet = feats.detach()
     keep = []
 
+    order = os.environ.get("AABR_BENCH_SITE_ORDER", SITE_ORDER_DEFAULT)
+
     def sites():
         md = SCN.Metadata_3()
         md.inputLayerEnqueue(SP, locs, 4, dev, asynchronous=False)
@@ -598,7 +600,22 @@ def scatter_block(torch, scn, locs, feats, tag):
         del keep[:-6]
     with torch.no_grad():
         t_sites = device_time(torch, sites)
-        md = SCN.Metadata_3()
+        t_brick = 0.0
+        if order == "brick":
+            # brick-major rows: the brick level of the input sites + their renumbering ride on top of the scatter
+            mdf = SCN.Metadata_3()
+            mdf.inputLayerEnqueue(SP, locs, 4, dev, asynchronous=False)
+            pend = mdf._pending
+            m = pend["meta"].tolist()
+
+            def brickify():
+                md2 = SCN.Metadata_3("brick")
+                md2.input = dict(mdf.input)
+                keep.append((md2._brickify_input(pend, m[0], m[8:12]), md2))
+                del keep[:-6]
+            t_brick = device_time(torch, brickify)
+            t_sites += t_brick
+        md = SCN.Metadata_3(order)
         V = md.inputLayer(SP, locs, 4, 4, dev)
         il = md.input
         out = torch.empty((V, fdet.shape[1]), device=dev)
@@ -609,12 +626,14 @@ def scatter_block(torch, scn, locs, feats, tag):
                                                4, ptr(il["meta"]), stream()))
         t_mean = device_time(torch, mean)
         inp = scn.InputLayer(3, [4096, 4096, 512], mode=4)
+        inp.site_order = order
         t_call = hip_time(torch, lambda: inp([locs, fdet]), 1, 10)
     n, c = int(locs.shape[0]), int(fdet.shape[1])
     by = n * (32 + 4 * c) + V * (4 * c + 16)
     t = t_sites + t_mean
-    return dict(workload=tag, points=n, sites=int(V), bytes=by, insert_form=int(SCN.scatter_variant),
-                device_seconds=round(t, 7), sites_seconds=round(t_sites, 7), mean_seconds=round(t_mean, 7),
+    return dict(workload=tag, points=n, sites=int(V), bytes=by, insert_form=int(SCN.scatter_variant), site_order=order,
+                device_seconds=round(t, 7), sites_seconds=round(t_sites, 7), brick_seconds=round(t_brick, 7),
+                mean_seconds=round(t_mean, 7),
                 device_gbs=round(by / t / 1e9, 2), device_frac_of_hbm_peak=round(by / t / 1e9 / PEAK_HBM_GBS, 5),
                 seconds=round(t_call, 7), achieved_gbs=round(by / t_call / 1e9, 2),
                 frac_of_hbm_peak=round(by / t_call / 1e9 / PEAK_HBM_GBS, 5))
@@ -635,7 +654,8 @@ def stage_rooflines(torch, scn, wl, table, V0):
     locs, feats = wl.batches[0]
     with torch.no_grad():
         # --- submanifold rule table of the input grid, k = 3: 27 probes per site into the hash grid
-        md = SCN.Metadata_3()
+        order = wl.net.site_order
+        md = SCN.Metadata_3(order)
         V = md.inputLayer(torch.LongTensor([4096, 4096, 512]), locs, 4, 4, dev)
         g = md.grids[(4096, 4096, 512)]
         table_ = torch.empty((27, g.V), dtype=torch.int32, device=dev)
@@ -643,12 +663,19 @@ def stage_rooflines(torch, scn, wl, table, V0):
         fs = _hip.i32x3((3, 3, 3))
 
         def subm():
-            check(lib.aabr_submanifold_table(ptr(g.coords), g.V, ptr(g.keys), g.cap, fs, ptr(table_), ptr(counts),
-                                             stream()))
+            if g.brick is not None:
+                check(lib.aabr_brick_submanifold_table(ptr(g.coords), g.V, g.brick.dims_c(), g.brick.dir_ptr(),
+                                                       g.brick.bricks_ptr(), fs, ptr(table_), ptr(counts), stream()))
+            else:
+                check(lib.aabr_submanifold_table(ptr(g.coords), g.V, ptr(g.keys), g.cap, fs, ptr(table_), ptr(counts),
+                                                 stream()))
         t = device_time(torch, subm)
         R = int((table_ >= 0).sum().item())
         by = 16 * g.V + 4 * 27 * g.V
-        out["rulebook_build"] = dict(what="aabr_submanifold_table, k = 3, input grid", sites=int(g.V), rules=R,
+        out["rulebook_build"] = dict(what="%s, k = 3, input grid" % ("aabr_brick_submanifold_table (brick grid: two dependent "
+                                                                     "16-byte loads per look-up)" if g.brick is not None
+                                                                     else "aabr_submanifold_table (hash grid)"),
+                                     site_order=order, sites=int(g.V), rules=R,
                                      seconds=round(t, 7), bytes=by, gbs=round(by / t / 1e9, 1),
                                      frac_of_hbm_peak=round(by / t / 1e9 / PEAK_HBM_GBS, 4),
                                      probes_per_s=round(27 * g.V / t, 1),
@@ -1029,10 +1056,14 @@ def main():
                                    "%s @ 2 cm per GPU and step (%d points -> %d voxels), voxel scatter + "
                                    "all rule books rebuilt every step, fwd + bwd + SGD, RPN head + label generation "
                                    "(criterion-6 IoU + the reference Matcher) + cross-scale top-2000 decode + rotated-3D "
-                                   "NMS per scene%s" %
+                                   "NMS per scene%s; the top-down levels below the four consumed maps are computed as "
+                                   "the reference computes them (fpn_net.py:181-196); rows of every level in %s order" %
                                    (args.config, "'walls' config" if args.config == 2 else "dense whole-building scene",
                                     "4 x S80k scenes" if args.config == 2 else "1 x S1.5M scene", n_pts, V0,
-                                    "" if args.dtype == "f32" else ", bf16 feature storage"),
+                                    "" if args.dtype == "f32" else ", bf16 feature storage",
+                                    "brick-major (brick grids, csrc/brick.hip)" if wl.net.site_order == "brick"
+                                    else "the reference's first-seen (hash grids)"),
+                       "site_order": wl.net.site_order,
                        "global_batch": world * SCENES_PER_STEP, "points_per_scene": N_POINTS,
                        "voxel_scale": VOXEL_SCALE, "parallelism": "dp%d" % world,
                        "proposals_per_scene": n_prop, "label_generation": bool(wl.label_generation),

@@ -101,6 +101,7 @@ class FpnOracle(object):
         self.strided = {}
         self.sites = {}
         self.acts = {}
+        self.act_spatial = {}  # name -> spatial size of the level the BatchNorm runs on (tests match rows by coordinates)
         self.override = None   # name -> array: replace a BN output (device activations => identical ReLU masks)
         self.timing = {}
 
@@ -238,6 +239,7 @@ class FpnOracle(object):
         if self.bf16:
             out = bf16_round(out)
         self.acts[name] = out
+        self.act_spatial[name] = x.spatial
         if self.override is not None and name in self.override:
             out = self.override[name]
         p["running_mean_out"], p["running_var_out"] = rm, rv

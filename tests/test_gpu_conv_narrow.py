@@ -86,6 +86,61 @@ def test_narrow_c_abi_forward_and_input_gradient_forms(npts, bf):
     assert lib.aabr_conv_narrow_ok(32, 64, V, V, vol, 1) == 0 and lib.aabr_conv_narrow_ok(64, 32, V, V, vol, 1) == 0
 
 
+@pytest.mark.parametrize("bf,order", [(True, "first_seen"), (True, "brick"), (False, "brick")])
+def test_narrow_c_abi_at_its_dispatch_size(bf, order):
+    """aabr_conv_forward_narrow[_bf16] through the C ABI against the oracle at >= 400 k output rows --
+    the size from which the library dispatches it by default (aabr_conv_narrow_ok without a knob) -- on a scene-shaped
+    rule book (1.5 M-point scene @ 2 cm), forward with bias and the mirrored input-gradient form; rows matched by
+    coordinates when the grid is brick-ordered"""
+    import _hip
+    import synth_scenes as S
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(77)
+    l, _ = S.make_scene(750000, 31, 50)
+    coords = np.concatenate([l, np.zeros((l.shape[0], 1), np.int64)], 1)
+    layer = scn.InputLayer(3, [4096, 4096, 512], mode=4)
+    layer.site_order = order
+    x = layer([_t(coords), _t(np.zeros((coords.shape[0], 1), np.float32))])
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    assert V >= 400000 and lib.aabr_conv_narrow_ok(32, 32, V, V, vol, 1) == 1       # default dispatch: no knob set
+    O.set_threads(16)
+    il = O.input_layer(coords, np.zeros((coords.shape[0], 1), np.float32), 4)
+    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
+    assert il["V"] == V
+    if order == "brick":
+        r = x.metadata.input["old_of_new"].cpu().numpy()         # device row i = oracle row r[i]
+    else:
+        np.testing.assert_array_equal(x.get_spatial_locations().numpy(), il["coords"])
+        r = np.arange(V)
+    W = (rng.standard_normal((vol, 1, 32, 32)) * 0.1).astype(np.float32)
+    Wd = _t(W)
+    dt = torch.bfloat16 if bf else torch.float32
+    fn = lib.aabr_conv_forward_narrow_bf16 if bf else lib.aabr_conv_forward_narrow
+    Wr = (Wd.bfloat16().float() if bf else Wd).cpu().numpy().reshape(vol, 32, 32)
+    f_o = rng.standard_normal((V, 32)).astype(np.float32)       # oracle row order
+    f = _t(f_o[r]).to(dt)
+    b = rng.standard_normal(32).astype(np.float32)
+    tol = dict(rtol=2 ** -7, atol=2 ** -7) if bf else dict(rtol=1e-4, atol=2e-5)
+    out = torch.full((V, 32), float("nan"), dtype=dt, device=DEV)
+    check(fn(ptr(f), V, ptr(out), V, ptr(ga.table), vol, ptr(Wd), ptr(_t(b)), 0, stream()))
+    assert _variant().startswith("k_conv_narrow<")
+    f_used = np.empty_like(f_o)
+    f_used[r] = f.float().cpu().numpy()                          # what the device read (bf16-rounded), oracle order
+    ref, _ = O.conv_fwd(f_used, Wr, rb, V, b)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref[r], rtol=tol["rtol"], atol=tol["atol"] * max(np.abs(ref).max(), 1.0))
+    g_o = rng.standard_normal((V, 32)).astype(np.float32)
+    g = _t(g_o[r]).to(dt)
+    d_in = torch.full((V, 32), float("nan"), dtype=dt, device=DEV)
+    check(fn(ptr(g), V, ptr(d_in), V, ptr(ga.table), vol, ptr(Wd), None, 3, stream()))
+    g_used = np.empty_like(g_o)
+    g_used[r] = g.float().cpu().numpy()
+    dref, _, _ = O.conv_bwd(np.zeros((V, 32), np.float32), g_used, Wr, rb, want_bias=False)
+    np.testing.assert_allclose(d_in.float().cpu().numpy(), dref[r], rtol=tol["rtol"], atol=tol["atol"] * max(np.abs(dref).max(), 1.0))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_narrow_through_the_layers(force_narrow, dtype):
     """SubmanifoldConvolution / Convolution / Deconvolution with 32 -> 32 planes dispatch the narrow kernel for their

@@ -71,7 +71,46 @@ def _oracle_net(P, storage="f32"):
                              [[256, 256, 32], [128, 128, 16], [64, 64, 8], [32, 32, 4]], storage=storage)
 
 
-def _bench_pass(dtype):
+class _Rows(object):
+    """device rows <-> oracle rows, level by level.  With the reference's site order ("first_seen") the two lists are
+    identical and every map is compared as it is; with brick-major order the device's rows of a sample are a permutation
+    (SURVEY.md 7): rows are matched by their coordinates and everything per-site is compared through that match."""
+
+    def __init__(self, md, oracle_sites, exact):
+        self.md, self.sites, self.exact, self.perm = md, oracle_sites, exact, {}
+
+    def of(self, spatial):
+        sp = tuple(int(v) for v in spatial)
+        p = self.perm.get(sp)
+        if p is None:
+            dev = self.md.getSpatialLocations(torch.LongTensor(list(sp))).numpy()
+            ref = self.sites[sp]
+            if self.exact:
+                np.testing.assert_array_equal(dev, ref)                       # site lists: exact
+                p = np.arange(len(ref))
+            else:
+                key = lambda c: ((c[:, 3].astype(np.int64) * 8192 + c[:, 0]) * 8192 + c[:, 1]) * 8192 + c[:, 2]
+                kd, kr = key(dev), key(ref)
+                assert len(kd) == len(kr)
+                o = np.argsort(kr)
+                pos = np.searchsorted(kr[o], kd)
+                assert (pos < len(kr)).all() and (kr[o][pos] == kd).all(), "site sets differ at %s" % (sp,)
+                p = o[pos]
+                assert len(np.unique(p)) == len(p)
+            self.perm[sp] = p
+        return p
+
+    def to_dev(self, spatial, a_oracle):
+        """oracle-ordered rows -> the device's order"""
+        return a_oracle[self.of(spatial)]
+
+    def to_oracle(self, spatial, a_dev):
+        out = np.empty_like(a_dev)
+        out[self.of(spatial)] = a_dev
+        return out
+
+
+def _bench_pass(dtype, order="first_seen", config=2):
     """one forward + backward of bench.Workload's network path on its own first batch; returns everything compared"""
     sys.path.insert(0, REPO)
     import bench
@@ -79,69 +118,94 @@ def _bench_pass(dtype):
     import sparseconvnet as scn
     from sparseconvnet import planExecutor
     assert planExecutor.dw_side_stream and planExecutor.fuse_adds and planExecutor.conv_bn_stats   # the bench's switches
-    wl = bench.Workload(scn, torch, dp, torch.device(DEV), dtype, 0, 1, 1)
+    saved = (bench.SCENES_PER_STEP, bench.N_POINTS, os.environ.get("AABR_BENCH_SITE_ORDER"))
+    if config == 4:                      # what `bench.py --config 4` sets: one 1.5 M-point scene per step
+        bench.SCENES_PER_STEP, bench.N_POINTS = 1, 1500000
+    os.environ["AABR_BENCH_SITE_ORDER"] = order
+    try:
+        wl = bench.Workload(scn, torch, dp, torch.device(DEV), dtype, 0, 1, 1)
+        n_pts = bench.N_POINTS
+    finally:
+        bench.SCENES_PER_STEP, bench.N_POINTS = saved[0], saved[1]
+        if saved[2] is None:
+            del os.environ["AABR_BENCH_SITE_ORDER"]
+        else:
+            os.environ["AABR_BENCH_SITE_ORDER"] = saved[2]
     net = wl.net
-    assert net.compiled_graph and net.voxel_scale == bench.VOXEL_SCALE
+    assert net.compiled_graph and net.voxel_scale == bench.VOXEL_SCALE and net.site_order == order
     locs_t, feats_t = wl.batches[0]
     locs, feats = locs_t.cpu().numpy(), feats_t.detach().cpu().numpy()
     # the same scenes bench.py times: seeds 9000.., 2 cm
-    l0, f0 = S.make_scene(bench.N_POINTS, 9000, bench.VOXEL_SCALE)
+    l0, f0 = S.make_scene(n_pts, 9000, bench.VOXEL_SCALE)
     assert (locs[:l0.shape[0], :3] == l0).all() and (feats[:l0.shape[0]] == f0).all()
     P = ref_net.fpn_params(net)
     bn_mods = ref_net.fpn_bn_modules(net)
     wl.flat.zero_grad()
     planExecutor.debug_passes = []
     before = planExecutor.stats["passes"]
+    from sparseconvnet import SCN
+    tr, SCN.trace = SCN.trace, None
     try:
         rpn_maps, roi_maps = net([locs_t, feats_t])
         assert planExecutor.stats["passes"] == before + 1          # the compiled graph ran, not the modules
         ps = planExecutor.debug_passes[-1]
     finally:
         planExecutor.debug_passes = None
+        SCN.trace = tr
+    md = rpn_maps[0].metadata
+    assert md.site_order == order
     by_mod = ps.bn_outputs()
     acts = {name: by_mod[m].detach().float().cpu().numpy() for name, m in bn_mods.items()}
     rng = np.random.default_rng(3)
-    G = [rng.standard_normal(m.features.shape).astype(np.float32) / m.features.shape[0] for m in rpn_maps]
-    torch.autograd.backward([m.features for m in rpn_maps], [torch.as_tensor(g).to(DEV) for g in G])
-    torch.cuda.synchronize()
+    # output gradients are drawn in the ORACLE's row order and handed to the device through the row match (below)
     return dict(net=net, wl=wl, locs=locs, feats=feats, P=P, bn_mods=bn_mods, acts=acts, rpn=rpn_maps, roi=roi_maps,
-                G=G, d_feats=feats_t.grad.detach().cpu().numpy())
+                rng=rng, feats_t=feats_t, md=md, order=order, ps=ps)
 
 
-def test_bench_path_fp32_matches_oracle_at_full_size():
-    r = _bench_pass(torch.float32)
+def _backward(r, rows):
+    """draw the output gradients (oracle row order), run the device's backward with them; returns the oracle-order list"""
+    G = [r["rng"].standard_normal(m.features.shape).astype(np.float32) / m.features.shape[0] for m in r["rpn"]]
+    torch.autograd.backward([m.features for m in r["rpn"]],
+                            [torch.as_tensor(rows.to_dev(m.spatial_size.tolist(), g)).to(DEV) for m, g in zip(r["rpn"], G)])
+    torch.cuda.synchronize()
+    r["d_feats"] = r["feats_t"].grad.detach().cpu().numpy()
+    return G
+
+
+def _check_fp32(r, min_sites):
     net, P, acts = r["net"], r["P"], r["acts"]
     O.set_threads(16)
     fo = _oracle_net(P)
     o_rpn, o_roi = fo.forward(r["locs"], r["feats"])
-    assert fo.il["V"] == r["rpn"][0].metadata.input["V"] > 300000
+    assert fo.il["V"] == r["md"].input["V"] > min_sites
+    rows = _Rows(r["md"], fo.sites, r["order"] == "first_seen")
     for i, (d, o) in enumerate(zip(r["rpn"], o_rpn)):
         assert tuple(d.spatial_size.tolist()) == o.spatial
-        np.testing.assert_array_equal(d.get_spatial_locations().numpy(), o.coords)        # site lists: exact
-        assert _relerr(d.features.detach().cpu().numpy(), o.v) < 2e-3, i
+        assert _relerr(d.features.detach().cpu().numpy(), rows.to_dev(o.spatial, o.v)) < 2e-3, i
     for d, o in zip(r["roi"], o_roi):
-        np.testing.assert_array_equal(d.get_spatial_locations().numpy(), o.coords)
-        assert _relerr(d.features.detach().cpu().numpy(), o.v) < 2e-3
+        assert _relerr(d.features.detach().cpu().numpy(), rows.to_dev(o.spatial, o.v)) < 2e-3
     # every BatchNorm output of the pass (read from the compiled graph's arena), ReLU masks flip only at rounding
     # distance of 0
     assert len(acts) == 34
     flips, worst = 0, 0.0
     for name, a in acts.items():
-        e = _relerr(a, fo.acts[name])
+        want = rows.to_dev(fo.act_spatial[name], fo.acts[name])
+        e = _relerr(a, want)
         worst = max(worst, e)
         assert e < 2e-3, name
-        flips += int(((a > 0) != (fo.acts[name] > 0)).sum())
+        flips += int(((a > 0) != (want > 0)).sum())
     assert flips <= 1e-4 * sum(a.size for a in acts.values()) + 4
     # every running statistic (momentum 0.95, unbiased variance)
     for name, m in r["bn_mods"].items():
         np.testing.assert_allclose(m.running_mean.cpu().numpy(), P[name]["running_mean_out"], rtol=2e-3, atol=2e-5)
         np.testing.assert_allclose(m.running_var.cpu().numpy(), P[name]["running_var_out"], rtol=2e-3, atol=2e-5)
     # ---- backward: the oracle replays its forward on the device's BatchNorm outputs (identical ReLU masks)
+    G = _backward(r, rows)
     P2 = {k: (dict(v) if isinstance(v, dict) else v) for k, v in P.items()}
     fo2 = _oracle_net(P2)
-    fo2.override = acts
+    fo2.override = {name: rows.to_oracle(fo.act_spatial[name], a) for name, a in acts.items()}
     fo2.forward(r["locs"], r["feats"])
-    grads = fo2.backward(r["G"])
+    grads = fo2.backward(G)
     names = ref_net.fpn_param_names(net)
     checked, gworst = 0, 0.0
     for key, par in names.items():
@@ -156,12 +220,16 @@ def test_bench_path_fp32_matches_oracle_at_full_size():
     assert checked >= 100
     e_in = _relerr(r["d_feats"], grads["d_feats"])
     assert e_in < 3e-3
-    print("full-size fp32 vs oracle: worst BN output %.2e, mask flips %d, worst parameter gradient %.2e over %d "
-          "tensors, input gradient %.2e" % (worst, flips, gworst, checked, e_in))
+    print("full-size fp32 (%s rows, %d sites) vs oracle: worst BN output %.2e, mask flips %d, worst parameter gradient "
+          "%.2e over %d tensors, input gradient %.2e" % (r["order"], fo.il["V"], worst, flips, gworst, checked, e_in))
 
 
-def test_bench_path_bf16_matches_bf16_oracle_at_full_size():
-    r = _bench_pass(torch.bfloat16)
+@pytest.mark.parametrize("order", ["first_seen", "brick"])
+def test_bench_path_fp32_matches_oracle_at_full_size(order):
+    _check_fp32(_bench_pass(torch.float32, order), 300000)
+
+
+def _check_bf16(r, min_sites):
     net, P, acts = r["net"], r["P"], r["acts"]
     O.set_threads(16)
     fails = []
@@ -173,25 +241,27 @@ def test_bench_path_bf16_matches_bf16_oracle_at_full_size():
     # (b) free-running oracle in the bf16 storage model
     fo = _oracle_net(P, "bf16")
     o_rpn, o_roi = fo.forward(r["locs"], r["feats"])
+    assert fo.il["V"] == r["md"].input["V"] > min_sites
+    rows = _Rows(r["md"], fo.sites, r["order"] == "first_seen")
     free = []
     for i, (d, o) in enumerate(zip(r["rpn"] + r["roi"], o_rpn + o_roi)):
         assert d.features.dtype == torch.float32
-        np.testing.assert_array_equal(d.get_spatial_locations().numpy(), o.coords)
-        free.append(_l2(d.features.detach().cpu().numpy(), o.v))
+        free.append(_l2(d.features.detach().cpu().numpy(), rows.to_dev(o.spatial, o.v)))
         need(free[-1] <= BF16_FREE_L2, ("free map", i, free[-1]))
     # (a) teacher-forced: the oracle's BatchNorm outputs replaced by the device's
     P2 = {k: (dict(v) if isinstance(v, dict) else v) for k, v in P.items()}
     fo2 = _oracle_net(P2, "bf16")
-    fo2.override = acts
+    fo2.override = {name: rows.to_oracle(fo.act_spatial[name], a) for name, a in acts.items()}
     t_rpn, t_roi = fo2.forward(r["locs"], r["feats"])
     tf_l2, tf_max = 0.0, 0.0
     for name, a in acts.items():
-        ref = fo2.acts[name]           # computed from teacher-forced inputs, before the override replaced it
+        ref = rows.to_dev(fo2.act_spatial[name], fo2.acts[name])   # from teacher-forced inputs, before the override
         l2, mx = _l2(a, ref), _relerr(a, ref)
         tf_l2, tf_max = max(tf_l2, l2), max(tf_max, mx)
         need(l2 <= BF16_TF_L2 and mx <= BF16_TF_MAX, ("teacher-forced", name, l2, mx))
     for i, (d, o) in enumerate(zip(r["rpn"] + r["roi"], t_rpn + t_roi)):
-        l2, mx = _l2(d.features.detach().cpu().numpy(), o.v), _relerr(d.features.detach().cpu().numpy(), o.v)
+        want = rows.to_dev(o.spatial, o.v)
+        l2, mx = _l2(d.features.detach().cpu().numpy(), want), _relerr(d.features.detach().cpu().numpy(), want)
         tf_l2, tf_max = max(tf_l2, l2), max(tf_max, mx)
         need(l2 <= BF16_TF_L2 and mx <= BF16_TF_MAX, ("teacher-forced map", i, l2, mx))
     rs = 0.0
@@ -202,7 +272,8 @@ def test_bench_path_bf16_matches_bf16_oracle_at_full_size():
             rs = max(rs, e)
             need(e <= 1.0, ("running statistic", name, e))
     # (c) gradients
-    grads = fo2.backward(r["G"])
+    G = _backward(r, rows)
+    grads = fo2.backward(G)
     names = ref_net.fpn_param_names(net)
     checked, g_l2, g_cos = 0, 0.0, 1.0
     for key, par in names.items():
@@ -218,12 +289,32 @@ def test_bench_path_bf16_matches_bf16_oracle_at_full_size():
     assert checked >= 100
     l2_in, c_in = _l2(r["d_feats"], grads["d_feats"]), _cos(r["d_feats"], grads["d_feats"])
     need(l2_in <= BF16_GRAD_L2 and c_in >= BF16_GRAD_COS, ("input gradient", l2_in, c_in))
-    print("full-size bf16 vs bf16-model oracle: free-running map L2 %s (bound %.2e); teacher-forced worst L2 %.2e "
-          "(bound %.2e), worst max-error %.2e (bound %.2e); running statistics worst %.2f of their tolerance; parameter "
-          "gradients worst L2 %.2e (bound %.2e), worst cosine %.5f over %d tensors; input gradient L2 %.2e cosine %.5f"
-          % (["%.2e" % v for v in free], BF16_FREE_L2, tf_l2, BF16_TF_L2, tf_max, BF16_TF_MAX, rs, g_l2, BF16_GRAD_L2,
-             g_cos, checked, l2_in, c_in))
+    print("full-size bf16 (%s rows, %d sites) vs bf16-model oracle: free-running map L2 %s (bound %.2e); teacher-forced "
+          "worst L2 %.2e (bound %.2e), worst max-error %.2e (bound %.2e); running statistics worst %.2f of their tolerance; "
+          "parameter gradients worst L2 %.2e (bound %.2e), worst cosine %.5f over %d tensors; input gradient L2 %.2e cosine "
+          "%.5f" % (r["order"], fo.il["V"], ["%.2e" % v for v in free], BF16_FREE_L2, tf_l2, BF16_TF_L2, tf_max,
+                     BF16_TF_MAX, rs, g_l2, BF16_GRAD_L2, g_cos, checked, l2_in, c_in))
     assert not fails, fails[:12]
+
+
+@pytest.mark.parametrize("order", ["first_seen", "brick"])
+def test_bench_path_bf16_matches_bf16_oracle_at_full_size(order):
+    _check_bf16(_bench_pass(torch.bfloat16, order), 300000)
+
+
+# ---- BASELINE configs[4]: one 1.5 M-point scene @ 2 cm through the same network and step (`bench.py --config 4`) -------
+# at this size the 32 -> 32 layers of the finest level dispatch to k_conv_narrow (bf16 storage, >= 400 k
+# output rows) -- the kernel and the compiled-graph path of this config had only met the oracle at <= 3,001 points.
+def test_config4_bf16_matches_bf16_oracle_at_full_size():
+    from sparseconvnet import SCN
+    r = _bench_pass(torch.bfloat16, "brick", 4)
+    V0 = r["md"].input["V"]
+    assert SCN.narrow_ok(32, 32, V0, V0, 27, True), "the 32 -> 32 layers of this config must run k_conv_narrow"
+    _check_bf16(r, 800000)
+
+
+def test_config4_fp32_matches_oracle_at_full_size():
+    _check_fp32(_bench_pass(torch.float32, "first_seen", 4), 800000)
 
 
 def test_bench_proposal_sets_nms_decision_and_survivors():
