@@ -90,17 +90,9 @@ _SIGS = {
                                         _i32, _vp, _vp]),
     "aabr_bn_forward_parts_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _vp,
                                              _i32, _vp, _vp]),
-    "aabr_conv_wpack_x3_elems": (C.c_int64, [_i32, _i32, _i32]),
-    "aabr_conv_wide_tile_rows_x3": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
-    "aabr_conv_forward_wide_x3": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp,
-                                            _vp]),
     "aabr_mailbox_create": (C.c_int, [_i64, _vp]),
     "aabr_mailbox_destroy": (C.c_int, [_vp]),
     "aabr_mailbox_post": (C.c_int, [_vp, _i64, _vp, C.c_uint32, _vp]),
-    "aabr_rs_words": (C.c_int64, [_i64, _i32, _i32]),
-    "aabr_build_rs": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
-    "aabr_conv_rs_unit_rows": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
-    "aabr_conv_forward_rs_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "aabr_conv_wpack_floats": (C.c_int64, [_i32, _i32, _i32]),
     "aabr_conv_forward": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "aabr_conv_dw_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),

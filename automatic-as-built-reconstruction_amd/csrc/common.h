@@ -14,10 +14,9 @@ void set_error(const char *fmt, ...);
 // no entry point calls getenv on its launch path.
 // ONE list: the enumerators and the names (api.cpp) are generated from it, so they cannot drift apart.
 #define AABR_KNOB_LIST(X)                                                                                            \
-  X(CONV_WLDS) X(CONV_SMALL) X(CONV_NBW) X(CONV_WPB) X(CONV_RS) X(RS_UNIT) X(WIDE_ROWS) X(CONV_WIDE) X(WIDE_NBUF)     \
-  X(CONV_WIDE_BF16) X(VOXEL_MEAN) X(WIDE_NCB) X(BN_SMALL) X(CONV_X3) X(X3_FORM) X(WIDE_PRIO) X(PLAN_SIDE_BATCH)       \
-  X(PLAN_SIDE_PRIO) X(SMALL_WPB) X(SMALL_MAX) X(WIDE_SPLIT) X(SPLIT_TARGET) X(SPLIT_NBUF) X(SPLIT_MIN_ITEMS) X(WIDE_OCC4) \
-  X(WIDE_DEFER) X(WIDE_NW8) X(CONV_NARROW)
+  X(CONV_WLDS) X(CONV_SMALL) X(CONV_NBW) X(CONV_WPB) X(WIDE_ROWS) X(CONV_WIDE) X(WIDE_NBUF) X(CONV_WIDE_BF16)         \
+  X(VOXEL_MEAN) X(WIDE_NCB) X(BN_SMALL) X(WIDE_PRIO) X(PLAN_SIDE_BATCH) X(PLAN_SIDE_PRIO) X(SMALL_WPB) X(SMALL_MAX)   \
+  X(WIDE_SPLIT) X(SPLIT_TARGET) X(SPLIT_NBUF) X(SPLIT_MIN_ITEMS) X(CONV_NARROW)
 #define AABR_KNOB_ENUM(n) K_##n,
 enum Knob { AABR_KNOB_LIST(AABR_KNOB_ENUM) K_COUNT };
 #undef AABR_KNOB_ENUM

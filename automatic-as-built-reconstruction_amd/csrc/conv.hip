@@ -104,14 +104,8 @@ static_assert(sizeof(PackJob) == 48, "PackJob layout is part of the C ABI");
 // FPN_Net at the head of every training step, on the critical path.
 constexpr int kPT = 64;                          // tile edge: 2 channel chunks x 4 column blocks
 __device__ inline void pack_store(void *dst, int64_t idx, float v, int mode, int64_t plane) {
-  if (mode == 2) { // three bf16 term planes of the fp32 weight (k_conv_cs<.., X3>): w = w1 + w2 + w3 to 2^-27 |w|
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      const __bf16 b = (__bf16)v;
-      reinterpret_cast<__bf16 *>(dst)[pl * plane + idx] = b;
-      v -= (float)b;
-    }
-  } else if (mode) reinterpret_cast<__bf16 *>(dst)[idx] = (__bf16)v;
+  (void)plane;
+  if (mode) reinterpret_cast<__bf16 *>(dst)[idx] = (__bf16)v;
   else reinterpret_cast<float *>(dst)[idx] = v;
 }
 

@@ -127,46 +127,28 @@ struct BnBwdStats {
   const float *out;                                 // bf16 storage only
 };
 
-// X3 (fp32 storage, fp32-equivalent arithmetic on the bf16 matrix pipe): every fp32 operand is split into three bf16
-// terms x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24 mantissa bits in 3 x 8, the
-// residual is <= 2^-27 |x|), the gathered rows at the stage store, the weights at pack time; a product a * w is formed as
-// the six terms a1w1 + a1w2 + a2w1 + a2w2 + a1w3 + a3w1 (each exact in the MFMA's fp32 accumulator; the dropped terms
-// are <= 2^-25 |a w|, below the rounding of an fp32 FMA chain) with v_mfma_f32_16x16x32_bf16: 6 x 16 cycles per 16 x 16
-// x 32 block instead of 8 x 32 cycles of v_mfma_f32_16x16x4_f32 -- 2.7x the matrix rate at fp32 accuracy.  KG counts
-// 64-channel chunks as for BF; rows are gathered and written in fp32.
-// RING (fp32, experiment behind the WIDE_OCC4 knob): the B operands of a pair leave LDS one 32-channel chunk ahead of
-// their MFMAs through a two-slot register ring instead of all at once (16 registers instead of 64), so that the kernel
-// fits 128 registers = FOUR waves per SIMD; with 80-row tiles (37 KiB of LDS) four workgroups share a CU.
-// DEFER (bf16 storage): the LDS tile rows a pair's results go to are read TOGETHER with the pair's operands (one LDS
-// round trip) and are the MFMA chains' starting accumulators; the stage barrier follows the reads at once, and the stage
-// store of the next pair, the MFMAs and the write-back of the rows all sit between the two barriers -- instead of
-// MFMAs | read .. add .. write | barrier | stage store | barrier in series.  The sum of a tile element is formed as
-// ((tile + p1) + p2) + .. instead of tile + ((p1 + p2) + ..): fp32 rounding apart, and fixed (run-to-run identical).
-// NW = waves per workgroup (bf16 storage: 8).  At 64-row tiles every wave re-loads its 8 KiB slice of W[k] for about ONE
-// pair step, and the CU's vector-memory path (64 B / clock) is busy ~175 of every ~160 cycles a wave-step may take with 12
-// waves resident: the weights, 3/4 of those bytes, set the pace.  Eight waves x 16 columns share a 128-row x 128-column
-// tile: half the weight bytes per output row, the same gathered bytes, 16 waves per CU (two workgroups) to hide latency.
-template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2, bool X3 = false, bool RING = false,
-          bool DEFER = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING ? 4 : ((NBUF == 2 || X3) ? 2 : 3))) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
+// Forms that were built, measured slower and removed in round 5 (their A/B tables are the record): fp32 on the bf16 pipe by
+// a three-term split (profiles/r03_conv_x3_ab.txt), a fourth resident workgroup through a two-slot operand ring
+// (r04_conv_occ4_ab.txt), the tile rows as the MFMA chains' starting accumulators (r04_conv_bf16_defer_ab.txt), eight-wave
+// workgroups on 128-column slabs (r04_conv_bf16_w8_ab.txt), the row-stationary kernel (r03_conv_rs_ab.txt).
+template <int KG, int DBG, int NBUF, bool BF = false, int NCB = 1, int NSET = 2>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float *__restrict__ in, int ci, int64_t in_bytes,
                                                     float *__restrict__ out, int co, int64_t V_out,
                                                     const int32_t *__restrict__ words, int64_t words_bytes, int vol,
                                                     int wflip, const float *__restrict__ Wp, int64_t wp_bytes,
                                                     const float *__restrict__ bias, int kT2,
                                                     const float *__restrict__ res, double *__restrict__ stats,
                                                     BnBwdStats bn) {
-  static_assert(!DEFER || (BF && !X3 && !RING && DBG == 0), "DEFER exists for the plain bf16-storage form");
-  static_assert(NW == 4 || (NW == 8 && BF && !X3 && !RING && DBG == 0 && (KG & 1) == 0),
-                "eight waves: plain bf16-storage form, rows of 16 x 16-byte granules or a multiple");
+  constexpr int NW = 4;                   // waves per workgroup
   constexpr int NT = 64 * NW;              // threads
   constexpr int LPR = NT / 32;             // lanes per gathered pair row (8 or 16)
   constexpr int RG = KG * 8;               // 16-byte granules per staged row
   constexpr int RF = KG * 32;              // floats per staged row
   constexpr int SWZ = (RG >= 16 && (RG & 15) == 0) ? 15 : 7; // XOR must stay inside the row's granules
   constexpr int STAGE = 2 * 16 * RF;       // floats per stage buffer (two blocks)
-  constexpr bool BFM = BF || X3;           // bf16 operands in the stage and the weight pack
-  constexpr int NP = X3 ? 3 : 1;           // bf16 terms per operand
-  constexpr int NGL = (X3 ? 2 * KG : KG) * 8 / LPR; // 16-byte gather loads per lane and pair (X3: fp32 rows, 32 channels per 128 B)
+  constexpr bool BFM = BF;                 // bf16 operands in the stage and the weight pack
+  constexpr int NP = 1;                    // operand planes
+  constexpr int NGL = KG * 8 / LPR;        // 16-byte gather loads per lane and pair
   extern __shared__ __align__(16) float smem[];
   float *Ct = smem;                        // [kT2 + 1][64] floats, granule-swizzled; the last row swallows padding entries
   constexpr int WS = 16 * NW * NCB;        // tile row stride in floats = slab width
@@ -235,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING ? 4 : ((NBUF == 2 || X
 #pragma unroll
       for (int c = 0; c < KG; ++c) { // nkc % KG == 0 (dispatch): every load is unconditional, so the compiler's
         const int kc = kg * KG + c;  // vmcnt bookkeeping stays exact and nothing waits for a prefetch it does not use
-        if (BFM) { // two 32-channel MFMA chunks per 64-channel row chunk, 1 KiB of packed weights each; X3: three term planes
+        if (BFM) { // two 32-channel MFMA chunks per 64-channel row chunk, 1 KiB of packed weights each
           const unsigned so = (unsigned)((((int64_t)kW * (2 * nkc) + 2 * kc) * nnb + nb0 + wave * NCB + cb) * 1024);
 #pragma unroll
           for (int pl = 0; pl < NP; ++pl) {
@@ -274,33 +256,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING ? 4 : ((NBUF == 2 || X
   };
   auto stage_store = [&](const GReg &q, int buf) {
     float *rowp = St + (NBUF == 2 ? buf : 0) * (NP * STAGE) + pr * RF;
-    if (X3) {
-      // four fp32 channels (fp32 granule G = seg + 8 i) -> their three bf16 terms, 8 bytes each, into half G & 1 of the
-      // bf16 granule G >> 1 of the three term planes
-#pragma unroll
-      for (int i = 0; i < NGL; ++i) {
-        const int G = seg + LPR * i;
-        float r[4];
-        u32x2 t[3];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = bcf_(q.v[i][j]);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          unsigned h[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const __bf16 b = (__bf16)r[j];                       // round to nearest even
-            h[j] = (unsigned)__builtin_bit_cast(unsigned short, b);
-            r[j] -= bcf_(h[j] << 16);                            // exact: the difference has fewer bits than fp32 holds
-          }
-          t[pl] = (u32x2){h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          *reinterpret_cast<u32x2 *>(rowp + pl * STAGE + (((G >> 1) ^ (pr & SWZ)) << 2) + (G & 1) * 2) = t[pl];
-      }
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < NGL; ++i)
       *reinterpret_cast<u32x4 *>(rowp + (((seg + LPR * i) ^ (pr & SWZ)) << 2)) = q.v[i];
@@ -377,83 +332,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING ? 4 : ((NBUF == 2 || X
         const float *sa = St + (NBUF == 2 ? par : 0) * STAGE + c16 * RF;
         const float *sb = sa + 16 * RF;
         f32x4 accA[NCB], accB[NCB];
-        f32x4 *da[NCB], *db[NCB];                              // DEFER: the tile rows the accumulators came from
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) { accA[cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[cb] = accA[cb]; da[cb] = db[cb] = nullptr; }
+        for (int cb = 0; cb < NCB; ++cb) { accA[cb] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[cb] = accA[cb]; }
         if (wflip & 2) __builtin_amdgcn_s_setprio(3);          // experiment (WIDE_PRIO knob): matrix phase at raised priority
-        if constexpr (X3) {
-          // term planes of the staged rows: plane pl at sa + pl * STAGE.  Products in the order small -> large:
-          // a1 w3, a3 w1, a2 w2, a1 w2, a2 w1, a1 w1 (plane indices 0-based below)
-          const float *sa = St + (NBUF == 2 ? par : 0) * (NP * STAGE) + c16 * RF;
-          const float *sb = sa + 16 * RF;
-          u32x4 a0[3][KG], a1[3][KG], b0[3][KG], b1[3][KG];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int c = 0; c < KG; ++c) {
-              const int q0 = ((c * 8 + g) ^ (c16 & SWZ)) << 2, q1 = ((c * 8 + 4 + g) ^ (c16 & SWZ)) << 2;
-              a0[pl][c] = *reinterpret_cast<const u32x4 *>(sa + pl * STAGE + q0);
-              b0[pl][c] = *reinterpret_cast<const u32x4 *>(sb + pl * STAGE + q0);
-              a1[pl][c] = *reinterpret_cast<const u32x4 *>(sa + pl * STAGE + q1);
-              b1[pl][c] = *reinterpret_cast<const u32x4 *>(sb + pl * STAGE + q1);
-            }
-          constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TW[6] = {2, 0, 1, 1, 0, 0};   // (row term, weight term)
-#pragma unroll
-          for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-              for (int c = 0; c < KG; ++c) {
-                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[TW[t]][cb][c]),
-                                                                   __builtin_bit_cast(bf16x8w, a0[TA[t]][c]), accA[cb], 0, 0, 0);
-                accA[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[TW[t]][cb][c]),
-                                                                   __builtin_bit_cast(bf16x8w, a1[TA[t]][c]), accA[cb], 0, 0, 0);
-              }
-          if (e0.hb) {
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-              for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int c = 0; c < KG; ++c) {
-                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w0[TW[t]][cb][c]),
-                                                                     __builtin_bit_cast(bf16x8w, b0[TA[t]][c]), accB[cb], 0, 0, 0);
-                  accB[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w.w1[TW[t]][cb][c]),
-                                                                     __builtin_bit_cast(bf16x8w, b1[TA[t]][c]), accB[cb], 0, 0, 0);
-                }
-          }
-        } else if constexpr (RING) {
-          u32x4 ra[2][2];
-          auto ld = [&](int sidx, int slot) {
-            const float *base = sidx < KG ? sa : sb;
-            const int c = sidx < KG ? sidx : sidx - KG;
-            ra[slot][0] = *reinterpret_cast<const u32x4 *>(base + (((c * 8 + g * 2) ^ (c16 & SWZ)) << 2));
-            ra[slot][1] = *reinterpret_cast<const u32x4 *>(base + (((c * 8 + g * 2 + 1) ^ (c16 & SWZ)) << 2));
-          };
-          ld(0, 0);
-#pragma unroll
-          for (int sidx = 0; sidx < 2 * KG; ++sidx) {
-            if (sidx + 1 < 2 * KG) ld(sidx + 1, (sidx + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const int c = sidx < KG ? sidx : sidx - KG;
-            if (sidx < KG) {
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[0][0][c][t]), bcf_(ra[sidx & 1][0][t]), accA[0], 0, 0, 0);
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[0][0][c][t]), bcf_(ra[sidx & 1][1][t]), accA[0], 0, 0, 0);
-            } else if (e0.hb) {
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                accB[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w0[0][0][c][t]), bcf_(ra[sidx & 1][0][t]), accB[0], 0, 0, 0);
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                accB[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcf_(w.w1[0][0][c][t]), bcf_(ra[sidx & 1][1][t]), accB[0], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else {
+        {
         // all of the pair's B operands leave LDS before the first MFMA (counted lgkmcnt waits follow)
         u32x4 a0[KG], a1[KG], b0[KG], b1[KG];
 #pragma unroll
@@ -466,18 +348,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING ? 4 : ((NBUF == 2 || X
           b0[c] = *reinterpret_cast<const u32x4 *>(sb + q0);
           a1[c] = *reinterpret_cast<const u32x4 *>(sa + q1);
           b1[c] = *reinterpret_cast<const u32x4 *>(sb + q1);
-        }
-        if constexpr (DEFER) {
-          const int ra = e0.ea >= 0 ? (e0.ea & 255) : kT2, rb = e0.eb >= 0 ? (e0.eb & 255) : kT2;
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-            da[cb] = reinterpret_cast<f32x4 *>(Ct + ra * WS + ((((wave * NCB + cb) * 4 + g) ^ (ra & 15)) << 2));
-            db[cb] = reinterpret_cast<f32x4 *>(Ct + rb * WS + ((((wave * NCB + cb) * 4 + g) ^ (rb & 15)) << 2));
-            accA[cb] = *da[cb];                                // (a padding entry: the dummy row, whatever it holds)
-            accB[cb] = *db[cb];
-          }
-          if (NBUF == 1) wg_barrier();                         // every wave holds its operands: the stage is free
-          if (pp[1].k < kend) stage_store(g_store, par ^ 1);   // the next pair, gathered NSET - 1 steps ago
         }
         if (DBG & 1) { // timing experiments: operands consumed, no MFMAs
 #pragma unroll
@@ -537,14 +407,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING ? 4 : ((NBUF == 2 || X
         }
         if (DBG & 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(accA[0]), "v"(accB[0])); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         if (wflip & 2) __builtin_amdgcn_s_setprio(0);
-        if constexpr (DEFER) {
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) { *da[cb] = accA[cb]; *db[cb] = accB[cb]; }
-        } else {
+        {
           accumulate2(e0.ea, accA, e0.eb, accB);
         }
       }
-      if constexpr (!DEFER) {
+      {
         if (NBUF == 1) wg_barrier();                         // single stage: every wave is done reading it
         if (pp[1].k < kend) stage_store(g_store, par ^ 1);   // the next pair, gathered NSET - 1 steps ago
       }
@@ -575,16 +442,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING ? 4 : ((NBUF == 2 || X
     WReg wA;
     int k = pp[0].k;
     load_w(wA, k, kg);
-    if constexpr (RING) {                  // one weight register set: the next offset's slice is requested when this one is done
-      for (;;) {
-        const int kn = next_offset(k);
-        while (pp[0].k == k) step2(wA);
-        if (kn >= kend) break;
-        k = kn;
-        load_w(wA, k, kg);
-      }
-      continue;
-    }
     WReg wB;
     for (;;) {
       int kn = next_offset(k);
@@ -864,15 +721,6 @@ static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, flo
   do {                                                                                                    \
     if (nbuf == 1) AABR_WIDE_CS_N(KG, D, 1); else AABR_WIDE_CS_N(KG, D, 2);                               \
   } while (0)
-#ifdef AABR_DEV   // measured slower (profiles/r04_conv_occ4_ab.txt): in `make DEV=1` builds only
-  if (kg == 4 && nbuf == 1 && !(dbg & 7) && knob(K_WIDE_OCC4) == 1 && tile_rows <= 80) {   // experiment: four workgroups per CU
-    AABR_LAUNCH_WIDE((k_conv_cs<4, 0, 1, false, 1, 2, false, true>), "k_conv_cs<4,0,1,ring>",
-                     (size_t)((tile_rows + 1) * kWS + 2 * 16 * 4 * 32) * sizeof(float), in_feats, n_in, in_bytes, out_feats,
-                     n_out, V_out, blocks, words_bytes, vol, flip, wpack, wp_bytes, bias, tile_rows, residual, stats, bn);
-    AABR_CHECK_LAUNCH();
-    return AABR_OK;
-  }
-#endif
 #ifdef AABR_DEV
     if (dbg & 7) { // timing experiments (tools/, `make DEV=1`): only the 128-channel-group instance carries the debug variants
       AABR_CHECK_ARG(kg == 4, "debug variants exist for n_in >= 128 only");
@@ -1034,14 +882,6 @@ extern "C" int aabr_conv_wide_tile_rows_bf16(int n_in, int n_out, int64_t rows_i
   // three workgroups per CU; 64-column slabs keep the 96-row tiles of round 2.
   const int ncb = wide_bf16_ncb(n_in, n_out);
   int T = ncb == 2 ? 64 : 96;
-#ifdef AABR_DEV
-  // DEV builds, WIDE_NW8 = 1: eight-wave workgroups (128 input channels, 128-column slabs) on 128-row tiles when that still
-  // leaves more than one round of the 512 resident workgroups (two per CU).  Measured on the bench's rule books (round 4,
-  // profiles/r04_conv_bf16_w8_ab.txt): 84 k rows 99 -> 111 us, 200 k rows 191 -> 199, 282 k rows 169 -> 178, only the
-  // sparsest book (310 k rows, 1.5 rules per row) gains, 138 -> 121 -- half the weight bytes per output row do not pay for
-  // twice the operand reads from the stage and an eight-wave barrier; not dispatched.
-  if (ncb == 2 && n_in == 128 && knob(K_WIDE_NW8) == 1 && ((V_out + 127) / 128) * (n_out / 128) >= 600) T = 128;
-#endif
   {
     const int64_t slabs = n_out / (64 * ncb);
     if (((V_out + T - 1) / T) * slabs <= 512)
@@ -1128,31 +968,8 @@ static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in,
     const int v = knob(K_WIDE_NBUF);
     if (v == 1 || v == 2) nbuf = v;
   }
-  // DEV builds, WIDE_DEFER knob: the tile rows as the MFMA chains' starting accumulators (k_conv_cs DEFER; 256-channel
-  // groups would spill 73 registers).  Measured on the bench's rule books (round 4): 128->128 at 84 k rows 99.1 -> 97.7 us,
-  // 64->64 at 200 k rows 82.6 -> 79.7 -- the read-add-write is not the exposed latency of a step (the stage store's wait
-  // for the gathered rows is), and the form changes the fp32 summation order, so it is not dispatched.
-  const bool defer = knob(K_WIDE_DEFER) == 1 && kg <= 3;
-  (void)defer;
   const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
   float *out_f = reinterpret_cast<float *>(out_feats);
-#ifdef AABR_DEV
-  if (kg == 2 && ncb == 2 && tile_rows >= 128 && knob(K_WIDE_NW8) == 1) {   // eight waves x 16 columns on a 128-column slab
-    static bool attr8 = false;
-    if (!attr8) {
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<2, 0, 1, true, 1, 2, false, false, false, 8>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      attr8 = true;
-    }
-    g_last_variant = "k_conv_cs<2,0,1,bf16,x128,w8>";
-    hipLaunchKernelGGL((k_conv_cs<2, 0, 1, true, 1, 2, false, false, false, 8>), grid, dim3(512),
-                       (size_t)((tile_rows + 1) * 128 + 2 * 16 * 2 * 32) * sizeof(float), st, in_f, n_in, in_bytes, out_f,
-                       n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias, tile_rows,
-                       (const float *)nullptr, stats, bn);
-    AABR_CHECK_LAUNCH();
-    return AABR_OK;
-  }
-#endif
 constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: measured slower, 100 -> 112 us)
 #define AABR_WIDE_BF(KG, NB, NCB) AABR_WIDE_BF_S(KG, NB, NCB, ((KG) <= 2 ? kBfSets : 2))
 #define AABR_WIDE_BF_D(KG, NB, NCB, D)                                                                              \
@@ -1164,25 +981,17 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
                        tile_rows, (const float *)nullptr, stats, bn);                                                      \
   } while (0)
-#ifdef AABR_DEV
-#define AABR_WIDE_BF_S(KG, NB, NCB, NS)                                                                             \
-  do {                                                                                                             \
-    if (defer) AABR_WIDE_BF_L(KG, NB, NCB, NS, true);                                                              \
-    else AABR_WIDE_BF_L(KG, NB, NCB, NS, false);                                                                   \
-  } while (0)
-#else
-#define AABR_WIDE_BF_S(KG, NB, NCB, NS) AABR_WIDE_BF_L(KG, NB, NCB, NS, false)
-#endif
-#define AABR_WIDE_BF_L(KG, NB, NCB, NS, DF)                                                                        \
+#define AABR_WIDE_BF_S(KG, NB, NCB, NS) AABR_WIDE_BF_L(KG, NB, NCB, NS)
+#define AABR_WIDE_BF_L(KG, NB, NCB, NS)                                                                            \
   do {                                                                                                             \
     static bool attr = false;                                                                                      \
     if (!attr) {                                                                                                   \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB, true, NCB, NS, false, false, DF>),    \
+      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB, true, NCB, NS>),    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                  \
       attr = true;                                                                                                 \
     }                                                                                                              \
     g_last_variant = NCB == 2 ? "k_conv_cs<" #KG ",0," #NB ",bf16,x128>" : "k_conv_cs<" #KG ",0," #NB ",bf16>";    \
-    hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS, false, false, DF>), grid, dim3(256),                   \
+    hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS>), grid, dim3(256),                   \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
                        tile_rows, (const float *)nullptr, stats, bn);                                              \
@@ -1294,114 +1103,3 @@ extern "C" int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n
   return AABR_OK;
 }
 
-// ---- fp32 storage on the bf16 matrix pipe (three-term split, k_conv_cs<.., X3>) -------------------------------------
-// weight pack: three bf16 term planes, each in the layout of aabr_conv_pack_weights2_bf16 (plane p at p * plane bytes)
-extern "C" int64_t aabr_conv_wpack_x3_elems(int vol, int n_in, int n_out) {
-  if (vol <= 0 || n_in <= 0 || n_out <= 0) return 0;
-  return 3 * (int64_t)vol * (n_in / 32) * (n_out / 16) * 512;
-}
-
-// form of the launch: 1 = 64-channel groups x 128-column slabs, 2 = 128-channel groups x 64-column slabs,
-// 3 = 64-channel groups x 64-column slabs; 0 = not supported
-[[maybe_unused]] static int x3_form(int n_in, int n_out) {
-  if (n_in <= 0 || n_out <= 0 || (n_in & 63) || (n_out & 63)) return 0;
-  const int v = knob(K_X3_FORM);
-  if (v == 2 && (n_in & 127) == 0) return 2;
-  if (v == 3) return 3;
-  if ((n_out & 127) == 0) return 1;
-  return (n_in & 127) == 0 ? 2 : 3;
-}
-
-// rows per tile for aabr_conv_forward_wide_x3, 0 = use the fp32-MFMA kernels
-extern "C" int aabr_conv_wide_tile_rows_x3(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol) {
-  // measured (profiles/r03_conv_x3_ab.txt): the matrix phase of a step shrinks 2.8x, but the steps are half as big (64
-  // channels or 64 columns: three term planes of weights do not fit the registers otherwise) and the split at the stage
-  // store costs more than the MFMAs saved -- 322-338 us against 326 us of the fp32-MFMA kernel on the dominant
-  // instance.  Off unless the CONV_X3 knob is 1 (tests, tools).
-#ifndef AABR_DEV
-  (void)n_in; (void)n_out; (void)rows_in; (void)V_out; (void)vol;
-  return 0;                                  // the three-term kernels are in `make DEV=1` builds only
-#else
-  if (vol <= 0 || vol > kMaxVol || knob(K_CONV_X3) != 1) return 0;
-  const int form = x3_form(n_in, n_out);
-  if (!form) return 0;
-  if (rows_in >= (1ll << 23) || rows_in * n_in * 4 >= (1ll << 31)) return 0;
-  int T = 64;
-  {                                                // tuning experiments only
-    const int v = knob(K_WIDE_ROWS);
-    if (v >= 64 && v <= kMaxTileRows && (v & 15) == 0) T = v;
-  }
-  if (wide_words(V_out, vol, T) * 4 >= (1ll << 31)) return 0;
-  if ((int64_t)vol * n_in * n_out * 6 >= (1ll << 31)) return 0;
-  return T;
-#endif
-}
-
-extern "C" int aabr_conv_forward_wide_x3(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
-                                         int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
-                                         int flags, const uint16_t *wpack, const float *residual, double *stats,
-                                         void *stream_) {
-#ifndef AABR_DEV
-  (void)in_feats; (void)n_in; (void)rows_in; (void)out_feats; (void)n_out; (void)V_out; (void)blocks; (void)tile_rows;
-  (void)vol; (void)bias; (void)flags; (void)wpack; (void)residual; (void)stats; (void)stream_;
-  aabr::set_error("aabr_conv_forward_wide_x3: measured no faster than the fp32-MFMA kernel (profiles/r03_conv_x3_ab.txt); "
-                  "in `make DEV=1` builds only");
-  return AABR_EINVAL;
-#else
-  hipStream_t st = (hipStream_t)stream_;
-  const int form = x3_form(n_in, n_out);
-  AABR_CHECK_ARG(form != 0, "plane counts: n_in % 64, n_out % 64");
-  AABR_CHECK_ARG(vol > 0 && vol <= kMaxVol && V_out >= 0 && rows_in >= 0, "bad sizes");
-  AABR_CHECK_ARG(tile_rows >= 64 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, 64..240");
-  if (V_out == 0) return AABR_OK;
-  AABR_CHECK_ARG(in_feats && out_feats && blocks && wpack && rows_in > 0, "null pointer / empty input");
-  AABR_CHECK_ARG(rows_in < (1ll << 23), "too many input rows for the wide block format");
-  const int64_t in_bytes = rows_in * n_in * 4, words_bytes = wide_words(V_out, vol, tile_rows) * 4;
-  AABR_CHECK_ARG(in_bytes < (1ll << 31) && words_bytes < (1ll << 31), "buffers must be < 2 GiB");
-  AABR_CHECK_ARG((((uintptr_t)in_feats | (uintptr_t)out_feats | (uintptr_t)wpack | (uintptr_t)residual) & 15) == 0 &&
-                     ((uintptr_t)stats & 7) == 0, "pointers must be 16-byte aligned");
-  const int64_t wp_bytes = 3 * (int64_t)vol * (n_in / 32) * (n_out / 16) * 1024;
-  AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
-  const int flip = (flags >> 1) & 1;
-  const float *wp_f = reinterpret_cast<const float *>(wpack);
-#define AABR_X3(KG, NCB, NAME)                                                                                        \
-  do {                                                                                                                \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, 1, false, NCB, 2, true>),                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                     \
-      attr = true;                                                                                                    \
-    }                                                                                                                 \
-    g_last_variant = NAME;                                                                                            \
-    dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / (64 * NCB)));                       \
-    hipLaunchKernelGGL((k_conv_cs<KG, 0, 1, false, NCB, 2, true>), grid, dim3(256),                                   \
-                       (size_t)((tile_rows + 1) * kWS * NCB + 3 * 2 * 16 * KG * 32) * sizeof(float), st, in_feats,    \
-                       n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias, \
-                       tile_rows, residual, stats, BnBwdStats{});                                                     \
-  } while (0)
-#ifdef AABR_DEV
-  if ((flags >> 8) & 4) {   // timing experiments (tools/tools_cs_phases.py x3): phase clocks -> the buffer passed as `bias`
-    dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / (form == 1 ? 128 : 64)));
-#define AABR_X3_D(KG, NCB)                                                                                            \
-    do {                                                                                                              \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 4, 1, false, NCB, 2, true>),                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                     \
-      hipLaunchKernelGGL((k_conv_cs<KG, 4, 1, false, NCB, 2, true>), grid, dim3(256),                                 \
-                         (size_t)((tile_rows + 1) * kWS * NCB + 3 * 2 * 16 * KG * 32) * sizeof(float), st, in_feats,  \
-                         n_in, in_bytes, out_feats, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes,     \
-                         bias, tile_rows, residual, stats, BnBwdStats{});                                             \
-    } while (0)
-    if (form == 1) AABR_X3_D(1, 2); else if (form == 2) AABR_X3_D(2, 1); else AABR_X3_D(1, 1);
-#undef AABR_X3_D
-    AABR_CHECK_LAUNCH();
-    return AABR_OK;
-  }
-#endif
-  if (form == 1) AABR_X3(1, 2, "k_conv_cs<1,0,1,x3,x128>");
-  else if (form == 2) AABR_X3(2, 1, "k_conv_cs<2,0,1,x3>");
-  else AABR_X3(1, 1, "k_conv_cs<1,0,1,x3>");
-#undef AABR_X3
-  AABR_CHECK_LAUNCH();
-  return AABR_OK;
-#endif
-}

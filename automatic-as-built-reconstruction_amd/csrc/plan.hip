@@ -226,12 +226,6 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
             : aabr_conv_forward_narrow((const float *)p[0], o.i64[0], (float *)p[1], o.i64[1], (const int32_t *)p[2],
                                        o.i32[2], (const float *)p[3], (const float *)p[4], o.i32[3], st);
     break;
-  case AABR_PLAN_CONV_RS:
-    AABR_CHECK_ARG(bf, "AABR_PLAN_CONV_RS exists for bf16 storage only");
-    rc = aabr_conv_forward_rs_bf16((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1], o.i64[1],
-                                   (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
-                                   (const uint16_t *)p[5], st);
-    break;
   case AABR_PLAN_CONV_DW:
     rc = bf ? aabr_conv_backward_weight_bf16((const uint16_t *)p[0], o.i32[0], (const uint16_t *)p[1], o.i32[1],
                                              o.i64[0], (const int32_t *)p[2], o.i32[2], o.i64[1], (float *)p[3],
@@ -521,9 +515,6 @@ extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
       break;
     case AABR_GEOM_OFFSET_PAIRS:
       rc = aabr_build_offset_pairs((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st);
-      break;
-    case AABR_GEOM_RS:
-      rc = aabr_build_rs((const int32_t *)p[0], o.i64[0], o.i32[0], o.i32[1], (int32_t *)p[1], st);
       break;
     case AABR_GEOM_CONV_SITES:
       rc = aabr_convolution_sites((const int32_t *)p[0], o.i64[0], &o.i32[0], &o.i32[3], &o.i32[6], (uint64_t *)p[1],

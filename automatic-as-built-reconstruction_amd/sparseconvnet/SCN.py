@@ -169,8 +169,8 @@ import struct as _struct
 
 _GEOM = _struct.Struct("<ii10i4q8Q")
 assert _GEOM.size == 144
-G_SUBM, G_TABLES, G_TILE, G_WIDE, G_PAIRS, G_RS, G_SITES, G_SOFF, G_BK_BUILD, G_BK_SUBM, G_BK_TABLES = \
-    1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+G_SUBM, G_TABLES, G_TILE, G_WIDE, G_PAIRS, G_SITES, G_SOFF, G_BK_BUILD, G_BK_SUBM, G_BK_TABLES = \
+    1, 2, 3, 4, 5, 7, 8, 9, 10, 11
 import threading as _threading
 
 
@@ -350,24 +350,11 @@ _BK_ROW = 64 + 16    # [V, per-sample offsets .. (64 words) | the level's meta b
 
 class _Gather(object):
     """one gather table [vol, rows] + its compiled streaming forms (built lazily, cached)"""
-    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_blocks256", "_pairs", "_host_counts", "_total", "_rs")
+    __slots__ = ("table", "counts", "vol", "rows", "_blocks", "_blocks256", "_pairs", "_host_counts", "_total")
 
     def __init__(self, table, counts, vol, rows):
         self.table, self.counts, self.vol, self.rows = table, counts, vol, rows
-        self._blocks = self._blocks256 = self._pairs = self._host_counts = self._total = self._rs = None
-
-    def rs_stream(self, unit_rows):
-        """row-stationary stream for aabr_conv_forward_rs_bf16 (rows of a unit regrouped by their offset mask)"""
-        if self._rs is None:
-            self._rs = {}
-        w = self._rs.get(unit_rows)
-        if w is None:
-            lib = _hip.load()
-            w = torch.empty(max(lib.aabr_rs_words(self.rows, self.vol, unit_rows), 4), dtype=torch.int32,
-                            device=self.table.device)
-            _geom(G_RS, (self.vol, unit_rows), (self.rows,), (_p(self.table), _p(w)))
-            self._rs[unit_rows] = w
-        return w
+        self._blocks = self._blocks256 = self._pairs = self._host_counts = self._total = None
 
     def total_slot(self):
         """(ring, generation, index) of this rule book's rule total on the device"""
@@ -567,8 +554,6 @@ class Metadata_3(object):
                 ts += [t for t in (ga.table, ga.counts, ga._blocks, ga._pairs) if t is not None]
                 if ga._blocks256:
                     ts += list(ga._blocks256.values())
-                if ga._rs:
-                    ts += list(ga._rs.values())
         return ts
 
     def getNActive(self, spatial_size):
@@ -1162,15 +1147,8 @@ def _conv_fwd(inp, out, n_rows_out, gather, weight, bias, flags, pack_t=None):
             flags |= 4
     if not (flags & 4) and n_rows_out > 0:
         pack_stats["own"] += 1                               # this call packs its weights itself
-    unit_rows = rs_unit_rows(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16, bool(flags & 4))
-    tile_rows = 0 if unit_rows else wide_tile_rows(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16,
-                                                   bool(flags & 4))
-    if unit_rows:
-        # bf16 storage, large launches: accumulators in registers, rows regrouped by offset mask (csrc/conv_rs.hip)
-        check(lib.aabr_conv_forward_rs_bf16(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
-                                            ptr(gather.rs_stream(unit_rows)), unit_rows, gather.vol, ptr(_opt(bias)),
-                                            flags & 3, ptr(wpack), stream()))
-    elif tile_rows and bf16:
+    tile_rows = wide_tile_rows(n_in, n_out, inp.size(0), n_rows_out, gather.vol, bf16, bool(flags & 4))
+    if tile_rows and bf16:
         check(lib.aabr_conv_forward_wide_bf16(ptr(inp), n_in, inp.size(0), ptr(out), n_out, n_rows_out,
                                               ptr(gather.blocks_wide(tile_rows)), tile_rows, gather.vol,
                                               ptr(_opt(bias)), flags & 3, ptr(wpack), stream()))
@@ -1308,14 +1286,6 @@ def wide_split(n_in, n_out, rows_in, rows_out, vol, bf16=False):
     return (v & 0xffff, v >> 16) if v else None
 
 
-def rs_unit_rows(n_in, n_out, rows_in, rows_out, vol, bf16, prepacked=True):
-    """rows per unit when this launch goes to the row-stationary bf16 kernel (csrc/conv_rs.hip), else 0 -- asked
-    before `wide_tile_rows` by the layer code, the stream pre-builder and the graph executor alike"""
-    if not bf16 or not prepacked or rows_out == 0:
-        return 0
-    return _hip.load().aabr_conv_rs_unit_rows(n_in, n_out, rows_in, rows_out, vol)
-
-
 def _conv_dw(inp, d_out, gather, d_weight, d_bias):
     lib = _hip.load()
     if d_weight.dim() == 4 and d_weight.size(1) != 1:     # groups: one launch per group (see _conv_fwd_groups)
@@ -1352,14 +1322,9 @@ def compile_streams(gather, rows_in, n_in, n_out, dtype, weight_grad=False):
         if weight_grad:
             gather.pairs()
         return
-    unit_rows = rs_unit_rows(n_in, n_out, rows_in, gather.rows, gather.vol, dtype == torch.bfloat16)
-    tile_rows = 0 if unit_rows else wide_tile_rows(n_in, n_out, rows_in, gather.rows, gather.vol,
-                                                   dtype == torch.bfloat16)
-    sp = None if (unit_rows or tile_rows) else wide_split(n_in, n_out, rows_in, gather.rows, gather.vol,
-                                                          dtype == torch.bfloat16)
-    if unit_rows:
-        gather.rs_stream(unit_rows)
-    elif tile_rows:
+    tile_rows = wide_tile_rows(n_in, n_out, rows_in, gather.rows, gather.vol, dtype == torch.bfloat16)
+    sp = None if tile_rows else wide_split(n_in, n_out, rows_in, gather.rows, gather.vol, dtype == torch.bfloat16)
+    if tile_rows:
         gather.blocks_wide(tile_rows)
     elif sp:
         gather.blocks_wide(sp[0])

@@ -39,7 +39,7 @@ from .deconvolution import Deconvolution
 
 _OP = struct.Struct("<ii6i4f4q12Q")          # AabrPlanOp (include/aabr_hip.h)
 assert _OP.size == 176
-K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST, K_RS, K_WSPLIT, K_NARROW = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+K_CONV, K_WIDE, K_DW, K_BNF, K_BNB, K_ADD, K_CAST, K_WSPLIT, K_NARROW = 1, 2, 3, 4, 5, 6, 7, 9, 10
 F_BF16, F_TO_BF16, F_SIDE, F_JOIN = 1, 2, 4, 8
 _ALIGN = 256
 BF16 = torch.bfloat16
@@ -481,11 +481,6 @@ class _Pass(object):
                  0.0, rows_in, rows_out, 0, 0, src, dst, gather.table.data_ptr(), p_w, 0, 0, 0, 0, 0, 0, 0, 0)
             if bf and narrow_stats:   # its write-out can form BatchNorm statistics too: one part per workgroup (negative = a part COUNT)
                 self._lw = -int(self.lib.aabr_conv_narrow_parts(rows_out))
-            return off + 176
-        U = SCN.rs_unit_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf) if not res else 0
-        if U:     # bf16 storage, row-stationary form (csrc/conv_rs.hip): the same choice SCN._conv_fwd makes
-            pack(buf, off, K_RS, xf | F_BF16, n_in, n_out, gather.vol, flags & 3, U, 0, 0.0, 0.0, 0.0, 0.0, rows_in,
-                 rows_out, 0, 0, src, dst, gather.rs_stream(U).data_ptr(), 0, 0, p_pack, 0, 0, 0, 0, 0, 0)
             return off + 176
         T = self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf)
         assert T or not res

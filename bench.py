@@ -429,27 +429,13 @@ def conv_kernel_table(torch, wl, dtype, max_rows=None):
                 wpack = torch.empty(lib.aabr_conv_wpack_floats(ga.vol, w.size(2), w.size(3)), device=dev)
                 conv = lib.aabr_conv_forward
             narrow = SCN.narrow_ok(n_in, n_out, rows_in, ga.rows, ga.vol, bf)        # the dispatch of SCN._conv_fwd
-            unit_rows = 0 if narrow else SCN.rs_unit_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
-            tile_rows = 0 if (unit_rows or narrow) else SCN.wide_tile_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
+            tile_rows = 0 if narrow else SCN.wide_tile_rows(n_in, n_out, rows_in, ga.rows, ga.vol, bf)
             if narrow:
                 nfn = lib.aabr_conv_forward_narrow_bf16 if bf else lib.aabr_conv_forward_narrow
 
                 def fn():
                     check(nfn(ptr(inp), rows_in, ptr(out), ga.rows, ptr(ga.table), ga.vol, ptr(w), None, g["flags"] & 3,
                               stream()))
-            elif unit_rows:
-                words = ga.rs_stream(unit_rows)
-                wt = torch.empty_like(wpack)
-                if tr_:     # w is the layer's own weight; the input-gradient launch reads its transposed pack
-                    check(lib.aabr_conv_pack_weights2_bf16(ptr(w), ga.vol, w.size(2), w.size(3), ptr(wt), ptr(wpack),
-                                                           stream()))
-                else:
-                    check(lib.aabr_conv_pack_weights2_bf16(ptr(w), ga.vol, w.size(2), w.size(3), ptr(wpack), ptr(wt),
-                                                           stream()))
-
-                def fn():
-                    check(lib.aabr_conv_forward_rs_bf16(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(words),
-                                                        unit_rows, ga.vol, None, g["flags"] & 3, ptr(wpack), stream()))
             elif tile_rows and bf:
                 ncb_ = 2 if (n_out % 128 == 0 and n_in <= 128) else 1      # 128-column slabs (conv_wide.hip)
                 g["grid_threads"] = ((ga.rows + tile_rows - 1) // tile_rows) * (n_out // (64 * ncb_)) * 256

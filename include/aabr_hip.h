@@ -37,14 +37,15 @@ const char *aabr_last_error(void);
 #define AABR_ABI_VERSION 500
 int aabr_version(void);
 /* Tuning knobs for experiments and tests (no counterpart in the reference; the defaults are what ships): CONV_WIDE,
- * CONV_WIDE_BF16, CONV_RS (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, RS_UNIT, CONV_WLDS,
+ * CONV_WIDE_BF16 (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, CONV_WLDS,
  * CONV_SMALL, CONV_NBW, CONV_WPB, VOXEL_MEAN.  A knob takes its value from the environment variable AABR_<NAME>,
  * read ONCE at its first use in the process; aabr_set_knob overrides it (unset != 0: back to "no value").  No entry
  * point reads the environment on its launch path.                                                              */
 int aabr_set_knob(const char *name, int value, int unset);
-/* bit 0: a `make DEV=1` build -- it additionally carries the A/B kernels that were measured slower and are never
- * dispatched (aabr_conv_forward_rs_bf16 / aabr_build_rs, aabr_conv_forward_wide_x3, the phase-clock variants); in a
- * release build those entry points return an error and their decision functions return 0.                      */
+/* bit 0: a `make DEV=1` build -- it additionally carries the phase-clock variants of k_conv_cs that tools/tools_cs_phases.py
+ * reads (flags >> 8 debug bits); a release build answers those flags with an error.  The A/B kernels of rounds 3-4 that
+ * were measured slower (row-stationary bf16, three-term fp32 split, four-workgroup ring, deferred accumulate, eight-wave
+ * workgroups) were removed in round 5; their tables under profiles/ are the record.                                  */
 int aabr_build_flags(void);
 /* number of int32 words of the `meta` block written by the geometry builders */
 #define AABR_META_WORDS 16
@@ -330,21 +331,6 @@ int aabr_bn_forward_parts_bf16(const uint16_t *in, uint16_t *out, int64_t rows, 
                                const float *bias, float eps, float momentum, float leakiness, const double *parts,
                                int nparts, float *scratch, void *stream);
 
-/* fp32 features and weights, fp32-equivalent arithmetic on the bf16 matrix pipe (extension; replaces the same gather-GEMM-
- * scatter loop as aabr_conv_forward_wide, SCN/CUDA/Convolution.cu:22-114 + RuleBookIterator.h:11-74): every operand is
- * split into three bf16 terms (x = x1 + x2 + x3 to 2^-27 |x|) and a product is formed from the six largest term
- * products in the MFMA's fp32 accumulator -- the dropped terms are <= 2^-25 of the product, below the rounding of an
- * fp32 FMA chain; tests/test_gpu_conv_wide.py measures both paths against fp64.  The weight pack holds the three term
- * planes (aabr_conv_wpack_x3_elems bf16 elements; written by aabr_conv_pack_weights_jobs with bf16 = 2, each plane in
- * the layout of aabr_conv_pack_weights2_bf16).  n_in % 64 == 0, n_out % 64 == 0; blocks = aabr_build_wide_blocks with
- * tile_rows = aabr_conv_wide_tile_rows_x3(...) (0: use aabr_conv_forward_wide).  residual / stats as
- * aabr_conv_forward_wide_stats.  Knob CONV_X3: 0 = never, 1 = whenever supported.                              */
-int64_t aabr_conv_wpack_x3_elems(int vol, int n_in, int n_out);
-int aabr_conv_wide_tile_rows_x3(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
-int aabr_conv_forward_wide_x3(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,
-                              int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias, int flags,
-                              const uint16_t *wpack, const float *residual, double *stats, void *stream);
-
 /* Name of the kernel instance (template arguments included) the last aabr_conv_forward[_bf16] /
  * aabr_conv_backward_weight[_bf16] call on this thread dispatched -- measurement provenance only.   */
 const char *aabr_conv_last_variant(void);
@@ -469,24 +455,6 @@ int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_ptrs, const v
                              float *nms_boxes, float *scores, float nms_thresh, int only_xy, int64_t post_max,
                              uint64_t *mask, int64_t *keep, int32_t *meta, void *stream);
 
-/* ---- row-stationary form of the same contraction for bf16 feature storage (csrc/conv_rs.hip; extension) -------
- * out[o] = bias + sum_k in[table[k][o]] @ Wl[k] exactly as aabr_conv_forward_bf16 (reference: the per-offset
- * gather-GEMM-scatter of SCN/CPU/Convolution.cpp:45-185 / Deconvolution.cpp:7-77), with the accumulators of a unit
- * of `unit_rows` output rows x up to 128 columns held in registers.  The rule book is compiled once per gather
- * table into the stream aabr_build_rs writes: the rows of a unit regrouped by their "offsets with a partner" mask
- * (what SubmanifoldConvolution_SgToRules, SubmanifoldConvolutionRules.h:26-45, appends rule by rule) so that
- * (16-row group, offset) items without any rule are skipped.
- *   aabr_rs_words: int32 words of the stream; aabr_conv_rs_unit_rows: 0 = use another kernel, else unit_rows.
- *   n_in 64 | 128, n_out % 64 == 0, vol <= 32, unit_rows % 16 == 0 and <= 192, wpack = the bf16 pack of
- *   aabr_conv_pack_weights2_bf16 (forward layout, or the transposed one with flags bit 0 set: input gradient);
- *   flags bit 1: mirrored offsets (submanifold input gradient).  Bit-reproducible; no atomics.            */
-int64_t aabr_rs_words(int64_t V, int vol, int unit_rows);
-int aabr_build_rs(const int32_t *table, int64_t V, int vol, int unit_rows, int32_t *words, void *stream);
-int aabr_conv_rs_unit_rows(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
-int aabr_conv_forward_rs_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
-                              int64_t V_out, const int32_t *rs_stream, int unit_rows, int vol, const float *bias,
-                              int flags, const uint16_t *wpack, void *stream);
-
 /* Offset split of the wide kernel for coarse maps (extension; same contraction, same results up to the summation
  * order over filter offsets, which is fixed: part order): when a layer has too few (tile, 64-column slab) items to
  * fill the chip -- the coarse FPN scales -- every item is cut into `parts` workgroups, each sweeping vol / parts filter
@@ -566,8 +534,6 @@ int aabr_conv_forward_narrow_bf16_bwd_stats(const uint16_t *in_feats, int64_t ro
 #define AABR_PLAN_BN_BWD 5
 #define AABR_PLAN_ADD 6
 #define AABR_PLAN_CAST 7
-#define AABR_PLAN_CONV_RS 8 /* aabr_conv_forward_rs_bf16(p0, i32[0], i64[0], p1, i32[1], i64[1], p2 rs_stream,
-                               i32[4] unit_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack); bf16 storage only */
 #define AABR_PLAN_CONV_WIDE_SPLIT 9 /* aabr_conv_forward_wide_split[_bf16](p0, i32[0], i64[0], p1, i32[1], i64[1], p2 blocks,
                                        i32[4] tile_rows, i32[2] vol, p4 bias, i32[3] flags, p5 wpack, p3 residual (fp32
                                        storage only), i32[5] parts, p6 scratch) */
@@ -610,7 +576,6 @@ void aabr_plan_launcher_stats(int64_t *busy_ns, int64_t *parts, int64_t *sleeps)
  *   AABR_GEOM_TILE_BLOCKS   aabr_build_tile_blocks(p0 table, i64[0] V, i32[0] vol, p1 blocks)
  *   AABR_GEOM_WIDE_BLOCKS   aabr_build_wide_blocks(p0 table, i64[0] V, i32[0] vol, i32[1] tile_rows, p1 blocks)
  *   AABR_GEOM_OFFSET_PAIRS  aabr_build_offset_pairs(p0 table, p1 block_counts, i64[0] V, i32[0] vol, p2 pairs)
- *   AABR_GEOM_RS            aabr_build_rs(p0 table, i64[0] V, i32[0] vol, i32[1] unit_rows, p1 words)
  *   AABR_GEOM_CONV_SITES    aabr_convolution_sites(p0 in_coords, i64[0] V_in, i32[0..2] size, i32[3..5] stride,
  *                           i32[6..8] out_spatial, p1 out_grid, i64[1] out_cap, p2 scratch, p3 out_coords, p4 meta)
  *   AABR_GEOM_SAMPLE_OFFSETS aabr_sample_offsets(p0 coords, p1 meta, i64[0] V_max, i32[0] max_samples, p2 out)
@@ -620,7 +585,6 @@ void aabr_plan_launcher_stats(int64_t *busy_ns, int64_t *parts, int64_t *sleeps)
 #define AABR_GEOM_TILE_BLOCKS 3
 #define AABR_GEOM_WIDE_BLOCKS 4
 #define AABR_GEOM_OFFSET_PAIRS 5
-#define AABR_GEOM_RS 6
 #define AABR_GEOM_CONV_SITES 7
 #define AABR_GEOM_SAMPLE_OFFSETS 8
 /* brick grids (one allocation per level: the directory, then the bricks; dims packed sbx | sby << 16 | sbz << 32 | nb << 48):

@@ -270,8 +270,10 @@ def test_knob_registry_rejects_unknown_names_and_takes_known_ones():
     import _hip
     lib = _hip.load()
     assert lib.aabr_set_knob(b"NO_SUCH_KNOB", 1, 0) != 0
+    for gone in (b"CONV_X3", b"CONV_RS", b"WIDE_OCC4", b"WIDE_DEFER", b"WIDE_NW8"):     # removed with their kernels (round 5)
+        assert lib.aabr_set_knob(gone, 1, 0) != 0
     assert b"unknown knob" in lib.aabr_last_error()
-    for name in ("CONV_WIDE", "WIDE_NBUF", "BN_SMALL", "CONV_X3", "X3_FORM", "WIDE_PRIO", "PLAN_SIDE_BATCH",
-                 "PLAN_SIDE_PRIO", "VOXEL_MEAN", "WIDE_NCB", "CONV_RS"):
+    for name in ("CONV_WIDE", "WIDE_NBUF", "BN_SMALL", "WIDE_PRIO", "PLAN_SIDE_BATCH", "PLAN_SIDE_PRIO", "VOXEL_MEAN",
+                 "WIDE_NCB", "CONV_NARROW"):
         assert lib.aabr_set_knob(name.encode(), 1, 0) == 0
         assert lib.aabr_set_knob(name.encode(), 0, 1) == 0                       # back to "unset"

@@ -301,113 +301,6 @@ def test_wide_write_out_statistics_feed_batchnorm(bf, nIn, nOut, npts, use_res):
     np.testing.assert_allclose(got[0], want[0], rtol=2 ** -7 if bf else 1e-6, atol=2 ** -7 if bf else 1e-6)
 
 
-def _pack_x3(lib, W, vol, nIn, nOut):
-    """three-term bf16 packs (forward and transposed orientation) of one weight through aabr_conv_pack_weights_jobs"""
-    import struct
-    from _hip import ptr, stream, check
-    n = int(lib.aabr_conv_wpack_x3_elems(vol, nIn, nOut))
-    pf = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
-    pt = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
-    rec = struct.pack("<QQQiiiiq", W.data_ptr(), pf.data_ptr(), pt.data_ptr(), vol, nIn, nOut, 2, 0)
-    jobs = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(DEV)
-    check(lib.aabr_conv_pack_weights_jobs(ptr(jobs), 1, int(lib.aabr_conv_pack_job_blocks(vol, nIn, nOut)), stream()))
-    return pf, pt
-
-
-@pytest.mark.parametrize("nIn,nOut,npts,form", [(64, 128, 2500, 0), (128, 128, 3000, 0), (128, 128, 3000, 2),
-                                                (64, 64, 129, 0), (128, 64, 1500, 0), (256, 128, 1200, 0),
-                                                (128, 128, 2000, 3)])
-def test_wide_x3_split_is_fp32_accurate(nIn, nOut, npts, form):
-    """k_conv_cs<.., X3>: fp32 operands split into three bf16 terms, six term products per multiply on the bf16 matrix
-    pipe.  Against the oracle at the SAME tolerance as the fp32-MFMA kernel, against an fp64 evaluation of the same
-    sums (its error must not exceed 2x the fp32-MFMA kernel's own -- both are fp32-accumulation errors), forward
-    form with bias + residual + BatchNorm statistics and input-gradient form, all three launch forms."""
-    import _hip as _h
-    if not (_h.load().aabr_build_flags() & 1):
-        assert _h.load().aabr_conv_wide_tile_rows_x3(nIn, nOut, 1000, 1000, 27) == 0
-        pytest.skip("release build: the three-term kernels are compiled into `make DEV=1` builds only")
-    import _hip
-    from _hip import ptr, stream, check
-    scn = _scn()
-    lib = _hip.load()
-    rng = np.random.default_rng(nIn + 11 * nOut + npts)
-    coords, _ = _scene(rng, npts, (12, 11, 5), 2, 1)
-    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
-    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
-    ga, V, vol = tb.out, tb.V_out, tb.vol
-    il = O.input_layer(coords, np.zeros((npts, 1), np.float32), 4)
-    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
-    _hip.set_knob("CONV_X3", 1)
-    _hip.set_knob("CONV_WIDE", 1)
-    if form:
-        _hip.set_knob("X3_FORM", form)
-    try:
-        T = lib.aabr_conv_wide_tile_rows_x3(nIn, nOut, V, V, vol)
-        Tb = lib.aabr_conv_wide_tile_rows_x3(nOut, nIn, V, V, vol)
-        T32 = lib.aabr_conv_wide_tile_rows(nIn, nOut, V, V, vol)
-        assert T >= 64 and Tb >= 64
-        if not T32:
-            pytest.skip("no fp32 wide-kernel instance to compare with for these plane counts")
-        # values with a wide dynamic range so every term of the split carries weight
-        f = (rng.standard_normal((V, nIn)) * np.exp(rng.uniform(-3, 3, (V, nIn)))).astype(np.float32)
-        W = (rng.standard_normal((vol, 1, nIn, nOut)) * 0.1 * np.exp(rng.uniform(-2, 2, (vol, 1, nIn, nOut)))).astype(np.float32)
-        bias = rng.standard_normal(nOut).astype(np.float32)
-        res = rng.standard_normal((V, nOut)).astype(np.float32)
-        fd, Wd, bd, rd = _t(f), _t(W), _t(bias), _t(res)
-        pf, pt = _pack_x3(lib, Wd, vol, nIn, nOut)
-        out = torch.empty((V, nOut), device=DEV)
-        ntile = (V + T - 1) // T
-        stats = torch.zeros((ntile, 2, nOut), dtype=torch.float64, device=DEV)
-        check(lib.aabr_conv_forward_wide_x3(ptr(fd), nIn, V, ptr(out), nOut, V, ptr(ga.blocks_wide(T)), T, vol, ptr(bd), 0,
-                                            ptr(pf), ptr(rd), ptr(stats), stream()))
-        assert ",x3" in _variant(), _variant()
-        wp = torch.empty(lib.aabr_conv_wpack_floats(vol, nIn, nOut), device=DEV)
-        check(lib.aabr_conv_pack_weights(ptr(Wd), vol, nIn, nOut, 0, ptr(wp), stream()))
-        out32 = torch.empty((V, nOut), device=DEV)
-        check(lib.aabr_conv_forward_wide_res(ptr(fd), nIn, V, ptr(out32), nOut, V, ptr(ga.blocks_wide(T32)), T32, vol,
-                                             ptr(bd), 0, ptr(wp), ptr(rd), stream()))
-        ref, _ = O.conv_fwd(f, W.reshape(vol, nIn, nOut), rb, V, bias)
-        ref = ref + res
-        got = out.cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * np.abs(ref).max() * nIn)
-        # fp64 evaluation of the same sums on the device
-        ex = torch.zeros((V, nOut), dtype=torch.float64, device=DEV)
-        f64, W64 = fd.double(), Wd.double().reshape(vol, nIn, nOut)
-        for k in range(vol):
-            r = torch.as_tensor(np.ascontiguousarray(rb.pairs(k))).to(DEV).long()          # [n_k, 2] = (in row, out row)
-            if r.numel():
-                ex.index_add_(0, r[:, 1], f64[r[:, 0]] @ W64[k])
-        ex = ex + bd.double() + rd.double()
-        scale = ex.abs().max().item()
-        e_x3 = (out.double() - ex).abs().max().item() / scale
-        e_32 = (out32.double() - ex).abs().max().item() / scale
-        assert e_x3 <= 2.0 * e_32 + 1e-7, (e_x3, e_32)
-        rms_x3 = (out.double() - ex).pow(2).mean().sqrt().item() / scale
-        rms_32 = (out32.double() - ex).pow(2).mean().sqrt().item() / scale
-        assert rms_x3 <= 2.0 * rms_32 + 1e-8, (rms_x3, rms_32)
-        # the write-out statistics are those of the stored values
-        o64 = out.double().cpu().numpy()
-        st = stats.cpu().numpy()
-        for j in range(ntile):
-            blk = o64[j * T:(j + 1) * T]
-            np.testing.assert_allclose(st[j, 0], blk.sum(0), rtol=1e-13, atol=1e-11)
-        # input-gradient form (transposed pack, mirrored offsets)
-        gr = rng.standard_normal((V, nOut)).astype(np.float32)
-        d_in = torch.empty((V, nIn), device=DEV)
-        check(lib.aabr_conv_forward_wide_x3(ptr(_t(gr)), nOut, V, ptr(d_in), nIn, V, ptr(ga.blocks_wide(Tb)), Tb, vol, None,
-                                            1 | 2, ptr(pt), None, None, stream()))
-        dref, _, _ = O.conv_bwd(np.zeros((V, nIn), np.float32), gr, W.reshape(vol, nIn, nOut), rb, want_bias=False)
-        np.testing.assert_allclose(d_in.cpu().numpy(), dref, rtol=1e-4, atol=2e-6 * np.abs(dref).max() * nOut)
-        # same launch, same bits
-        out2 = torch.empty_like(out)
-        check(lib.aabr_conv_forward_wide_x3(ptr(fd), nIn, V, ptr(out2), nOut, V, ptr(ga.blocks_wide(T)), T, vol, ptr(bd), 0,
-                                            ptr(pf), ptr(rd), None, stream()))
-        assert torch.equal(out, out2)
-    finally:
-        for k in ("CONV_X3", "CONV_WIDE", "X3_FORM"):
-            _hip.set_knob(k, None)
-
-
 @pytest.mark.parametrize("nIn,nOut,npts,use_res,leak,affine", [(64, 64, 3000, False, 0.0, True), (128, 128, 2500, True, 0.2, True),
                                                                (128, 64, 900, False, 0.0, False)])
 def test_wide_write_out_backward_statistics_feed_batchnorm_backward(force_wide, nIn, nOut, npts, use_res, leak, affine):
@@ -718,101 +611,3 @@ def test_wide_bf16_write_out_backward_statistics_feed_batchnorm_backward(nIn, nO
     finally:
         _hip.set_knob("BN_SMALL", None)
         _hip.set_knob("CONV_WIDE_BF16", None)
-
-
-@pytest.mark.parametrize("nOut,npts,transposed", [(128, 3000, False), (256, 2500, False), (128, 2200, True)])
-def test_wide_bf16_eight_wave_workgroups(nOut, npts, transposed):
-    """k_conv_cs<.., NW = 8> (128 input channels, eight waves x 16 columns on a 128-row x 128-column tile): the bits of
-    the four-wave form on the same block stream (every output element takes one contribution per filter offset, in offset
-    order, either way), the oracle within the bf16 tolerance, and the write-out statistics (forward sums; backward sums
-    with the sign from the stored BatchNorm output) equal to numpy's on the stored values."""
-    import _hip
-    from _hip import ptr, stream, check
-    scn = _scn()
-    lib = _hip.load()
-    if not (lib.aabr_build_flags() & 1):
-        pytest.skip("the eight-wave form is compiled into `make DEV=1` builds only (measured slower, not dispatched)")
-    nIn = 128
-    rng = np.random.default_rng(nOut + npts)
-    coords, _ = _scene(rng, npts, (12, 11, 5), 2, 1)
-    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
-    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
-    ga, V, vol = tb.out, tb.V_out, tb.vol
-    il = O.input_layer(coords, np.zeros((npts, 1), np.float32), 4)
-    rb = O.submanifold_rules(il["coords"], [3, 3, 3])
-    T = 128
-    blocks = ga.blocks_wide(T)
-    ntile = (V + T - 1) // T
-    W = _t((rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32))
-    n = int(lib.aabr_conv_wpack_bf16_elems(vol, nIn, nOut))
-    pf = torch.empty(n, dtype=torch.bfloat16, device=DEV)
-    pt = torch.empty(n, dtype=torch.bfloat16, device=DEV)
-    check(lib.aabr_conv_pack_weights2_bf16(ptr(W), vol, nIn, nOut, ptr(pf), ptr(pt), stream()))
-    Wr = W.bfloat16().float().cpu().numpy().reshape(vol, nIn, nOut)
-    if transposed:       # input-gradient form of a 128 <- nOut... layer: swap the roles so that the LAUNCH has 128 inputs
-        f = _t(rng.standard_normal((V, nIn)).astype(np.float32)).bfloat16()
-        pack, flags = pf, 0
-    else:
-        f = _t(rng.standard_normal((V, nIn)).astype(np.float32)).bfloat16()
-        pack, flags = pf, 0
-    b = _t(rng.standard_normal(nOut).astype(np.float32))
-    xb = _t((rng.standard_normal((V, nOut)) * 1.3 + 0.2).astype(np.float32)).bfloat16()
-    yb = _t(rng.standard_normal((V, nOut)).astype(np.float32)).bfloat16()
-    sm = _t(rng.standard_normal(nOut).astype(np.float32))
-
-    def run(nw8):
-        _hip.set_knob("WIDE_NW8", 1 if nw8 else 0)
-        try:
-            out = torch.empty((V, nOut), dtype=torch.bfloat16, device=DEV)
-            st = torch.full((ntile, 2, nOut), float("nan"), dtype=torch.float64, device=DEV)
-            check(lib.aabr_conv_forward_wide_bf16_stats(ptr(f), nIn, V, ptr(out), nOut, V, ptr(blocks), T, vol, ptr(b),
-                                                        flags, ptr(pack), ptr(st), stream()))
-            var = _variant()
-            out2 = torch.empty_like(out)
-            st2 = torch.full((ntile, 2, nOut), float("nan"), dtype=torch.float64, device=DEV)
-            check(lib.aabr_conv_forward_wide_bf16_bwd_stats(ptr(f), nIn, V, ptr(out2), nOut, V, ptr(blocks), T, vol,
-                                                            ptr(b), flags, ptr(pack), ptr(st2), ptr(xb), ptr(yb), ptr(sm),
-                                                            0.2, stream()))
-            return out, st, out2, st2, var
-        finally:
-            _hip.set_knob("WIDE_NW8", None)
-
-    o8, s8, o8b, s8b, v8 = run(True)
-    o4, s4, o4b, s4b, v4 = run(False)
-    assert v8.endswith("w8>") and not v4.endswith("w8>"), (v8, v4)
-    assert torch.equal(o8, o4) and torch.equal(o8b, o4b) and torch.equal(o8, o8b)
-    ref, _ = O.conv_fwd(f.float().cpu().numpy(), Wr, rb, V, b.cpu().numpy())
-    np.testing.assert_allclose(o8.float().cpu().numpy(), ref, rtol=2 ** -7, atol=2 ** -7 * np.abs(ref).max())
-    o = o8.float().cpu().numpy().astype(np.float64)
-    st = s8.cpu().numpy()
-    d32 = o8.float().cpu().numpy()
-    dm = np.where(yb.float().cpu().numpy() > 0, d32, d32 * np.float32(0.2)).astype(np.float64)
-    xc = (xb.float().cpu().numpy() - sm.cpu().numpy()).astype(np.float64)
-    stb = s8b.cpu().numpy()
-    for j in range(ntile):
-        sl = slice(j * T, (j + 1) * T)
-        np.testing.assert_allclose(st[j, 0], o[sl].sum(0), rtol=1e-12, atol=1e-11)
-        np.testing.assert_allclose(st[j, 1], (o[sl] ** 2).sum(0), rtol=1e-12, atol=1e-11)
-        np.testing.assert_allclose(stb[j, 0], dm[sl].sum(0), rtol=1e-12, atol=1e-11)
-        np.testing.assert_allclose(stb[j, 1], (xc[sl] * dm[sl]).sum(0), rtol=1e-12, atol=1e-11)
-    np.testing.assert_allclose(s8.cpu().numpy(), s4.cpu().numpy(), rtol=1e-13, atol=1e-12)
-    if transposed:       # transposed + mirrored flags (the input-gradient launch) through both forms
-        g = _t(rng.standard_normal((V, nIn)).astype(np.float32)).bfloat16()
-        pk = torch.empty(int(lib.aabr_conv_wpack_bf16_elems(vol, nIn, nIn)), dtype=torch.bfloat16, device=DEV)
-        pkt = torch.empty_like(pk)
-        W2 = _t((rng.standard_normal((vol, 1, nIn, nIn)) * 0.1).astype(np.float32))
-        check(lib.aabr_conv_pack_weights2_bf16(ptr(W2), vol, nIn, nIn, ptr(pk), ptr(pkt), stream()))
-        res = []
-        for nw8 in (1, 0):
-            _hip.set_knob("WIDE_NW8", nw8)
-            try:
-                d_in = torch.empty((V, nIn), dtype=torch.bfloat16, device=DEV)
-                check(lib.aabr_conv_forward_wide_bf16(ptr(g), nIn, V, ptr(d_in), nIn, V, ptr(blocks), T, vol, None, 3,
-                                                      ptr(pkt), stream()))
-                res.append(d_in)
-            finally:
-                _hip.set_knob("WIDE_NW8", None)
-        assert torch.equal(res[0], res[1])
-        W2r = W2.bfloat16().float().cpu().numpy().reshape(vol, nIn, nIn)
-        dref, _, _ = O.conv_bwd(np.zeros((V, nIn), np.float32), g.float().cpu().numpy(), W2r, rb, want_bias=False)
-        np.testing.assert_allclose(res[0].float().cpu().numpy(), dref, rtol=2 ** -7, atol=2 ** -7 * np.abs(dref).max())

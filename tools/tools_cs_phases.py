@@ -50,30 +50,3 @@ if len(sys.argv) > 1 and sys.argv[1] == "bf16":
     for i, nme in enumerate(names):
         print("%-28s %8.1f clocks/iteration  %5.1f %%" % (nme, d[:, i].sum() / it, 100 * d[:, i].sum() / tot))
     print("total %.1f clocks/iteration (s_memtime ticks)" % (tot / it))
-
-if len(sys.argv) > 1 and sys.argv[1] == "x3":
-    import struct
-    for form in (0, 2, 3):
-        _hip.set_knob("CONV_X3", 1)
-        if form:
-            _hip.set_knob("X3_FORM", form)
-        T = lib.aabr_conv_wide_tile_rows_x3(n_in, n_out, rows_in, ga.rows, ga.vol)
-        n = int(lib.aabr_conv_wpack_x3_elems(ga.vol, n_in, n_out))
-        pf = torch.zeros(n, dtype=torch.bfloat16, device=dev); pt = torch.zeros(n, dtype=torch.bfloat16, device=dev)
-        rec = struct.pack("<QQQiiiiq", w.data_ptr(), pf.data_ptr(), pt.data_ptr(), ga.vol, n_in, n_out, 2, 0)
-        jobs = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
-        check(lib.aabr_conv_pack_weights_jobs(ptr(jobs), 1, int(lib.aabr_conv_pack_job_blocks(ga.vol, n_in, n_out)), stream()))
-        b = ga.blocks_wide(T)
-        ntile = (ga.rows + T - 1) // T
-        dbg = torch.zeros((2 * ntile * 4, 5), dtype=torch.int64, device=dev)
-        for _ in range(3):
-            check(lib.aabr_conv_forward_wide_x3(ptr(inp), n_in, rows_in, ptr(out), n_out, ga.rows, ptr(b), T, ga.vol, ptr(dbg),
-                                                4 << 8, ptr(pf), None, None, stream()))
-        torch.cuda.synchronize()
-        d = dbg.double().cpu(); d = d[d[:, 4] > 0]
-        it = d[:, 4].sum(); tot = d[:, :4].sum()
-        print("x3 form %d: tile rows %d, waves %d, iterations/wave avg %.1f" % (form, T, d.shape[0], it / d.shape[0]))
-        for i, nme in enumerate(names):
-            print("%-28s %8.1f clocks/iteration  %5.1f %%" % (nme, d[:, i].sum() / it, 100 * d[:, i].sum() / tot))
-        print("total %.1f clocks/iteration (s_memtime ticks)" % (tot / it))
-        _hip.set_knob("X3_FORM", None); _hip.set_knob("CONV_X3", None)
