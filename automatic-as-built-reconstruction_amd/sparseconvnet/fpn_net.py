@@ -29,6 +29,12 @@ class FPN_Net(torch.nn.Module):
         self.grids_from_input = True    # extension: see _grids_from_input
         self.compiled_graph = False     # extension: planExecutor.run_fpn (one launch list per pass)
         self.site_order = "first_seen"  # extension: "brick" = brick-major rows over brick grids (see set_site_order)
+        # extension (opt-in, never the default): the reference's forward_fpn runs the whole top-down path to scale 0
+        # (fpn_net.py:181-196; the `continue` that would stop it is commented out) although only ups[i], i in
+        # fpn_scales_from_top + roi_scales_from_top, are returned.  True: stop the top-down path behind the last consumed
+        # level -- m_ups / m_shortcuts / m_mergeds below it are not run (and get no gradient, as before: nothing returned
+        # depends on them).  Returned maps are bit-identical; forward_pass_multiplyAdd_count is smaller by their MACs.
+        self.prune_unused_levels = False
         self.bn_momentum = bn_momentum
         self.track_running_stats = track_running_stats
         self.dimension = dimension
@@ -164,7 +170,8 @@ class FPN_Net(torch.nn.Module):
         for k in range(nscale):
             sz = sizes[k]
             md.getSubmanifoldRuleBook(sz, three)
-            md.getSubmanifoldRuleBook(sz, one)
+            if (nscale - 1 - k) <= self._top_down_levels():      # (the lateral 1x1x1 of a level the top-down path reaches)
+                md.getSubmanifoldRuleBook(sz, one)
             if k + 1 < nscale:
                 ks, st = sp["down"][k]
                 md.getRuleBook(sz, sizes[k + 1], ks, st)
@@ -303,16 +310,19 @@ class FPN_Net(torch.nn.Module):
 
         planes = [self.m_shortcuts[k].nIn for k in range(nscale)]
         nM = self.m_shortcuts[0].nOut
+        live = lambda k: (nscale - 1 - k) <= self._top_down_levels()   # the top-down path reaches scale k
         subm(0, three, in_channels, planes[0], f32)               # layers_in convolution runs in fp32
         for k in range(nscale):
             subm(k, three, planes[k], planes[k], dt)              # residual blocks
-            subm(k, one, planes[k], nM, dt)                       # lateral 1x1x1
+            if live(k):
+                subm(k, one, planes[k], nM, dt)                   # lateral 1x1x1
             if k + 1 < nscale:
                 ks, st = tuple(self.down_kernels[k]), tuple(self.down_strides[k])
                 tb = md.rulebooks[key(sizes[k]) + ks + st]
                 strided(tb, planes[k], planes[k + 1], dt, False)  # down-sampling convolution
-                strided(tb, nM, nM, dt, True)                     # up-sampling deconvolution of the same book
-            if k < nscale - 1:
+                if live(k):
+                    strided(tb, nM, nM, dt, True)                 # up-sampling deconvolution of the same book
+            if k < nscale - 1 and live(k):
                 subm(k, three, nM, nM, dt)                        # merged 3x3x3 on the up path
         for i, scale_from_top in enumerate(self.fpn_scales_from_top):
             msz = sizes[nscale - 1 - scale_from_top]
@@ -383,6 +393,13 @@ class FPN_Net(torch.nn.Module):
         rpn_maps, roi_maps = self.forward_fpn(self._cast(net1, self.feature_dtype))
         return ([self._cast(m, torch.float32) for m in rpn_maps], [self._cast(m, torch.float32) for m in roi_maps])
 
+    def _top_down_levels(self):
+        """m_ups / m_mergeds stages forward_fpn runs: all of them (the reference), or up to the last consumed map"""
+        n = len(self.m_downs) - 1
+        if not self.prune_unused_levels:
+            return n
+        return min(n, max(list(self.fpn_scales_from_top) + list(self.roi_scales_from_top)))
+
     def forward_fpn(self, net):
         scales_num = len(self.m_downs)
         downs = []
@@ -391,7 +408,7 @@ class FPN_Net(torch.nn.Module):
             downs.append(net)
         net = self.m_shortcuts[-1](net)
         ups = [net]
-        for k in range(scales_num - 1):
+        for k in range(self._top_down_levels()):
             j = scales_num - 1 - k - 1
             net = self.m_ups[k](net)
             shorcut = self.m_shortcuts[j](downs[j])

@@ -893,7 +893,7 @@ def _fpn_graph(net, ps, x):
         downs.append(x)
     x = ps.run(net.m_shortcuts[-1], x)
     ups = [x]
-    for k in range(n - 1):
+    for k in range(net._top_down_levels()):      # all n - 1 stages (the reference), or up to the last consumed map
         j = n - 1 - k - 1
         x = ps.run(net.m_ups[k], x)
         mark = len(ps.fops)
@@ -923,7 +923,7 @@ def _template(net, x_spatial, x_planes, plan):
             raise Unsupported("hooks")
         mode = mode * 2 + (1 if m.training else 0)
     cache = net.__dict__.setdefault("_graph_templates", {})
-    key = (x_spatial, x_planes, net.feature_dtype, mode)
+    key = (x_spatial, x_planes, net.feature_dtype, mode, bool(net.prune_unused_levels))
     tpl = cache.get(key)
     if tpl is not None and tpl.sig == tpl.signature(plan):
         return tpl

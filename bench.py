@@ -1144,6 +1144,26 @@ def main():
                     del wl2
                 except Exception as e:  # pragma: no cover
                     extras["other_dtype_error"] = repr(e)[:200]
+                try:
+                    # SECOND line, never the headline: the same step with FPN_Net.prune_unused_levels (opt-in) -- the
+                    # top-down stages below the last consumed map (m_ups / m_shortcuts / m_mergeds of scales 3..0, which the
+                    # reference computes and nobody reads, fpn_net.py:181-196) are not run; returned maps bit-identical
+                    # (tests/test_gpu_fpn.py::test_prune_unused_levels_is_bit_identical_and_opt_in)
+                    wl.net.prune_unused_levels = True
+                    n3 = max(20, min(args.steps, 60))
+                    el3, ti3 = timed_steps(torch, dist, wl, n3, 5, 1, dev, min_timed_s=0.0, prewarm=not args.no_prewarm)
+                    rf3, table3 = roofline_block(torch, wl, head_dtype, el3 / n3 * 1e6)
+                    extras["pruned"] = {
+                        "ms_per_step": round(el3 / n3 * 1e3, 3), "scenes_per_s": round(n3 * SCENES_PER_STEP / el3, 2),
+                        "steps": n3, "dtype": args.dtype,
+                        "workload": "same step, FPN_Net.prune_unused_levels = True (opt-in; NOT the reference's work: its "
+                                    "forward_fpn also computes the top-down levels below the four consumed maps)",
+                        "conv_step_us_total": round(sum(r["step_us"] for r in table3), 1),
+                        "conv_step_us_removed": round(sum(r["step_us"] for r in table) - sum(r["step_us"] for r in table3), 1)}
+                except Exception as e:  # pragma: no cover
+                    extras["pruned_error"] = repr(e)[:200]
+                finally:
+                    wl.net.prune_unused_levels = False
                 line["extras"] = extras
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, torch)

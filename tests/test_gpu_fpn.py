@@ -416,6 +416,52 @@ def test_compiled_graph_pipelined_hand_over_is_bit_equal_to_one_call():
         planExecutor.pipeline_records = keep
 
 
+def test_prune_unused_levels_is_bit_identical_and_opt_in():
+    """`FPN_Net.prune_unused_levels` (off by default -- the reference runs the whole top-down path,
+    fpn_net.py:181-196) stops the top-down path behind the last consumed level.  Returned maps, input gradient and the
+    gradients of every live parameter are bit-identical to the unpruned pass (module path and compiled graph, both site
+    orders); the dead stages' parameters get no gradient either way; the MAC counter is smaller by their launches."""
+    import sparseconvnet as scn
+    torch.manual_seed(8)
+    net = _fpn().to(DEV)
+    assert net.prune_unused_levels is False and net._top_down_levels() == 8
+    locs, feats = S.make_batch(2, 20000, 43, 20)
+    l = _t(locs)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def run(prune, compiled, order):
+        net.load_state_dict(state)
+        net.prune_unused_levels, net.compiled_graph = prune, compiled
+        net.set_site_order(order)
+        f = _t(feats).requires_grad_(True)
+        net.zero_grad()
+        scn.forward_pass_multiplyAdd_count = 0
+        rpn, roi = net([l, f])
+        macs = float(scn.forward_pass_multiplyAdd_count)
+        w = [torch.linspace(0.5, 1.5, m.features.numel(), device=DEV).view_as(m.features) for m in rpn + roi]
+        sum((m.features * wi).square().mean() for m, wi in zip(rpn + roi, w)).backward()
+        torch.cuda.synchronize()
+        return ([m.features.detach().clone() for m in rpn + roi], f.grad.clone(), macs,
+                {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0})
+
+    try:
+        for compiled in (False, True):
+            for order in ("first_seen", "brick"):
+                a, b = run(False, compiled, order), run(True, compiled, order)
+                assert net._top_down_levels() == 4
+                for x, y in zip(a[0], b[0]):
+                    assert torch.equal(x, y)
+                assert torch.equal(a[1], b[1])
+                assert b[2] < a[2]                                    # fewer multiply-adds counted ...
+                assert a[3].keys() == b[3].keys()                     # ... and the same parameters receive a gradient
+                for n in a[3]:
+                    assert torch.equal(a[3][n], b[3][n]), n
+                assert not any(n.startswith(("m_ups.4", "m_ups.7", "m_mergeds.4", "m_mergeds.7", "m_shortcuts.0"))
+                               for n in a[3])
+    finally:
+        net.prune_unused_levels = False
+
+
 def test_fpn_compiled_graph_matches_module_path():
     """FPN_Net.compiled_graph (sparseconvnet/planExecutor.py: every layer between the input layer and the returned
     maps as one launch list per pass, one autograd node) against the module path on the same net and input:
