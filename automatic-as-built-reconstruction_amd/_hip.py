@@ -59,6 +59,8 @@ _SIGS = {
     "aabr_conv_wide_split": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
     "aabr_conv_wide_split_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),
     "aabr_conv_narrow_ok": (C.c_int, [_i32, _i32, _i64, _i64, _i32, _i32]),
+    "aabr_conv_rb_ok": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
+    "aabr_conv_forward_rb_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
     "aabr_conv_forward_narrow": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp]),
     "aabr_conv_forward_narrow_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp]),
     "aabr_conv_narrow_parts": (C.c_int, [_i64]),
@@ -146,6 +148,8 @@ _SIGS = {
                                        _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "aabr_rpn_label_generation": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _f32p, _vp, _i32, _f32, _vp, _i32p, _f32p,
                                             _i32, _i32, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "aabr_rpn_topk_scratch_words": (C.c_int64, [_i32]),
+    "aabr_rpn_topk_maps": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _i32, _i32p, _vp, _i64, _vp, _vp, _vp]),
     "aabr_rpn_gather_logits": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _i32, _i64, _vp, _vp]),
     "aabr_rpn_proposals_batch": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32p, _i32p, _f32p, _vp, _i32, _f32, _f32p, _f32,
                                            _f32, _f32, _vp, _i64, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _vp, _vp]),

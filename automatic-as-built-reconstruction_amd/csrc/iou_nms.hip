@@ -718,6 +718,178 @@ extern "C" int aabr_rpn_gather_logits(int n_maps, const void *const *logit_ptrs,
   return AABR_OK;
 }
 
+// ---- fused cross-scale top-k (round 5; replaces torch.topk + torch.cat of the proposal stage) ----------------------------
+// The reference's RPNPostProcessor does, per example, objectness.sigmoid() -> topk(pre_nms_top_n, sorted) over the anchors
+// of all maps (rpn/inference_3d.py:107-112).  torch.topk is a chain of ~9 rocprim launches per example (radix select +
+// merge sort), run per example on a concatenated copy.  Here the examples of a step go through FOUR launches together and
+// nothing is concatenated (the j-th logit of an example is read through the segment table, like k_rpn_decode_maps does):
+//   K1 histogram of the 12 leading bits of the order-preserving key of every logit (LDS histogram per workgroup);
+//   K2 every workgroup finds the bin where the count from the top reaches k, histogram of the NEXT 12 bits inside it;
+//   K3 the same one level down, then every logit whose 24-bit prefix is >= the threshold prefix goes to the candidate
+//      list (<= 4096: k plus the ties of one 24-bit prefix; more = overflow, reported, the caller falls back);
+//   K4 one workgroup per example sorts the candidates (bitonic, in LDS) by (logit descending, index ascending) and
+//      writes the first k indices.
+// Same selection as torch.topk(sorted=True) except between EXACTLY equal logits, where torch leaves the order (and the
+// choice at the cut) open and this picks the lower index -- deterministic.
+constexpr int kTopkBins = 4096, kTopkCand = 4096;
+struct RpnTopkParams {
+  RpnGatherParams g;
+  int32_t k[kMaxRpnBatch];
+};
+// per example: hist1[4096], hist2[4096], then 8 control words, then the candidates (uint64 x kTopkCand)
+constexpr int kTopkCtl = 8, kTopkWordsPerEx = 2 * kTopkBins + kTopkCtl + 2 * kTopkCand;
+enum { kTkBin1 = 0, kTkAbove1 = 1, kTkCount = 2, kTkOverflow = 3 };
+__device__ inline uint32_t topk_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // ascending in the float order (-0 < +0: harmless)
+}
+__device__ inline float topk_logit(const RpnGatherParams &p, int b, int64_t j) {
+  int m = 0;
+  while (m + 1 < p.n_maps && j >= p.seg_begin[b][m + 1]) ++m;
+  return p.logits[m][(int64_t)p.src_begin[b][m] + (j - p.seg_begin[b][m])];
+}
+// the bin (from the top) in which the running count reaches `need`: returns it, and the count ABOVE it through `above`
+__device__ inline int topk_find_bin(const int32_t *__restrict__ hist, int need, int &above) {
+  __shared__ int s_part[256], s_bin, s_above;
+  const int t = threadIdx.x;
+  int sum = 0;                                                // thread t owns bins [4095 - 16 t - 15, 4095 - 16 t], top first
+  for (int q = 0; q < 16; ++q) sum += hist[kTopkBins - 1 - (16 * t + q)];
+  s_part[t] = sum;
+  if (t == 0) { s_bin = 0; s_above = 0; }
+  __syncthreads();
+  if (t == 0) {
+    int run = 0, bt = 255;
+    for (int i = 0; i < 256; ++i) {
+      if (run + s_part[i] >= need) { bt = i; break; }
+      run += s_part[i];
+    }
+    int bin = 0, ab = run;
+    for (int q = 0; q < 16; ++q) {
+      const int bq = kTopkBins - 1 - (16 * bt + q);
+      const int c = hist[bq];
+      if (ab + c >= need || q == 15) { bin = bq; break; }
+      ab += c;
+    }
+    s_bin = bin;
+    s_above = ab;
+  }
+  __syncthreads();
+  above = s_above;
+  return s_bin;
+}
+template <int LEVEL>   // 1: leading 12 bits of every logit; 2: the next 12 bits of the logits inside the level-1 threshold bin
+__global__ __launch_bounds__(256) void k_rpn_topk_hist(RpnTopkParams p, int32_t *__restrict__ scratch) {
+  __shared__ int32_t s_hist[kTopkBins];
+  const int b = blockIdx.y;
+  int32_t *sc = scratch + (int64_t)b * kTopkWordsPerEx;
+  const int64_t n = p.g.seg_begin[b][p.g.n_maps];
+  int bin1 = 0;
+  if (LEVEL == 2) {
+    int above;
+    bin1 = topk_find_bin(sc, p.k[b], above);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[2 * kTopkBins + kTkBin1] = bin1; sc[2 * kTopkBins + kTkAbove1] = above; }
+  }
+  for (int q = threadIdx.x; q < kTopkBins; q += 256) s_hist[q] = 0;
+  __syncthreads();
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+    const uint32_t key = topk_key(topk_logit(p.g, b, j));
+    if (LEVEL == 1) atomicAdd(&s_hist[key >> 20], 1);
+    else if ((int)(key >> 20) == bin1) atomicAdd(&s_hist[(key >> 8) & 4095u], 1);
+  }
+  __syncthreads();
+  int32_t *h = sc + (LEVEL == 1 ? 0 : kTopkBins);
+  for (int q = threadIdx.x; q < kTopkBins; q += 256)
+    if (s_hist[q]) atomicAdd(&h[q], s_hist[q]);
+}
+__global__ __launch_bounds__(256) void k_rpn_topk_compact(RpnTopkParams p, int32_t *__restrict__ scratch) {
+  const int b = blockIdx.y;
+  int32_t *sc = scratch + (int64_t)b * kTopkWordsPerEx;
+  int32_t *ctl = sc + 2 * kTopkBins;
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(ctl + kTopkCtl);
+  const int64_t n = p.g.seg_begin[b][p.g.n_maps];
+  const int bin1 = ctl[kTkBin1];
+  int above2;
+  const int bin2 = topk_find_bin(sc + kTopkBins, p.k[b] - ctl[kTkAbove1], above2);
+  const uint32_t thr = ((uint32_t)bin1 << 12) | (uint32_t)bin2;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+    const uint32_t key = topk_key(topk_logit(p.g, b, j));
+    if ((key >> 8) >= thr) {
+      const int pos = atomicAdd(&ctl[kTkCount], 1);
+      if (pos < kTopkCand) cand[pos] = ((unsigned long long)(~key) << 32) | (unsigned long long)(uint32_t)j;
+      else ctl[kTkOverflow] = 1;
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void k_rpn_topk_sort(RpnTopkParams p, int32_t *__restrict__ scratch, int64_t *__restrict__ sel,
+                                                        int64_t sel_stride, int32_t *__restrict__ info) {
+  __shared__ unsigned long long s[kTopkCand];
+  const int b = blockIdx.x;
+  int32_t *ctl = scratch + (int64_t)b * kTopkWordsPerEx + 2 * kTopkBins;
+  const unsigned long long *cand = reinterpret_cast<const unsigned long long *>(ctl + kTopkCtl);
+  int C = ctl[kTkCount];
+  C = C < kTopkCand ? C : kTopkCand;
+  for (int i = threadIdx.x; i < kTopkCand; i += 1024) s[i] = i < C ? cand[i] : ~0ull;
+  for (int size = 2; size <= kTopkCand; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < kTopkCand; i += 1024) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const unsigned long long a = s[i], c = s[j];
+          const bool up = (i & size) == 0;
+          if ((a > c) == up) { s[i] = c; s[j] = a; }
+        }
+      }
+    }
+  __syncthreads();
+  const int k = p.k[b];
+  for (int i = threadIdx.x; i < k; i += 1024) sel[(int64_t)b * sel_stride + i] = (int64_t)(uint32_t)s[i];
+  if (threadIdx.x == 0) {
+    info[2 * b] = ctl[kTkCount];
+    info[2 * b + 1] = (ctl[kTkOverflow] || ctl[kTkCount] < k) ? 1 : 0;
+  }
+}
+
+extern "C" int64_t aabr_rpn_topk_scratch_words(int nb) { return (int64_t)(nb > 0 ? nb : 0) * kTopkWordsPerEx; }
+
+extern "C" int aabr_rpn_topk_maps(int n_maps, const void *const *logit_ptrs, int nb, const int32_t *seg_begin_host,
+                                  const int32_t *site_begin_host, int num_anchors, const int32_t *k_host, int64_t *selected,
+                                  int64_t sel_stride, int32_t *info, int32_t *scratch, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(n_maps >= 1 && n_maps <= kMaxRpnMaps && nb >= 1 && nb <= kMaxRpnBatch && num_anchors > 0,
+                 "bad arguments (at most 8 maps, 16 examples)");
+  AABR_CHECK_ARG(logit_ptrs && seg_begin_host && site_begin_host && k_host && selected && info && scratch, "null pointer");
+  AABR_CHECK_ARG(((uintptr_t)scratch & 7) == 0, "scratch must be 8-byte aligned");
+  RpnTopkParams p;
+  p.g.n_maps = n_maps; p.g.nb = nb;
+  int64_t nmax = 0;
+  for (int m = 0; m < kMaxRpnMaps; ++m) p.g.logits[m] = m < n_maps ? (const float *)logit_ptrs[m] : nullptr;
+  for (int b = 0; b < nb; ++b) {
+    for (int m = 0; m <= n_maps; ++m) p.g.seg_begin[b][m] = seg_begin_host[b * (n_maps + 1) + m];
+    for (int m = 0; m < n_maps; ++m) {
+      p.g.src_begin[b][m] = site_begin_host[b * n_maps + m] * num_anchors;
+      AABR_CHECK_ARG(p.g.seg_begin[b][m + 1] >= p.g.seg_begin[b][m], "segment table must be non-decreasing");
+      AABR_CHECK_ARG(p.g.seg_begin[b][m + 1] == p.g.seg_begin[b][m] || p.g.logits[m], "null map pointer");
+    }
+    const int64_t n = p.g.seg_begin[b][n_maps];
+    AABR_CHECK_ARG(k_host[b] >= 0 && k_host[b] <= n && k_host[b] <= kTopkCand / 2 && k_host[b] <= sel_stride,
+                   "k: 0 .. min(anchors of the example, 2048, sel_stride)");
+    p.k[b] = k_host[b];
+    nmax = n > nmax ? n : nmax;
+  }
+  for (int b = nb; b < kMaxRpnBatch; ++b) p.k[b] = 0;
+  AABR_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)nb * kTopkWordsPerEx * sizeof(int32_t), st));
+  if (nmax == 0) { AABR_CHECK_HIP(hipMemsetAsync(info, 0, (size_t)nb * 2 * sizeof(int32_t), st)); return AABR_OK; }
+  int64_t gx = ceil_div(nmax, 256 * 8);
+  gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+  hipLaunchKernelGGL(k_rpn_topk_hist<1>, dim3((unsigned)gx, (unsigned)nb), dim3(256), 0, st, p, scratch);
+  hipLaunchKernelGGL(k_rpn_topk_hist<2>, dim3((unsigned)gx, (unsigned)nb), dim3(256), 0, st, p, scratch);
+  hipLaunchKernelGGL(k_rpn_topk_compact, dim3((unsigned)gx, (unsigned)nb), dim3(256), 0, st, p, scratch);
+  hipLaunchKernelGGL(k_rpn_topk_sort, dim3((unsigned)nb), dim3(1024), 0, st, p, scratch, selected, sel_stride, info);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
 extern "C" int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_ptrs, const void *const *logit_ptrs,
                                         const void *const *regression_ptrs, int nb, const int32_t *seg_begin_host,
                                         const int32_t *site_begin_host, const float *strides_host,

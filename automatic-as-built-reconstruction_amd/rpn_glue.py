@@ -78,6 +78,8 @@ def rpn_proposals_single_map(tensor, objectness, box_regression, base_anchors, v
     return out
 
 
+fused_topk = True      # aabr_rpn_topk_maps instead of torch.cat + torch.topk per example (False: the round-4 path, for A/B)
+topk_stats = {"fallbacks": 0}
 _trace = None     # tools/tools_step_timeline.py: called with a label at the stage's host-side boundaries
 debug_nms_inputs = None   # tests: a list here receives (nms_boxes [k,7], scores [k]) of every example's NMS call
 
@@ -159,6 +161,27 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
     coords_p, obj_p, reg_p = _hip.ptrs([g.coords for g in grids]), _hip.ptrs(obj), _hip.ptrs(reg)
     strides_h = _hip.f32xn([v for st in strides for v in st])
     weights_h = _hip.f32xn(weights)
+    # fused cross-scale top-k (csrc/iou_nms.hip aabr_rpn_topk_maps): every example's selection in four launches, nothing
+    # concatenated; torch.topk per example (a chain of ~9 rocprim launches each, on a concatenated copy) stays as the
+    # fallback for shapes the kernel does not take and for the (reported) case of > 4096 exactly tied logits at the cut
+    sel_all = topk_info = None
+    if fused_topk and 1 <= nb <= 16 and n_maps <= 8 and pre_nms_top_n <= 2048:
+        segs, sites, s0 = [], [], [0] * n_maps
+        for bi in range(nb):
+            seg = [0]
+            for m in range(n_maps):
+                seg.append(seg[-1] + counts[m][bi] * A)
+            segs += seg
+            sites += s0
+            s0 = [s0[m] + counts[m][bi] for m in range(n_maps)]
+        ks = [min(pre_nms_top_n, segs[bi * (n_maps + 1) + n_maps]) for bi in range(nb)]
+        kmax = max(max(ks), 1)
+        sel_all = torch.empty((nb, kmax), dtype=torch.int64, device=dev)
+        topk_info = torch.empty((nb, 2), dtype=torch.int32, device=dev)
+        tscr = _hip.workspace("rpn_topk", int(lib.aabr_rpn_topk_scratch_words(nb)) + 2, torch.int32, dev)
+        tso = (-tscr.data_ptr() // 4) % 2
+        check(lib.aabr_rpn_topk_maps(n_maps, obj_p, nb, _hip.i32xn(segs), _hip.i32xn(sites), A, _hip.i32xn(ks), ptr(sel_all),
+                                     kmax, ptr(topk_info), tscr.data_ptr() + 4 * tso, stream()))
     site0 = [0] * n_maps
     out, pending = [], []
     for bi in range(nb):
@@ -169,9 +192,12 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
         if n_anchor == 0:
             out.append((torch.zeros(0, 7, device=dev), torch.zeros(0, device=dev)))
             continue
-        logit_b = torch.cat([obj[m][site0[m] * A:(site0[m] + counts[m][bi]) * A] for m in range(n_maps)])
         k = min(pre_nms_top_n, n_anchor)
-        _, sel = logit_b.topk(k, dim=0, sorted=True)
+        if sel_all is not None:
+            sel = sel_all[bi, :k]
+        else:
+            logit_b = torch.cat([obj[m][site0[m] * A:(site0[m] + counts[m][bi]) * A] for m in range(n_maps)])
+            _, sel = logit_b.topk(k, dim=0, sorted=True)
         boxes = torch.empty((k, 7), dtype=torch.float32, device=dev)
         nms_boxes = torch.empty((k, 7), dtype=torch.float32, device=dev)
         scores = torch.empty(k, dtype=torch.float32, device=dev)
@@ -184,7 +210,7 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
         # every example's launches go out first; the numbers kept are read once, after the last one
         keep, meta = _nms.rotate_nms_sorted(nms_boxes, nms_thresh, post_nms_top_n, _nms.REFERENCE_DEBUG_ONLY_XY,
                                             lazy=True)
-        pending.append((len(out), boxes, scores, keep, meta))
+        pending.append((len(out), boxes, scores, keep, meta, bi, list(seg), list(site0)))
         out.append(None)
         for m in range(n_maps):
             site0[m] += counts[m][bi]
@@ -192,10 +218,28 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
         if pending:
             if _trace is not None:
                 _trace("proposal launches enqueued")
-            kept = _hip.read_back(torch.stack([p[4][0] for p in pending]))      # the one read of the NMS stage
+            words = [p[4][0:1] for p in pending]
+            if topk_info is not None:
+                words.append(topk_info[:, 1])
+            vals = _hip.read_back(torch.cat(words))                             # the one read of the stage
+            kept, over = vals[:len(pending)], vals[len(pending):]
             if _trace is not None:
                 _trace("proposal counts read")
-            for (i, boxes, scores, keep, meta), nk in zip(pending, kept):
+            for (i, boxes, scores, keep, meta, bi, seg, st0), nk in zip(pending, kept):
+                if over and over[bi]:
+                    # > 4096 exactly tied logits at the cut: this example again, selected by a full torch.topk
+                    topk_stats["fallbacks"] += 1
+                    logit_b = torch.cat([obj[m][st0[m] * A:st0[m] * A + (seg[m + 1] - seg[m])] for m in range(n_maps)])
+                    k_ = boxes.shape[0]
+                    _, sel = logit_b.topk(k_, dim=0, sorted=True)
+                    nms_boxes = torch.empty((k_, 7), dtype=torch.float32, device=dev)
+                    check(lib.aabr_rpn_decode_maps(n_maps, coords_p, obj_p, reg_p, _hip.i32xn(seg), _hip.i32xn(st0), strides_h,
+                                                   ptr(ba), A, float(voxel_scale), weights_h, float(bbox_xform_clip),
+                                                   float(nms_aug_thickness[0]), float(nms_aug_thickness[1]), ptr(sel), k_,
+                                                   ptr(boxes), ptr(nms_boxes), ptr(scores), stream()))
+                    kp = _nms.rotate_nms_sorted(nms_boxes, nms_thresh, post_nms_top_n, _nms.REFERENCE_DEBUG_ONLY_XY)
+                    out[i] = (boxes[kp], scores[kp])
+                    continue
                 k = keep[:nk]
                 out[i] = (boxes[k], scores[k])
         return out

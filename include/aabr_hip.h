@@ -37,7 +37,7 @@ const char *aabr_last_error(void);
 #define AABR_ABI_VERSION 500
 int aabr_version(void);
 /* Tuning knobs for experiments and tests (no counterpart in the reference; the defaults are what ships): CONV_WIDE,
- * CONV_WIDE_BF16 (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, CONV_WLDS,
+ * CONV_WIDE_BF16, CONV_RB (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, CONV_WLDS,
  * CONV_SMALL, CONV_NBW, CONV_WPB, VOXEL_MEAN.  A knob takes its value from the environment variable AABR_<NAME>,
  * read ONCE at its first use in the process; aabr_set_knob overrides it (unset != 0: back to "no value").  No entry
  * point reads the environment on its launch path.                                                              */
@@ -445,6 +445,16 @@ int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *ou
  * aabr_rpn_proposals_batch: per example aabr_rpn_decode_maps on selected[b] followed by aabr_rotate_nms_sorted of
  *   the decoded list; boxes / nms_boxes [nb,k,7], scores [nb,k], mask [nb][k*ceil(k/64)], keep [nb,k],
  *   meta [nb][AABR_META_WORDS] (meta[b][0] = number kept, left on the device).  At most 8 maps, 16 examples.  */
+/* aabr_rpn_topk_maps (round 5): the per-example `objectness.topk(pre_nms_top_n, sorted=True)` of RPNPostProcessor
+ *   (rpn/inference_3d.py:107-112) for ALL examples of a step in four launches, on the logits (sigmoid is monotone), with
+ *   nothing concatenated: selected[b][0..k_host[b]) = indices into example b's cross-scale anchor list (tables as for
+ *   aabr_rpn_gather_logits) in descending logit order, equal logits by ascending index.  info[2b] = candidates gathered,
+ *   info[2b+1] != 0: more than 4096 logits share the 24-bit prefix at the cut (exact ties en masse) -- selected[b] is then
+ *   not valid and the caller falls back to a full sort.  k <= 2048.  scratch: aabr_rpn_topk_scratch_words(nb) int32.  */
+int64_t aabr_rpn_topk_scratch_words(int nb);
+int aabr_rpn_topk_maps(int n_maps, const void *const *logit_ptrs, int nb, const int32_t *seg_begin_host,
+                       const int32_t *site_begin_host, int num_anchors, const int32_t *k_host, int64_t *selected,
+                       int64_t sel_stride, int32_t *info, int32_t *scratch, void *stream);
 int aabr_rpn_gather_logits(int n_maps, const void *const *logit_ptrs, int nb, const int32_t *seg_begin_host,
                            const int32_t *site_begin_host, int num_anchors, int64_t lmax, float *out, void *stream);
 int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_ptrs, const void *const *logit_ptrs,
@@ -474,6 +484,19 @@ int aabr_conv_wide_split_bf16(int n_in, int n_out, int64_t rows_in, int64_t V_ou
 int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
                                       int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
                                       int flags, const uint16_t *wpack, int parts, float *scratch, void *stream);
+
+/* Wide layers in bf16 storage with register accumulators over 256-row tiles (csrc/conv_rb.hip; extension): the same sum as
+ * aabr_conv_forward_wide_bf16 (Convolution.cpp:117-185), read from the GATHER TABLE `table` [vol][V_out] instead of a block
+ * stream: a workgroup owns 256 consecutive output rows x all columns, an offset's weights are fetched once per tile by
+ * LDS-DMA, partner rows go straight into the MFMA operand layout.  Meant for brick-major rows (a tile's rows are spatial
+ * neighbours and share their empty offsets); correct for any order.  n_in, n_out in {64, 128}, vol <= 27; wpack = the bf16
+ * pack of aabr_conv_pack_weights2_bf16 in the orientation of the launch (flags bit 0: the caller passes the transposed
+ * pack; bit 1: mirrored offsets, the submanifold input-gradient form).  aabr_conv_rb_ok: 1 = the dispatch sends this
+ * launch here (knob CONV_RB: 0 never, 1 whenever supported).                                                       */
+int aabr_conv_rb_ok(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
+int aabr_conv_forward_rb_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
+                              int64_t V_out, const int32_t *table, int vol, const float *bias, int flags,
+                              const uint16_t *wpack, void *stream);
 
 /* 32 -> 32 plane layers (the finest scales; csrc/conv_narrow.hip): the same sum as aabr_conv_forward (Convolution.cpp:
  * 117-185), read from the GATHER TABLE `table` [vol][V_out] (input row of output row o at offset k, or -1 -- what

@@ -684,3 +684,94 @@ def test_grouped_convolutions_match_block_diagonal_oracle(groups, nIn, nOut):
     for k in range(groups):
         np.testing.assert_allclose(gd[:, k], dWd[:, k * ip:(k + 1) * ip, k * op:(k + 1) * op], rtol=1e-4,
                                    atol=1e-5 * np.abs(dWd).max())
+
+
+def test_fused_cross_scale_topk_matches_torch_topk():
+    """aabr_rpn_topk_maps (csrc/iou_nms.hip): the per-example `objectness.topk(pre_nms_top_n, sorted=True)` of
+    RPNPostProcessor (rpn/inference_3d.py:107-112) for all examples in four launches, over the maps' logit vectors through
+    the segment table (nothing concatenated) -- against torch.topk on the concatenated copy: same values in the same order,
+    same index set, equal logits by ascending index; k > half the list, k = the whole list, an empty example, negative /
+    zero / repeated logits; > 4096 exact ties at the cut are reported, and rpn_proposals then falls back."""
+    import _hip
+    from _hip import ptr, stream, check
+    lib = _hip.load()
+    rng = np.random.default_rng(77)
+    A, n_maps, nb = 4, 3, 4
+    counts = [[5000, 3000, 0, 700], [800, 0, 0, 90], [64, 10, 0, 3]]       # sites per (map, example)
+    obj = []
+    for m in range(n_maps):
+        v = rng.standard_normal(sum(counts[m]) * A).astype(np.float32)
+        v[rng.integers(0, v.size, v.size // 50)] = 0.0                      # repeated values (exact ties)
+        v[rng.integers(0, v.size, v.size // 80)] = 1.25
+        obj.append(_t(v))
+    segs, sites, s0 = [], [], [0] * n_maps
+    for bi in range(nb):
+        seg = [0]
+        for m in range(n_maps):
+            seg.append(seg[-1] + counts[m][bi] * A)
+        segs += seg
+        sites += s0
+        s0 = [s0[m] + counts[m][bi] for m in range(n_maps)]
+    ns = [segs[bi * (n_maps + 1) + n_maps] for bi in range(nb)]
+    for kreq in (2000, 600, 1):
+        ks = [min(kreq, n) for n in ns]
+        kmax = max(ks)
+        sel = torch.full((nb, kmax), -1, dtype=torch.int64, device=DEV)
+        info = torch.full((nb, 2), -1, dtype=torch.int32, device=DEV)
+        scr = torch.empty(int(lib.aabr_rpn_topk_scratch_words(nb)) + 2, dtype=torch.int32, device=DEV)
+        off = (-scr.data_ptr() // 4) % 2
+        check(lib.aabr_rpn_topk_maps(n_maps, _hip.ptrs(obj), nb, _hip.i32xn(segs), _hip.i32xn(sites), A, _hip.i32xn(ks),
+                                     ptr(sel), kmax, ptr(info), scr.data_ptr() + 4 * off, stream()))
+        inf = info.cpu().numpy()
+        st = [0] * n_maps
+        for bi in range(nb):
+            cat = torch.cat([obj[m][st[m] * A:(st[m] + counts[m][bi]) * A] for m in range(n_maps)])
+            st = [st[m] + counts[m][bi] for m in range(n_maps)]
+            k = ks[bi]
+            assert inf[bi, 1] == 0 and inf[bi, 0] >= k
+            if k == 0:
+                continue
+            got = sel[bi, :k]
+            tv, ti = cat.topk(k, sorted=True)
+            assert torch.equal(cat[got], tv)                                  # the same values, in the same order
+            # equal logits come out by ascending index; the selection at the cut takes the lowest indices
+            c = cat.cpu().numpy()
+            order = np.lexsort((np.arange(c.size), -c.astype(np.float64)))
+            np.testing.assert_array_equal(got.cpu().numpy(), order[:k])
+    # > 4096 exactly equal logits at the cut: reported
+    flat = [_t(np.full(sum(counts[m]) * A, 0.5, np.float32)) for m in range(n_maps)]
+    ks = [min(2000, n) for n in ns]
+    check(lib.aabr_rpn_topk_maps(n_maps, _hip.ptrs(flat), nb, _hip.i32xn(segs), _hip.i32xn(sites), A, _hip.i32xn(ks), ptr(sel),
+                                 max(ks), ptr(info), scr.data_ptr() + 4 * off, stream()))
+    inf = info.cpu().numpy()
+    assert inf[0, 1] == 1 and inf[1, 1] == 1 and inf[2, 1] == 0 and inf[3, 1] == 0     # 35 k / 12 k tied; empty; 3,172 tied: sorted
+    assert lib.aabr_rpn_topk_maps(n_maps, _hip.ptrs(flat), nb, _hip.i32xn(segs), _hip.i32xn(sites), A, _hip.i32xn([3000] * nb),
+                                  ptr(sel), 3000, ptr(info), scr.data_ptr() + 4 * off, stream()) != 0   # k <= 2048
+
+
+def test_rpn_proposals_fall_back_when_the_cut_is_tied_en_masse():
+    """all logits equal (an untrained head can do that): the fused top-k reports the overflow and rpn_proposals selects that
+    example with torch.topk instead -- same proposals as the round-4 path"""
+    scn = _scn()
+    import rpn_glue
+    rng = np.random.default_rng(5)
+    n, sp, A = 3000, (64, 64, 8), 4
+    coords = np.stack([rng.integers(0, sp[0], n), rng.integers(0, sp[1], n), rng.integers(0, sp[2], n),
+                       np.zeros(n, np.int64)], 1).astype(np.int64)
+    x = scn.InputLayer(3, list(sp), mode=3)([_t(coords), _t(np.zeros((n, 1), np.float32))])
+    V = x.features.shape[0]
+    base = np.zeros((A, 7), np.float32)
+    base[:, 3:6] = [0.2, 1.5, 2.6]
+    base[:, 6] = [0.0, -1.57, -0.785, 0.785]
+    obj = _t(np.full(V * A, 0.25, np.float32))
+    reg = _t((rng.standard_normal((V * A, 7)) * 0.3).astype(np.float32))
+    args = ([x], [obj], [reg], [torch.as_tensor(base)], [(4.0, 4.0, 4.0)], 20.0, 600, 150, 0.5, (0.3, 0.3))
+    f0 = rpn_glue.topk_stats["fallbacks"]
+    a = rpn_glue.rpn_proposals(*args)
+    assert rpn_glue.topk_stats["fallbacks"] == f0 + 1
+    rpn_glue.fused_topk = False
+    try:
+        b = rpn_glue.rpn_proposals(*args)
+    finally:
+        rpn_glue.fused_topk = True
+    assert len(a) == len(b) == 1 and a[0][0].shape == b[0][0].shape and a[0][0].shape[0] > 0
