@@ -42,7 +42,7 @@ _SIGS = {
     "aabr_sample_offsets": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "aabr_brick_scratch_words": (C.c_int64, [_i64, _i64]),
     "aabr_brick_build": (C.c_int, [_vp, _i64, _vp, _i32p, _i32p, _i32p, _i32p, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
-                                   _vp]),
+                                   _i32, _vp]),
     "aabr_brick_renumber": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                                       _vp, _vp]),
     "aabr_brick_submanifold_table": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _i32p, _vp, _vp, _vp]),
@@ -304,6 +304,45 @@ def read_back(t):
         return flat if t.dim() == 1 else flat[0]
     import numpy as _np
     return _np.array(flat).reshape(tuple(t.shape)).tolist()
+
+
+class Mailbox(object):
+    """A mailbox of its own for a read that is POSTED now and COLLECTED later (read_back above posts and spins at once):
+    `post(tensor)` enqueues the copy kernel on the current stream, `wait()` spins until it has run and returns the list.
+    One post in flight per object."""
+
+    def __init__(self, nbytes=_MB_BYTES):
+        box = C.c_void_p()
+        self.ok = load().aabr_mailbox_create(nbytes, C.byref(box)) == 0 and bool(box.value)
+        self.box, self.seq, self.nbytes = box.value, 0, nbytes
+        self.word = C.c_uint32.from_address(box.value) if self.ok else None
+        self.pending = None
+
+    def post(self, t):
+        assert self.pending is None, "one post in flight per mailbox"
+        ct = _CT[t.dtype]
+        n = t.numel()
+        if not self.ok or n * t.element_size() > self.nbytes:
+            self.pending = ("sync", t)
+            return
+        t = t.contiguous()
+        self.seq = (self.seq % 0x7fffffff) + 1
+        check(load().aabr_mailbox_post(ptr(t), n * t.element_size(), self.box, self.seq, stream()))
+        self.pending = ("box", t, ct, n)        # (the tensor stays alive until the kernel has read it)
+
+    def wait(self):
+        p, self.pending = self.pending, None
+        if p[0] == "sync":
+            return p[1].reshape(-1).tolist()
+        _, t, ct, n = p
+        t0, spins = None, 0
+        while self.word.value != self.seq:
+            spins += 1
+            if spins & 0xfffff == 0:
+                t0 = t0 or _time.monotonic()
+                if _time.monotonic() - t0 > 120.0:
+                    raise RuntimeError("aabr mailbox: no answer from the device after 120 s")
+        return list((ct * n).from_address(self.box + 8))
 
 
 def last_post_clock():

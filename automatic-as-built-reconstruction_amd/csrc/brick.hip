@@ -270,8 +270,10 @@ extern "C" int64_t aabr_brick_scratch_words(int64_t dir_words_, int64_t nb_cap) 
 extern "C" int aabr_brick_build(const int32_t *in_coords, int64_t vin_bound, const int32_t *vin_count_dev,
                                 const int32_t *size_host, const int32_t *stride_host, const int32_t *out_spatial_host,
                                 const int32_t *dims_host, void *dir, void *bricks, int64_t nb_cap, int32_t *bcoord,
-                                int32_t *out_coords, int64_t v_cap, int32_t *meta, int32_t *scratch, void *stream_) {
+                                int32_t *out_coords, int64_t v_cap, int32_t *meta, int32_t *scratch, int flags,
+                                void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG((flags & ~1) == 0, "flags: bit 0 = the caller has cleared dir / bricks / meta / scratch");
   AABR_CHECK_ARG(vin_bound >= 0 && vin_bound < (int64_t)0x7fffffff && size_host && stride_host && out_spatial_host,
                  "bad arguments");
   ConvGeom g;
@@ -289,14 +291,16 @@ extern "C" int aabr_brick_build(const int32_t *in_coords, int64_t vin_bound, con
   unsigned long long *status0 = reinterpret_cast<unsigned long long *>(scratch);
   unsigned long long *status1 = status0 + c0;
   int32_t *tickets = reinterpret_cast<int32_t *>(status1 + c1);
-  if ((char *)bricks == (char *)dir + (size_t)nw * 16)       // one allocation (the layout the Python side uses): ONE fill
-    AABR_CHECK_HIP(hipMemsetAsync(dir, 0, (size_t)(nw + nb_cap) * 16, st));
-  else {
-    AABR_CHECK_HIP(hipMemsetAsync(dir, 0, (size_t)nw * 16, st));
-    AABR_CHECK_HIP(hipMemsetAsync(bricks, 0, (size_t)nb_cap * 16, st));
+  if (!(flags & 1)) {
+    if ((char *)bricks == (char *)dir + (size_t)nw * 16)     // one allocation (the layout the Python side uses): ONE fill
+      AABR_CHECK_HIP(hipMemsetAsync(dir, 0, (size_t)(nw + nb_cap) * 16, st));
+    else {
+      AABR_CHECK_HIP(hipMemsetAsync(dir, 0, (size_t)nw * 16, st));
+      AABR_CHECK_HIP(hipMemsetAsync(bricks, 0, (size_t)nb_cap * 16, st));
+    }
+    AABR_CHECK_HIP(hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st));
+    AABR_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)(2 * (c0 + c1) + 4) * sizeof(int32_t), st));
   }
-  AABR_CHECK_HIP(hipMemsetAsync(meta, 0, AABR_META_WORDS * sizeof(int32_t), st));
-  AABR_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)(2 * (c0 + c1) + 4) * sizeof(int32_t), st));
   if (vin_bound > 0)
     hipLaunchKernelGGL(k_brick_mark<1>, grid1(vin_bound, 256), dim3(256), 0, st, in_coords, vin_bound, vin_count_dev, g,
                        d, (uint4 *)dir, (uint4 *)bricks, nb_cap, (int4 *)bcoord, meta);

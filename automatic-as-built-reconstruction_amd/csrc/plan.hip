@@ -529,7 +529,7 @@ extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
       char *lvl = (char *)p[2];
       rc = aabr_brick_build((const int32_t *)p[0], o.i64[0], (const int32_t *)p[1], &o.i32[0], &o.i32[3], &o.i32[6], dims,
                             lvl, lvl + dir_bytes(dims), o.i64[2], (int32_t *)p[3], (int32_t *)p[4], o.i64[3],
-                            (int32_t *)p[5], (int32_t *)p[6], st);
+                            (int32_t *)p[5], (int32_t *)p[6], o.i32[9], st);
       break;
     }
     case AABR_GEOM_BRICK_SUBM: {

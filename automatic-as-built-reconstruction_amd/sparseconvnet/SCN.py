@@ -259,7 +259,7 @@ class _Brick(object):
     axis) the directory covers, `dims` = (super-bricks per axis x3, samples)."""
     __slots__ = ("level", "dims", "packed", "nw", "nb_cap", "v_cap", "bcoord", "meta", "ext", "coords_full")
 
-    def __init__(self, ext, nsamples, nb_bound, v_bound, device, meta):
+    def __init__(self, ext, nsamples, nb_bound, v_bound, device, meta, alloc=True):
         self.ext = tuple(int(e) for e in ext)
         self.dims = tuple(max((e + 15) // 16, 1) for e in self.ext) + (max(int(nsamples), 1),)
         assert all(d <= 4096 for d in self.dims[:3]) and self.dims[3] <= 65535
@@ -267,7 +267,7 @@ class _Brick(object):
         self.nw = self.dims[0] * self.dims[1] * self.dims[2] * self.dims[3]
         self.v_cap = max(min(int(v_bound), self.nw * 4096), 1)
         self.nb_cap = max(min(int(nb_bound), self.v_cap, self.nw * 64), 1)
-        self.level = torch.empty(4 * (self.nw + self.nb_cap), dtype=torch.int32, device=device)
+        self.level = torch.empty(4 * (self.nw + self.nb_cap), dtype=torch.int32, device=device) if alloc else None
         self.bcoord = torch.empty((self.nb_cap, 4), dtype=torch.int32, device=device)
         self.coords_full = torch.empty((self.v_cap, 4), dtype=torch.int32, device=device)
         self.meta = meta
@@ -285,15 +285,17 @@ class _Brick(object):
         return [self.level, self.bcoord, self.coords_full, self.meta]
 
 
-def _brick_build(src_coords, vin_bound, vin_count_ptr, size, stride, out_sp, bk):
-    """record / launch aabr_brick_build of level `bk` from the sites `src_coords`"""
+def _brick_build(src_coords, vin_bound, vin_count_ptr, size, stride, out_sp, bk, flags=0, scratch=None):
+    """record / launch aabr_brick_build of level `bk` from the sites `src_coords` (flags: 1 = buffers already cleared by
+    the caller)"""
     lib = _hip.load()
-    scratch = torch.empty(int(lib.aabr_brick_scratch_words(bk.nw, bk.nb_cap)) + 2, dtype=torch.int32,
-                          device=bk.level.device)
-    so = (-scratch.data_ptr() // 4) % 2          # 8-byte aligned status words
-    _geom(G_BK_BUILD, tuple(size) + tuple(stride) + tuple(out_sp), (vin_bound, bk.packed, bk.nb_cap, bk.v_cap),
+    if scratch is None:
+        scratch = torch.empty(int(lib.aabr_brick_scratch_words(bk.nw, bk.nb_cap)) + 2, dtype=torch.int32,
+                              device=bk.level.device)
+    sp = scratch.data_ptr() + 4 * ((-scratch.data_ptr() // 4) % 2)              # 8-byte aligned status words
+    _geom(G_BK_BUILD, tuple(size) + tuple(stride) + tuple(out_sp) + (flags,), (vin_bound, bk.packed, bk.nb_cap, bk.v_cap),
           (_p(src_coords), vin_count_ptr, bk.level.data_ptr(), bk.bcoord.data_ptr(), bk.coords_full.data_ptr(),
-           bk.meta.data_ptr(), scratch.data_ptr() + 4 * so))
+           bk.meta.data_ptr(), sp))
     _keep(scratch)
     return scratch
 
@@ -344,6 +346,7 @@ def _brick_dir_words(extent):
     return w
 
 
+_geom_mailboxes = []     # recycled _hip.Mailbox objects of deferred pyramid reads
 _BK_MAX_LEVELS = 48  # brick levels of one Metadata (input + strided levels); one read-back row each:
 _BK_ROW = 64 + 16    # [V, per-sample offsets .. (64 words) | the level's meta block (16 words)]
 
@@ -777,12 +780,23 @@ class Metadata_3(object):
         g = _Grid(bk.coords_full[:V], None, None, 0, V, None, bk)
         return g
 
-    def _brick_read(self):
+    def _brick_read(self, post_only=False, posted=None):
         """ONE host read for every brick level enqueued since the last one: [V, per-sample offsets (64 words), meta (16)]
-        per level; checks the error flags"""
-        flush_geom()
+        per level; checks the error flags.  `post_only`: enqueue the read (a mailbox of this thread's own) and return the
+        handle; `posted`: collect such a read -- the host does other work while the levels are built."""
         n = self._brick_nrows
-        rows = _hip.read_back(self._brick_rows[:n].reshape(-1))
+        if posted is None:
+            flush_geom()
+            if post_only:
+                mb = _geom_mailboxes.pop() if _geom_mailboxes else _hip.Mailbox()
+                mb.post(self._brick_rows[:n].reshape(-1))
+                return (mb, n)
+            rows = _hip.read_back(self._brick_rows[:n].reshape(-1))
+        else:
+            mb, n = posted
+            rows = mb.wait()
+            if len(_geom_mailboxes) < 4:
+                _geom_mailboxes.append(mb)
         rows = [rows[i * _BK_ROW:(i + 1) * _BK_ROW] for i in range(n)]
         for i, r in enumerate(rows):
             if r[64 + 2]:
@@ -794,16 +808,25 @@ class Metadata_3(object):
                                  % (rows[0][64], g0.V))
         return rows
 
-    def buildBrickPyramid(self, specs):
+    def finishBrickPyramid(self):
+        """collect a pyramid enqueued with `buildBrickPyramid(.., defer=True)` (no-op when there is none)"""
+        pend = self.__dict__.pop("_pyramid_pending", None)
+        if pend is not None:
+            self._pyramid_collect(*pend)
+
+    def buildBrickPyramid(self, specs, defer=False):
         """Extension: the strided levels of a pass as brick grids, each built from its parent LEVEL by device-side counts
         (aabr_brick_build), all enqueued back to back, ONE host read for all of their site counts and per-sample offsets.
         specs = [(out_spatial key, source spatial key, size, stride)] in dependency order."""
+        self.finishBrickPyramid()
         todo = [sp for sp in specs if sp[0] not in self.grids]
         if not todo:
             return
         dev = self._brick_rows.device
+        lib = _hip.load()
         made = {}
         first_row = self._brick_nrows
+        plan = []
         for osz, src, size, stride in todo:
             gs = made.get(src) or self.grids[src]
             bs = gs.brick
@@ -814,11 +837,30 @@ class Metadata_3(object):
             row = self._brick_rows[self._brick_nrows]
             self._brick_nrows += 1
             assert self._brick_nrows <= _BK_MAX_LEVELS
-            bk = _Brick(ext, bs.dims[3], bs.nb_cap * maxout, bs.v_cap * maxout, dev, row[64:64 + _hip.META_WORDS])
-            _brick_build(bs.coords_full, bs.v_cap, bs.meta.data_ptr(), size, stride, osz, bk)
-            _geom(G_SOFF, (MAX_SAMPLES + 1,), (bk.v_cap,), (_p(bk.coords_full), bk.meta.data_ptr(), row.data_ptr()))
+            bk = _Brick(ext, bs.dims[3], bs.nb_cap * maxout, bs.v_cap * maxout, dev, row[64:64 + _hip.META_WORDS], alloc=False)
             made[osz] = _Grid(None, None, None, 0, None, None, bk)
-        rows = self._brick_read()
+            plan.append((osz, bs, size, stride, bk, row))
+        # ONE allocation and ONE fill for the directories, bricks and scan scratch of all the levels built here
+        words, offs = 0, []
+        for osz, bs, size, stride, bk, row in plan:
+            lw = 4 * (bk.nw + bk.nb_cap)
+            sw = (int(lib.aabr_brick_scratch_words(bk.nw, bk.nb_cap)) + 3) // 4 * 4
+            offs.append((words, lw, sw))
+            words += lw + sw
+        arena = torch.zeros(max(words, 4), dtype=torch.int32, device=dev)
+        self._brick_rows[first_row:self._brick_nrows].zero_()
+        self._brick_keep.append(arena)
+        for (osz, bs, size, stride, bk, row), (o, lw, sw) in zip(plan, offs):
+            bk.level = arena[o:o + lw]
+            _brick_build(bs.coords_full, bs.v_cap, bs.meta.data_ptr(), size, stride, osz, bk, 1, arena[o + lw:o + lw + sw])
+            _geom(G_SOFF, (MAX_SAMPLES + 1,), (bk.v_cap,), (_p(bk.coords_full), bk.meta.data_ptr(), row.data_ptr()))
+        if defer:        # the levels are being built; the host collects their counts later (finishBrickPyramid)
+            self._pyramid_pending = (todo, made, first_row, self._brick_read(post_only=True))
+            return
+        self._pyramid_collect(todo, made, first_row, None)
+
+    def _pyramid_collect(self, todo, made, first_row, posted):
+        rows = self._brick_read(posted=posted) if posted is not None else self._brick_read()
         pre = self.__dict__.setdefault("_pregrids", set())
         for (osz, src, size, stride), r in zip(todo, rows[first_row:]):
             g = made[osz]

@@ -275,7 +275,7 @@ class FPN_Net(torch.nn.Module):
         if g0 is not None and g0.brick is not None:
             # brick grids: every level from its PARENT level with device-side counts, the z-collapse grids from their own
             # level -- ONE host read for the whole pyramid (Metadata_3.buildBrickPyramid)
-            md.buildBrickPyramid(self._brick_specs(sp))
+            md.buildBrickPyramid(self._brick_specs(sp), defer=bool(getattr(md, "_defer_pyramid", False)))
             return
         if sp["rounds"] is None:
             return
@@ -334,7 +334,15 @@ class FPN_Net(torch.nn.Module):
         rule tables, compiled block streams -- on `stream` while the current batch still trains on the main stream.
         The geometry depends on the coordinates only, so this is the device-side analogue of a data-loader prefetch;
         its host reads (one site count per grid) wait for `stream` alone.  `forward` picks the prepared Metadata up
-        when it is called with the same coordinate tensor (InputLayer._prepared)."""
+        when it is called with the same coordinate tensor (InputLayer._prepared).
+        = `prepare_begin` + `prepare_end`: a caller with other launches to enqueue puts them between the two, and the host
+        then does not sit waiting while the device builds the level pyramid (brick grids only)."""
+        self.prepare_begin(input, stream)
+        self.prepare_end()
+
+    def prepare_begin(self, input, stream):
+        """first half of `prepare`: voxel scatter, (brick grids:) the input level's bricks and the whole pyramid of strided
+        levels ENQUEUED, their counts' read posted"""
         coords = input[0]
         inp_layer = self.layers_in[0]
         dev = coords.device if coords.is_cuda else torch.device("cuda", torch.cuda.current_device())
@@ -344,6 +352,24 @@ class FPN_Net(torch.nn.Module):
         SCN._reap_handed_over()      # geometry of earlier passes whose parking event has passed (also reaped by forward)
         with torch.cuda.stream(stream):
             md.inputLayerFinish()
+            g0 = md.grids.get(SCN._key(inp_layer.spatial_size))
+            if g0 is not None and g0.brick is not None and self.grids_from_input:
+                sp = self._size_plan(inp_layer.spatial_size)
+                md._defer_pyramid = True
+                try:
+                    with SCN.geom_plan():
+                        self._grids_from_input(md, sp)
+                finally:
+                    md._defer_pyramid = False
+        self._preparing = (md, stream)
+
+    def prepare_end(self):
+        """second half of `prepare`: collect the pyramid's counts, then every rule table and block stream"""
+        md, stream = self.__dict__.pop("_preparing")
+        inp_layer = self.layers_in[0]
+        from . import SCN
+        with torch.cuda.stream(stream):
+            md.finishBrickPyramid()
             stub = scn.SparseConvNetTensor(None, md, inp_layer.spatial_size)
             with SCN.geom_plan():     # the builders' launches as a few lists (one per blocking read) instead of ~250 calls
                 sizes = self._prebuild_geometry(stub)

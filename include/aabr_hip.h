@@ -170,12 +170,15 @@ int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t
  * Convolution_InputSgToRulesAndOutputSg creates (ConvolutionRules.h:11-34).  Writes dir, bricks, bcoord [NB] int32x4
  * brick coordinates, out_coords [V] int32x4 (x, y, z, batch) in row order and meta (meta[0] = V, meta[1] = NB, meta[2] != 0:
  * a site outside the extent `dims` covers, or more than nb_cap bricks / v_cap sites).  Nothing is read back: a chain of
- * levels is enqueued back to back with device-side counts.  scratch: aabr_brick_scratch_words(dir words, nb_cap) int32. */
+ * levels is enqueued back to back with device-side counts.  scratch: aabr_brick_scratch_words(dir words, nb_cap) int32.
+ * flags bit 0: the caller has zeroed dir, bricks, meta and scratch (a pyramid's levels share ONE fill).  A one-workgroup
+ * form for the coarse levels (every phase in a single launch) was built and measured slower than the eight small launches it
+ * replaced (returning atomics in a serial loop: 930 vs 615 us for the 12 strided grids of the bench batch) and removed.  */
 int64_t aabr_brick_scratch_words(int64_t dir_words, int64_t nb_cap);
 int aabr_brick_build(const int32_t *in_coords, int64_t vin_bound, const int32_t *vin_count_dev, const int32_t *size_host,
                      const int32_t *stride_host, const int32_t *out_spatial_host, const int32_t *dims_host, void *dir,
                      void *bricks, int64_t nb_cap, int32_t *bcoord, int32_t *out_coords, int64_t v_cap, int32_t *meta,
-                     int32_t *scratch, void *stream);
+                     int32_t *scratch, int flags, void *stream);
 /* Input level: the voxel scatter numbers its sites in first-seen order (IOLayersRules.h:86-91); old_coords [V] are those
  * sites, (dir, bricks) the brick level built from them.  new_of_old[r] / old_of_new[i] = the permutation; first_pt /
  * cnt_extra / head re-indexed by the new rows; point_site2[p] = new row of point p's site.                           */
@@ -613,7 +616,7 @@ void aabr_plan_launcher_stats(int64_t *busy_ns, int64_t *parts, int64_t *sleeps)
 /* brick grids (one allocation per level: the directory, then the bricks; dims packed sbx | sby << 16 | sbz << 32 | nb << 48):
  *   AABR_GEOM_BRICK_BUILD   aabr_brick_build(p0 in_coords, i64[0] vin_bound, p1 vin_count_dev, i32[0..2] size, i32[3..5]
  *                           stride, i32[6..8] out_spatial, i64[1] dims, p2 level, i64[2] nb_cap, p3 bcoord, p4 out_coords,
- *                           i64[3] v_cap, p5 meta, p6 scratch)
+ *                           i64[3] v_cap, p5 meta, p6 scratch, i32[9] flags)
  *   AABR_GEOM_BRICK_SUBM    aabr_brick_submanifold_table(p0 coords, i64[0] V, i64[1] dims, p1 level, i32[0..2] filter,
  *                           p2 table, p3 block counts)
  *   AABR_GEOM_BRICK_TABLES  aabr_brick_convolution_tables(p0 in_coords, i64[0] V_in, i64[2] in dims, p1 in level,

@@ -297,3 +297,33 @@ def test_brick_fpn_net_equals_first_seen_fpn_net_site_by_site():
         if ga is not None:
             worst = max(worst, rel_l2(ga, gb))
     assert worst <= 1e-2, worst
+
+
+def test_prepare_in_two_halves_gives_the_same_pass():
+    """FPN_Net.prepare_begin / prepare_end (the level pyramid enqueued, its counts collected later, other launches in
+    between) against a pass without any prefetch: same maps, bit for bit"""
+    scn = _scn()
+    import synth_scenes as S
+    from test_cabi_and_host import default_fpn
+    torch.manual_seed(4)
+    net = default_fpn().to(DEV)
+    net.compiled_graph = True
+    net.set_site_order("brick")
+    locs, feats = S.make_batch(2, 6000, 50, 50)
+    l, f = _t(locs), _t(feats)
+    with torch.no_grad():
+        a_rpn, a_roi = net([l, f])
+        want = [(m.get_spatial_locations().numpy(), m.features.clone()) for m in a_rpn + a_roi]
+        side = torch.cuda.Stream()
+        net.prepare_begin([l, f], side)
+        filler = torch.randn(1024, 1024, device=DEV) @ torch.randn(1024, 1024, device=DEV)    # other work in between
+        md = net._preparing[0]
+        assert md.__dict__.get("_pyramid_pending") is not None and len(md.grids) == 1       # levels enqueued, not collected
+        net.prepare_end()
+        assert len(md.grids) > 9 and md.__dict__.get("_pyramid_pending") is None
+        b_rpn, b_roi = net([l, f])
+        assert b_rpn[0].metadata is md                                                      # the prepared geometry was used
+    for (lw, fw), m in zip(want, b_rpn + b_roi):
+        np.testing.assert_array_equal(m.get_spatial_locations().numpy(), lw)
+        assert torch.equal(m.features, fw)
+    del filler
