@@ -45,6 +45,8 @@ _SIGS = {
                                    _i32, _vp]),
     "aabr_brick_renumber": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                                       _vp, _vp]),
+    "aabr_points_prepare": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "aabr_points_sites": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aabr_brick_submanifold_table": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _i32p, _vp, _vp, _vp]),
     "aabr_brick_convolution_tables": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _i64, _i32p, _vp, _vp, _i32p, _i32p,
                                                 _i32p, _vp, _vp, _vp, _vp, _vp]),

@@ -22,16 +22,17 @@ constexpr int kBkMetaV = 0, kBkMetaNB = 1, kBkMetaErr = 2;   // meta words of a 
 
 // OR `bits` into arr[idx] (64-bit words) for every lane with idx >= 0.  Lanes of a wave that address the same word --
 // the common case: consecutive items are spatial neighbours -- are merged into one atomic; after kAggRounds distinct
-// words the rest go out on their own.  Returns, per lane, the word's value BEFORE this wave's update.  Wave-uniform call.
+// words the rest go out on their own.  Nobody reads the old value: the atomics are fire-and-forget (a returning atomic
+// in the merge loop made every round wait for its round trip).  Returns true in the lanes that issued an atomic (one per
+// distinct word and round).  Wave-uniform call.
 constexpr int kAggRounds = 4;
-__device__ inline unsigned long long wave_or64(unsigned long long *arr, int64_t idx, unsigned long long bits) {
-  bool active = idx >= 0;
-  unsigned long long old = ~0ull;
+__device__ inline bool wave_or64(unsigned long long *arr, int64_t idx, unsigned long long bits) {
+  bool active = idx >= 0, issued = false;
   const int lane = threadIdx.x & 63;
 #pragma unroll 1
   for (int it = 0; it < kAggRounds; ++it) {
     const unsigned long long am = __ballot(active);
-    if (!am) return old;
+    if (!am) return issued;
     const int leader = __ffsll((long long)am) - 1;
     const int lo = __shfl((int)(uint32_t)idx, leader), hi = __shfl((int)(uint32_t)((uint64_t)idx >> 32), leader);
     const int64_t k = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
@@ -42,20 +43,17 @@ __device__ inline unsigned long long wave_or64(unsigned long long *arr, int64_t 
       vlo |= (uint32_t)__shfl_xor((int)vlo, d);
       vhi |= (uint32_t)__shfl_xor((int)vhi, d);
     }
-    unsigned long long o = 0ull;
-    if (lane == leader) o = atomicOr(&arr[k], ((unsigned long long)vhi << 32) | vlo);
-    const uint32_t olo = (uint32_t)__shfl((int)(uint32_t)o, leader), ohi = (uint32_t)__shfl((int)(uint32_t)(o >> 32), leader);
-    if (same) old = ((unsigned long long)ohi << 32) | olo;
+    if (lane == leader) { atomicOr(&arr[k], ((unsigned long long)vhi << 32) | vlo); issued = true; }
     active = active && !same;
   }
-  if (active) old = atomicOr(&arr[idx], bits);
-  return old;
+  if (active) { atomicOr(&arr[idx], bits); issued = true; }
+  return issued;
 }
 
 // Rounds 1 and 2 of a level build.  Items = (input site u, l-th cell of its output region).
 //   ROUND 1: the item's output voxel marks its brick in the directory word of its super-brick;
-//   ROUND 2 (the directory prefix is known): the voxel sets its cell bit in its brick's mask; the wave that finds the
-//            mask empty writes the brick's coordinates.
+//   ROUND 2 (the directory prefix is known): the voxel sets its cell bit in its brick's mask and leaves the brick's
+//            coordinates (no old value is read back: every sender stores the same coordinates).
 template <int ROUND>
 __global__ __launch_bounds__(256) void k_brick_mark(const int32_t *__restrict__ in_coords, int64_t vin_bound,
                                                     const int32_t *__restrict__ vin_dev, ConvGeom g, BrickDims d,
@@ -89,9 +87,9 @@ __global__ __launch_bounds__(256) void k_brick_mark(const int32_t *__restrict__ 
         bi = (int64_t)e.z + __popcll(word & ((1ull << jb) - 1ull));     // the bit itself was set in round 1
         if (bi >= nb_cap) { err = true; bi = -1; }
       }
-      const unsigned long long old = wave_or64(reinterpret_cast<unsigned long long *>(bricks), bi >= 0 ? 2 * bi : -1,
-                                               1ull << brick_cell(j[0], j[1], j[2]));
-      if (bi >= 0 && old == 0ull)      // (several lanes of the first wave may store the same value)
+      const bool wrote = wave_or64(reinterpret_cast<unsigned long long *>(bricks), bi >= 0 ? 2 * bi : -1,
+                                   1ull << brick_cell(j[0], j[1], j[2]));
+      if (wrote)        // whoever sends a brick's atomic also stores its coordinates (the same value from every sender)
         bcoord[bi] = make_int4(j[0] >> 2, j[1] >> 2, j[2] >> 2, ic.w);
     }
   }
@@ -105,9 +103,13 @@ constexpr int kBsThreads = 256, kBsItems = 4, kBsChunk = kBsThreads * kBsItems;
 __device__ inline unsigned long long bs_pack(unsigned flag, unsigned v) {
   return ((unsigned long long)flag << 62) | (unsigned long long)v;
 }
+// MODE 1's write-out also produces what follows from its result: the level's site list (brick by brick, cell by cell:
+// the brick's coordinates + the cell) -- no separate pass.
 template <int MODE>
 __global__ __launch_bounds__(kBsThreads) void k_brick_scan(uint4 *arr, int64_t n_bound, unsigned long long *status,
-                                                           int32_t *ticket, int32_t *meta, int64_t total_cap) {
+                                                           int32_t *ticket, int32_t *meta, int64_t total_cap, BrickDims d,
+                                                           int4 *__restrict__ bcoord, int32_t *__restrict__ site_coords,
+                                                           int64_t v_cap) {
   __shared__ int s_chunk;
   __shared__ int s_wsum[kBsThreads / 64];
   __shared__ unsigned s_excl;
@@ -119,12 +121,15 @@ __global__ __launch_bounds__(kBsThreads) void k_brick_scan(uint4 *arr, int64_t n
   if (MODE == 1) { const int64_t nb = meta[kBkMetaNB]; n = nb < n ? nb : n; }
   const int64_t base = (int64_t)chunk * kBsChunk + (int64_t)threadIdx.x * kBsItems;
   int v[kBsItems], a = 0;
+  unsigned long long bits[kBsItems];
 #pragma unroll
   for (int j = 0; j < kBsItems; ++j) {
     const int64_t i = base + j;
     v[j] = 0;
+    bits[j] = 0ull;
     if (i < n) {
       const uint4 e = arr[i];
+      bits[j] = lo64(e);
       v[j] = __popc(e.x) + __popc(e.y);
     }
     a += v[j];
@@ -187,32 +192,21 @@ __global__ __launch_bounds__(kBsThreads) void k_brick_scan(uint4 *arr, int64_t n
     const int64_t i = base + j;
     if (i < n) {
       reinterpret_cast<int32_t *>(arr + i)[2] = run;
+      unsigned long long m = bits[j];
+      if (MODE == 1 && m) {
+        const int4 bc = bcoord[i];
+        int64_t row = run;
+        while (m) {
+          const int c = __ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          if (row < v_cap)
+            *reinterpret_cast<int4 *>(site_coords + 4 * row) =
+                make_int4(4 * bc.x + (c >> 4), 4 * bc.y + ((c >> 2) & 3), 4 * bc.z + (c & 3), bc.w);
+          ++row;
+        }
+      }
       run += v[j];
     }
-  }
-}
-
-// the sites of a finished level, brick by brick, cell by cell.  One thread per brick walks its set cells: on scene data a
-// brick of the fine levels holds 1.5-3 sites (a lane per CELL launched 64 threads for them: 20 M threads at 310 k bricks),
-// and where bricks are full there are few of them.
-__global__ __launch_bounds__(256) void k_brick_expand(const uint4 *__restrict__ bricks, const int4 *__restrict__ bcoord,
-                                                      int64_t nb_cap, const int32_t *__restrict__ meta, int64_t v_cap,
-                                                      int32_t *__restrict__ site_coords) {
-  const int64_t bi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t NB = meta[kBkMetaNB];
-  NB = NB < nb_cap ? NB : nb_cap;
-  if (bi >= NB) return;
-  const uint4 br = bricks[bi];
-  unsigned long long m = lo64(br);
-  const int4 bc = bcoord[bi];
-  int64_t row = (int64_t)(int)br.z;
-  while (m) {
-    const int c = __ffsll((long long)m) - 1;
-    m &= m - 1ull;
-    if (row < v_cap)
-      *reinterpret_cast<int4 *>(site_coords + 4 * row) =
-          make_int4(4 * bc.x + (c >> 4), 4 * bc.y + ((c >> 2) & 3), 4 * bc.z + (c & 3), bc.w);
-    ++row;
   }
 }
 
@@ -244,6 +238,83 @@ __global__ __launch_bounds__(256) void k_brick_remap_points(const int32_t *__res
   if (p >= n) return;
   const int s = point_site[p];
   point_site2[p] = s >= 0 ? new_of_old[s] : s;
+}
+
+// ---- voxel scatter straight into a brick grid (InputLayer without a hash table) ----------------------------------------
+// The reference's inputLayerRules (IOLayersRules.h:18-125) dedups the points of a sample in a hash map and numbers the
+// voxels in first-seen order; voxel_scatter.hip does that on the device (LDS-binned hash build + a first-seen scan) and
+// the brick path then renumbered those sites.  Brick-major rows need neither the hash nor the first-seen numbers: a
+// voxel's row follows from where it lies.  So the POINTS are the items of the level build (aabr_brick_build with size =
+// stride = 1: duplicates set the same bits), and per point
+//   k_points_prepare : int64 (x, y, z[, b]) -> int32x4 (x = -1: skipped), validity, the scene's extent (meta[8..11]);
+//   k_points_sites   : row = brick_find(point) -> point_site; first_pt[row] = min point index (ONE atomic per point);
+//   k_points_chains  : every point that is not its voxel's first pushes itself on the voxel's chain and counts itself --
+//                      the same first_pt / cnt_extra / head / nxt the mean and backward kernels of voxel_scatter.hip read.
+// (a few hundred workgroups stride over the points: the extent costs one atomic per workgroup and axis at most -- one per
+// WAVE of a point-per-thread launch was 20 k same-address atomics, 280 us at 320 k points)
+__global__ __launch_bounds__(256) void k_points_prepare(const int64_t *__restrict__ coords, int64_t n, int ncols,
+                                                        int4 *__restrict__ pc, int32_t *meta) {
+  int ext[4] = {-1, -1, -1, -1};
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t *c = coords + i * ncols;
+    const int64_t x = c[0], y = c[1], z = c[2], b = ncols == 4 ? c[3] : 0;
+    int4 o = make_int4(-1, -1, -1, 0);
+    if (x == -1 && y == -1 && z == -1) {
+      // dropped by aabr_quantize_points (outside FULL_SCALE): skipped silently
+    } else if (x < 0 || y < 0 || z < 0 || b < 0 || x > kMaxCoord || y > kMaxCoord || z > kMaxCoord || b > kMaxCoord) {
+      bad = true;
+    } else {
+      o = make_int4((int)x, (int)y, (int)z, (int)b);
+      ext[0] = o.x > ext[0] ? o.x : ext[0]; ext[1] = o.y > ext[1] ? o.y : ext[1];
+      ext[2] = o.z > ext[2] ? o.z : ext[2]; ext[3] = o.w > ext[3] ? o.w : ext[3];
+    }
+    pc[i] = o;
+  }
+  __shared__ int s_ext[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int m = ext[q];
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+      const int o = __shfl_xor(m, dd);
+      m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) s_ext[threadIdx.x >> 6][q] = m;
+  }
+  const bool anybad = __syncthreads_or(bad ? 1 : 0) != 0;
+  if (threadIdx.x < 4) {
+    const int q = threadIdx.x;
+    int m = s_ext[0][q];
+    for (int w = 1; w < 4; ++w) m = s_ext[w][q] > m ? s_ext[w][q] : m;
+    if (m > __builtin_nontemporal_load(&meta[8 + q])) atomicMax(&meta[8 + q], m);
+  }
+  if (anybad && threadIdx.x == 0) atomicAnd(&meta[2], 0);      // meta starts at all ones: 0 = a coordinate out of range
+}
+__global__ __launch_bounds__(256) void k_points_sites(const int4 *__restrict__ pc, int64_t n, BrickLevel L,
+                                                      int32_t *__restrict__ point_site, uint32_t *first_pt,
+                                                      int32_t *meta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = pc[i];
+  int row = -1;
+  if (c.x >= 0) {
+    row = brick_find(L, c.w, c.x, c.y, c.z);
+    if (row < 0) meta[kBkMetaErr] = 1;           // (cannot happen: the point itself set the bits)
+    else atomicMin(&first_pt[row], (uint32_t)i);
+  }
+  point_site[i] = row;
+}
+__global__ __launch_bounds__(256) void k_points_chains(int64_t n, const int32_t *__restrict__ point_site,
+                                                       const uint32_t *__restrict__ first_pt, int32_t *head,
+                                                       int32_t *cnt_extra, int32_t *__restrict__ nxt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int row = point_site[i];
+  if (row >= 0 && first_pt[row] != (uint32_t)i) {          // a further point of its voxel (rare: N / V ~ 1.03 on scenes)
+    nxt[i] = atomicExch(&head[row], (int32_t)i);
+    atomicAdd(&cnt_extra[row], 1);
+  }
 }
 
 static int make_dims(const int32_t *dims_host, BrickDims &d) {
@@ -305,14 +376,12 @@ extern "C" int aabr_brick_build(const int32_t *in_coords, int64_t vin_bound, con
     hipLaunchKernelGGL(k_brick_mark<1>, grid1(vin_bound, 256), dim3(256), 0, st, in_coords, vin_bound, vin_count_dev, g,
                        d, (uint4 *)dir, (uint4 *)bricks, nb_cap, (int4 *)bcoord, meta);
   hipLaunchKernelGGL(k_brick_scan<0>, dim3((unsigned)c0), dim3(kBsThreads), 0, st, (uint4 *)dir, nw, status0, tickets,
-                     meta, nb_cap);
+                     meta, nb_cap, d, (int4 *)bcoord, (int32_t *)nullptr, (int64_t)0);
   if (vin_bound > 0)
     hipLaunchKernelGGL(k_brick_mark<2>, grid1(vin_bound, 256), dim3(256), 0, st, in_coords, vin_bound, vin_count_dev, g,
                        d, (uint4 *)dir, (uint4 *)bricks, nb_cap, (int4 *)bcoord, meta);
   hipLaunchKernelGGL(k_brick_scan<1>, dim3((unsigned)c1), dim3(kBsThreads), 0, st, (uint4 *)bricks, nb_cap, status1,
-                     tickets + 1, meta, v_cap);
-  hipLaunchKernelGGL(k_brick_expand, grid1(nb_cap, 256), dim3(256), 0, st, (const uint4 *)bricks,
-                     (const int4 *)bcoord, nb_cap, (const int32_t *)meta, v_cap, out_coords);
+                     tickets + 1, meta, v_cap, d, (int4 *)bcoord, out_coords, v_cap);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -390,6 +459,45 @@ extern "C" int aabr_brick_convolution_tables(const int32_t *in_coords, int64_t V
     hipLaunchKernelGGL(k_conv_table_in<BrickFinder>, dim3((unsigned)ceil_div(V_in, 256), (unsigned)vol), dim3(256), 0, st,
                        in_coords, V_in, fo, g, table_in, counts_in);
   }
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_points_prepare(const int64_t *coords, int64_t n, int ncols, int32_t *pc, int32_t *meta, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(n >= 0 && n < (1ll << 31) - 65536 && (ncols == 3 || ncols == 4), "0 <= n < 2^31, ncols in {3,4}");
+  AABR_CHECK_ARG(meta && (n == 0 || (coords && pc)) && ((uintptr_t)pc & 15) == 0, "null / misaligned pointer");
+  AABR_CHECK_HIP(hipMemsetAsync(meta, 0xFF, AABR_META_WORDS * sizeof(int32_t), st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_points_prepare, dim3((unsigned)(ceil_div(n, 1024) < 512 ? ceil_div(n, 1024) : 512)), dim3(256), 0, st,
+                       coords, n, ncols, (int4 *)pc, meta);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_points_sites(const int32_t *pc, int64_t n, const int32_t *dims_host, const void *dir, const void *bricks,
+                                 int32_t *point_site, int32_t *first_pt, int32_t *cnt_extra, int32_t *head, int32_t *nxt,
+                                 int32_t *meta, void *stream_) {
+  hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(n >= 0, "bad n");
+  BrickLevel L;
+  AABR_CHECK_ARG(make_dims(dims_host, L.d) == 0, "bad dims");
+  if (n == 0) return AABR_OK;
+  AABR_CHECK_ARG(pc && dir && bricks && point_site && first_pt && cnt_extra && head && nxt && meta, "null pointer");
+  L.dir = (const uint4 *)dir;
+  L.bricks = (const uint4 *)bricks;
+  // first_pt and head start at all ones (no first point yet / empty chain), cnt_extra at 0
+  if (head == first_pt + n)
+    AABR_CHECK_HIP(hipMemsetAsync(first_pt, 0xFF, (size_t)2 * n * sizeof(int32_t), st));
+  else {
+    AABR_CHECK_HIP(hipMemsetAsync(first_pt, 0xFF, (size_t)n * sizeof(int32_t), st));
+    AABR_CHECK_HIP(hipMemsetAsync(head, 0xFF, (size_t)n * sizeof(int32_t), st));
+  }
+  AABR_CHECK_HIP(hipMemsetAsync(cnt_extra, 0, (size_t)n * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_points_sites, grid1(n, 256), dim3(256), 0, st, (const int4 *)pc, n, L, point_site,
+                     (uint32_t *)first_pt, meta);
+  hipLaunchKernelGGL(k_points_chains, grid1(n, 256), dim3(256), 0, st, n, (const int32_t *)point_site,
+                     (const uint32_t *)first_pt, head, cnt_extra, nxt);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

@@ -202,17 +202,29 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_number(
       __hip_atomic_store(&grid[s[j]].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // self-contained value
     }
   }
-  // the scene's extent (meta[8..11], counting up from the fill's -1): what a brick grid's directory is sized by.
-  // One atomic per wave and axis, and none when the running maximum already covers it.
+  // the scene's extent (meta[8..11], counting up from the fill's -1): what a brick grid's directory is sized by.  One
+  // atomic per CHUNK and axis at most, and none when the running maximum already covers it (one per wave was 20 k
+  // same-address atomics at 320 k points: +35 us on this kernel)
+  {
+    __shared__ int s_ext[kVsThreads / 64][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    int m = ext[q];
+    for (int q = 0; q < 4; ++q) {
+      int m = ext[q];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const int o = __shfl_xor(m, d);
-      m = o > m ? o : m;
+      for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(m, d);
+        m = o > m ? o : m;
+      }
+      if (lane == 0) s_ext[wave][q] = m;
     }
-    if (lane == 0 && m > __builtin_nontemporal_load(&meta[kMetaExtent + q])) atomicMax(&meta[kMetaExtent + q], m);
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const int q = threadIdx.x;
+      int m = s_ext[0][q];
+#pragma unroll
+      for (int w = 1; w < kVsThreads / 64; ++w) m = s_ext[w][q] > m ? s_ext[w][q] : m;
+      if (m > __builtin_nontemporal_load(&meta[kMetaExtent + q])) atomicMax(&meta[kMetaExtent + q], m);
+    }
   }
   // the other points of a voxel: their first point lies in this or an earlier (already running) chunk
 #pragma unroll

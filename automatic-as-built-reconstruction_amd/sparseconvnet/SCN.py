@@ -325,7 +325,11 @@ class _Grid(object):
 import os as _os
 scatter_variant = int(_os.environ.get("AABR_SCATTER", "2"))
 SCATTER_MIN_POINTS = int(_os.environ.get("AABR_SCATTER_MIN_POINTS", "32768"))
-scatter_stats = {"variant0": 0, "variant1": 0, "variant2": 0, "redone": 0}
+scatter_stats = {"variant0": 0, "variant1": 0, "variant2": 0, "redone": 0, "brick": 0}
+# brick-major rows: the voxel scatter straight into the brick grid (csrc/brick.hip aabr_points_prepare / aabr_points_sites:
+# no hash table, no first-seen numbering); False (AABR_BRICK_SCATTER=0): the hash scatter above followed by a renumbering
+# (Metadata_3._brickify_input, the first round-5 form) -- kept for the A/B and as a second implementation to test against
+brick_scatter = _os.environ.get("AABR_BRICK_SCATTER", "1") != "0"
 
 def derived_cap(E):
     """slots of a derived (strided-level) grid that receives at most E keys: 1.5 E rounded up to a power of two --
@@ -652,6 +656,8 @@ class Metadata_3(object):
         self.device = device
         coords = coords.to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
         n, ncols = coords.shape
+        if self.site_order == "brick" and brick_scatter and n > 0:
+            return self._enqueue_brick_scatter(spatial_size, coords, coords_src, mode, device, asynchronous)
         cap = _hip.next_pow2(2 * n)
         n1 = max(n, 1)
         nst = int(lib.aabr_input_layer_status_words(n))
@@ -715,9 +721,95 @@ class Metadata_3(object):
                           head=piece["head"], nxt=piece["nxt"], last_pt=piece["last_pt"], meta=meta, n=n, V=None,
                           mode=int(mode), spatial=_key(spatial_size), coords_src=coords_src)
 
+    def _enqueue_brick_scatter(self, spatial_size, coords, coords_src, mode, device, asynchronous):
+        """brick-major rows WITHOUT a hash table (csrc/brick.hip "voxel scatter straight into a brick grid"): the points are
+        converted and their extent reduced now (one kernel + the asynchronous read of the extent); `inputLayerFinish` sizes
+        the directory by it, builds the input level from the points and hands every point its row"""
+        lib = _hip.load()
+        n, ncols = coords.shape
+        names = [("pc", 4 * n), ("meta", _hip.META_WORDS), ("point_site", n), ("nxt", n), ("first_pt", n), ("head", n),
+                 ("cnt_extra", n), ("last_pt", n)]
+        offs, tot = {}, 0
+        for name, sz in names:
+            offs[name] = tot
+            tot += (sz + 3) & ~3 if name != "first_pt" else sz          # first_pt | head contiguous: ONE fill for the two
+        buf = torch.empty(tot + 4, dtype=torch.int32, device=device)
+        piece = {name: buf[offs[name]:offs[name] + sz] for name, sz in names}
+        meta = piece["meta"]
+        check(lib.aabr_points_prepare(ptr(coords), n, ncols, piece["pc"].data_ptr(), meta.data_ptr(), stream()))
+        host = ev = None
+        if asynchronous:
+            host, ev = _pinned_pool.pop() if _pinned_pool else (
+                torch.empty(_hip.META_WORDS, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+            host.copy_(meta, non_blocking=True)
+            ev.record()
+        self._pending = dict(kind="brick", host=host, event=ev, meta=meta, coords=coords, buf=buf, piece=piece,
+                             spatial_t=spatial_size, mode=mode, device=device)
+        scatter_stats["brick"] = scatter_stats.get("brick", 0) + 1
+        self.input = dict(point_site=piece["point_site"], first_pt=piece["first_pt"], cnt_extra=piece["cnt_extra"],
+                          head=piece["head"], nxt=piece["nxt"], last_pt=piece["last_pt"], meta=meta, n=n, V=None,
+                          mode=int(mode), spatial=_key(spatial_size), coords_src=coords_src)
+
+    def _brick_scatter_launch(self, piece, n, key, extent, dev):
+        """the launches of the brick-native scatter behind the extent read: input level from the points, then every point's
+        row / first point / chain (no host read in here -- bench.py times exactly this)"""
+        lib = _hip.load()
+        rows = self._brick_rows = torch.empty((_BK_MAX_LEVELS, _BK_ROW), dtype=torch.int32, device=dev)
+        self._brick_nrows = 1
+        bk = _Brick([e + 1 for e in extent[:3]], extent[3] + 1, n, n, dev, rows[0, 64:64 + _hip.META_WORDS])
+        scratch = _brick_build(piece["pc"], n, 0, (1, 1, 1), (1, 1, 1), key, bk)
+        flush_geom()
+        check(lib.aabr_points_sites(piece["pc"].data_ptr(), n, bk.dims_c(), bk.dir_ptr(), bk.bricks_ptr(),
+                                    ptr(piece["point_site"]), ptr(piece["first_pt"]), ptr(piece["cnt_extra"]),
+                                    ptr(piece["head"]), ptr(piece["nxt"]), bk.meta.data_ptr(), stream()))
+        return bk, scratch
+
+    def _finish_brick_scatter(self, pend):
+        lib = _hip.load()
+        if pend["event"] is not None:
+            pend["event"].synchronize()
+            m = pend["host"].tolist()
+            if len(_pinned_pool) < 16:
+                _pinned_pool.append((pend["host"], pend["event"]))
+        else:
+            m = _hip.read_back(pend["meta"])
+        self._pending = None
+        il = self.input
+        key, n, dev, piece = il["spatial"], il["n"], pend["device"], pend["piece"]
+        if m[2] == 0:
+            raise _hip.AabrError("InputLayer: coordinates must lie in [0, 65534] (batch index too)")
+        if m[8] < 0:                                   # no valid point
+            self.grids[key] = _Grid(torch.empty((0, 4), dtype=torch.int32, device=dev), None, None, 0, 0)
+            il["V"] = 0
+            self.input_spatial = key
+            return
+        if _brick_dir_words(m[8:12]) > BRICK_MAX_DIR_WORDS:
+            # a few sites spread over a huge extent: the dense directory would not pay -- hash grids for this scene
+            self.site_order = "first_seen"
+            brick_stats["declined"] += 1
+            src = il["coords_src"]
+            self.input = None
+            self.inputLayerEnqueue(pend["spatial_t"], pend["coords"], pend["mode"], dev, asynchronous=False)
+            self.input["coords_src"] = src
+            return self.inputLayerFinish()
+        brick_stats["built"] += 1
+        bk, scratch = self._brick_scatter_launch(piece, n, key, m[8:12], dev)
+        bm = _hip.read_back(bk.meta)                   # the site count sizes every later tensor
+        if bm[2]:
+            raise _hip.AabrError("brick grid of the input level: a point outside the directory's extent or a capacity "
+                                 "overflow (meta %s)" % (bm[:4],))
+        V = bm[0]
+        self._brick_keep = [pend["buf"], self._brick_rows, scratch]
+        self.grids[key] = _Grid(bk.coords_full[:V], None, None, 0, V, None, bk)
+        il["V"] = V
+        self.input_spatial = key
+
     def inputLayerFinish(self):
         """wait for the read-back (the one host sync of the input layer: V sizes every later tensor)"""
         pend = getattr(self, "_pending", None)
+        if pend is not None and pend.get("kind") == "brick":
+            self._finish_brick_scatter(pend)
+            return self.input["V"]
         if pend is not None:
             if pend["event"] is not None:
                 pend["event"].synchronize()

@@ -598,8 +598,22 @@ def scatter_block(torch, scn, locs, feats, tag):
     with torch.no_grad():
         t_sites = device_time(torch, sites)
         t_brick = 0.0
-        if order == "brick":
-            # brick-major rows: the brick level of the input sites + their renumbering ride on top of the scatter
+        if order == "brick" and SCN.brick_scatter:
+            # brick-major rows: the scatter goes straight into the brick grid (csrc/brick.hip): points converted + extent,
+            # input level built from the points, every point handed its row / first point / chain -- no hash table
+            md0 = SCN.Metadata_3("brick")
+            md0.inputLayerEnqueue(SP, locs, 4, dev, asynchronous=False)
+            ext = md0._pending["meta"].tolist()[8:12]
+
+            def sites():
+                md = SCN.Metadata_3("brick")
+                md.inputLayerEnqueue(SP, locs, 4, dev, asynchronous=False)
+                p_ = md._pending
+                keep.append((md, md._brick_scatter_launch(p_["piece"], md.input["n"], md.input["spatial"], ext, dev)))
+                del keep[:-6]
+            t_sites = device_time(torch, sites)
+        elif order == "brick":
+            # (AABR_BRICK_SCATTER=0) the hash scatter followed by the brick level + renumbering of its sites
             mdf = SCN.Metadata_3()
             mdf.inputLayerEnqueue(SP, locs, 4, dev, asynchronous=False)
             pend = mdf._pending
@@ -628,7 +642,7 @@ def scatter_block(torch, scn, locs, feats, tag):
     n, c = int(locs.shape[0]), int(fdet.shape[1])
     by = n * (32 + 4 * c) + V * (4 * c + 16)
     t = t_sites + t_mean
-    return dict(workload=tag, points=n, sites=int(V), bytes=by, insert_form=int(SCN.scatter_variant), site_order=order,
+    return dict(workload=tag, points=n, sites=int(V), bytes=by, insert_form=("brick-native (no hash table)" if (order == "brick" and SCN.brick_scatter) else int(SCN.scatter_variant)), site_order=order,
                 device_seconds=round(t, 7), sites_seconds=round(t_sites, 7), brick_seconds=round(t_brick, 7),
                 mean_seconds=round(t_mean, 7),
                 device_gbs=round(by / t / 1e9, 2), device_frac_of_hbm_peak=round(by / t / 1e9 / PEAK_HBM_GBS, 5),

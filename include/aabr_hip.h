@@ -186,6 +186,19 @@ int aabr_brick_renumber(const int32_t *old_coords, int64_t V, const int32_t *dim
                         int32_t *new_of_old, int32_t *old_of_new, const int32_t *first_pt, const int32_t *cnt_extra,
                         const int32_t *head, int32_t *first_pt2, int32_t *cnt_extra2, int32_t *head2,
                         const int32_t *point_site, int64_t n, int32_t *point_site2, int32_t *meta, void *stream);
+/* Voxel scatter straight into a brick grid -- InputLayer (Metadata::inputLayer -> inputLayerRules, Metadata.cpp:405-417,
+ * IOLayersRules.h:18-125) without a hash table and without first-seen numbers: the POINTS are the items of the input
+ * level's aabr_brick_build (size = stride = 1), a voxel's row follows from where it lies.
+ *   aabr_points_prepare: coords int64 [n, ncols] -> pc int32 [n,4] (x, y, z, batch; x = -1: a point the layer skips),
+ *     meta (AABR_META_WORDS, starts at all ones): meta[2] == 0: a coordinate outside [0, 65534]; meta[8..11] = largest
+ *     x, y, z, batch index of the valid points (-1: none) -- the extent the directory is sized by.
+ *   aabr_points_sites (after aabr_brick_build(pc, n, ..)): point_site[i] = row of point i's voxel (-1: skipped),
+ *     first_pt[row] = lowest point index of the voxel, cnt_extra[row] = its further points, head / nxt = their chain --
+ *     the arrays aabr_input_layer_forward / _backward / _rule_table read; sized n (rows < V are meaningful).        */
+int aabr_points_prepare(const int64_t *coords, int64_t n, int ncols, int32_t *pc, int32_t *meta, void *stream);
+int aabr_points_sites(const int32_t *pc, int64_t n, const int32_t *dims_host, const void *dir, const void *bricks,
+                      int32_t *point_site, int32_t *first_pt, int32_t *cnt_extra, int32_t *head, int32_t *nxt,
+                      int32_t *meta, void *stream);
 /* aabr_submanifold_table / aabr_convolution_tables2 over brick levels: same tables, same block counts
  * (Metadata.cpp:429-443,484-510; SubmanifoldConvolutionRules.h:26-45; ConvolutionRules.h:11-34).                       */
 int aabr_brick_submanifold_table(const int32_t *site_coords, int64_t V, const int32_t *dims_host, const void *dir,

@@ -71,8 +71,27 @@ def _assert_brick_major(coords):
 
 
 # ------------------------------------------------------------------------------------ input level
+@pytest.fixture(params=["native", "renumbered"])
+def scatter_form(request):
+    """the two ways to a brick-ordered input level: the scatter straight into the brick grid (default), or the hash scatter
+    followed by a renumbering of its first-seen sites (SCN.brick_scatter = False)"""
+    from sparseconvnet import SCN
+    old = SCN.brick_scatter
+    SCN.brick_scatter = request.param == "native"
+    yield request.param
+    SCN.brick_scatter = old
+
+
+def _rows(x, ref_coords):
+    """(r, inv): device row i holds the oracle's row r[i]; inv = the other way"""
+    r = _match(x.get_spatial_locations().numpy(), ref_coords)
+    inv = np.empty_like(r)
+    inv[r] = np.arange(len(r))
+    return r, inv
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
-def test_brick_input_layer_is_a_row_permutation_of_the_oracle(mode):
+def test_brick_input_layer_is_a_row_permutation_of_the_oracle(mode, scatter_form):
     scn = _scn()
     rng = np.random.default_rng(110 + mode)
     coords, feats = _rand_scene(rng, 6000, (40, 23, 9), 3, 7)
@@ -84,10 +103,14 @@ def test_brick_input_layer_is_a_row_permutation_of_the_oracle(mode):
     loc = md.getSpatialLocations(x.spatial_size).numpy()
     _assert_brick_major(loc)
     r = _match(loc, ref["coords"])                      # device row i holds the oracle's row r[i]
-    np.testing.assert_array_equal(md.input["old_of_new"].cpu().numpy(), r)
     inv = np.empty_like(r)
     inv[r] = np.arange(len(r))
-    np.testing.assert_array_equal(md.input["new_of_old"].cpu().numpy(), inv)
+    if scatter_form == "renumbered":                    # (that form keeps the permutation it applied)
+        np.testing.assert_array_equal(md.input["old_of_new"].cpu().numpy(), r)
+        np.testing.assert_array_equal(md.input["new_of_old"].cpu().numpy(), inv)
+    else:
+        from sparseconvnet import SCN
+        assert md.grids[tuple(x.spatial_size.tolist())].keys is None and SCN.scatter_stats["brick"] > 0     # no hash table
     # the point -> site map, renumbered
     np.testing.assert_array_equal(md.input["point_site"].cpu().numpy(), inv[ref["point_voxel"]])
     # reference-format rule table, row-permuted
@@ -101,7 +124,7 @@ def test_brick_input_layer_is_a_row_permutation_of_the_oracle(mode):
     np.testing.assert_array_equal(f.grad.cpu().numpy(), O.input_layer_bwd(ref, g))
 
 
-def test_brick_input_edge_cases():
+def test_brick_input_edge_cases(scatter_form):
     scn = _scn()
     from sparseconvnet import SCN
     # single point, all points in one voxel, a site at the far corner of the layer, 3-column coordinates
@@ -153,8 +176,7 @@ def test_brick_submanifold_tables_match_oracle_under_the_permutation():
     coords, feats = _rand_scene(rng, 9000, (50, 37, 11), 3, 3)
     x, _ = _input(scn, coords, feats, (64, 64, 16), 3)
     ref_il = O.input_layer(coords, feats, 3)
-    r = x.metadata.input["old_of_new"].cpu().numpy()
-    inv = x.metadata.input["new_of_old"].cpu().numpy()
+    r, inv = _rows(x, ref_il["coords"])
     for fs in ([3, 3, 3], [1, 1, 1], [3, 1, 5]):
         tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor(fs))
         rb = O.submanifold_rules(ref_il["coords"], fs)
@@ -183,7 +205,7 @@ def test_brick_strided_levels_and_tables_match_oracle(fs, st):
     loc_out = x.metadata.getSpatialLocations(torch.LongTensor(osz)).numpy()
     _assert_brick_major(loc_out)
     ro = _match(loc_out, oc)                                            # device output row -> oracle output row
-    ri = x.metadata.input["old_of_new"].cpu().numpy()                   # device input row -> oracle input row
+    ri, _ = _rows(x, ref_il["coords"])                                  # device input row -> oracle input row
     np.testing.assert_array_equal(np.array(tb.rule_counts()), rb.counts)
     t_out = tb.out.table.cpu().numpy()                                  # [vol, V_out]: device input row per output row
     t_in = tb.inn.table.cpu().numpy()                                   # [vol, V_in]: device output row per input row
@@ -239,7 +261,7 @@ def test_brick_submanifold_conv_forward_backward(nIn, nOut):
     conv = scn.SubmanifoldConvolution(3, nIn, nOut, 3, False).to(DEV)
     y = conv(x)
     ref_il = O.input_layer(coords, feats, 3)
-    r = x.metadata.input["old_of_new"].cpu().numpy()
+    r, _ = _rows(x, ref_il["coords"])
     rb = O.submanifold_rules(ref_il["coords"], [3, 3, 3])
     W = conv.weight.detach().cpu().numpy().reshape(27, nIn, nOut)
     want, _ = O.conv_fwd(ref_il["out"], W, rb, ref_il["V"])

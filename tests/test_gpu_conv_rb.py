@@ -26,6 +26,16 @@ def _scene(rng, n, size, batch):
     return coords.astype(np.int64)
 
 
+def _match_rows(dev_coords, ref_coords):
+    """oracle row of every device row (the same sites, matched by their coordinates)"""
+    key = lambda c: ((np.asarray(c[:, 3], np.int64) * 70000 + c[:, 0]) * 70000 + c[:, 1]) * 70000 + c[:, 2]
+    kd, kr = key(dev_coords), key(ref_coords)
+    o = np.argsort(kr)
+    pos = np.searchsorted(kr[o], kd)
+    assert (kr[o][pos] == kd).all()
+    return o[pos]
+
+
 def _pack(lib, Wd, vol, a, b):
     from _hip import ptr, stream, check
     n = int(lib.aabr_conv_wpack_bf16_elems(vol, a, b))
@@ -51,7 +61,7 @@ def test_rb_submanifold_forward_and_input_gradient(nIn, nOut, npts, order):
     ga, V, vol = tb.out, tb.V_out, tb.vol
     il = O.input_layer(coords, np.zeros((npts, 1), np.float32), 4)
     rb = O.submanifold_rules(il["coords"], [3, 3, 3])
-    r = x.metadata.input["old_of_new"].cpu().numpy() if order == "brick" else np.arange(V)   # device row i = oracle row r[i]
+    r = _match_rows(x.get_spatial_locations().numpy(), il["coords"])    # device row i = oracle row r[i]
     W = (rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32)
     Wd = _t(W)
     Wr = Wd.bfloat16().float().cpu().numpy().reshape(vol, nIn, nOut)
@@ -108,7 +118,7 @@ def test_rb_strided_forms(nIn, nOut):
                                 torch.LongTensor([2, 2, 2]))
     il = O.input_layer(coords, np.zeros((4000, 1), np.float32), 4)
     rb, oc = O.convolution_rules(il["coords"], [2, 2, 2], [2, 2, 2], [16, 16, 4])
-    ri = x.metadata.input["old_of_new"].cpu().numpy()
+    ri = _match_rows(x.get_spatial_locations().numpy(), il["coords"])
     loc = x.metadata.getSpatialLocations(torch.LongTensor([16, 16, 4])).numpy()
     key = lambda c: ((c[:, 3] * 64 + c[:, 0]) * 64 + c[:, 1]) * 64 + c[:, 2]
     o = np.argsort(key(oc))
