@@ -428,8 +428,8 @@ extern "C" int aabr_brick_submanifold_table(const int32_t *site_coords, int64_t 
   AABR_CHECK_ARG(site_coords && dir && bricks && table, "null pointer");
   f.L.dir = (const uint4 *)dir;
   f.L.bricks = (const uint4 *)bricks;
-  hipLaunchKernelGGL(k_submanifold_table<BrickFinder>, dim3((unsigned)ceil_div(V, 256), (unsigned)vol), dim3(256), 0, st,
-                     site_coords, V, f, fs, table, counts);
+  hipLaunchKernelGGL(k_submanifold_table_rows<BrickFinder>, dim3((unsigned)ceil_div(V, 256)), dim3(256), 0, st, site_coords, V,
+                     f, fs, table, counts);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -451,13 +451,13 @@ extern "C" int aabr_brick_convolution_tables(const int32_t *in_coords, int64_t V
   fo.L.dir = (const uint4 *)out_dir; fo.L.bricks = (const uint4 *)out_bricks;
   if (V_out > 0 && table_out) {
     AABR_CHECK_ARG(out_coords && in_dir && in_bricks, "null pointer");
-    hipLaunchKernelGGL(k_conv_table_out<BrickFinder>, dim3((unsigned)ceil_div(V_out, 256), (unsigned)vol), dim3(256), 0,
-                       st, out_coords, V_out, fi, g, table_out, counts);
+    hipLaunchKernelGGL((k_conv_table_rows<BrickFinder, 0>), dim3((unsigned)ceil_div(V_out, 256)), dim3(256), 0, st, out_coords,
+                       V_out, fi, g, table_out, counts);
   }
   if (V_in > 0 && table_in) {
     AABR_CHECK_ARG(in_coords && out_dir && out_bricks, "null pointer");
-    hipLaunchKernelGGL(k_conv_table_in<BrickFinder>, dim3((unsigned)ceil_div(V_in, 256), (unsigned)vol), dim3(256), 0, st,
-                       in_coords, V_in, fo, g, table_in, counts_in);
+    hipLaunchKernelGGL((k_conv_table_rows<BrickFinder, 1>), dim3((unsigned)ceil_div(V_in, 256)), dim3(256), 0, st, in_coords,
+                       V_in, fo, g, table_in, counts_in);
   }
   AABR_CHECK_LAUNCH();
   return AABR_OK;

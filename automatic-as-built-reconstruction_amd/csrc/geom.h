@@ -194,6 +194,104 @@ __global__ __launch_bounds__(256) void k_conv_table_in(const int32_t *__restrict
   if (counts) block_count_store(hit, counts, k);   // per 256-row block and offset, like k_conv_table_out
 }
 
+// ---- the same tables, one thread per ROW over all offsets (brick grids) --------------------------------------------------
+// With a hash grid every (row, offset) is one independent random probe and a thread per (row, offset) -- the grid's y
+// dimension over the offsets -- is the widest form.  With a brick grid the 27 look-ups of a row fall into <= 8 bricks that
+// the thread (and its neighbours: rows are brick-major) has just touched, while the y-dimension form re-reads the site
+// list once per offset (27 x 16 V bytes: PMC counted 120 MB of fetches for a 38 MB table when the L2s did not hold it).
+// Here a thread reads its site once, walks the offsets and stores table[k][row] -- for a fixed k consecutive lanes store
+// consecutive rows (coalesced) -- and the per-block counts come from one ballot per offset.
+template <class Finder>
+__global__ __launch_bounds__(256) void k_submanifold_table_rows(const int32_t *__restrict__ site_coords, int64_t V,
+                                                                Finder find, Filter3 fs, int32_t *__restrict__ table,
+                                                                int32_t *__restrict__ counts) {
+  __shared__ int s_cnt[4][64];
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vol = fs.size[0] * fs.size[1] * fs.size[2];
+  int4 c = make_int4(0, 0, 0, 0);
+  if (v < V) c = *reinterpret_cast<const int4 *>(site_coords + 4 * v);
+  for (int k0 = 0; k0 < vol; k0 += 64) {
+    int mine = 0;                                            // lane q keeps the wave's count of offset k0 + q
+    const int kend = vol - k0 < 64 ? vol - k0 : 64;
+    for (int q = 0; q < kend; ++q) {
+      const int k = k0 + q;
+      const int dz = k % fs.size[2], t = k / fs.size[2];
+      const int dy = t % fs.size[1], dx = t / fs.size[1];
+      int r = -1;
+      if (v < V) {
+        r = find(c.w, c.x + dx - fs.size[0] / 2, c.y + dy - fs.size[1] / 2, c.z + dz - fs.size[2] / 2);
+        table[(int64_t)k * V + v] = r;
+      }
+      const int n = (int)__popcll(__ballot(r >= 0));
+      if (lane == q) mine = n;
+    }
+    if (counts) {
+      s_cnt[wave][lane] = mine;
+      __syncthreads();
+      if (threadIdx.x < kend)
+        counts[(int64_t)(k0 + threadIdx.x) * gridDim.x + blockIdx.x] =
+            s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+      __syncthreads();
+    }
+  }
+}
+
+// MODE 0: table_out[k][o] = input row at o * stride + k (k_conv_table_out); MODE 1: table_in[k][u] = the output row whose
+// window holds input u at offset k (k_conv_table_in).  vol <= 64 per pass of the offset loop, any vol.
+template <class Finder, int MODE>
+__global__ __launch_bounds__(256) void k_conv_table_rows(const int32_t *__restrict__ coords, int64_t V, Finder find,
+                                                         ConvGeom g, int32_t *__restrict__ table,
+                                                         int32_t *__restrict__ counts) {
+  __shared__ int s_cnt[4][64];
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vol = g.size[0] * g.size[1] * g.size[2];
+  int4 c = make_int4(0, 0, 0, 0);
+  if (v < V) c = *reinterpret_cast<const int4 *>(coords + 4 * v);
+  for (int k0 = 0; k0 < vol; k0 += 64) {
+    int mine = 0;
+    const int kend = vol - k0 < 64 ? vol - k0 : 64;
+    for (int q = 0; q < kend; ++q) {
+      const int k = k0 + q;
+      int d[3];
+      d[2] = k % g.size[2];
+      const int t = k / g.size[2];
+      d[1] = t % g.size[1];
+      d[0] = t / g.size[1];
+      int r = -1;
+      if (v < V) {
+        if (MODE == 0) {
+          r = find(c.w, c.x * g.stride[0] + d[0], c.y * g.stride[1] + d[1], c.z * g.stride[2] + d[2]);
+        } else {
+          const int p[3] = {c.x, c.y, c.z};
+          int j[3];
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int qq = p[i] - d[i];
+            if (qq < 0 || qq % g.stride[i] != 0) { ok = false; break; }
+            j[i] = qq / g.stride[i];
+            if (j[i] > g.out_sp[i] - 1) { ok = false; break; }
+          }
+          if (ok) r = find(c.w, j[0], j[1], j[2]);
+        }
+        table[(int64_t)k * V + v] = r;
+      }
+      const int n = (int)__popcll(__ballot(r >= 0));
+      if (lane == q) mine = n;
+    }
+    if (counts) {
+      s_cnt[wave][lane] = mine;
+      __syncthreads();
+      if (threadIdx.x < kend)
+        counts[(int64_t)(k0 + threadIdx.x) * gridDim.x + blockIdx.x] =
+            s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+      __syncthreads();
+    }
+  }
+}
+
 static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)ceil_div(n > 0 ? n : 1, bs)); }
 
 } // namespace aabr

@@ -59,7 +59,7 @@ N_GT = 40                       # ground-truth walls per scene (label generation
 # cfg.MODEL.RPN.LABEL_AUG_THICKNESS_{Y,Z}_TAR_ANC (config/defaults.py:161-162; rpn/loss_3d.py:351)
 LABEL_AUG = {"target_Y": 0.4, "anchor_Y": 0.0, "target_Z": 0.8, "anchor_Z": 0.0}
 MIN_TIMED_S = 0.2               # a timed region shorter than this is reported as such (`timed_region_short`)
-PMC_PROFILE = "r04_pmc_fetch_write_per_kernel.json"   # committed --pmc passes of this command (tools/tools_pmc.sh)
+PMC_PROFILE = "r05_pmc_fetch_write_per_kernel.json"   # committed --pmc passes of this command (tools/tools_pmc.sh)
 
 # RPN constants of the reference config (defaults.py:127-131,159-181)
 ANCHOR_SIZES_3D = [[0.4, 1.5, 1.5], [1.5, 1.5, 1.0], [4, 4, 1.5], [0.2, 0.5, 3], [0.4, 1.5, 3], [0.6, 2.5, 3]]
@@ -1109,12 +1109,18 @@ def main():
             # batch and on one 1.5 M-point scene (BASELINE configs[4]'s size)
             locs, feats = wl.batches[0]
             vs = scatter_block(torch, scn, locs, feats, "the step's batch")
-            tr, src = pmc_kernels_traffic(("aabr::k_voxel", "k_voxel")) if args.config == 2 else \
+            from sparseconvnet import SCN as SCN_
+            native = wl.net.site_order == "brick" and SCN_.brick_scatter
+            # (brick-native scatter: the level build's mark / scan kernels run for every level of the pyramid too -- the
+            # profile's LARGEST grid of each is the input level's launch; the fills are hipMemsetAsync, not in the sum)
+            prefixes = ("k_points_", "k_brick_mark", "k_brick_scan", "k_voxel_mean") if native else ("aabr::k_voxel", "k_voxel")
+            tr, src = pmc_kernels_traffic(prefixes) if args.config == 2 else \
                 (None, "the committed PMC passes are over the --config 2 command")
             vs["traffic"], vs["traffic_source"] = tr, src
             if tr:
                 vs["traffic_over_algorithmic"] = round(tr / vs["bytes"], 2)
-            vs["note"] = ("device_seconds = sites_seconds (fill + insert + numbering) + mean_seconds, launches queued "
+            vs["note"] = ("device_seconds = sites_seconds (brick order: points -> brick grid -> rows / chains; first-seen order: "
+                          "fill + insert + numbering) + mean_seconds, launches queued "
                           "behind a busy-wait kernel so that no host gap is in the figure; `seconds`: the whole "
                           "InputLayer call incl. its host read of V")
             line["voxel_scatter"] = vs

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd database (the default output of `rocprofv3 --kernel-trace --stats` on ROCm 7.2)
 as a per-kernel CSV (name, calls, total / average / min / max duration in ns, share) -- the same columns as
-rocprofv3's kernel_stats.csv.  usage: rocpd_stats.py results.db [out.csv] [--after-frac F] [--by-grid]
+rocprofv3's kernel_stats.csv.  usage: rocpd_stats.py results.db [out.csv] [--after-frac F] [--last N] [--by-grid]
+--last N: only the last N kernel launches of the trace (a tool that ends with N launches of ONE instance -- tools/
+tools_dominant_instance.py -- gives that instance a row of its own, whatever else shares its kernel name and grid).
 --by-grid: one row per (kernel, grid size in threads) -- `name|grid=N`, the key bench.py's roofline object and the PMC
 summaries use -- so that the average duration of ONE instance (e.g. the dominant convolution launch) can be read from the
 committed profile instead of from the kernel's average over all its grids."""
@@ -45,6 +47,8 @@ def main():
     if "--after-frac" in sys.argv:
         frac = float(sys.argv[sys.argv.index("--after-frac") + 1])
     rows = rows[int(len(rows) * frac):]
+    if "--last" in sys.argv:
+        rows = rows[-int(sys.argv[sys.argv.index("--last") + 1]):]
     agg = {}
     for n, s, e in rows:
         a = agg.setdefault(short(n), [0, 0, 1 << 62, 0])

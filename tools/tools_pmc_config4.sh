@@ -19,7 +19,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r.get("Counter_Name") != c:
                 continue
             n = r["Kernel_Name"]
-            if "k_conv_narrow" not in n and "k_conv_cs" not in n and "k_submanifold_table" not in n:
+            if not any(t in n for t in ("k_conv_narrow", "k_conv_cs", "k_submanifold_table", "k_conv_table", "k_brick_", "k_points_",
+                                        "k_voxel_mean", "k_build_tileT", "k_fill_offset_pairs")):
                 continue
             key = n.split("(")[0].replace("aabr::", "").replace("void ", "") + "|grid=" + r.get("Grid_Size", "?")
             acc[key][0] += float(r["Counter_Value"]); acc[key][1] += 1
