@@ -741,6 +741,7 @@ def test_fused_cross_scale_topk_matches_torch_topk():
     # > 4096 exactly equal logits at the cut: reported
     flat = [_t(np.full(sum(counts[m]) * A, 0.5, np.float32)) for m in range(n_maps)]
     ks = [min(2000, n) for n in ns]
+    sel = torch.full((nb, 3000), -1, dtype=torch.int64, device=DEV)        # (the loop's last `sel` holds one column)
     check(lib.aabr_rpn_topk_maps(n_maps, _hip.ptrs(flat), nb, _hip.i32xn(segs), _hip.i32xn(sites), A, _hip.i32xn(ks), ptr(sel),
                                  max(ks), ptr(info), scr.data_ptr() + 4 * off, stream()))
     inf = info.cpu().numpy()
