@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/aabr_hip.h"
 
 namespace aabr {
@@ -46,6 +47,22 @@ int knob(Knob k);            // kKnobUnset when neither the environment nor aabr
     }                                                                         \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: one flag per (call site, device), set only
+// after the call succeeded, readable from the launcher thread and the caller's thread alike.
+struct DynLdsOnce {
+  std::atomic<uint64_t> done{0};   // bit d = set on device d (64 devices; beyond that the call is simply repeated)
+};
+inline hipError_t dyn_lds_once(DynLdsOnce &o, const void *kernel, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = dev < 64 ? 1ull << dev : 0ull;
+  if (o.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) o.done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
 constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kMaxCoord = 65534;
 
@@ -75,8 +92,9 @@ struct __align__(16) GridEnt {
 static_assert(sizeof(GridEnt) == 16, "GridEnt is 16 bytes");
 
 // Probe sequence of every grid: linear inside the key's home BLOCK of kGridBlock slots (wrapping at the block's end),
-// and only when all kGridBlock slots of that block have been visited -- the tables are at most half full, so a full
-// block is a > 40 sigma event for mixed keys -- on through the slots behind the block.  Find and insert walk the same
+// and only when all kGridBlock slots of that block have been visited -- input grids are at most half full (a full block
+// is a > 40 sigma event for mixed keys), derived grids at most 2/3 full (SCN.derived_cap / `2 cap >= 3 E` in geometry.hip:
+// ~26 sigma; unsuccessful probe chains about twice as long as at load 1/2) -- on through the slots behind the block.  Find and insert walk the same
 // sequence.  The block rule is what lets the LDS-binned voxel scatter (voxel_scatter.hip) build one block per
 // workgroup entirely in LDS and write it out with coalesced stores; it also keeps a probe chain inside one 64 KiB
 // window.  Tables smaller than a block are one block.

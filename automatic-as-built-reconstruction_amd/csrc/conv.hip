@@ -1972,12 +1972,8 @@ extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_i
       const size_t lds = (size_t)(w_lds + nw * tile_lds);
 #define AABR_LAUNCH_WLDS(NBW, NKC, AL)                                                                   \
   do {                                                                                                   \
-    static bool attr_set = false;                                                                        \
-    if (!attr_set) {                                                                                     \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)k_conv_blocks_mfma_wlds<NBW, NKC, AL>,            \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
-      attr_set = true;                                                                                   \
-    }                                                                                                    \
+    static DynLdsOnce attr_set;                                                                          \
+    AABR_CHECK_HIP(dyn_lds_once(attr_set, (const void *)k_conv_blocks_mfma_wlds<NBW, NKC, AL>, 160 * 1024)); \
     g_last_variant = "k_conv_blocks_mfma_wlds<" #NBW "," #NKC "," #AL ">";                                \
     hipLaunchKernelGGL((k_conv_blocks_mfma_wlds<NBW, NKC, AL>), dim3((unsigned)wgx, (unsigned)slabs),    \
                        dim3(64 * nw), lds, st, in_feats, n_in, in_bytes, out_feats, n_out, V_out,        \

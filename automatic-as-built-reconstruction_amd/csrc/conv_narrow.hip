@@ -255,12 +255,9 @@ static int conv_narrow_launch(const void *in, int64_t rows_in, void *out, int64_
   AABR_CHECK_ARG((flags & ~3) == 0, "flags: bit 0 transposed weights, bit 1 mirrored offsets");
   AABR_CHECK_ARG(rows_in * kNarrowC * (BF ? 2 : 4) < (1ll << 31), "input matrix must be < 2 GiB");
   const size_t lds = (size_t)vol * 2 * 64 * (BF ? 16 : 32) + (STATS ? 16 * 2 * kNarrowC * sizeof(double) : 0);
-  static bool attr = false;
-  if (!attr) {
-    AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_narrow<BF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kNarrowVol * 2 * 64 * 32 + 16 * 2 * kNarrowC * (int)sizeof(double)));
-    attr = true;
-  }
+  static DynLdsOnce attr;
+  AABR_CHECK_HIP(dyn_lds_once(attr, (const void *)(k_conv_narrow<BF, STATS>),
+                              kNarrowVol * 2 * 64 * 32 + 16 * 2 * kNarrowC * (int)sizeof(double)));
   g_last_variant = BF ? (STATS == 2 ? "k_conv_narrow<bf16,bwd_stats>" : STATS == 1 ? "k_conv_narrow<bf16,stats>" : "k_conv_narrow<bf16>")
                       : "k_conv_narrow<f32>";
   hipLaunchKernelGGL((k_conv_narrow<BF, STATS>), dim3(narrow_grid(V_out)), dim3(kNarrowThreads), lds, (hipStream_t)stream_, in,

@@ -221,8 +221,8 @@ template <int KC, int NNB>
 static int conv_rb_launch(const uint16_t *in, int64_t rows_in, uint16_t *out, int64_t V_out, const int32_t *table, int vol,
                           const uint16_t *wpack, const float *bias, int mirror, hipStream_t st) {
   const size_t lds = (size_t)2 * KC * NNB * 1024 + (size_t)vol * kRbTile * sizeof(int32_t);
-  AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_rb<KC, NNB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     2 * KC * NNB * 1024 + kRbMaxVol * kRbTile * (int)sizeof(int32_t)));
+  static DynLdsOnce attr;
+  AABR_CHECK_HIP(dyn_lds_once(attr, (const void *)(k_conv_rb<KC, NNB>), 2 * KC * NNB * 1024 + kRbMaxVol * kRbTile * (int)sizeof(int32_t)));
   const int64_t ntiles = (V_out + kRbTile - 1) / kRbTile;
   int64_t grid = ntiles < 256 ? (ntiles + 7) / 8 * 8 : 256;   // one workgroup per CU, a multiple of the 8 XCDs
   hipLaunchKernelGGL((k_conv_rb<KC, NNB>), dim3((unsigned)grid), dim3(kRbThreads), lds, st,

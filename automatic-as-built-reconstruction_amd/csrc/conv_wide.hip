@@ -704,11 +704,8 @@ static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, flo
   }
 #define AABR_LAUNCH_WIDE(KERNEL, NAME, LDS, ...)                                                          \
   do {                                                                                                    \
-    static bool attr = false;                                                                             \
-    if (!attr) {                                                                                          \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
-      attr = true;                                                                                        \
-    }                                                                                                     \
+    static DynLdsOnce attr;                                                                               \
+    AABR_CHECK_HIP(dyn_lds_once(attr, (const void *)KERNEL, 80 * 1024));          \
     g_last_variant = NAME;                                                                                \
     hipLaunchKernelGGL(KERNEL, grid, dim3(256), (LDS), st, __VA_ARGS__);                                  \
   } while (0)
@@ -838,12 +835,8 @@ extern "C" int aabr_conv_forward_wide_split(const float *in_feats, int n_in, int
   const int nbuf = knob(K_SPLIT_NBUF) == 2 ? 2 : 1;   // single stage buffer: three workgroups per CU (latency-bound launches)
 #define AABR_SPLIT_CS_N(KG, NB)                                                                                        \
   do {                                                                                                                 \
-    static bool attr = false;                                                                                          \
-    if (!attr) {                                                                                                       \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         80 * 1024));                                                                  \
-      attr = true;                                                                                                     \
-    }                                                                                                                  \
+    static DynLdsOnce attr;                                                                               \
+    AABR_CHECK_HIP(dyn_lds_once(attr, (const void *)(k_conv_cs<KG, 0, NB>), 80 * 1024));          \
     g_last_variant = "k_conv_cs<" #KG ",0," #NB ",split>";                                                             \
     hipLaunchKernelGGL((k_conv_cs<KG, 0, NB>), grid, dim3(256),                                                        \
                        (size_t)((tile_rows + 1) * kWS + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_feats, n_in,     \
@@ -974,8 +967,8 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
 #define AABR_WIDE_BF(KG, NB, NCB) AABR_WIDE_BF_S(KG, NB, NCB, ((KG) <= 2 ? kBfSets : 2))
 #define AABR_WIDE_BF_D(KG, NB, NCB, D)                                                                              \
   do {                                                                                                             \
-    AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, D, NB, true, NCB, kBfSets>),                   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                    \
+    static DynLdsOnce attr;                                                                                        \
+    AABR_CHECK_HIP(dyn_lds_once(attr, (const void *)(k_conv_cs<KG, D, NB, true, NCB, kBfSets>), 80 * 1024));       \
     hipLaunchKernelGGL((k_conv_cs<KG, D, NB, true, NCB, kBfSets>), grid, dim3(256),                                \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
@@ -984,12 +977,8 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
 #define AABR_WIDE_BF_S(KG, NB, NCB, NS) AABR_WIDE_BF_L(KG, NB, NCB, NS)
 #define AABR_WIDE_BF_L(KG, NB, NCB, NS)                                                                            \
   do {                                                                                                             \
-    static bool attr = false;                                                                                      \
-    if (!attr) {                                                                                                   \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, NB, true, NCB, NS>),    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                  \
-      attr = true;                                                                                                 \
-    }                                                                                                              \
+    static DynLdsOnce attr;                                                                                        \
+    AABR_CHECK_HIP(dyn_lds_once(attr, (const void *)(k_conv_cs<KG, 0, NB, true, NCB, NS>), 80 * 1024));          \
     g_last_variant = NCB == 2 ? "k_conv_cs<" #KG ",0," #NB ",bf16,x128>" : "k_conv_cs<" #KG ",0," #NB ",bf16>";    \
     hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS>), grid, dim3(256),                   \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
@@ -1082,12 +1071,8 @@ extern "C" int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n
   const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
 #define AABR_SPLIT_BF(KG)                                                                                              \
   do {                                                                                                                 \
-    static bool attr = false;                                                                                          \
-    if (!attr) {                                                                                                       \
-      AABR_CHECK_HIP(hipFuncSetAttribute((const void *)(k_conv_cs<KG, 0, 1, true, 1, 2>),                              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));                      \
-      attr = true;                                                                                                     \
-    }                                                                                                                  \
+    static DynLdsOnce attr;                                                                                        \
+    AABR_CHECK_HIP(dyn_lds_once(attr, (const void *)(k_conv_cs<KG, 0, 1, true, 1, 2>), 80 * 1024));          \
     g_last_variant = "k_conv_cs<" #KG ",0,1,bf16,split>";                                                              \
     hipLaunchKernelGGL((k_conv_cs<KG, 0, 1, true, 1, 2>), grid, dim3(256),                                             \
                        (size_t)((tile_rows + 1) * kWS + 2 * 16 * KG * 32) * sizeof(float), st, in_f, n_in, in_bytes,    \

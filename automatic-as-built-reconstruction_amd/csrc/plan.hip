@@ -379,7 +379,13 @@ static int plan_run_part(const AabrPlanOp *ops, int n_ops, void *st_, int hold) 
   return AABR_OK;
 }
 
-extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) { return plan_run_part(ops, n_ops, st_, 0); }
+static bool launcher_has_work();
+extern "C" int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *st_) {
+  // the second stream's join state and event pool are shared with the launcher thread: a pass handed over in parts must
+  // have been drained before another list is run directly
+  AABR_CHECK_ARG(!launcher_has_work(), "parts submitted with aabr_plan_submit are still queued: call aabr_plan_drain first");
+  return plan_run_part(ops, n_ops, st_, 0);
+}
 
 // ---- pipelined submission ---------------------------------------------------------------------------------------------
 // A pass's list costs the host twice: the caller fills the records (interpreter time) and this library issues their
@@ -396,8 +402,9 @@ struct Launcher {
   std::condition_variable cv_work, cv_idle;
   std::deque<Job> q;
   bool busy = false, started = false;
-  int rc = AABR_OK;
-  std::string err;
+  int rc = AABR_OK;          // first failure since the last drain: STICKY -- every part behind it, of this pass or a later
+  std::string err;           // one, is dropped until aabr_plan_drain has reported it
+  const char *variant = "";  // aabr_conv_last_variant() as the launcher thread saw it after its last part
   long long busy_ns = 0, jobs = 0, sleeps = 0;   // (tools: time spent issuing, parts issued, times the queue ran dry)
   void run() {
     int cur_dev = -1;
@@ -425,6 +432,7 @@ struct Launcher {
       {
         std::lock_guard<std::mutex> l(m);
         if (r != AABR_OK && rc == AABR_OK) { rc = r; err = aabr_last_error(); }
+        if (!skip) variant = aabr_conv_last_variant();
         busy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         ++jobs;
         busy = false;
@@ -436,6 +444,12 @@ struct Launcher {
 Launcher *g_launcher = nullptr;           // created on first use and never destroyed (its thread outlives static destruction)
 std::once_flag g_launcher_once;
 } // namespace
+static bool launcher_has_work() {
+  if (!g_launcher) return false;
+  std::lock_guard<std::mutex> l(g_launcher->m);
+  return !g_launcher->q.empty() || g_launcher->busy;
+}
+namespace aabr { extern thread_local const char *g_last_variant; }   // conv.hip
 
 extern "C" int aabr_plan_submit(const AabrPlanOp *ops, int n_ops, void *st, int hold_side) {
   AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
@@ -470,6 +484,7 @@ extern "C" int aabr_plan_drain(void) {
   std::unique_lock<std::mutex> l(g_launcher->m);
   g_launcher->cv_idle.wait(l, [&] { return g_launcher->q.empty() && !g_launcher->busy; });
   const int rc = g_launcher->rc;
+  if (g_launcher->variant[0]) aabr::g_last_variant = g_launcher->variant;   // what the drained parts dispatched last
   if (rc != AABR_OK) {
     aabr::set_error("%s", g_launcher->err.c_str());
     g_launcher->rc = AABR_OK;

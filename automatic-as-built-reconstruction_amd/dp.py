@@ -21,7 +21,7 @@ class FlatParams(object):
     the flat gradient buffer by a single multi-tensor copy right before the collective."""
 
     def __init__(self, modules, grad_dtype=None):
-        """`grad_dtype=torch.bfloat16` (option): the gradient MESSAGE of the flat all-reduce travels in bf16 -- half the
+        """`grad_dtype=torch.bfloat16` (option): the gradient MESSAGE of the all-reduce (flat or bucketed) travels in bf16 -- half the
         bytes over xGMI (85 -> 42 MB for FPN_Net; SURVEY 5: "bf16 grads halve the message") -- the local gradients are
         rounded once before the collective, the sum is formed by the backend in bf16 and the mean + update in fp32.
         Default None: the reference's fp32 all-reduce."""
@@ -124,7 +124,8 @@ class FlatParams(object):
         a rank whose graph fell back to the per-module path (or cut its list differently) raises on every rank instead
         of hanging the others in a mismatched collective -- from step 0 on."""
         from sparseconvnet import planExecutor
-        self._bk = dict(works=[], params=[], grads=[], bufs=[], group=group, bytes=0, launched_early=0, sizes=[])
+        self._bk = dict(works=[], params=[], grads=[], bufs=[], msgs=[], group=group, bytes=0, launched_early=0, sizes=[])
+        msg_dtype = self.grad_dtype
         plan = getattr(self, "_bucket_plan", None)
 
         def ready(piece, n_pieces, flat, pairs):
@@ -134,11 +135,13 @@ class FlatParams(object):
                                    "ranks says %s" % (piece, n_pieces, flat.numel(), plan))
             bk["sizes"].append(flat.numel())
             buf = flat.clone()           # main stream; the collective below is ordered behind it
+            msg = buf.to(msg_dtype) if msg_dtype is not None else buf    # (option) the message travels in bf16
             bk["bufs"].append(buf)
+            bk["msgs"].append(msg)
             if plan is not None:         # agreed plan: launch underneath the rest of the backward pass
-                bk["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+                bk["works"].append(dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group, async_op=True))
                 bk["launched_early"] += 1 if piece < n_pieces - 1 else 0
-            bk["bytes"] += buf.numel() * buf.element_size()
+            bk["bytes"] += msg.numel() * msg.element_size()
             base = flat.data_ptr()
             for p_, g_ in pairs:
                 o = (g_.data_ptr() - base) // g_.element_size()
@@ -204,8 +207,8 @@ class FlatParams(object):
             except RuntimeError:
                 self.abort_bucketed()
                 raise
-            for buf in bk["bufs"]:
-                bk["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=bk["group"], async_op=True))
+            for msg in bk["msgs"]:
+                bk["works"].append(dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=bk["group"], async_op=True))
         if rest:
             buf = torch.empty(n, device=self.flat.device, dtype=self.flat.dtype)
             views, o = [], 0
@@ -213,9 +216,11 @@ class FlatParams(object):
                 views.append(buf[o:o + p_.numel()].view_as(p_))
                 o += p_.numel()
             torch._foreach_copy_(views, [p_.grad for p_ in rest])
+            msg = buf.to(self.grad_dtype) if self.grad_dtype is not None else buf
             bk["bufs"].append(buf)
-            bk["works"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=bk["group"], async_op=True))
-            bk["bytes"] += n * buf.element_size()
+            bk["msgs"].append(msg)
+            bk["works"].append(dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=bk["group"], async_op=True))
+            bk["bytes"] += n * msg.element_size()
             bk["params"] += rest
             bk["grads"] += views
         t0 = time.perf_counter()
@@ -223,6 +228,8 @@ class FlatParams(object):
             w.wait()
         self.wait_ms.append((time.perf_counter() - t0) * 1e3)
         del self.wait_ms[:-512]
+        if self.grad_dtype is not None and bk["bufs"]:
+            torch._foreach_copy_(bk["bufs"], bk["msgs"])      # widen the summed message back into the fp32 buckets
         if bk["params"]:
             if world_size > 1:
                 torch._foreach_mul_(bk["bufs"], 1.0 / world_size)

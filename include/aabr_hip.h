@@ -599,7 +599,10 @@ int aabr_plan_run(const AabrPlanOp *ops, int n_ops, void *stream);
  * issued strictly in submission order with the semantics of aabr_plan_run; with hold_side != 0 the part leaves the
  * second stream unjoined for the part that follows (the last part of a pass passes 0).  aabr_plan_drain blocks until
  * every submitted part has been ISSUED and returns the first failing part's code (aabr_last_error() holds its
- * message; the parts behind a failed one are dropped): call it before enqueuing anything else on the streams used. */
+ * message): call it before enqueuing anything else on the streams used.  The failure is STICKY: from the failing part
+ * on every submitted part -- of this pass or of a later one -- is dropped until aabr_plan_drain has returned the code.
+ * aabr_plan_run refuses to run while submitted parts are queued or being issued (AABR_EINVAL); after the drain
+ * aabr_conv_last_variant() on the calling thread names what the drained parts dispatched last. */
 int aabr_plan_submit(const AabrPlanOp *ops, int n_ops, void *stream, int hold_side);
 int aabr_plan_drain(void);
 /* (tools) the launcher's counters since process start: time spent issuing parts, parts issued, times it found its

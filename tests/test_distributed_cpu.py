@@ -109,7 +109,7 @@ def test_bench_without_gpu_fails_loudly_in_every_rank():
 
 
 # ---------------------------------------------------------------------------------------------- bucketed all-reduce
-def _bucket_worker(rank, world, port, q, cheat):
+def _bucket_worker(rank, world, port, q, cheat, bf16_msg=False):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here))
     import importlib
@@ -121,7 +121,7 @@ def _bucket_worker(rank, world, port, q, cheat):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
-    fp = dp.FlatParams([net])
+    fp = dp.FlatParams([net], grad_dtype=torch.bfloat16 if bf16_msg else None)
     fp.broadcast(0)
     w0 = fp.flat.clone()
     ps = list(net.parameters())           # 6 tensors; the "compiled graph" below owns the last four
@@ -163,18 +163,18 @@ def _bucket_worker(rank, world, port, q, cheat):
         # step 0 agrees the plan first and launches nothing early; later steps launch each piece as it arrives
         assert fp.bucket_stats["launched_during_backward"] == (0 if step == 0 else 1)
         out.append(("ok", [p.grad.numpy().copy() for p in ps], [g.numpy().copy() for g in local],
-                    fp.flat.detach().numpy().copy()))
+                    fp.flat.detach().numpy().copy(), fp.bucket_stats["bytes"]))
     q.put((rank, w0.numpy().copy(), out))     # numpy: plain pickles (torch would share storage with a dying process)
     if not cheat:
         dist.barrier()
     dist.destroy_process_group()
 
 
-def _run_bucket(cheat):
+def _run_bucket(cheat, bf16_msg=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + 7 + 3 * int(cheat)) % 1000
-    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q, cheat)) for r in range(2)]
+    port = 29500 + (os.getpid() + 7 + 3 * int(cheat) + 11 * int(bf16_msg)) % 1000
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q, cheat, bf16_msg)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
@@ -191,7 +191,7 @@ def test_two_rank_bucketed_allreduce_leaves_mean_gradients():
     (r0, w0, o0), (r1, w1, o1) = _run_bucket(False)
     assert np.array_equal(w0, w1) and len(o0) == len(o1) == 3
     w = w0
-    for (s0, g0, l0, f0), (s1, g1, l1, f1) in zip(o0, o1):
+    for (s0, g0, l0, f0, _), (s1, g1, l1, f1, _) in zip(o0, o1):
         assert s0 == s1 == "ok"
         mean = [(a + b) / 2 for a, b in zip(l0, l1)]
         for a, b, m in zip(g0, g1, mean):
@@ -200,6 +200,23 @@ def test_two_rank_bucketed_allreduce_leaves_mean_gradients():
         np.testing.assert_allclose(f0, w - 0.1 * np.concatenate([m.reshape(-1) for m in mean]), rtol=1e-5, atol=1e-6)
         assert np.array_equal(f0, f1)
         w = f0
+
+
+def test_two_rank_bucketed_allreduce_with_bf16_message():
+    """`FlatParams(grad_dtype=torch.bfloat16)` in the BUCKETED form -- every bucket's message travels in
+    bf16 (half the bytes), p.grad afterwards is the mean within one bf16 rounding of the local gradients' scale, both
+    replicas hold the same bytes"""
+    import numpy as np
+    (r0, w0, o0), (r1, w1, o1) = _run_bucket(False, bf16_msg=True)
+    (_, _, ref), _ = _run_bucket(False)
+    assert len(o0) == len(o1) == 3
+    for (s0, g0, l0, f0, b0), (s1, g1, l1, f1, b1), (_, _, _, _, bref) in zip(o0, o1, ref):
+        assert s0 == s1 == "ok" and b0 == b1 == bref // 2
+        for a, b, x, y in zip(g0, g1, l0, l1):
+            m = (x + y) / 2
+            tol = 2.0 ** -7 * max(np.abs(x).max(), np.abs(y).max()) + 1e-12
+            assert np.abs(a - m).max() <= tol and np.array_equal(a, b)
+        assert np.array_equal(f0, f1)
 
 
 def test_bucket_plan_mismatch_raises_instead_of_hanging():
