@@ -1514,6 +1514,30 @@ __global__ __launch_bounds__(256) void k_fill_offset_pairs(const int32_t *__rest
 // reduction dimension.  Pair indices are loaded 64 at a time (coalesced) and handed to the lane
 // groups by shuffles; 16 pairs are gathered per step before their MFMAs issue.  The four waves'
 // accumulators are summed through LDS in wave order (deterministic).  CB x NB blocks of 16.
+__device__ inline bool dw_chunk_range(const int32_t *__restrict__ words, int vol, int chunk_pairs, int direct, int chunk,
+                                      int lane, int &k, int &p0, int &p1) {
+  if (direct) {
+    k = chunk;
+    p0 = 0;
+    p1 = words[k];
+    return true;
+  }
+  const int32_t *cstart = words + vol + (chunk_pairs == 256 ? vol + 1 : 0);
+  if (chunk >= cstart[vol]) return false;                  // workgroup-uniform
+  k = 0;
+  for (int k0 = 0; k0 < vol; k0 += 64) {
+    int kk = k0 + lane;
+    bool mine = kk < vol && cstart[kk] <= chunk && chunk < cstart[kk + 1];
+    unsigned long long m = __ballot(mine);
+    if (m) { k = k0 + (__ffsll((long long)m) - 1); break; }
+  }
+  const int rk = words[k];
+  p0 = (chunk - cstart[k]) * chunk_pairs;
+  p1 = p0 + chunk_pairs;
+  if (p1 > rk) p1 = rk;
+  return true;
+}
+
 __device__ inline float ldf(const float *p, int64_t i) { return p[i]; }
 __device__ inline float ldf(const __bf16 *p, int64_t i) { return (float)p[i]; }
 
@@ -1521,7 +1545,7 @@ template <int CB, int NB, typename T>
 __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in, int ci,
                                                        const T *__restrict__ d_out, int co, int64_t V,
                                                        const int32_t *__restrict__ words, int vol,
-                                                       int chunk_pairs, float *__restrict__ partial) {
+                                                       int chunk_pairs, float *__restrict__ partial, int direct) {
   __shared__ f32x4 red[CB * NB][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, c16 = lane & 15;
@@ -1530,20 +1554,12 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in,
   const int tile = blockIdx.y;
   const int cb0 = (tile / tiles_n) * CB, nb0 = (tile % tiles_n) * NB;
   const int chunk = blockIdx.x;
-  const int32_t *cstart = words + vol + (chunk_pairs == 256 ? vol + 1 : 0);
-  if (chunk >= cstart[vol]) return;                        // workgroup-uniform
-  // which offset owns this chunk (cstart is non-decreasing)
-  int k = 0;
-  for (int k0 = 0; k0 < vol; k0 += 64) {
-    int kk = k0 + lane;
-    bool mine = kk < vol && cstart[kk] <= chunk && chunk < cstart[kk + 1];
-    unsigned long long m = __ballot(mine);
-    if (m) { k = k0 + (__ffsll((long long)m) - 1); break; }
-  }
+  int k, c0, c1;                                           // the chunk's offset and pair range; each wave a quarter
+  if (!dw_chunk_range(words, vol, chunk_pairs, direct, chunk, lane, k, c0, c1)) return;
   const int rk = words[k];
-  const int p0 = (chunk - cstart[k]) * chunk_pairs + wave * (chunk_pairs / 4);
+  const int p0 = c0 + wave * (chunk_pairs / 4);
   int p1 = p0 + chunk_pairs / 4;
-  if (p1 > rk) p1 = rk;
+  if (p1 > c1) p1 = c1;
   const int2 *pairs = reinterpret_cast<const int2 *>(words + op_hdr(vol) + (int64_t)vol * op_nb256(V)) +
                       (int64_t)k * V;
   f32x4 acc[CB][NB];
@@ -1639,7 +1655,7 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs(const T *__restrict__ in,
   }
   if (wave != 0) return;
   // D[i = c (row of dW) = g*4 + r][j = n = c16]
-  float *P = partial + (int64_t)chunk * ci * co;
+  float *P = partial + (int64_t)(direct ? k : chunk) * ci * co;
 #pragma unroll
   for (int a = 0; a < CB; ++a)
 #pragma unroll
@@ -1665,7 +1681,7 @@ template <int CB, int NB>
 __global__ __launch_bounds__(256) void k_conv_dw_pairs_bf16(const __bf16 *__restrict__ in, int ci,
                                                             const __bf16 *__restrict__ d_out, int co, int64_t V,
                                                             const int32_t *__restrict__ words, int vol,
-                                                            int chunk_pairs, float *__restrict__ partial) {
+                                                            int chunk_pairs, float *__restrict__ partial, int direct) {
   constexpr int SX = CB * 32 + 16, SG = NB * 32 + 16; // LDS row strides (bytes)
   constexpr int XCH = CB * 2, GCH = NB * 2;           // 16-byte chunks per row
   constexpr int XIT = (32 * XCH) / 64, GIT = (32 * GCH) / 64; // chunks per lane and batch
@@ -1678,19 +1694,11 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs_bf16(const __bf16 *__rest
   const int tile = blockIdx.y;
   const int cb0 = (tile / tiles_n) * CB, nb0 = (tile % tiles_n) * NB;
   const int chunk = blockIdx.x;
-  const int32_t *cstart = words + vol + (chunk_pairs == 256 ? vol + 1 : 0);
-  if (chunk >= cstart[vol]) return;                        // workgroup-uniform
-  int k = 0;
-  for (int k0 = 0; k0 < vol; k0 += 64) {
-    int kk = k0 + lane;
-    bool mine = kk < vol && cstart[kk] <= chunk && chunk < cstart[kk + 1];
-    unsigned long long m = __ballot(mine);
-    if (m) { k = k0 + (__ffsll((long long)m) - 1); break; }
-  }
-  const int rk = words[k];
-  const int p0 = (chunk - cstart[k]) * chunk_pairs + wave * (chunk_pairs / 4);
+  int k, c0, c1;
+  if (!dw_chunk_range(words, vol, chunk_pairs, direct, chunk, lane, k, c0, c1)) return;
+  const int p0 = c0 + wave * (chunk_pairs / 4);
   int p1 = p0 + chunk_pairs / 4;
-  if (p1 > rk) p1 = rk;
+  if (p1 > c1) p1 = c1;
   const int2 *pairs = reinterpret_cast<const int2 *>(words + op_hdr(vol) + (int64_t)vol * op_nb256(V)) +
                       (int64_t)k * V;
   unsigned char *xs = stage[wave], *gs = stage[wave] + 32 * SX;
@@ -1782,7 +1790,7 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs_bf16(const __bf16 *__rest
     __syncthreads();
   }
   if (wave != 0) return;
-  float *P = partial + (int64_t)chunk * ci * co;
+  float *P = partial + (int64_t)(direct ? k : chunk) * ci * co;
 #pragma unroll
   for (int a = 0; a < CB; ++a)
 #pragma unroll
@@ -1794,6 +1802,305 @@ __global__ __launch_bounds__(256) void k_conv_dw_pairs_bf16(const __bf16 *__rest
         if (c < ci && n < co) P[(int64_t)c * co + n] = t[r];
       }
     }
+}
+
+// ---- full-tile weight gradient (round 5) -------------------------------------------------------------------------------
+// k_conv_dw_pairs[_bf16] give a workgroup ONE 64 x 64 block of dW: a 128 x 128 layer is four workgroups per chunk and
+// every gathered row (input features and output gradients) is fetched twice -- at the dominant level 800 MB (bf16) /
+// 1.6 GB (fp32) of row gathers per launch, ~5.5 TB/s out of the L2s, which is what those kernels run at.  Here a
+// workgroup forms a whole 128 x 128 block for its chunk: the 256 threads gather each pair's two rows ONCE (full 128-plane
+// slices, 16-byte loads, whole 256- / 512-byte segments) into LDS, the four waves own one 64 x 64 quadrant each and read
+// their operand fragments from there.  All waves walk all pairs of the chunk, so there is no cross-wave sum at the end;
+// the summation order (pairs ascending per quadrant element, workgroups ascending in k_conv_dw_reduce_ranges) is fixed.
+//
+// Work split: a workgroup per 1024-pair chunk is 787 workgroups of equal weight for 768 resident slots at the dominant
+// level -- a CU that receives four takes a third longer than the average of 3.07, and every workgroup here is four times as
+// heavy as a 64 x 64 one.  So the pairs of ALL offsets are laid end to end (offset k owns [s_k, s_k + R_k) of R = sum R_k)
+// and workgroup w takes [w per, (w + 1) per), per = ceil(R / n_wg): every workgroup the same number of pairs, whatever the
+// offsets' sizes.  A workgroup whose range crosses offset boundaries writes one partial block per offset it touches, into
+// slot w + (number of non-empty offsets before k): along the staircase of (w, k) cells that sum grows by one per cell, so
+// slots are unique, at most n_wg + vol of them, and offset k's are contiguous: w_lo(k) + ne_k .. w_hi(k) + ne_k.
+constexpr int kDwMinPer = 128;                             // pairs per workgroup at least (tiny rule books: fewer workgroups)
+__device__ inline int64_t dw_range_per(int64_t rtot, int n_wg) {
+  const int64_t per = (rtot + n_wg - 1) / n_wg;
+  return per < kDwMinPer ? kDwMinPer : per;
+}
+__device__ inline int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(v, d);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+__device__ inline int64_t dw_total_pairs(const int32_t *__restrict__ words, int vol, int lane) {
+  int64_t rtot = 0;
+  for (int k0 = 0; k0 < vol; k0 += 64) {
+    const int c = k0 + lane < vol ? words[k0 + lane] : 0;
+    rtot += __shfl(wave_incl_scan(c, lane), 63);
+  }
+  return rtot;
+}
+// calls seg(k, p0, p1, slot) for every offset k the range [lo, hi) of the concatenated pair list touches, k ascending;
+// wave-uniform (every wave of a workgroup walks the same segments)
+template <typename F>
+__device__ inline void dw_for_segments(const int32_t *__restrict__ words, int vol, int lane, int64_t lo, int64_t hi, int w,
+                                       F seg) {
+  int64_t base = 0;
+  int ne_base = 0;
+  for (int k0 = 0; k0 < vol && base < hi; k0 += 64) {
+    const int c = k0 + lane < vol ? words[k0 + lane] : 0;
+    const int incl = wave_incl_scan(c, lane);
+    const int64_t s = base + incl - c;
+    const unsigned long long nz = __ballot(c > 0);
+    unsigned long long m = __ballot(c > 0 && s < hi && s + c > lo);
+    while (m) {
+      const int j = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int64_t sk = base + __shfl(incl - c, j);
+      const int ck = __shfl(c, j);
+      const int ne = ne_base + (int)__popcll(nz & ((1ull << j) - 1ull));
+      const int64_t a = lo > sk ? lo : sk, b = hi < sk + ck ? hi : sk + ck;
+      seg(k0 + j, (int)(a - sk), (int)(b - sk), w + ne);
+    }
+    base += __shfl(incl, 63);
+    ne_base += (int)__popcll(nz);
+  }
+}
+// bf16 storage: batches of 64 pairs; a row slice is 256 bytes = 16 chunks of 16 bytes, stored unpadded with the chunk
+// index XOR-swizzled by the row ((row & 3) | (row >> 3 & 1) << 2) << 1, so that the eight rows one half-wave of a
+// ds_read_b64_tr_b16 touches land in eight different 32-byte bank groups; the pair -> LDS row assignment is free (the
+// pair index is the reduction dimension) and the same for both operands.
+__global__ __launch_bounds__(256) void k_conv_dw_full_bf16(const __bf16 *__restrict__ in, int ci,
+                                                           const __bf16 *__restrict__ d_out, int co, int64_t V,
+                                                           const int32_t *__restrict__ words, int vol,
+                                                           float *__restrict__ partial) {
+  constexpr int kB = 64;                                   // pairs per batch
+  __shared__ __attribute__((aligned(16))) unsigned char xs[kB * 256];
+  __shared__ __attribute__((aligned(16))) unsigned char gs[kB * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int tiles_n = co >> 7;
+  const int tc = (int)blockIdx.y / tiles_n, tn = (int)blockIdx.y % tiles_n;
+  const int wc = wave >> 1, wn = wave & 1;
+  const int64_t rtot = dw_total_pairs(words, vol, lane);
+  const int64_t per = dw_range_per(rtot, (int)gridDim.x);
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < rtot ? lo + per : rtot;
+  if (lo >= hi) return;                                    // workgroup-uniform
+  const int2 *pairs0 = reinterpret_cast<const int2 *>(words + op_hdr(vol) + (int64_t)vol * op_nb256(V));
+  const __bf16 *inb = in + tc * 128, *gb = d_out + tn * 128;
+  auto sw = [](int row) { return (((row & 3) | (((row >> 3) & 1) << 2)) << 1); };
+  const int q4 = c16 >> 2, p4 = c16 & 3;
+  dw_for_segments(words, vol, lane, lo, hi, (int)blockIdx.x, [&](int k, int p0, int p1, int slot) {
+  const int2 *pairs = pairs0 + (int64_t)k * V;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 xr[4], gr[4];
+  // the pair entries of a batch are loaded one batch ahead of its rows (a wave issues in order: waiting for them in
+  // front of the row loads would stall the MFMAs behind)
+  auto load_pairs = [&](int q0) {
+    const int q = q0 + lane;
+    return (q < p1) ? pairs[q] : make_int2(-1, -1);
+  };
+  auto load_batch = [&](int2 pr) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 16 + wave * 4 + g;              // this lane's chunk: (row, c16)
+      const int t = __shfl(pr.x, row), o = __shfl(pr.y, row);
+      xr[it] = (u32x4){0u, 0u, 0u, 0u};
+      gr[it] = (u32x4){0u, 0u, 0u, 0u};
+      if (t >= 0) {
+        xr[it] = *reinterpret_cast<const u32x4 *>(inb + (int64_t)t * ci + c16 * 8);
+        gr[it] = *reinterpret_cast<const u32x4 *>(gb + (int64_t)o * co + c16 * 8);
+      }
+    }
+  };
+  auto store_batch = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 16 + wave * 4 + g;
+      const int off = row * 256 + ((c16 ^ sw(row)) << 4);
+      *reinterpret_cast<u32x4 *>(xs + off) = xr[it];
+      *reinterpret_cast<u32x4 *>(gs + off) = gr[it];
+    }
+  };
+  // transposed operand of one K step (32 pairs = LDS rows r0 .. r0+31): pairs g*8 .. g*8+7 of plane blk*16 + c16
+  auto tr_frag = [&](const unsigned char *base, int r0, int blk) {
+    const int rl = r0 + g * 8 + q4, rh = rl + 4;
+    const int ch = blk * 2 + (p4 >> 1), hb = (p4 & 1) << 3;
+    const unsigned char *al = base + rl * 256 + ((ch ^ sw(rl)) << 4) + hb;
+    const unsigned char *ah = base + rh * 256 + ((ch ^ sw(rh)) << 4) + hb;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)al);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)ah);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  {
+    load_batch(load_pairs(p0));
+    int2 prn = load_pairs(p0 + kB);
+    for (int q0 = p0; q0 < p1; q0 += kB) {
+      store_batch();
+      __syncthreads();
+      if (q0 + kB < p1) load_batch(prn);                   // in flight under this batch's MFMAs
+      prn = load_pairs(q0 + 2 * kB);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[4], bf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) af[a] = tr_frag(xs, ks * 32, wc * 4 + a);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bf[b] = tr_frag(gs, ks * 32, wn * 4 + b);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();                                     // every wave has read the batch before it is overwritten
+    }
+  }
+  float *P = partial + (int64_t)slot * ci * co;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = tc * 128 + (wc * 4 + a) * 16 + g * 4 + r, n = tn * 128 + (wn * 4 + b) * 16 + c16;
+        P[(int64_t)c * co + n] = acc[a][b][r];
+      }
+  });
+}
+
+// fp32: batches of 32 pairs; a row slice is 512 bytes, LDS rows padded to 144 words so that the four rows x 16 planes
+// one operand read touches are 64 different banks.
+__global__ __launch_bounds__(256) void k_conv_dw_full_f32(const float *__restrict__ in, int ci,
+                                                          const float *__restrict__ d_out, int co, int64_t V,
+                                                          const int32_t *__restrict__ words, int vol,
+                                                          float *__restrict__ partial) {
+  constexpr int kB = 32, kS = 144;                         // pairs per batch, LDS row stride in words
+  __shared__ __attribute__((aligned(16))) float xs[kB * kS];
+  __shared__ __attribute__((aligned(16))) float gs[kB * kS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int tiles_n = co >> 7;
+  const int tc = (int)blockIdx.y / tiles_n, tn = (int)blockIdx.y % tiles_n;
+  const int wc = wave >> 1, wn = wave & 1;
+  const int64_t rtot = dw_total_pairs(words, vol, lane);
+  const int64_t per = dw_range_per(rtot, (int)gridDim.x);
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < rtot ? lo + per : rtot;
+  if (lo >= hi) return;                                    // workgroup-uniform
+  const int2 *pairs0 = reinterpret_cast<const int2 *>(words + op_hdr(vol) + (int64_t)vol * op_nb256(V));
+  const float *inb = in + tc * 128, *gb = d_out + tn * 128;
+  const int h = lane >> 5, c32 = lane & 31;                // this lane's chunks: rows it*8 + wave*2 + h, 16-byte chunk c32
+  dw_for_segments(words, vol, lane, lo, hi, (int)blockIdx.x, [&](int k, int p0, int p1, int slot) {
+  const int2 *pairs = pairs0 + (int64_t)k * V;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 xr[4], gr[4];
+  auto load_pairs = [&](int q0) {
+    const int q = q0 + c32;
+    return (q < p1) ? pairs[q] : make_int2(-1, -1);
+  };
+  auto load_batch = [&](int2 pr) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + wave * 2 + h;
+      const int t = __shfl(pr.x, row), o = __shfl(pr.y, row);
+      xr[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      gr[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t >= 0) {
+        xr[it] = *reinterpret_cast<const f32x4 *>(inb + (int64_t)t * ci + c32 * 4);
+        gr[it] = *reinterpret_cast<const f32x4 *>(gb + (int64_t)o * co + c32 * 4);
+      }
+    }
+  };
+  auto store_batch = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + wave * 2 + h;
+      *reinterpret_cast<f32x4 *>(xs + row * kS + c32 * 4) = xr[it];
+      *reinterpret_cast<f32x4 *>(gs + row * kS + c32 * 4) = gr[it];
+    }
+  };
+  {
+    load_batch(load_pairs(p0));
+    int2 prn = load_pairs(p0 + kB);
+    for (int q0 = p0; q0 < p1; q0 += kB) {
+      store_batch();
+      __syncthreads();
+      if (q0 + kB < p1) load_batch(prn);
+      prn = load_pairs(q0 + 2 * kB);
+      const float *xa = xs + g * kS + wc * 64 + c16, *ga = gs + g * kS + wn * 64 + c16;
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {                     // four pairs per MFMA step: A[i = plane][k = pair g]
+        float fa[4], fb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = xa[st * 4 * kS + a * 16];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fb[b] = ga[st * 4 * kS + b * 16];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  float *P = partial + (int64_t)slot * ci * co;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = tc * 128 + (wc * 4 + a) * 16 + g * 4 + r, n = tn * 128 + (wn * 4 + b) * 16 + c16;
+        P[(int64_t)c * co + n] = acc[a][b][r];
+      }
+  });
+}
+
+// dW[k][i] = sum over the workgroups w_lo(k) .. w_hi(k) of the full-tile launch of their partial block for offset k, in
+// workgroup order (four slices as below, combined in slice order): deterministic.  Offsets without rules: zeros.
+__global__ __launch_bounds__(256) void k_conv_dw_reduce_ranges(const float *__restrict__ partial,
+                                                               const int32_t *__restrict__ words, int vol, int n_wg,
+                                                               int64_t cico, float *__restrict__ dW) {
+  __shared__ float red[4][64];
+  const int k = blockIdx.y, col = threadIdx.x & 63, sl = threadIdx.x >> 6, lane = col;
+  const int64_t i = (int64_t)blockIdx.x * 64 + col;
+  // s_k, R_k, ne_k of this block's offset and the total (every wave the same values)
+  int64_t base = 0, sk = 0;
+  int ne = 0, ck = 0;
+  for (int k0 = 0; k0 < vol; k0 += 64) {
+    const int c = k0 + lane < vol ? words[k0 + lane] : 0;
+    const int incl = wave_incl_scan(c, lane);
+    const unsigned long long nz = __ballot(c > 0);
+    if (k >= k0 && k < k0 + 64) {
+      const int j = k - k0;
+      sk = base + __shfl(incl - c, j);
+      ck = __shfl(c, j);
+      ne += (int)__popcll(nz & ((1ull << j) - 1ull));
+    } else if (k >= k0 + 64) ne += (int)__popcll(nz);
+    base += __shfl(incl, 63);
+  }
+  float s = 0.0f;
+  if (ck > 0 && i < cico) {
+    const int64_t per = dw_range_per(base, n_wg);
+    const int64_t w0 = sk / per, w1 = (sk + ck - 1) / per;
+#pragma unroll 4
+    for (int64_t w = w0 + sl; w <= w1; w += 4) s += partial[(w + ne) * cico + i];
+  }
+  red[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < cico) dW[(int64_t)k * cico + i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // dW[k][i] = sum of the partials of offset k's chunks (fixed order => deterministic): a block takes 64
@@ -1856,6 +2163,29 @@ static void launch_col_sum(const T *d_out, int64_t rows, int co, float *d_bias, 
   hipLaunchKernelGGL(k_col_sum_final, dim3((unsigned)ceil_div(co, 256)), dim3(256), 0, st, scratch, co, (int)S, d_bias);
 }
 
+// the full-tile kernels (k_conv_dw_full_*): whole 128 x 128 blocks, 16-byte row loads; knob DW_FULL = 0 keeps the
+// 64 x 64-block kernels (A/B)
+// Returns the number of workgroups per 128 x 128 block, or 0 when the 64 x 64-block kernels should run.  Measured on
+// the bench's rule books (tools/tools_dw_ab.py): the full-tile kernels win from ~250 k rules on and lose below (few, heavy
+// workgroups: latency-bound); a workgroup count that is a multiple of the 256 CUs (every CU the same number of equal
+// ranges) beats anything in between by 10-25 %; two per CU pay from ~600 k rules.  The rule count is on the device: it
+// is estimated from the table's size (a 3^3 submanifold table of a scene is about a third full, vol 1 is full).
+static int dw_full_workgroups(int ci, int co, const void *in, const void *d_out, int64_t max_chunks, int vol, int64_t V_out) {
+  if (ci % 128 || co % 128 || ((uintptr_t)in & 15) || ((uintptr_t)d_out & 15) || knob(K_DW_FULL) == 0) return 0;
+  const int tiles = (ci >> 7) * (co >> 7);
+  const int64_t slots = max_chunks - vol;                  // n_wg + vol partial blocks must fit the caller's scratch buffer
+  const int knob_min = knob(K_DW_FULL_MIN), knob_wgs = knob(K_DW_FULL_WGS);
+  if (knob_wgs > 0) return knob_wgs <= slots ? knob_wgs : 0;             // (A/B: a given number of workgroups)
+  if (knob_min > 0) {                                                    // (tests: small rule books through the kernel)
+    const int64_t n = slots < 256 / tiles ? slots : 256 / tiles;
+    return n >= knob_min ? (int)n : 0;
+  }
+  const int64_t r_est = vol == 1 ? V_out : (int64_t)vol * V_out / 3;
+  if (r_est < 250000) return 0;
+  int64_t n = (r_est >= 600000 ? 512 : 256) / tiles;
+  if (n > slots) n = 256 / tiles;
+  return n >= 1 && n <= slots ? (int)n : 0;
+}
 static void dw_tiling(int ci, int co, int &cb, int &nb, int &tiles) {
   int ncb = nnb_of(ci), nnb = nnb_of(co);
   cb = ncb >= 4 ? 4 : (ncb >= 2 ? 2 : 1);
@@ -2119,13 +2449,29 @@ static int conv_backward_weight_t(const T *in_feats, int n_in, const T *d_out, i
   int cb, nb, tiles;
   dw_tiling(n_in, n_out, cb, nb, tiles);
   AABR_CHECK_ARG(tiles <= 65535, "too many tiles");
-  dim3 grid((unsigned)max_chunks, (unsigned)tiles);
   const int chunk_pairs = dw_chunk(V_out, vol, n_in, n_out);
+  // an offset has at most V_out rules: with V_out <= chunk_pairs every offset is one chunk at most, workgroup x is offset
+  // x, writes dW[x] itself and no reduce follows
+  const int direct = V_out <= chunk_pairs ? 1 : 0;
+  float *dst = direct ? dW : scratch;
+  dim3 grid((unsigned)(direct ? vol : max_chunks), (unsigned)tiles);
+  const int n_wg = direct ? 0 : dw_full_workgroups(n_in, n_out, in_feats, d_out, max_chunks, vol, V_out);
+  if (sizeof(T) == 4 && n_wg) {
+    g_last_variant = "k_conv_dw_full_f32";
+    hipLaunchKernelGGL(k_conv_dw_full_f32, dim3((unsigned)n_wg, (unsigned)((n_in >> 7) * (n_out >> 7))), dim3(256), 0, st,
+                       reinterpret_cast<const float *>(in_feats), n_in, reinterpret_cast<const float *>(d_out), n_out,
+                       V_out, pairs, vol, scratch);
+    hipLaunchKernelGGL(k_conv_dw_reduce_ranges, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
+                       scratch, pairs, vol, n_wg, cico, dW);
+    if (d_bias) launch_col_sum<T>(d_out, V_out, n_out, d_bias, scratch, max_chunks * cico, st);
+    AABR_CHECK_LAUNCH();
+    return AABR_OK;
+  }
 #define AABR_LAUNCH_DW(CB, NB)                                                                           \
   do {                                                                                                   \
     g_last_variant = sizeof(T) == 4 ? "k_conv_dw_pairs<" #CB "," #NB ",float>" : "k_conv_dw_pairs<" #CB "," #NB ",bf16>"; \
     hipLaunchKernelGGL((k_conv_dw_pairs<CB, NB, T>), grid, dim3(256), 0, st, in_feats, n_in, d_out, n_out, \
-                       V_out, pairs, vol, chunk_pairs, scratch);                                         \
+                       V_out, pairs, vol, chunk_pairs, dst, direct);                                     \
   } while (0)
   if (cb == 1 && nb == 1) AABR_LAUNCH_DW(1, 1);
   else if (cb == 1 && nb == 2) AABR_LAUNCH_DW(1, 2);
@@ -2137,8 +2483,9 @@ static int conv_backward_weight_t(const T *in_feats, int n_in, const T *d_out, i
   else if (cb == 4 && nb == 2) AABR_LAUNCH_DW(4, 2);
   else AABR_LAUNCH_DW(4, 4);
 #undef AABR_LAUNCH_DW
-  hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
-                     scratch, pairs, vol, chunk_pairs, cico, dW);
+  if (!direct)
+    hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
+                       scratch, pairs, vol, chunk_pairs, cico, dW);
   if (d_bias) launch_col_sum<T>(d_out, V_out, n_out, d_bias, scratch, max_chunks * cico, st);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
@@ -2168,20 +2515,34 @@ extern "C" int aabr_conv_backward_weight_bf16(const uint16_t *in_feats, int n_in
     AABR_CHECK_ARG(tiles <= 65535, "too many tiles");
     const int chunk_pairs = dw_chunk(V_out, vol, n_in, n_out);
     const int64_t cico = (int64_t)n_in * n_out;
-    dim3 grid((unsigned)max_chunks, (unsigned)tiles);
+    const int direct = V_out <= chunk_pairs ? 1 : 0;       // (as in conv_backward_weight_t)
+    float *dst = direct ? dW : scratch;
+    dim3 grid((unsigned)(direct ? vol : max_chunks), (unsigned)tiles);
+    const int n_wg = direct ? 0 : dw_full_workgroups(n_in, n_out, in_feats, d_out, max_chunks, vol, V_out);
+    if (n_wg) {
+      g_last_variant = "k_conv_dw_full_bf16";
+      hipLaunchKernelGGL(k_conv_dw_full_bf16, dim3((unsigned)n_wg, (unsigned)((n_in >> 7) * (n_out >> 7))), dim3(256), 0,
+                         st, in16, n_in, do16, n_out, V_out, pairs, vol, scratch);
+      hipLaunchKernelGGL(k_conv_dw_reduce_ranges, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
+                         scratch, pairs, vol, n_wg, cico, dW);
+      if (d_bias) launch_col_sum<__bf16>(do16, V_out, n_out, d_bias, scratch, max_chunks * cico, st);
+      AABR_CHECK_LAUNCH();
+      return AABR_OK;
+    }
 #define AABR_LAUNCH_DW16(CB, NB)                                                                          \
   do {                                                                                                    \
     g_last_variant = "k_conv_dw_pairs_bf16<" #CB "," #NB ">";                                             \
     hipLaunchKernelGGL((k_conv_dw_pairs_bf16<CB, NB>), grid, dim3(256), 0, st, in16, n_in, do16, n_out, V_out, \
-                       pairs, vol, chunk_pairs, scratch);                                                 \
+                       pairs, vol, chunk_pairs, dst, direct);                                             \
   } while (0)
     if (cb == 2 && nb == 2) AABR_LAUNCH_DW16(2, 2);
     else if (cb == 2 && nb == 4) AABR_LAUNCH_DW16(2, 4);
     else if (cb == 4 && nb == 2) AABR_LAUNCH_DW16(4, 2);
     else AABR_LAUNCH_DW16(4, 4);
 #undef AABR_LAUNCH_DW16
-    hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
-                       scratch, pairs, vol, chunk_pairs, cico, dW);
+    if (!direct)
+      hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)ceil_div(cico, 64), (unsigned)vol), dim3(256), 0, st,
+                         scratch, pairs, vol, chunk_pairs, cico, dW);
     if (d_bias) launch_col_sum<__bf16>(do16, V_out, n_out, d_bias, scratch, max_chunks * cico, st);
     AABR_CHECK_LAUNCH();
     return AABR_OK;

@@ -4,9 +4,9 @@
 R=${1:-r05}
 mkdir -p gpurun_out
 timeout -k 10 500 python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
-timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras > gpurun_out/${R}_bench_line_driver_command.json 2>/dev/null
-timeout -k 10 400 python bench.py --dtype bf16 --no-extras > gpurun_out/${R}_bench_line_bf16.json 2>/dev/null
-timeout -k 10 400 python bench.py --config 4 --no-extras > gpurun_out/${R}_bench_line_config4.json 2>/dev/null
+timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_line_driver_command.json 2>/dev/null
+timeout -k 10 500 python bench.py --dtype bf16 > gpurun_out/${R}_bench_line_bf16.json 2>/dev/null
+timeout -k 10 500 python bench.py --config 4 > gpurun_out/${R}_bench_line_config4.json 2>/dev/null
 python - <<PY
 import json
 for f in ["", "_driver_command", "_bf16", "_config4"]:
