@@ -39,6 +39,16 @@ def main():
         busy = sum(e - s for s, e, _ in v)
         print("  %s=%s: %6d kernels busy %9.3f ms (%.1f %% of span), %.3f ms/step" %
               (qcol, q, len(v), busy / 1e6, 100.0 * busy / span, busy / 1e6 / steps))
+    if "--per-stream" in sys.argv:      # what each stream's busy time is made of
+        for q, v in sorted(per_q.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+            by = defaultdict(lambda: [0, 0])
+            for s_, e_, n_ in v:
+                a = by[short(n_)]
+                a[0] += 1
+                a[1] += e_ - s_
+            print("  kernels of %s=%s (ms/step, launches/step):" % (qcol, q))
+            for n_, a in sorted(by.items(), key=lambda kv: -kv[1][1])[:18]:
+                print("    %8.3f %7.1f  %s" % (a[1] / 1e6 / steps, a[0] / steps, n_))
     # union of busy intervals
     iv = sorted((s, e) for _, s, e, _ in rows)
     u, cs, ce = 0, iv[0][0], iv[0][1]

@@ -7,6 +7,7 @@ cd $root
 echo "floor rc=$?"
 timeout -k 10 300 python tools/tools_brick_bench.py > gpurun_out/r05_brick_geometry_ab.txt 2> gpurun_out/r05_brick_geometry_ab.err; echo "geom rc=$?"
 timeout -k 10 300 python tools/tools_rb_ab.py brick > gpurun_out/r05_conv_rb_ab.txt 2>&1; echo "rb rc=$?"
+(cat profiles/r05_conv_dw_ab.head; timeout -k 10 300 python tools/tools_dw_ab.py bf16 2>/dev/null; timeout -k 10 300 python tools/tools_dw_ab.py f32 2>/dev/null) > gpurun_out/r05_conv_dw_ab.txt; echo "dw rc=$?"
 bash tools/tools_profile_cmd.sh r05_fp32 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/r05_prof_fp32.txt 2>&1
 bash tools/tools_profile_cmd.sh r05_bf16 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --dtype bf16 > gpurun_out/r05_prof_bf16.txt 2>&1
 bash tools/tools_profile_cmd.sh r05_c4 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --config 4 > gpurun_out/r05_prof_c4.txt 2>&1

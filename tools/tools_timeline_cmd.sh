@@ -9,6 +9,6 @@ mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp && rm -rf $root/gpurun_out/prof_$tag
 timeout -k 10 600 rocprofv3 --kernel-trace -d $root/gpurun_out/prof_$tag -o run -- python3 $script "$@" > $root/gpurun_out/prof_$tag.log 2>&1; echo "prof rc=$?"
 db=$(find $root/gpurun_out/prof_$tag -name "*.db" | head -1)
-python3 $root/tools/rocpd_timeline.py $db --after-frac 0.5 --step-marker "k_rpn_label_maps<0>" > $root/gpurun_out/timeline_$tag.txt 2>&1
+python3 $root/tools/rocpd_timeline.py $db --after-frac 0.5 --step-marker "k_rpn_label_maps<0>" --per-stream > $root/gpurun_out/timeline_$tag.txt 2>&1
 rm -rf $root/gpurun_out/prof_$tag
-tail -60 $root/gpurun_out/timeline_$tag.txt
+tail -120 $root/gpurun_out/timeline_$tag.txt
