@@ -891,7 +891,7 @@ extern "C" int aabr_conv_wide_split(int n_in, int n_out, int64_t rows_in, int64_
   if (items >= 320) return 0;
   const int min_items = knob(K_SPLIT_MIN_ITEMS) == kKnobUnset ? 8 : knob(K_SPLIT_MIN_ITEMS);   // below: the 16-column item kernel wins
   if (items < min_items) return 0;
-  const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 1024 : knob(K_SPLIT_TARGET);   // workgroups aimed at (measured 512 / 1024 / 1536)
+  const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 768 : knob(K_SPLIT_TARGET);   // workgroups aimed at (round 5, with the XCD-range launch: 512 .. 1536 measured; 768 and 1280 best by ~3 %)
   int P = (int)((target + items - 1) / items);
   if (P > vol) P = vol;
   if (P > 32) P = 32;
@@ -1132,7 +1132,7 @@ extern "C" int aabr_conv_wide_split_bf16(int n_in, int n_out, int64_t rows_in, i
   if (items >= 320) return 0;
   const int min_items = knob(K_SPLIT_MIN_ITEMS) == kKnobUnset ? 8 : knob(K_SPLIT_MIN_ITEMS);
   if (items < min_items) return 0;
-  const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 1024 : knob(K_SPLIT_TARGET);
+  const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 768 : knob(K_SPLIT_TARGET);   // (bf16: 768 / 1024 / 1280 -> 1156 / 1192 / 1204 us of coarse-scale convolutions per step)
   int P = (int)((target + items - 1) / items);
   if (P > vol) P = vol;
   if (P > 32) P = 32;
