@@ -54,7 +54,6 @@ _SIGS = {
     "aabr_spatial_locations": (C.c_int, [_vp, _i64, _vp, _vp]),
     "aabr_conv_last_variant": (C.c_char_p, []),
     "aabr_conv_wide_tile_rows": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
-    "aabr_conv_wide_launch_workgroups": (_i64, [_i64, _i32]),
     "aabr_wide_blocks_words": (C.c_int64, [_i64, _i32, _i32]),
     "aabr_build_wide_blocks": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "aabr_conv_pack_weights": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -40,71 +40,8 @@ constexpr int kMaxVol = 63;  // vol + 1 prefix entries live in the lanes of one 
 //   entry = (partner_row << 8) | local_row; padding entries repeat the block's first pair with bit 31 set.
 // Pairs of one offset are in ascending local-row order (deterministic).
 // T = rows per tile (a multiple of 16, <= 128); the workgroup has ceil(T/64) waves
-// XCD ranges of the launches that will read this stream: tile boundaries b[0..8] behind the entries, b[x] .. b[x+1] = the
-// contiguous tiles of XCD x, cut so that every XCD carries the same weight (16-pair blocks + w0 per tile for the tile's
-// fixed costs), no range longer than cs_xcd_cap tiles.  w0 < 0: equal tile counts (the rule before round 5; A/B).
-// Computed by the LAST workgroup of the builder to finish (a ticket in a small pool that the last workgroup re-arms).
-__device__ int g_tile_ticket[64];
-// Tiles per XCD a k_conv_cs launch has workgroups for: an eighth of the tiles x 1.25 (+ 1): the weight-balanced ranges may
-// hold that many.  The launch is 8 cap tiles x ny: the hardware deals workgroups to the XCDs by linear id % 8, so every
-// XCD gets exactly cap x ny of them.
-__host__ __device__ inline int64_t cs_xcd_cap(int64_t ntiles) { return (ntiles * 5 + 31) / 32 + 1; }
-__device__ inline void cs_xcd_bounds(int32_t *__restrict__ words, int64_t ntiles, int vol, int maxb, int w0, int *s_sum,
-                                     long long *s_pre, int *s_raw) {
-  const int nth = (int)blockDim.x, tid = (int)threadIdx.x;
-  int32_t *xb = words + (ntiles * (vol + 1) + ntiles * (int64_t)maxb * 16);
-  const int64_t cap = cs_xcd_cap(ntiles);
-  if (w0 < 0 || ntiles < 16) {
-    if (tid <= 8) xb[tid] = (int32_t)(ntiles * tid / 8);
-    return;
-  }
-  // weight of a tile = its 16-pair blocks + w0; every thread sums one chunk of consecutive tiles
-  const int64_t per = (ntiles + nth - 1) / nth, a = (int64_t)tid * per, b = a + per < ntiles ? a + per : ntiles;
-  int sum = 0;
-  for (int64_t t = a; t < b; ++t) sum += words[t * (vol + 1) + vol] + w0;
-  s_sum[tid] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    long long acc = 0;
-    for (int i = 0; i < nth; ++i) { s_pre[i] = acc; acc += s_sum[i]; }
-    s_pre[nth] = acc;
-  }
-  __syncthreads();
-  if (tid >= 1 && tid < 8) {               // boundary x = tid: the first tile whose prefix weight would pass x/8 of the total
-    const long long target = s_pre[nth] * tid / 8;
-    int c = 0;
-    while (c + 1 < nth && s_pre[c + 1] <= target) ++c;
-    long long w = s_pre[c];
-    int64_t t = (int64_t)c * per;
-    const int64_t e = t + per < ntiles ? t + per : ntiles;
-    while (t < e) {
-      const int wt = words[t * (vol + 1) + vol] + w0;
-      if (w + wt > target) break;
-      w += wt;
-      ++t;
-    }
-    s_raw[tid] = (int)(t < ntiles ? t : ntiles);
-  }
-  __syncthreads();
-  if (tid == 0) {                           // no range longer than `cap` tiles, and what follows must stay placeable
-    int64_t lo = 0;
-    xb[0] = 0;
-    for (int x = 1; x < 8; ++x) {
-      int64_t u = s_raw[x];
-      const int64_t need = ntiles - (int64_t)(8 - x) * cap;
-      if (u > lo + cap) u = lo + cap;
-      if (u < need) u = need;
-      if (u < lo) u = lo;
-      if (u > ntiles) u = ntiles;
-      xb[x] = (int32_t)u;
-      lo = u;
-    }
-    xb[8] = (int32_t)ntiles;
-  }
-}
-
 __global__ __launch_bounds__(256) void k_build_tileT(const int32_t *__restrict__ table, int64_t V, int vol, int T,
-                                                      int32_t *__restrict__ words, int ticket_slot, int w0) {
+                                                      int32_t *__restrict__ words) {
   const int kT = T;
   const int NWV = (T + 63) / 64;
   __shared__ int s_cnt[4][kMaxVol];
@@ -155,19 +92,6 @@ __global__ __launch_bounds__(256) void k_build_tileT(const int32_t *__restrict__
     const int pad = ((tot + 15) & ~15) - tot;
     if ((int)threadIdx.x < pad) ent[s_base[k] * 16 + tot + threadIdx.x] = s_first[k] | (int)0x80000000;
   }
-  // the last workgroup to get here cuts the XCD ranges (every tile's block count is in its prefix row by then)
-  __shared__ int s_last;
-  __shared__ int s_sum[256];
-  __shared__ long long s_pre[257];
-  __shared__ int s_raw[8];
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(&g_tile_ticket[ticket_slot], 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  cs_xcd_bounds(words, ntiles, vol, maxb, w0, s_sum, s_pre, s_raw);
-  if (threadIdx.x == 0) g_tile_ticket[ticket_slot] = 0;    // re-armed for the launch that takes this slot next
 }
 
 __device__ inline float bcf_(unsigned int v) { return __builtin_bit_cast(float, v); }
@@ -202,18 +126,6 @@ struct BnBwdStats {
   float leak;
   const float *out;                                 // bf16 storage only
 };
-
-// launch of k_conv_cs over ntiles x ny items: 8 XCDs x cs_xcd_cap tiles x ny (the surplus workgroups return at once)
-static inline dim3 cs_grid(int64_t ntiles, int ny) { return dim3((unsigned)(8 * cs_xcd_cap(ntiles)), (unsigned)ny); }
-
-} // namespace aabr
-// workgroups a wide launch over `ntiles` tiles and `ny` (slab, part) items per tile is made of (tools: the grid size a
-// kernel trace or a PMC pass shows for that launch)
-extern "C" int64_t aabr_conv_wide_launch_workgroups(int64_t ntiles, int ny) {
-  const dim3 g = aabr::cs_grid(ntiles, ny);
-  return (int64_t)g.x * g.y;
-}
-namespace aabr {
 
 // Forms that were built, measured slower and removed in round 5 (their A/B tables are the record): fp32 on the bf16 pipe by
 // a three-term split (profiles/r03_conv_x3_ab.txt), a fourth resident workgroup through a two-slot operand ring
@@ -253,27 +165,14 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   // Offset split (coarse maps: too few (tile, slab) items to fill the chip): grid.y = slabs x P, part p of a (tile, slab)
   // sweeps the filter offsets [p vol / P, (p + 1) vol / P) only and writes its fp32 partial tile to out + p V_out co;
   // k_split_reduce adds the parts in part order (bias, residual and the storage rounding happen there).
-  // Round 5: the eight ranges are cut by WEIGHT, not by count -- in brick order the 16-pair blocks per tile vary by
-  // region (scenes differ in density) and the heaviest eighth carried 5-13 % more than the mean while the other XCDs
-  // idled (tools/dev/tile_balance.py).  k_build_tileT's last workgroup leaves nine tile boundaries behind the entries
-  // (cs_xcd_bounds); the launch carries kCsSlack x the items so that a range with more tiles than an eighth still finds
-  // its workgroups on its XCD; the surplus ones return here.  (Interleaving smaller segments over the XCDs instead
-  // balances as well and costs the L2 locality: dominant instance 318 -> 342 us, measured and dropped.)
   const int nparts = (wflip >> 8) & 0xff;
-  const int64_t ntiles = (V_out + kT2 - 1) / kT2;
-  const int maxb = (kT2 / 16) * vol;
   int64_t tile;
   int nb0, part = 0;
-  unsigned item_id;
   {
-    const unsigned ny = gridDim.y;
+    const unsigned ny = gridDim.y, total = gridDim.x * ny;
     const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned x = lin & 7u, j = lin >> 3;
-    const int32_t *xb = words + (ntiles * (vol + 1) + ntiles * (int64_t)maxb * 16);
-    const unsigned t0 = (unsigned)xb[x], t1 = (unsigned)xb[x + 1];
-    if (j >= (t1 - t0) * ny) return;                       // workgroup-uniform, before any barrier
-    const unsigned wi = t0 * ny + j;
-    item_id = wi;
+    const unsigned per = total >> 3, rem = total & 7u, x = lin & 7u;
+    const unsigned wi = x * per + (x < rem ? x : rem) + (lin >> 3);
     tile = wi / ny;
     unsigned sp = wi % ny;
     if (nparts > 1) { part = (int)(sp % (unsigned)nparts); sp /= (unsigned)nparts; }
@@ -282,6 +181,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   const int k_lo = nparts > 1 ? part * vol / nparts : 0;
   const int kend = nparts > 1 ? (part + 1) * vol / nparts : vol;   // offsets >= kend are past the end for this part
   const int64_t row0 = tile * kT2;
+  const int64_t ntiles = (V_out + kT2 - 1) / kT2;
+  const int maxb = (kT2 / 16) * vol;
   const int vpre = lane <= vol ? words[tile * (vol + 1) + lane] : 0;
   {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -558,7 +459,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
   if (DBG & 4) { // timing experiments: per-wave phase clocks -> the buffer passed as `bias` (which is then not added)
     if (lane == 0) {
       long long *d = reinterpret_cast<long long *>(const_cast<float *>(bias)) +
-                     ((int64_t)item_id * 4 + wave) * 5;
+                     (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 5;
       for (int q = 0; q < 5; ++q) d[q] = dbg_t[q];
     }
     bias = nullptr;
@@ -658,7 +559,7 @@ using namespace aabr;
 
 static int64_t wide_words(int64_t V, int vol, int T) {
   const int64_t nt = (V + T - 1) / T;
-  return nt * (vol + 1) + nt * (int64_t)(T / 16) * vol * 16 + 16;    // + the nine XCD boundaries (cs_xcd_bounds)
+  return nt * (vol + 1) + nt * (int64_t)(T / 16) * vol * 16;
 }
 
 extern "C" int64_t aabr_wide_blocks_words(int64_t V, int vol, int tile_rows) { return wide_words(V, vol, tile_rows); }
@@ -670,10 +571,8 @@ extern "C" int aabr_build_wide_blocks(const int32_t *table, int64_t V, int vol, 
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(table && blocks, "null pointer");
   const unsigned nt = (unsigned)((V + tile_rows - 1) / tile_rows);
-  static std::atomic<unsigned> seq{0};
-  const int w0 = knob(K_WIDE_XCD_W0) == kKnobUnset ? 16 : knob(K_WIDE_XCD_W0);
   hipLaunchKernelGGL(k_build_tileT, dim3(nt), dim3(64 * ((tile_rows + 63) / 64)), 0, (hipStream_t)stream_, table, V, vol,
-                     tile_rows, blocks, (int)(seq.fetch_add(1) & 63u), w0);
+                     tile_rows, blocks);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -790,10 +689,10 @@ static int wide_launch_f32(const float *in_feats, int n_in, int64_t rows_in, flo
   const int64_t wp_bytes = (int64_t)vol * nkc * (n_out / 16) * 2048;
   AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
   AABR_CHECK_ARG(n_in <= 128 || (n_in & 127) == 0, "n_in above 128 must be a multiple of 128");
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / 64));
   // bit 1: the waves raise their priority for the matrix phase of a step (s_setprio): the wave that holds its operands
   // gets the pipe, the others issue their gathers -- measured 331 -> 323.5 us on the dominant instance; WIDE_PRIO knob 0: off
   const int flip = ((flags >> 1) & 1) | (knob(K_WIDE_PRIO) == 0 ? 0 : 2);
-  const dim3 grid = cs_grid((V_out + tile_rows - 1) / tile_rows, n_out / 64);
   const int kg = nkc >= 4 ? 4 : nkc;
   // LDS stage buffers: with 128-channel groups the double-buffered stage (32 KiB) allows two workgroups per CU, a
   // single buffer three (49 KiB each) at the price of a second barrier per pair: measured +4...+10 % (128->128 at 84k
@@ -891,7 +790,7 @@ extern "C" int aabr_conv_wide_split(int n_in, int n_out, int64_t rows_in, int64_
   if (items >= 320) return 0;
   const int min_items = knob(K_SPLIT_MIN_ITEMS) == kKnobUnset ? 8 : knob(K_SPLIT_MIN_ITEMS);   // below: the 16-column item kernel wins
   if (items < min_items) return 0;
-  const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 768 : knob(K_SPLIT_TARGET);   // workgroups aimed at (round 5, with the XCD-range launch: 512 .. 1536 measured; 768 and 1280 best by ~3 %)
+  const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 768 : knob(K_SPLIT_TARGET);   // workgroups aimed at (round 5: 512 .. 1536 re-measured; 768 and 1280 best by ~3 %)
   int P = (int)((target + items - 1) / items);
   if (P > vol) P = vol;
   if (P > 32) P = 32;
@@ -930,8 +829,8 @@ extern "C" int aabr_conv_forward_wide_split(const float *in_feats, int n_in, int
   const int64_t wp_bytes = (int64_t)vol * nkc * (n_out / 16) * 2048;
   AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
   AABR_CHECK_ARG(n_in <= 128 || (n_in & 127) == 0, "n_in above 128 must be a multiple of 128");
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)((n_out / 64) * parts));
   const int flip = ((flags >> 1) & 1) | (knob(K_WIDE_PRIO) == 0 ? 0 : 2) | (parts << 8);
-  const dim3 grid = cs_grid((V_out + tile_rows - 1) / tile_rows, (n_out / 64) * parts);
   const int kg = nkc >= 4 ? 4 : nkc;
   const int nbuf = knob(K_SPLIT_NBUF) == 2 ? 2 : 1;   // single stage buffer: three workgroups per CU (latency-bound launches)
 #define AABR_SPLIT_CS_N(KG, NB)                                                                                        \
@@ -1054,8 +953,8 @@ static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in,
   AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
   AABR_CHECK_ARG(n_in <= 256 || (n_in & 255) == 0, "n_in above 256 must be a multiple of 256");
   const int ncb = wide_bf16_ncb(n_in, n_out);
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)(n_out / (64 * ncb)));
   const int flip = ((flags >> 1) & 1) | (knob(K_WIDE_PRIO) == 1 ? 2 : 0);   // bf16: priority only on request (measured below)
-  const dim3 grid = cs_grid((V_out + tile_rows - 1) / tile_rows, n_out / (64 * ncb));
   const int kg = nkc >= 4 ? 4 : nkc;
   int nbuf = 1;
   {                                                // tuning experiments only
@@ -1166,8 +1065,8 @@ extern "C" int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n
   const int64_t wp_bytes = (int64_t)vol * (n_in / 32) * (n_out / 16) * 1024;
   AABR_CHECK_ARG(wp_bytes < (1ll << 31), "packed weights must be < 2 GiB");
   AABR_CHECK_ARG(n_in <= 256 || (n_in & 255) == 0, "n_in above 256 must be a multiple of 256");
+  dim3 grid((unsigned)((V_out + tile_rows - 1) / tile_rows), (unsigned)((n_out / 64) * parts));
   const int flip = ((flags >> 1) & 1) | (parts << 8);
-  const dim3 grid = cs_grid((V_out + tile_rows - 1) / tile_rows, (n_out / 64) * parts);
   const int kg = nkc >= 4 ? 4 : nkc;
   const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
 #define AABR_SPLIT_BF(KG)                                                                                              \

@@ -449,7 +449,7 @@ def conv_kernel_table(torch, wl, dtype, max_rows=None):
                               stream()))
             elif tile_rows and bf:
                 ncb_ = 2 if (n_out % 128 == 0 and n_in <= 128) else 1      # 128-column slabs (conv_wide.hip)
-                g["grid_threads"] = int(lib.aabr_conv_wide_launch_workgroups((ga.rows + tile_rows - 1) // tile_rows, n_out // (64 * ncb_))) * 256
+                g["grid_threads"] = ((ga.rows + tile_rows - 1) // tile_rows) * (n_out // (64 * ncb_)) * 256
                 blocks = ga.blocks_wide(tile_rows)
                 wt = torch.empty_like(wpack)
                 if tr_:     # w is the layer's own weight; the input-gradient launch reads its transposed pack
@@ -464,7 +464,7 @@ def conv_kernel_table(torch, wl, dtype, max_rows=None):
                                                           ptr(blocks), tile_rows, ga.vol, None, g["flags"] & 3,
                                                           ptr(wpack), stream()))
             elif tile_rows:
-                g["grid_threads"] = int(lib.aabr_conv_wide_launch_workgroups((ga.rows + tile_rows - 1) // tile_rows, n_out // 64)) * 256
+                g["grid_threads"] = ((ga.rows + tile_rows - 1) // tile_rows) * (n_out // 64) * 256
                 blocks = ga.blocks_wide(tile_rows)
                 check(lib.aabr_conv_pack_weights(ptr(w), ga.vol, n_in, n_out, tr_, ptr(wpack), stream()))
 

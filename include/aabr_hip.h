@@ -283,9 +283,6 @@ int aabr_build_offset_pairs(const int32_t *table, const int32_t *block_counts, i
  *   aabr_conv_forward_wide: n_in % 32 == 0, n_out % 64 == 0; `wpack` must already hold the packed weights of
  *     this orientation; flags bit1: mirrored offsets (submanifold input-gradient through the forward table). */
 int aabr_conv_wide_tile_rows(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
-/* (tools) number of workgroups of a wide launch over `ntiles` tiles x `ny` (slab, part) items per tile: a few more than
- * items -- the items are dealt to the 8 XCDs in interleaved segments and the surplus workgroups return at once */
-int64_t aabr_conv_wide_launch_workgroups(int64_t ntiles, int ny);
 int64_t aabr_wide_blocks_words(int64_t V, int vol, int tile_rows);
 int aabr_build_wide_blocks(const int32_t *table, int64_t V, int vol, int tile_rows, int32_t *blocks, void *stream);
 int aabr_conv_pack_weights(const float *W, int vol, int n_in, int n_out, int transpose, float *wpack, void *stream);

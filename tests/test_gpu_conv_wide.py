@@ -612,54 +612,3 @@ def test_wide_bf16_write_out_backward_statistics_feed_batchnorm_backward(nIn, nO
         _hip.set_knob("BN_SMALL", None)
         _hip.set_knob("CONV_WIDE_BF16", None)
 
-
-def test_block_stream_carries_weight_balanced_xcd_ranges():
-    """round 5: the builder's last workgroup leaves nine tile boundaries behind the entries -- contiguous ranges of equal
-    WEIGHT (16-pair blocks + 16 per tile) for the eight XCDs, none longer than the launch has workgroups for; knob
-    WIDE_XCD_W0 = -1 gives the equal-count split; which workgroup computes a tile never changes a bit of the result"""
-    import _hip
-    import synth_scenes as S
-    scn = _scn()
-    lib = _hip.load()
-    l, _ = S.make_batch(2, 60000, 9000, 50)
-    x = scn.InputLayer(3, [4096, 4096, 512], mode=4)([_t(l), _t(np.zeros((l.shape[0], 1), np.float32))])
-    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
-    ga, T = tb.out, 128
-    nt = (ga.rows + T - 1) // T
-    cap = (nt * 5 + 31) // 32 + 1
-    assert lib.aabr_conv_wide_launch_workgroups(nt, 2) == 8 * cap * 2
-
-    def bounds(knob):
-        _hip.set_knob("WIDE_XCD_W0", knob)
-        try:
-            ga._blocks256 = {}
-            w = ga.blocks_wide(T)
-            scn.SCN.flush_geom()
-            torch.cuda.synchronize()
-        finally:
-            _hip.set_knob("WIDE_XCD_W0", None)
-        hdr = w[: nt * (ga.vol + 1)].view(nt, ga.vol + 1).cpu().numpy()
-        return w, hdr[:, ga.vol].astype(np.int64), w[-16:-7].cpu().numpy().astype(np.int64)
-
-    w_eq, nb, b_eq = bounds(-1)
-    np.testing.assert_array_equal(b_eq, [nt * i // 8 for i in range(9)])
-    w_bal, nb2, b = bounds(None)
-    np.testing.assert_array_equal(nb, nb2)
-    assert b[0] == 0 and b[8] == nt and (np.diff(b) >= 0).all() and (np.diff(b) <= cap).all()
-    wt = nb + 16
-    per = np.array([wt[b[i]:b[i + 1]].sum() for i in range(8)], dtype=np.float64)
-    per_eq = np.array([wt[b_eq[i]:b_eq[i + 1]].sum() for i in range(8)], dtype=np.float64)
-    assert per.max() / per.mean() < 1.02 <= max(1.02, per_eq.max() / per_eq.mean())
-    # the same convolution through both splits: bit-equal
-    torch.manual_seed(0)
-    f = torch.randn(ga.rows, 128, device=DEV)
-    W = torch.randn(27, 128, 128, device=DEV) * 0.05
-    wp = torch.empty(int(lib.aabr_conv_wpack_floats(27, 128, 128)), device=DEV)
-    _hip.check(lib.aabr_conv_pack_weights(_hip.ptr(W), 27, 128, 128, 0, _hip.ptr(wp), _hip.stream()))
-    outs = []
-    for blocks in (w_eq, w_bal):
-        o = torch.full((ga.rows, 128), float("nan"), device=DEV)
-        _hip.check(lib.aabr_conv_forward_wide(_hip.ptr(f), 128, ga.rows, _hip.ptr(o), 128, ga.rows, _hip.ptr(blocks), T, 27,
-                                              None, 0, _hip.ptr(wp), _hip.stream()))
-        outs.append(o)
-    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
