@@ -785,9 +785,10 @@ extern "C" int aabr_conv_wide_split(int n_in, int n_out, int64_t rows_in, int64_
   if (rows_in >= (1ll << 23) || rows_in * n_in * 4 >= (1ll << 31)) return 0;
   if (n_in < 64 || (n_in > 128 && (n_in & 127))) return 0;
   if (knob(K_WIDE_SPLIT) == 0) return 0;
-  const int T = 64;
+  if (((V_out + 63) / 64) * (n_out / 64) >= 320) return 0;
+  int T = V_out >= 1024 ? 96 : 64;     // fp32, round 5: 96-row tiles from ~1 k rows on (5,565 rows 54 -> 49 us, 1,382 rows 57 -> 53; 332 rows 27 vs 29)
+  { const int v = knob(K_SPLIT_ROWS); if (v >= 64 && v <= 128 && (v & 15) == 0) T = v; }   // (A/B)
   const int64_t items = ((V_out + T - 1) / T) * (n_out / 64);
-  if (items >= 320) return 0;
   const int min_items = knob(K_SPLIT_MIN_ITEMS) == kKnobUnset ? 8 : knob(K_SPLIT_MIN_ITEMS);   // below: the 16-column item kernel wins
   if (items < min_items) return 0;
   const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 768 : knob(K_SPLIT_TARGET);   // workgroups aimed at (round 5: 512 .. 1536 re-measured; 768 and 1280 best by ~3 %)
@@ -1026,9 +1027,10 @@ extern "C" int aabr_conv_wide_split_bf16(int n_in, int n_out, int64_t rows_in, i
   if (rows_in >= (1ll << 23) || rows_in * n_in * 2 >= (1ll << 31)) return 0;
   if (n_in > 256 && (n_in & 255)) return 0;
   if (knob(K_WIDE_SPLIT) == 0 || knob(K_CONV_WIDE_BF16) == 0) return 0;
-  const int T = 64;
+  int T = 64;
+  if (((V_out + 63) / 64) * (n_out / 64) >= 320) return 0;
+  { const int v = knob(K_SPLIT_ROWS); if (v >= 64 && v <= 128 && (v & 15) == 0) T = v; }   // (A/B)
   const int64_t items = ((V_out + T - 1) / T) * (n_out / 64);
-  if (items >= 320) return 0;
   const int min_items = knob(K_SPLIT_MIN_ITEMS) == kKnobUnset ? 8 : knob(K_SPLIT_MIN_ITEMS);
   if (items < min_items) return 0;
   const int target = knob(K_SPLIT_TARGET) == kKnobUnset ? 768 : knob(K_SPLIT_TARGET);   // (bf16: 768 / 1024 / 1280 -> 1156 / 1192 / 1204 us of coarse-scale convolutions per step)
