@@ -469,6 +469,11 @@ class _Pass(object):
             v = self._wide[key] = SCN.wide_split(n_in, n_out, rows_in, rows_out, vol, bf) or ()
         return v or None
 
+    def res_ok(self, n_in, n_out, rows_in, rows_out, vol):
+        """an fp32 launch that can add a residual in its write-out: the wide kernel, or the offset split (its second
+        stage, k_split_reduce, adds it)"""
+        return bool(self.wide_rows(n_in, n_out, rows_in, rows_out, vol) or self.split_of(n_in, n_out, rows_in, rows_out, vol))
+
     def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf,
                     xf=0, res=0):
         """the record of the launch SCN._conv_fwd makes for a prepacked weight; returns the new write offset"""
@@ -483,9 +488,9 @@ class _Pass(object):
                 self._lw = -int(self.lib.aabr_conv_narrow_parts(rows_out))
             return off + 176
         T = self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf)
-        assert T or not res
         self._lw = T
         sp = None if T else self.split_of(n_in, n_out, rows_in, rows_out, gather.vol, bf)
+        assert T or (sp and not bf) or not res
         if T:
             pack(buf, off, K_WIDE, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0,
                  0.0, rows_in, rows_out, 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), res, 0, p_pack, 0, 0, 0, 0,
@@ -499,7 +504,7 @@ class _Pass(object):
             self._tmp.append(tmp)
             ws = tmp.data_ptr()
             pack(buf, off, K_WSPLIT, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, Ts, P, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
-                 0, 0, src, dst, gather.blocks_wide(Ts).data_ptr(), 0, 0, p_pack, ws, 0, 0, 0, 0, 0)
+                 0, 0, src, dst, gather.blocks_wide(Ts).data_ptr(), 0 if bf else res, 0, p_pack, ws, 0, 0, 0, 0, 0)
         else:
             pack(buf, off, K_CONV, (F_BF16 if bf else 0) | xf, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,
                  rows_in, rows_out, 0, 0, src, dst, gather.blocks().data_ptr(), p_w, 0, p_pack, 0, 0, 0, 0, 0, 0)
@@ -519,7 +524,7 @@ class _Pass(object):
             if kind == "conv":
                 x, y, lvl, lo, n_in, n_out, book, side = op[1:9]
                 fz = fuse.get(id(op))
-                if fz is not None and V[lo] and self.wide_rows(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
+                if fz is not None and V[lo] and self.res_ok(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
                     add_op, other = fz
                     skip.add(id(add_op))
                     steps.append(((x, other), add_op[3]))
@@ -620,7 +625,7 @@ class _Pass(object):
             if kind == "conv":
                 x, y, lvl, lo, n_in, n_out, book, side, p_w, pf = op[1:11]
                 fz = fuse.get(id(op))
-                if fz is not None and V[lo] and self.wide_rows(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
+                if fz is not None and V[lo] and self.res_ok(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
                     add_op, other = fz           # out = conv + other, written where the add would have written
                     skip.add(id(add_op))
                     off0 = off
@@ -774,7 +779,7 @@ class _Pass(object):
                                            n_out, g, p_w, pt, flags, flg == F_BF16)
                     if (self._lw >= 64 or self._lw < 0) and off > off0:
                         last_din = (gx, off0, self._lw, n_out)
-                elif V[lvl] and self.wide_rows(n_in, n_out, V[lo], V[lvl], g.vol):
+                elif V[lvl] and self.res_ok(n_in, n_out, V[lo], V[lvl], g.vol):
                     off0 = off
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
                                            n_out, g, p_w, pt, flags, False, 0, AD[res[0]][res[1]])
