@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libaabr_hip.so")
 
 _lib = None
 META_WORDS = 16
-ABI_VERSION = 500      # include/aabr_hip.h AABR_ABI_VERSION this binding (_SIGS) was written for
+ABI_VERSION = 600      # include/aabr_hip.h AABR_ABI_VERSION this binding (_SIGS) was written for
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 _i32p = C.POINTER(C.c_int32)
@@ -61,8 +61,6 @@ _SIGS = {
     "aabr_conv_wide_split": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
     "aabr_conv_wide_split_scratch_floats": (C.c_int64, [_i64, _i32, _i32]),
     "aabr_conv_narrow_ok": (C.c_int, [_i32, _i32, _i64, _i64, _i32, _i32]),
-    "aabr_conv_rb_ok": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
-    "aabr_conv_forward_rb_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
     "aabr_conv_forward_narrow": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp]),
     "aabr_conv_forward_narrow_bf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp]),
     "aabr_conv_narrow_parts": (C.c_int, [_i64]),
@@ -150,6 +148,11 @@ _SIGS = {
                                        _f32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "aabr_rpn_label_generation": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _f32p, _vp, _i32, _f32, _vp, _i32p, _f32p,
                                             _i32, _i32, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "aabr_rpn_label_generation_targets": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _f32p, _vp, _i32, _f32, _vp, _i32p,
+                                                    _f32p, _i32, _i32, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp,
+                                                    _f32p, _vp, _vp]),
+    "aabr_box_encode": (C.c_int, [_vp, _vp, _i64, _f32p, _vp, _vp]),
+    "aabr_box_decode": (C.c_int, [_vp, _vp, _i64, _i32, _f32p, _f32, _vp, _vp]),
     "aabr_rpn_topk_scratch_words": (C.c_int64, [_i32]),
     "aabr_rpn_topk_maps": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _i32, _i32p, _vp, _i64, _vp, _vp, _vp]),
     "aabr_rpn_gather_logits": (C.c_int, [_i32, _vp, _i32, _i32p, _i32p, _i32, _i64, _vp, _vp]),

@@ -17,7 +17,7 @@ void set_error(const char *fmt, ...);
 #define AABR_KNOB_LIST(X)                                                                                            \
   X(CONV_WLDS) X(CONV_SMALL) X(CONV_NBW) X(CONV_WPB) X(WIDE_ROWS) X(CONV_WIDE) X(WIDE_NBUF) X(CONV_WIDE_BF16)         \
   X(VOXEL_MEAN) X(WIDE_NCB) X(BN_SMALL) X(WIDE_PRIO) X(PLAN_SIDE_BATCH) X(PLAN_SIDE_PRIO) X(SMALL_WPB) X(SMALL_MAX)   \
-  X(WIDE_SPLIT) X(SPLIT_TARGET) X(SPLIT_NBUF) X(SPLIT_MIN_ITEMS) X(CONV_NARROW) X(CONV_RB) X(DW_FULL) X(DW_FULL_MIN) X(DW_FULL_WGS) X(SPLIT_ROWS)
+  X(WIDE_SPLIT) X(SPLIT_TARGET) X(SPLIT_NBUF) X(SPLIT_MIN_ITEMS) X(CONV_NARROW) X(DW_FULL) X(DW_FULL_MIN) X(DW_FULL_WGS) X(SPLIT_ROWS)
 #define AABR_KNOB_ENUM(n) K_##n,
 enum Knob { AABR_KNOB_LIST(AABR_KNOB_ENUM) K_COUNT };
 #undef AABR_KNOB_ENUM

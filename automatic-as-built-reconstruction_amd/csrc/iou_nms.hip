@@ -549,8 +549,29 @@ struct RpnLabelParams {
   float aug[4];                                     // target_Y, target_Z, anchor_Y, anchor_Z
   int n_maps, A, criterion, only_xy, use_yaw, allow_low;
   float voxel_scale, fg, bg, yaw_thr;
+  float w[7];                                       // BoxCoder3D weights of the regression targets
 };
 constexpr int kLabelTgtChunk = 128;
+
+// BoxCoder3D.encode_centroid_box (modeling/box_coder_3d.py:46-51) = second_box_encode(targets, anchors, smooth_dim=True)
+// (second/pytorch/core/box_torch_ops.py:82-116; both boxes split positionally as x, y, z, w, l, h, r), the yaw difference
+// wrapped by limit_period(., 0.5, pi) (utils3d/geometric_torch.py:4-10), times the coder's weights -- the same fp32
+// operations in the same order as the torch expressions (no contraction: -ffp-contract=off)
+__device__ __forceinline__ void box_encode7(const float *g, const float *a, const float *w, float *o) {
+  const float diagonal = sqrtf(a[4] * a[4] + a[3] * a[3]);
+  float e[7];
+  e[0] = (g[0] - a[0]) / diagonal;
+  e[1] = (g[1] - a[1]) / diagonal;
+  e[2] = (g[2] - a[2]) / a[5];
+  e[3] = g[3] / a[3] - 1.0f;
+  e[4] = g[4] / a[4] - 1.0f;
+  e[5] = g[5] / a[5] - 1.0f;
+  const float kPi = 3.14159274101257324f;             // (float)math.pi
+  const float rt = g[6] - a[6];
+  e[6] = rt - floorf(rt / kPi + 0.5f) * kPi;
+#pragma unroll
+  for (int d = 0; d < 7; ++d) o[d] = e[d] * w[d];
+}
 
 // order-preserving float -> uint32 key (0 = below every float): the row maxima are reduced with integer atomicMax
 __device__ __forceinline__ uint32_t label_key(float v) {
@@ -586,7 +607,8 @@ template <int PASS>
 __global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const float *__restrict__ base_anchors,
                                                         int64_t *__restrict__ matched_idx,
                                                         float *__restrict__ matched_val, float *__restrict__ iou_out,
-                                                        uint32_t *__restrict__ gt_best) {
+                                                        uint32_t *__restrict__ gt_best,
+                                                        float *__restrict__ reg_targets) {
   __shared__ float s_t5[kLabelTgtChunk][5];
   __shared__ float s_tz[kLabelTgtChunk][2];
   __shared__ uint32_t s_key[kLabelTgtChunk];        // PASS 0: this workgroup's row maxima
@@ -597,6 +619,7 @@ __global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const 
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int G = p.n_targets[b];
   float a5[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, az0 = 0.f, az1 = 0.f;
+  float an[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (t < N) {
     int m = 0;
 #pragma unroll
@@ -607,7 +630,6 @@ __global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const 
     const int a = r % p.A;
     const int32_t *sc = p.coords[m] + 4 * site;
     const float *ba = base_anchors + 7 * ((int64_t)m * p.A + a);
-    float an[7];
 #pragma unroll
     for (int d = 0; d < 3; ++d) an[d] = (float)sc[d] / p.voxel_scale * p.stride[m][d] + ba[d];
 #pragma unroll
@@ -670,7 +692,17 @@ __global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const 
   }
   if (PASS == 1 && t < N) {
     const int64_t o = p.out_begin[b] + t;
-    if (G == 0) { matched_idx[o] = -1; matched_val[o] = 0.f; return; }
+    if (G == 0) {
+      matched_idx[o] = -1;
+      matched_val[o] = 0.f;
+      if (reg_targets) {       // an example without ground truth: matched_targets = anchor (loss_3d.py:91-94)
+        float e[7];
+        box_encode7(an, an, p.w, e);
+#pragma unroll
+        for (int d = 0; d < 7; ++d) reg_targets[7 * o + d] = e[d];
+      }
+      return;
+    }
     matched_val[o] = best;
     int64_t mi = best < p.bg ? -1 : (best < p.fg ? -2 : best_g);   // BELOW_LOW_THRESHOLD / BETWEEN_THRESHOLDS
     if (p.allow_low) {
@@ -678,6 +710,17 @@ __global__ __launch_bounds__(256) void k_rpn_label_maps(RpnLabelParams p, const 
       if (mi == -1 && near) mi = -2;                   // IGNORE_HIGHEST_MATCH_NEARBY
     }
     matched_idx[o] = mi;
+    if (reg_targets) {
+      // regression target of EVERY anchor, as RPNLossComputation.prepare_targets forms it (loss_3d.py:186-196):
+      // box_coder.encode(target[matched_idxs.clamp(min=0)], anchor) -- the un-thickened boxes, anchor and ground truth
+      const float *tb = p.targets[b] + 7 * (mi < 0 ? 0 : mi);
+      float g7[7], e[7];
+#pragma unroll
+      for (int d = 0; d < 7; ++d) g7[d] = tb[d];
+      box_encode7(g7, an, p.w, e);
+#pragma unroll
+      for (int d = 0; d < 7; ++d) reg_targets[7 * o + d] = e[d];
+    }
   }
 }
 
@@ -915,14 +958,15 @@ extern "C" int aabr_rpn_proposals_batch(int n_maps, const void *const *coords_pt
   return AABR_OK;
 }
 
-extern "C" int aabr_rpn_label_generation(int n_maps, const void *const *coords_ptrs, int nb,
+extern "C" int aabr_rpn_label_generation_targets(int n_maps, const void *const *coords_ptrs, int nb,
                                          const int32_t *seg_begin_host, const int32_t *site_begin_host,
                                          const float *strides_host, const float *base_anchors, int num_anchors,
                                          float voxel_scale, const void *const *target_ptrs,
                                          const int32_t *n_targets_host, const float *aug_host, int criterion,
                                          int only_xy, float fg_iou, float bg_iou, float yaw_threshold,
                                          int allow_low_quality_matches, int64_t *matched_idx, float *matched_val,
-                                         float *iou_out, uint32_t *row_max_scratch, void *stream_) {
+                                         float *iou_out, uint32_t *row_max_scratch, const float *weights_host,
+                                         float *regression_targets, void *stream_) {
   AABR_CHECK_ARG(n_maps >= 1 && n_maps <= kMaxRpnMaps && nb >= 0 && nb <= kMaxRpnBatch && num_anchors > 0 &&
                      voxel_scale > 0, "bad arguments (<= 8 maps, <= 16 examples)");
   AABR_CHECK_ARG(coords_ptrs && seg_begin_host && site_begin_host && strides_host && target_ptrs && n_targets_host &&
@@ -967,16 +1011,99 @@ extern "C" int aabr_rpn_label_generation(int n_maps, const void *const *coords_p
   p.use_yaw = yaw_threshold > 1.58f ? 0 : 1;
   p.yaw_thr = yaw_threshold;
   p.allow_low = allow_low_quality_matches ? 1 : 0;
+  AABR_CHECK_ARG(!regression_targets || weights_host, "regression targets need the coder's 7 weights");
+  for (int d = 0; d < 7; ++d) p.w[d] = regression_targets ? weights_host[d] : 1.0f;
   const dim3 grid((unsigned)ceil_div(nmax, 256), (unsigned)nb);
   if (p.allow_low && gts > 0) {
     AABR_CHECK_ARG(row_max_scratch, "allow_low_quality_matches needs the row-maximum scratch (sum of n_targets words)");
     AABR_CHECK_HIP(hipMemsetAsync(row_max_scratch, 0, sizeof(uint32_t) * (size_t)gts, (hipStream_t)stream_));
     hipLaunchKernelGGL(k_rpn_label_maps<0>, grid, dim3(256), 0, (hipStream_t)stream_, p, base_anchors, matched_idx,
-                       matched_val, iou_out, row_max_scratch);
+                       matched_val, iou_out, row_max_scratch, (float *)nullptr);
     AABR_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_rpn_label_maps<1>, grid, dim3(256), 0, (hipStream_t)stream_, p, base_anchors, matched_idx,
-                     matched_val, iou_out, row_max_scratch);
+                     matched_val, iou_out, row_max_scratch, regression_targets);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+extern "C" int aabr_rpn_label_generation(int n_maps, const void *const *coords_ptrs, int nb,
+                                         const int32_t *seg_begin_host, const int32_t *site_begin_host,
+                                         const float *strides_host, const float *base_anchors, int num_anchors,
+                                         float voxel_scale, const void *const *target_ptrs,
+                                         const int32_t *n_targets_host, const float *aug_host, int criterion,
+                                         int only_xy, float fg_iou, float bg_iou, float yaw_threshold,
+                                         int allow_low_quality_matches, int64_t *matched_idx, float *matched_val,
+                                         float *iou_out, uint32_t *row_max_scratch, void *stream_) {
+  return aabr_rpn_label_generation_targets(n_maps, coords_ptrs, nb, seg_begin_host, site_begin_host, strides_host,
+                                           base_anchors, num_anchors, voxel_scale, target_ptrs, n_targets_host, aug_host,
+                                           criterion, only_xy, fg_iou, bg_iou, yaw_threshold, allow_low_quality_matches,
+                                           matched_idx, matched_val, iou_out, row_max_scratch, nullptr, nullptr, stream_);
+}
+
+// BoxCoder3D.encode on two [N,7] lists (modeling/box_coder_3d.py:34-51)
+struct BoxEncodeW { float w[7]; };
+__global__ __launch_bounds__(256) void k_box_encode(const float *__restrict__ targets, const float *__restrict__ anchors,
+                                                    int64_t n, BoxEncodeW w, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g[7], a[7], e[7];
+#pragma unroll
+  for (int d = 0; d < 7; ++d) { g[d] = targets[7 * i + d]; a[d] = anchors[7 * i + d]; }
+  box_encode7(g, a, w.w, e);
+#pragma unroll
+  for (int d = 0; d < 7; ++d) out[7 * i + d] = e[d];
+}
+
+extern "C" int aabr_box_encode(const float *targets, const float *anchors, int64_t n, const float *weights_host,
+                               float *out, void *stream_) {
+  AABR_CHECK_ARG(n >= 0 && weights_host, "bad arguments");
+  if (n == 0) return AABR_OK;
+  AABR_CHECK_ARG(targets && anchors && out, "null pointer");
+  BoxEncodeW w;
+  for (int d = 0; d < 7; ++d) w.w[d] = weights_host[d];
+  hipLaunchKernelGGL(k_box_encode, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream_, targets, anchors,
+                     n, w, out);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
+// BoxCoder3D.decode_centroid_box on lists (modeling/box_coder_3d.py:53-80): encodings [n, 7 * num_classes] against
+// anchors [n, 7] (the anchor of a row serves all its classes) -> boxes [n, 7 * num_classes]
+__global__ __launch_bounds__(256) void k_box_decode(const float *__restrict__ enc, const float *__restrict__ anchors,
+                                                    int64_t n, int nc, BoxEncodeW w, float clip, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * nc) return;
+  const float *an = anchors + 7 * (i / nc);
+  float e[7];
+#pragma unroll
+  for (int d = 0; d < 7; ++d) e[d] = enc[7 * i + d] / w.w[d];
+#pragma unroll
+  for (int d = 3; d < 6; ++d) e[d] = e[d] > clip ? clip : e[d];
+  const float diagonal = sqrtf(an[4] * an[4] + an[3] * an[3]);
+  float o[7];
+  o[0] = e[0] * diagonal + an[0];
+  o[1] = e[1] * diagonal + an[1];
+  o[2] = e[2] * an[5] + an[2];
+  o[3] = (e[3] + 1) * an[3];
+  o[4] = (e[4] + 1) * an[4];
+  o[5] = (e[5] + 1) * an[5];
+  const float period = 3.14159274101257324f;
+  const float rg = e[6] + an[6];
+  o[6] = rg - floorf(rg / period + 0.5f) * period;
+#pragma unroll
+  for (int d = 0; d < 7; ++d) out[7 * i + d] = o[d];
+}
+
+extern "C" int aabr_box_decode(const float *encodings, const float *anchors, int64_t n, int num_classes,
+                               const float *weights_host, float clip, float *out, void *stream_) {
+  AABR_CHECK_ARG(n >= 0 && num_classes >= 1 && weights_host, "bad arguments");
+  if (n == 0) return AABR_OK;
+  AABR_CHECK_ARG(encodings && anchors && out, "null pointer");
+  BoxEncodeW w;
+  for (int d = 0; d < 7; ++d) w.w[d] = weights_host[d];
+  hipLaunchKernelGGL(k_box_decode, dim3((unsigned)ceil_div(n * num_classes, 256)), dim3(256), 0, (hipStream_t)stream_,
+                     encodings, anchors, n, num_classes, w, clip, out);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

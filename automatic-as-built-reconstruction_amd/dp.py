@@ -275,7 +275,9 @@ def reduce_loss_dict(loss_dict, group=None):
     with torch.no_grad():
         names = sorted(loss_dict.keys())
         stacked = torch.stack([torch.as_tensor(loss_dict[k]).detach().reshape(()) for k in names], dim=0)
-        dist.reduce(stacked, dst=0, group=group)
+        # `dst` is a GLOBAL rank: the first member of the group (global rank 0 for the default group)
+        dst = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.reduce(stacked, dst=dst, group=group)
         if dist.get_rank(group) == 0:
             stacked /= world
         return {k: v for k, v in zip(names, stacked)}
@@ -293,6 +295,8 @@ def gather_predictions(predictions_per_rank, group=None):
             return o.detach().cpu()
         if isinstance(o, dict):
             return {k: to_host(v) for k, v in o.items()}
+        if isinstance(o, tuple) and hasattr(o, "_fields"):      # namedtuple: positional fields
+            return type(o)(*[to_host(v) for v in o])
         if isinstance(o, (list, tuple)):
             return type(o)(to_host(v) for v in o)
         return o

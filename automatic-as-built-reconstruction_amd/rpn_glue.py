@@ -252,7 +252,7 @@ def rpn_proposals(maps, objectness, box_regression, base_anchors, strides, voxel
 
 def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thickness, criterion=6,
                       fg_iou=0.55, bg_iou=0.2, batch_size=None, return_matrix=False, yaw_threshold=0.7,
-                      allow_low_quality_matches=True):
+                      allow_low_quality_matches=True, regression_targets=False, weights=(1.0,) * 7):
     """The label-generation half of the RPN's training step on the device: per example the IoU of its ground-truth
     boxes against the anchors of ALL maps, `boxlist_iou_3d(target, anchor, aug_thickness, criterion,
     flag='rpn_label_generation')` (RPNLossComputation.match_targets_to_anchors, modeling/rpn/loss_3d.py:91-100;
@@ -270,7 +270,12 @@ def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thi
     the maps' site lists (AnchorGenerator.grid_anchors, anchor_generator_sparse3d.py:88-104, example-major like
     `cat_scales_anchor`), the per-example row ranges come from the grids' per-sample offsets (no host read), the
     [G_b, N_b] matrices are written only with `return_matrix`.
-    Returns a list over examples of (matched_idxs int64 [N_b], matched_vals fp32 [N_b], iou [G_b, N_b] or None)."""
+    `regression_targets` True: the same launch also writes what RPNLossComputation.prepare_targets computes next
+    (loss_3d.py:186-196) -- `box_coder.encode(target[matched_idxs.clamp(min=0)], anchor)` for every anchor, BoxCoder3D's
+    centroid form with `weights` (box_coder_3d.py:46-51; an example without ground truth encodes its anchors against
+    themselves, loss_3d.py:91-94) -- and every tuple gets it as a fourth entry, fp32 [N_b, 7].
+    Returns a list over examples of (matched_idxs int64 [N_b], matched_vals fp32 [N_b], iou [G_b, N_b] or None
+    [, regression targets])."""
     from utils3d import rotate_nms_3d_torch as R
     lib = _hip.load()
     n_maps = len(maps)
@@ -309,16 +314,18 @@ def rpn_label_matches(maps, base_anchors, strides, voxel_scale, targets, aug_thi
                aug_thickness["anchor_Z"])
         n_gt = sum(int(t.shape[0]) for t in tg)
         rowmax = torch.empty(max(n_gt, 1), dtype=torch.int32, device=dev) if allow_low_quality_matches else None
-        check(lib.aabr_rpn_label_generation(
+        regt = torch.empty((total, 7), dtype=torch.float32, device=dev) if regression_targets else None
+        check(lib.aabr_rpn_label_generation_targets(
             n_maps, _hip.ptrs([g.coords for g in grids]), b1 - b0, _hip.i32xn(seg), _hip.i32xn(site),
             _hip.f32xn([v for st in strides for v in st]), ptr(ba), A, float(voxel_scale), _hip.ptrs(tg),
             _hip.i32xn([int(t.shape[0]) for t in tg]), _hip.f32x4(aug), int(criterion), int(bool(R.DEBUG)),
             float(fg_iou), float(bg_iou), float(yaw_threshold), int(bool(allow_low_quality_matches)), ptr(midx),
-            ptr(mval), ptr(mat), ptr(rowmax), stream()))
+            ptr(mval), ptr(mat), ptr(rowmax), _hip.f32xn(weights), ptr(regt), stream()))
         o = mo = 0
         for n, t in zip(n_anch, tg):
             G = int(t.shape[0])
-            out.append((midx[o:o + n], mval[o:o + n], mat[mo:mo + G * n].view(G, n) if return_matrix else None))
+            row = (midx[o:o + n], mval[o:o + n], mat[mo:mo + G * n].view(G, n) if return_matrix else None)
+            out.append(row + (regt[o:o + n],) if regression_targets else row)
             o += n
             mo += G * n
     return out

@@ -757,7 +757,10 @@ class Metadata_3(object):
         rows = self._brick_rows = torch.empty((_BK_MAX_LEVELS, _BK_ROW), dtype=torch.int32, device=dev)
         self._brick_nrows = 1
         bk = _Brick([e + 1 for e in extent[:3]], extent[3] + 1, n, n, dev, rows[0, 64:64 + _hip.META_WORDS])
-        scratch = _brick_build(piece["pc"], n, 0, (1, 1, 1), (1, 1, 1), key, bk)
+        # the level is clamped to the EXTENT of the points, not to the layer's spatial size: a coordinate beyond
+        # spatial_size (<= 65534) is a site here as it is for the hash form and the reference's InputLayer
+        out_sp = tuple(max(int(k), int(e) + 1) for k, e in zip(key, extent[:3]))
+        scratch = _brick_build(piece["pc"], n, 0, (1, 1, 1), (1, 1, 1), out_sp, bk)
         flush_geom()
         check(lib.aabr_points_sites(piece["pc"].data_ptr(), n, bk.dims_c(), bk.dir_ptr(), bk.bricks_ptr(),
                                     ptr(piece["point_site"]), ptr(piece["first_pt"]), ptr(piece["cnt_extra"]),
@@ -857,7 +860,8 @@ class Metadata_3(object):
         self._brick_nrows = 1
         bk = _Brick(ext, nsamples, V, V, dev, rows[0, 64:64 + _hip.META_WORDS])
         old_coords = pend["site_coords"]
-        scratch = _brick_build(old_coords, V, 0, (1, 1, 1), (1, 1, 1), il["spatial"], bk)
+        out_sp = tuple(max(int(k), int(e)) for k, e in zip(il["spatial"], ext))       # see _brick_scatter_launch
+        scratch = _brick_build(old_coords, V, 0, (1, 1, 1), (1, 1, 1), out_sp, bk)
         flush_geom()
         nb = torch.empty(5 * V + n + 8, dtype=torch.int32, device=dev)
         new_of_old, old_of_new, first2, extra2, head2 = (nb[i * V:(i + 1) * V] for i in range(5))
@@ -1045,7 +1049,9 @@ class Metadata_3(object):
             fs, st, osz = _key(filter_size), _key(filter_stride), _key(out_spatial)
             dev = gi.coords.device
             vol = fs[0] * fs[1] * fs[2]
-            if gi.brick is not None and gi.V > 0 and osz not in self.__dict__.get("_pregrids", ()):
+            have = self.grids.get(osz)
+            if gi.brick is not None and gi.V > 0 and osz not in self.__dict__.get("_pregrids", ()) and \
+                    not (have is not None and have.brick is not None):
                 self.buildBrickPyramid([(osz, _key(in_spatial), fs, st)])       # (one host read)
             elif self.site_order == "brick" and gi.V == 0:                      # an empty level under an empty level
                 self.grids[osz] = _Grid(gi.coords[:0], None, None, 0, 0)
@@ -1055,8 +1061,16 @@ class Metadata_3(object):
                 self.rulebooks[k] = tb
                 return tb
             go = self.grids.get(osz) if osz in self.__dict__.get("_pregrids", ()) else None
-            if go is not None:         # built ahead by buildGridsFromInput
-                self._pregrids.discard(osz)
+            if go is None and gi.brick is not None:
+                # brick order: an output level that already exists (a second rule book onto the same output size, with
+                # another filter or stride) is served from that level, as the reference serves it from its existing grid
+                # (Metadata.cpp:484-510) -- rebuilding it would renumber rows that already carry features.  A brick
+                # level never falls through to the hash builders below.
+                go = self.grids.get(osz)
+                if go is None or go.brick is None:
+                    raise RuntimeError("site_order='brick': no brick level for output size %r" % (osz,))
+            if go is not None:         # built ahead by buildGridsFromInput / buildBrickPyramid
+                self.__dict__.setdefault("_pregrids", set()).discard(osz)
                 V_out = go.V
                 t_out = torch.empty((vol, V_out), dtype=torch.int32, device=dev)
                 t_in = torch.empty((vol, gi.V), dtype=torch.int32, device=dev)

@@ -1,43 +1,42 @@
-"""SparseToDense (reference: SparseConvNet/sparseconvnet/sparseToDense.py): sparse hidden layer ->
-dense [batch, planes, X, Y, Z] tensor."""
+"""SparseToDense: a sparse hidden layer written out as a dense [batch, planes, X, Y, Z] tensor, zeros where no site is
+active (reference: SparseConvNet/sparseconvnet/sparseToDense.py:14-73; same class name, arguments and output layout)."""
 from torch.autograd import Function
 from torch.nn import Module
 
 from . import SCN
 
 
-class SparseToDenseFunction(Function):
-    @staticmethod
-    def forward(ctx, input_features, input_metadata, spatial_size, dimension, nPlanes):
-        ctx.input_metadata = input_metadata
-        ctx.dimension = dimension
-        ctx.spatial_size = spatial_size
-        ctx.save_for_backward(input_features)
-        output = input_features.new()
-        SCN.SparseToDense_updateOutput(spatial_size, input_metadata, input_features, output, nPlanes)
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        grad_input = grad_output.new()
-        input_features, = ctx.saved_tensors
-        SCN.SparseToDense_updateGradInput(ctx.spatial_size, ctx.input_metadata, input_features, grad_input,
-                                          grad_output.contiguous())
-        return grad_input, None, None, None, None
-
-
 class SparseToDense(Module):
     def __init__(self, dimension, nPlanes):
         Module.__init__(self)
-        self.dimension = dimension
-        self.nPlanes = nPlanes
+        self.dimension, self.nPlanes = dimension, nPlanes
 
     def forward(self, input):
-        return SparseToDenseFunction.apply(input.features, input.metadata, input.spatial_size, self.dimension,
-                                           self.nPlanes)
+        return _Densify.apply(input.features, input.metadata, input.spatial_size, self.nPlanes)
 
     def input_spatial_size(self, out_size):
         return out_size
 
     def __repr__(self):
-        return "SparseToDense(" + str(self.dimension) + "," + str(self.nPlanes) + ")"
+        return "SparseToDense(%s,%s)" % (self.dimension, self.nPlanes)
+
+
+class _Densify(Function):
+    @staticmethod
+    def forward(ctx, x, metadata, spatial_size, nPlanes):
+        ctx.where = (metadata, spatial_size)
+        ctx.save_for_backward(x)
+        dense = x.new()
+        SCN.SparseToDense_updateOutput(spatial_size, metadata, x, dense, nPlanes)
+        return dense
+
+    @staticmethod
+    def backward(ctx, d_dense):
+        x, = ctx.saved_tensors
+        metadata, spatial_size = ctx.where
+        dx = d_dense.new()
+        SCN.SparseToDense_updateGradInput(spatial_size, metadata, x, dx, d_dense.contiguous())
+        return dx, None, None, None
+
+
+SparseToDenseFunction = _Densify     # the reference's name for the autograd node

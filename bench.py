@@ -106,7 +106,7 @@ SITE_ORDER_DEFAULT = "brick"
 
 
 # ------------------------------------------------------------------------------------------------ workload
-def build_net(scn, torch, dev, dtype):
+def build_net(scn, torch, dev, dtype, site_order=None):
     torch.manual_seed(0)
     net = scn.FPN_Net([4096, 4096, 512], 3, ["xyz", "color", "normal"], 1,
                       [32, 64, 64, 128, 128, 128, 256, 256, 256], 128, True, [4, 3, 2, 1], [4, 3, 2, 1],
@@ -118,7 +118,7 @@ def build_net(scn, torch, dev, dtype):
     net.compiled_graph = os.environ.get("AABR_BENCH_COMPILED_GRAPH", "1") != "0"
     # site order of every level (FPN_Net.set_site_order): "brick" = brick-major rows over brick grids (csrc/brick.hip),
     # "first_seen" = the reference's numbering over hash grids; same sites, features and gradients per site either way
-    net.set_site_order(os.environ.get("AABR_BENCH_SITE_ORDER", SITE_ORDER_DEFAULT))
+    net.set_site_order(site_order or os.environ.get("AABR_BENCH_SITE_ORDER", SITE_ORDER_DEFAULT))
 
     class RpnHead(torch.nn.Module):
         """SingleConvRPNHead_Sparse3D (rpn_sparse3d.py:81-131): 1x1 conv + ReLU, objectness and box heads --
@@ -151,10 +151,10 @@ def rpn_constants(torch):
 
 
 class Workload(object):
-    def __init__(self, scn, torch, dp, dev, dtype, rank, world, n_batches):
+    def __init__(self, scn, torch, dp, dev, dtype, rank, world, n_batches, site_order=None):
         import synth_scenes as S
         self.scn, self.torch, self.dev, self.world = scn, torch, dev, world
-        self.net, self.head = build_net(scn, torch, dev, dtype)
+        self.net, self.head = build_net(scn, torch, dev, dtype, site_order)
         self.flat = dp.FlatParams([self.net, self.head])
         self.flat.broadcast(0)
         self.base, self.strides = rpn_constants(torch)
@@ -1155,10 +1155,13 @@ def main():
             if world == 1:
                 extras = {}
                 try:
+                    # the other storage type, warmed exactly as the headline is (same resident batches, same warm-up
+                    # steps, same settle loop): round 5's driver line had this leg 3 % under its stand-alone figure
+                    # because it started timing one resident batch after 5 steps
                     other = torch.float32 if args.dtype == "bf16" else torch.bfloat16
-                    wl2 = Workload(scn, torch, dp, dev, other, 0, 1, 1)
+                    wl2 = Workload(scn, torch, dp, dev, other, 0, 1, args.batches)
                     n2 = max(20, min(args.steps, 60))
-                    el2, ti2 = timed_steps(torch, dist, wl2, n2, 5, 1, dev, min_timed_s=0.0,
+                    el2, ti2 = timed_steps(torch, dist, wl2, n2, max(args.warmup, 10), 1, dev, min_timed_s=0.0,
                                            prewarm=not args.no_prewarm)
                     name = "bf16" if other == torch.bfloat16 else "f32"
                     rf2, table2 = roofline_block(torch, wl2, other, el2 / n2 * 1e6)
@@ -1175,6 +1178,24 @@ def main():
                     del wl2
                 except Exception as e:  # pragma: no cover
                     extras["other_dtype_error"] = repr(e)[:200]
+                try:
+                    # the same step in the OTHER site order (headline brick-major -> the reference's first-seen rows over
+                    # hash grids, and the other way round): what the internal row order is worth, measured by whoever
+                    # runs this file
+                    so = "first_seen" if wl.net.site_order == "brick" else "brick"
+                    wl4 = Workload(scn, torch, dp, dev, head_dtype, 0, 1, args.batches, site_order=so)
+                    n4 = max(20, min(args.steps, 60))
+                    el4, ti4 = timed_steps(torch, dist, wl4, n4, max(args.warmup, 10), 1, dev, min_timed_s=0.0,
+                                           prewarm=not args.no_prewarm)
+                    extras[so] = {
+                        "ms_per_step": round(el4 / n4 * 1e3, 3), "scenes_per_s": round(n4 * SCENES_PER_STEP / el4, 2),
+                        "steps": n4, "dtype": args.dtype, "step_ms": ti4["step_ms"],
+                        "workload": "same step, same storage type, rows of every level in %s order" %
+                                    ("the reference's first-seen (hash grids; the library's default)" if so == "first_seen"
+                                     else "brick-major (brick grids)")}
+                    del wl4
+                except Exception as e:  # pragma: no cover
+                    extras["site_order_error"] = repr(e)[:200]
                 try:
                     # SECOND line, never the headline: the same step with FPN_Net.prune_unused_levels (opt-in) -- the
                     # top-down stages below the last consumed map (m_ups / m_shortcuts / m_mergeds of scales 3..0, which the

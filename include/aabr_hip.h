@@ -33,11 +33,12 @@ extern "C" {
 
 const char *aabr_last_error(void);
 /* ABI version: bumped whenever a signature, a record layout or AABR_META_WORDS changes; a binding written for one value
- * must refuse a library that reports another (`_hip.load()` does).  500 = round 5 (16-word meta blocks, brick grids). */
-#define AABR_ABI_VERSION 500
+ * must refuse a library that reports another (`_hip.load()` does).  500 = round 5 (16-word meta blocks, brick grids);
+ * 600 = round 6 (regression targets out of the label kernel, list encode / decode, fused small-map records). */
+#define AABR_ABI_VERSION 600
 int aabr_version(void);
 /* Tuning knobs for experiments and tests (no counterpart in the reference; the defaults are what ships): CONV_WIDE,
- * CONV_WIDE_BF16, CONV_RB (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, CONV_WLDS,
+ * CONV_WIDE_BF16 (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, CONV_WLDS,
  * CONV_SMALL, CONV_NBW, CONV_WPB, VOXEL_MEAN.  A knob takes its value from the environment variable AABR_<NAME>,
  * read ONCE at its first use in the process; aabr_set_knob overrides it (unset != 0: back to "no value").  No entry
  * point reads the environment on its launch path.                                                              */
@@ -45,7 +46,8 @@ int aabr_set_knob(const char *name, int value, int unset);
 /* bit 0: a `make DEV=1` build -- it additionally carries the phase-clock variants of k_conv_cs that tools/tools_cs_phases.py
  * reads (flags >> 8 debug bits); a release build answers those flags with an error.  The A/B kernels of rounds 3-4 that
  * were measured slower (row-stationary bf16, three-term fp32 split, four-workgroup ring, deferred accumulate, eight-wave
- * workgroups) were removed in round 5; their tables under profiles/ are the record.                                  */
+ * workgroups) were removed in round 5, the register-accumulator kernel over the gather table (k_conv_rb, 0.73-0.91x) in
+ * round 6; their tables under profiles/ are the record.                                  */
 int aabr_build_flags(void);
 /* number of int32 words of the `meta` block written by the geometry builders */
 #define AABR_META_WORDS 16
@@ -501,19 +503,6 @@ int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_
                                       int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
                                       int flags, const uint16_t *wpack, int parts, float *scratch, void *stream);
 
-/* Wide layers in bf16 storage with register accumulators over 256-row tiles (csrc/conv_rb.hip; extension): the same sum as
- * aabr_conv_forward_wide_bf16 (Convolution.cpp:117-185), read from the GATHER TABLE `table` [vol][V_out] instead of a block
- * stream: a workgroup owns 256 consecutive output rows x all columns, an offset's weights are fetched once per tile by
- * LDS-DMA, partner rows go straight into the MFMA operand layout.  Meant for brick-major rows (a tile's rows are spatial
- * neighbours and share their empty offsets); correct for any order.  n_in, n_out in {64, 128}, vol <= 27; wpack = the bf16
- * pack of aabr_conv_pack_weights2_bf16 in the orientation of the launch (flags bit 0: the caller passes the transposed
- * pack; bit 1: mirrored offsets, the submanifold input-gradient form).  aabr_conv_rb_ok: 1 = the dispatch sends this
- * launch here (knob CONV_RB: 0 never, 1 whenever supported).                                                       */
-int aabr_conv_rb_ok(int n_in, int n_out, int64_t rows_in, int64_t V_out, int vol);
-int aabr_conv_forward_rb_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
-                              int64_t V_out, const int32_t *table, int vol, const float *bias, int flags,
-                              const uint16_t *wpack, void *stream);
-
 /* 32 -> 32 plane layers (the finest scales; csrc/conv_narrow.hip): the same sum as aabr_conv_forward (Convolution.cpp:
  * 117-185), read from the GATHER TABLE `table` [vol][V_out] (input row of output row o at offset k, or -1 -- what
  * aabr_submanifold_table / aabr_convolution_tables leave behind) instead of a block stream, with the fp32 master weights
@@ -707,6 +696,28 @@ int aabr_rpn_label_generation(int n_maps, const void *const *coords_ptrs, int nb
                               float fg_iou, float bg_iou, float yaw_threshold, int allow_low_quality_matches,
                               int64_t *matched_idx, float *matched_val, float *iou_out, uint32_t *row_max_scratch,
                               void *stream);
+/* The same call with the other half of RPNLossComputation.prepare_targets (modeling/rpn/loss_3d.py:186-196):
+ * regression_targets [sum_b N_b, 7] (optional, may be NULL) = box_coder.encode(target[matched_idx.clamp(min=0)], anchor) for
+ * EVERY anchor, in the pass that has the anchor and its match in registers -- BoxCoder3D.encode_centroid_box
+ * (modeling/box_coder_3d.py:46-51): second_box_encode(., ., smooth_dim=True) (second/pytorch/core/box_torch_ops.py:82-116),
+ * yaw difference through limit_period(., 0.5, pi), times weights_host[7]; the un-thickened anchor and ground-truth box.
+ * An example without ground truth encodes every anchor against itself (loss_3d.py:91-94: matched_targets = anchor).   */
+int aabr_rpn_label_generation_targets(int n_maps, const void *const *coords_ptrs, int nb, const int32_t *seg_begin_host,
+                                      const int32_t *site_begin_host, const float *strides_host,
+                                      const float *base_anchors, int num_anchors, float voxel_scale,
+                                      const void *const *target_ptrs, const int32_t *n_targets_host,
+                                      const float *aug_host, int criterion, int only_xy, float fg_iou, float bg_iou,
+                                      float yaw_threshold, int allow_low_quality_matches, int64_t *matched_idx,
+                                      float *matched_val, float *iou_out, uint32_t *row_max_scratch,
+                                      const float *weights_host, float *regression_targets, void *stream);
+/* BoxCoder3D.encode (modeling/box_coder_3d.py:34-51, centroid form) on two [n,7] lists: out [n,7].                  */
+int aabr_box_encode(const float *targets, const float *anchors, int64_t n, const float *weights_host, float *out,
+                    void *stream);
+/* BoxCoder3D.decode (modeling/box_coder_3d.py:40-44,53-80, centroid form): encodings [n, 7*num_classes] / weights, sizes
+ * clamped at `clip` (bbox_xform_clip), second_box_decode with smooth_dim (box_torch_ops.py:118-154) against anchors [n,7]
+ * (one anchor per row, shared by its classes), yaw through limit_period(., 0.5, pi): out [n, 7*num_classes].         */
+int aabr_box_decode(const float *encodings, const float *anchors, int64_t n, int num_classes,
+                    const float *weights_host, float clip, float *out, void *stream);
 /* RPN glue: anchors of the selected flat indices t = site*A + yaw, generated from
  * the sparse site coordinates (modeling/rpn/anchor_generator_sparse3d.py:88-104:
  * centroid = loc / voxel_scale * stride, + base anchor), fused with BoxCoder3D.decode_centroid_box

@@ -223,6 +223,43 @@ def test_brick_strided_levels_and_tables_match_oracle(fs, st):
         assert g.sample_counts(3) == cnt.tolist()
 
 
+def test_brick_second_rule_book_onto_an_existing_output_level():
+    """Two strided rule books with different filters onto ONE output size (the reference serves the second from the grid
+    the first one built, Metadata.cpp:484-510): under site_order='brick' the existing level is used as it is -- same rows,
+    no renumbering under features that already live on it, no fall-through to the hash builders (advisor, round 5) -- and
+    the second book's tables are the oracle's rules under the two levels' permutations."""
+    scn = _scn()
+    rng = np.random.default_rng(123)
+    size = np.array([48, 36, 8])
+    coords, feats = _rand_scene(rng, 6000, tuple(size), 2, 3)
+    x, _ = _input(scn, coords, feats, tuple(size), 3)
+    md = x.metadata
+    ref_il = O.input_layer(coords, feats, 3)
+    osz = size // 2
+    L = lambda v: torch.LongTensor(list(int(i) for i in v))
+    tb1 = md.getRuleBook(x.spatial_size, L(osz), L([2, 2, 2]), L([2, 2, 2]))
+    loc1 = md.getSpatialLocations(L(osz)).numpy().copy()
+    g1 = md.grids[tuple(int(v) for v in osz)]
+    tb2 = md.getRuleBook(x.spatial_size, L(osz), L([1, 1, 1]), L([2, 2, 2]))       # even sites only: a subset of the level
+    assert md.grids[tuple(int(v) for v in osz)] is g1 and tb2 is not tb1
+    np.testing.assert_array_equal(md.getSpatialLocations(L(osz)).numpy(), loc1)
+    _, oc1 = O.convolution_rules(ref_il["coords"], [2, 2, 2], [2, 2, 2], osz)
+    rb2, oc2 = O.convolution_rules(ref_il["coords"], [1, 1, 1], [2, 2, 2], osz)
+    ro = _match(loc1, oc1)                                              # device output row -> oracle row of book 1's level
+    ri, _ = _rows(x, ref_il["coords"])
+    t_out = tb2.out.table.cpu().numpy()
+    t_in = tb2.inn.table.cpu().numpy()
+    assert rb2.vol == 1 and 0 < rb2.counts[0] < ref_il["V"]
+    # oracle pairs of book 2 are (input row, row in ITS OWN output list oc2): compare through coordinates
+    key = lambda c: tuple(int(v) for v in c)
+    want = {(int(a), key(oc2[int(b)])) for a, b in rb2.pairs(0)}
+    o = np.nonzero(t_out[0] >= 0)[0]
+    assert {(int(ri[t_out[0, j]]), key(oc1[ro[j]])) for j in o} == want
+    u = np.nonzero(t_in[0] >= 0)[0]
+    assert {(int(ri[j]), key(oc1[ro[t_in[0, j]]])) for j in u} == want
+    assert list(tb2.rule_counts()) == [int(rb2.counts[0])]
+
+
 def test_brick_pyramid_one_read_and_chain_of_levels():
     """a chain of non-overlapping levels + a z-collapse level, built level from level with device-side counts"""
     scn = _scn()

@@ -125,6 +125,73 @@ def test_rpn_label_matches_vs_oracle_composition():
         assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
 
 
+def test_box_coder_encode_decode_vs_reference_torch_golden(golden_dir):
+    """BoxCoder3D.encode / decode (maskrcnn_benchmark.modeling.box_coder_3d, lists through aabr_box_encode /
+    aabr_box_decode) against the reference's own BoxCoder3D run by tests/golden/gen_box_golden.py: `enc_w1` / `enc_w2`
+    (256 ground-truth boxes against 256 anchors whose yaws make limit_period wrap, unit and (10,10,10,5,5,5,2) weights),
+    `dec_w1` / `dec_w2` (incl. a row beyond bbox_xform_clip) and the 3-class layout `dec3_w1`.  Tolerance: the device's
+    division and sqrt are correctly rounded and nothing is contracted, so 1e-6 absolute / relative is slack for the
+    last bit only."""
+    from maskrcnn_benchmark.modeling.box_coder_3d import BoxCoder3D
+    g = np.load(os.path.join(golden_dir, "box_golden.npz"))
+    for name in ("w1", "w2"):
+        w = None if name == "w1" else tuple(g["weights_w2"].tolist())
+        coder = BoxCoder3D(False, w)
+        np.testing.assert_array_equal(coder.weights.numpy().reshape(7), g["weights_" + name])
+        enc = coder.encode(_t(g["enc_targets"]), _t(g["dec_anchors"])).cpu().numpy()
+        np.testing.assert_allclose(enc, g["enc_" + name], rtol=1e-6, atol=1e-6)
+        dec = coder.decode(_t(g["dec_enc"]), _t(g["dec_anchors"])).cpu().numpy()
+        np.testing.assert_allclose(dec, g["dec_" + name], rtol=1e-6, atol=1e-6)
+    dec3 = BoxCoder3D(False, None).decode(_t(g["dec3_enc"]), _t(g["dec_anchors"][:64])).cpu().numpy()
+    np.testing.assert_allclose(dec3, g["dec3_w1"], rtol=1e-6, atol=1e-6)
+    assert BoxCoder3D(False, None).encode(_t(np.zeros((0, 7), np.float32)), _t(np.zeros((0, 7), np.float32))).shape == (0, 7)
+
+
+def test_rpn_regression_targets_at_training_size_vs_oracle():
+    """The regression targets of RPNLossComputation.prepare_targets (rpn/loss_3d.py:186-196) out of the label kernel:
+    `box_coder.encode(target[matched_idxs.clamp(min=0)], anchor)` for EVERY anchor of the six maps of a 4-scene batch at
+    the bench's size (>= 10^5 anchors per call, 40 ground-truth boxes per scene, one scene without any), against
+    oracle/box_oracle.encode_centroid_box (pinned by box_golden.npz) evaluated on the oracle's anchors and the device's
+    own match indices; with the RPN's BoxCoder3D weights (1,...,1) and with a non-trivial weight vector.  The labels
+    themselves must not change when the targets are asked for."""
+    import box_oracle as BO
+    import rpn_glue
+    from test_cabi_and_host import default_fpn
+    torch.manual_seed(2)
+    net = default_fpn().to(DEV)
+    locs, feats = S.make_batch(4, 80000, 77, 50)
+    with torch.no_grad():
+        rpn, _ = net([_t(locs), _t(feats)])
+    yaws = (0, -1.57, -0.785, 0.785)
+    sizes = [[0.4, 1.5, 1.5], [1.5, 1.5, 1.0], [4, 4, 1.5], [0.2, 0.5, 3], [0.4, 1.5, 3], [0.6, 2.5, 3]]
+    base = [torch.tensor([[0.0, 0.0, 0.0] + list(s) + [y] for y in yaws], dtype=torch.float32) for s in sizes]
+    strides = [[2.0 ** s] * 3 for s in (5, 6, 7)] + [[2.0 ** s] * 3 for s in (4, 5, 6)]
+    targets = [S.make_gt_boxes(40, 21), S.make_gt_boxes(40, 22), np.zeros((0, 7), np.float32), S.make_gt_boxes(3, 23)]
+    tg_dev = [_t(t) for t in targets]
+    coords = [m.get_spatial_locations().numpy() for m in rpn]
+    plain = rpn_glue.rpn_label_matches(rpn, base, strides, 50.0, tg_dev, LABEL_AUG, 6)
+    total = 0
+    for w in ((1.0,) * 7, (10.0, 10.0, 10.0, 5.0, 5.0, 5.0, 2.0)):
+        res = rpn_glue.rpn_label_matches(rpn, base, strides, 50.0, tg_dev, LABEL_AUG, 6, regression_targets=True,
+                                         weights=w)
+        assert len(res) == 4
+        for b in range(4):
+            an = np.concatenate([BO.grid_anchors(c[c[:, 3] == b], base[m].numpy(), 50.0, strides[m])
+                                 for m, c in enumerate(coords)], 0).astype(np.float32)
+            idx = res[b][0].cpu().numpy()
+            got = res[b][3].cpu().numpy()
+            assert got.shape == (an.shape[0], 7) and torch.equal(res[b][0], plain[b][0]) and torch.equal(res[b][1], plain[b][1])
+            matched = targets[b][np.maximum(idx, 0)] if len(targets[b]) else an
+            want = BO.encode_centroid_box(matched, an, w)
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+            total += an.shape[0]
+            if len(targets[b]):
+                assert (idx >= 0).any() and (idx < 0).any()
+            else:
+                assert (got == 0).all()          # an anchor against itself
+    assert total >= 2 * 100000, total
+
+
 def test_boxlist_nms_3d_roi_post():
     """the ROI post-processor's flavour (boxlist_ops_3d.py:38-39; roi_heads/box_head_3d/inference.py:133-136):
     flag 'roi_post' demands max_proposals == -1, which becomes 500; cfg.MODEL.ROI_HEADS.NMS = 0.45 with

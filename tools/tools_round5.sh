@@ -1,12 +1,14 @@
 #!/bin/bash
 # usage (GPU box, repo root): bash tools/tools_round5.sh  -- the measurements profiles/r05_* come from: the scatter-floor
 # microbenchmark, the geometry and kernel A/B tables, kernel-trace summaries of the three bench lines, the PMC passes.
+set -u
+: "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets it)}"
 root=$GRAFT_REPO_ROOT
 cd $root
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/dev/scatter_floor.hip -o /tmp/scatter_floor && timeout -k 10 120 /tmp/scatter_floor > gpurun_out/r05_scatter_floor.txt 2>&1
 echo "floor rc=$?"
 timeout -k 10 300 python tools/tools_brick_bench.py > gpurun_out/r05_brick_geometry_ab.txt 2> gpurun_out/r05_brick_geometry_ab.err; echo "geom rc=$?"
-timeout -k 10 300 python tools/tools_rb_ab.py brick > gpurun_out/r05_conv_rb_ab.txt 2>&1; echo "rb rc=$?"
+# (tools_rb_ab.py and k_conv_rb were removed in round 6; profiles/r05_conv_rb_ab.txt is the record)
 (cat profiles/r05_conv_dw_ab.head; timeout -k 10 300 python tools/tools_dw_ab.py bf16 2>/dev/null; timeout -k 10 300 python tools/tools_dw_ab.py f32 2>/dev/null) > gpurun_out/r05_conv_dw_ab.txt; echo "dw rc=$?"
 bash tools/tools_profile_cmd.sh r05_fp32 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/r05_prof_fp32.txt 2>&1
 bash tools/tools_profile_cmd.sh r05_bf16 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --dtype bf16 > gpurun_out/r05_prof_bf16.txt 2>&1
