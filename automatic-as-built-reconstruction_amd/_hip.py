@@ -45,8 +45,8 @@ _SIGS = {
                                    _i32, _vp]),
     "aabr_brick_renumber": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                                       _vp, _vp]),
-    "aabr_points_prepare": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
-    "aabr_points_sites": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aabr_points_prepare": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "aabr_points_sites": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "aabr_brick_submanifold_table": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _i32p, _vp, _vp, _vp]),
     "aabr_brick_convolution_tables": (C.c_int, [_vp, _i64, _i32p, _vp, _vp, _vp, _i64, _i32p, _vp, _vp, _i32p, _i32p,
                                                 _i32p, _vp, _vp, _vp, _vp, _vp]),
@@ -70,6 +70,11 @@ _SIGS = {
     "aabr_conv_wide_split_bf16": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),
     "aabr_conv_forward_wide_split_bf16": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp,
                                                     _i32, _vp, _vp]),
+    "aabr_conv_forward_wide_split_bf16_res": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp,
+                                                        _i32, _vp, _vp, _vp]),
+    "aabr_conv_forward_wide_bf16_res": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp,
+                                                  _vp, _vp, _vp, _vp, _f32, _vp]),
+    "aabr_bn_backward_add_bf16": (C.c_int, [_vp] * 4 + [_i64, _i32] + [_vp] * 6 + [_f32, _vp, _i32, _vp, _vp, _vp]),
     "aabr_conv_forward_wide_split": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _i32, _i32, _vp, _i32, _vp, _vp,
                                                _i32, _vp, _vp]),
     "aabr_conv_wide_tile_rows_bf16": (C.c_int, [_i32, _i32, _i64, _i64, _i32]),

@@ -21,8 +21,11 @@ namespace aabr {
 #endif
 
 constexpr int kMaxParts = 512;
-constexpr int kFinSlices = 32; // finalize: 8 planes x 32 slices of the partial list per block
-constexpr int kFinPlanes = 8;
+// finalize: FP planes x 256 / FP slices of the partial list per 256-thread block.  8 x 32 for short lists; 2 x 128 for
+// long ones (the statistics a wide convolution's write-out leaves: one part per tile, 2,502 parts x 64 planes at the
+// 282 k-row level -- eight blocks walked 78 dependent steps each, 12 us; 32 blocks walk 20: round 6)
+constexpr int kFinLongList = 96;
+__host__ __device__ constexpr int fin_planes(int nparts) { return nparts > kFinLongList ? 2 : 8; }
 
 // feature element access: fp32 (reference precision) or bf16 storage (extension, fp32/fp64 maths)
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -36,6 +39,10 @@ __device__ inline void st4(__bf16 *p, int64_t i, float4 v) {
   bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
   *reinterpret_cast<bf16x4 *>(p + i) = o;
 }
+// a value as the storage type would hold it (a fused "+ d_in_add" must see the BatchNorm gradient as the separate add would
+// have read it back: rounded once in bf16 storage, untouched in fp32)
+__device__ inline float stored(const float *, float v) { return v; }
+__device__ inline float stored(const __bf16 *, float v) { return (float)(__bf16)v; }
 __device__ inline float ld1(const float *p, int64_t i) { return p[i]; }
 __device__ inline float ld1(const __bf16 *p, int64_t i) { return (float)p[i]; }
 __device__ inline void st1(float *p, int64_t i, float v) { p[i] = v; }
@@ -133,8 +140,10 @@ __global__ __launch_bounds__(256) void k_bn_partials(const T *__restrict__ x, co
 
 // sum the per-block partials of one plane: 32 threads take interleaved slices of the list (loads
 // in flight instead of one dependent chain), then a fixed-order combine => deterministic.
+template <int kFinPlanes>
 __device__ inline void reduce_partials(const double *__restrict__ part, int nparts, int planes, int p,
                                        double &s0, double &s1) {
+  constexpr int kFinSlices = 256 / kFinPlanes;
   __shared__ double ra[kFinSlices][kFinPlanes], rb[kFinSlices][kFinPlanes];
   const int pl = threadIdx.x % kFinPlanes, sl = threadIdx.x / kFinPlanes;
   double a = 0.0, b = 0.0;
@@ -152,6 +161,7 @@ __device__ inline void reduce_partials(const double *__restrict__ part, int npar
 }
 
 // forward finalize (CPU/BatchNormalization.cpp:33-48): coef[p] = {w, b} with y = x*w + b.
+template <int kFinPlanes>
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const double *__restrict__ part, int nparts,
                                                          int64_t rows, int planes, float *save_mean,
                                                          float *save_invstd, float *running_mean,
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const double *__restric
   AABR_BN_SETPRIO();
   const int p = blockIdx.x * kFinPlanes + (threadIdx.x % kFinPlanes);
   double s = 0.0, ss = 0.0;
-  if (train) reduce_partials(part, nparts, planes, p, s, ss);
+  if (train) reduce_partials<kFinPlanes>(part, nparts, planes, p, s, ss);
   if (p >= planes || threadIdx.x >= kFinPlanes) return;
   float mean, invstd;
   if (train) {
@@ -213,6 +223,7 @@ __global__ __launch_bounds__(256) void k_bn_fwd_apply1(const T *__restrict__ x, 
 }
 
 // backward finalize (CPU/BatchNormalization.cpp:85-90,103-106): coef = {gradMean, k, invstd*w}
+template <int kFinPlanes>
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double *__restrict__ part, int nparts,
                                                          int64_t rows, int planes, const float *save_invstd,
                                                          const float *weight, float *d_weight, float *d_bias,
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double *__restric
   AABR_BN_SETPRIO();
   const int p = blockIdx.x * kFinPlanes + (threadIdx.x % kFinPlanes);
   double s, dp;
-  reduce_partials(part, nparts, planes, p, s, dp);
+  reduce_partials<kFinPlanes>(part, nparts, planes, p, s, dp);
   if (p >= planes || threadIdx.x >= kFinPlanes) return;
   float is = save_invstd[p];
   if (d_bias) d_bias[p] = (float)s;
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, T
                             : ld1(out, i);
   d = (o > 0.0f) ? d : d * leak;
   float r = (d - coef[p] - (ld1(x, i) - mean[p]) * coef[planes + p]) * coef[2 * planes + p];
-  if (res) r += ld1(res, i);
+  if (res) r = stored(res, r) + ld1(res, i);
   st1(d_in, i, r);
 }
 
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const T *__restrict__ x, 
   d = ov.w > 0.0f ? dv.w : dv.w * leak; r.w = (d - gm.w - (xv.w - mu.w) * kk.w) * sw.w;
   if (res) { // d_in = BatchNorm gradient + another contribution to the same tensor's gradient
     const float4 q = ld4(res, i);
-    r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    r.x = stored(res, r.x) + q.x; r.y = stored(res, r.y) + q.y; r.z = stored(res, r.z) + q.z; r.w = stored(res, r.w) + q.w;
   }
   st4(d_in, i, r);
 }
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(kSmallThreadsB) void k_bn_bwd_small(const T *__rest
       o.w = (dv[j][3] - gm[3] - (xv[j][3] - mu[3]) * kk[3]) * sw[3];
       if (res) {
         const float4 q = ld4(res, i);
-        o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+        o.x = stored(res, o.x) + q.x; o.y = stored(res, o.y) + q.y; o.z = stored(res, o.z) + q.z; o.w = stored(res, o.w) + q.w;
       }
       st4(d_in, i, o);
     }
@@ -510,9 +521,12 @@ static int bn_forward_t(const T *in, T *out, int64_t rows, int planes, float *sa
       hipLaunchKernelGGL((k_bn_partials<0, 1, T>), dim3(nparts), dim3(256), 0, st, in, (const T *)nullptr,
                          (const T *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
   }
-  hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
-                     rows, planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps,
-                     momentum, train, coef);
+  if (fin_planes(nparts) == 2)
+    hipLaunchKernelGGL(k_bn_fwd_finalize<2>, dim3((unsigned)ceil_div(planes, 2)), dim3(256), 0, st, part, nparts, rows,
+                       planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, train, coef);
+  else
+    hipLaunchKernelGGL(k_bn_fwd_finalize<8>, dim3((unsigned)ceil_div(planes, 8)), dim3(256), 0, st, part, nparts, rows,
+                       planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, train, coef);
   int64_t total = rows * planes;
   if ((planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
     hipLaunchKernelGGL((k_bn_fwd_apply<T>), dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, out,
@@ -565,8 +579,12 @@ static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int
   else
     hipLaunchKernelGGL((k_bn_partials<1, 1, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
                        leakiness, rows, planes, part, save_invstd, weight, bias, recompute);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, fin_part, nparts,
-                     rows, planes, save_invstd, weight, d_weight, d_bias, coef);
+  if (fin_planes(nparts) == 2)
+    hipLaunchKernelGGL(k_bn_bwd_finalize<2>, dim3((unsigned)ceil_div(planes, 2)), dim3(256), 0, st, fin_part, nparts, rows,
+                       planes, save_invstd, weight, d_weight, d_bias, coef);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_finalize<8>, dim3((unsigned)ceil_div(planes, 8)), dim3(256), 0, st, fin_part, nparts, rows,
+                       planes, save_invstd, weight, d_weight, d_bias, coef);
   int64_t total = rows * planes;
   if (v4 && (((uintptr_t)d_in | (uintptr_t)save_mean | (uintptr_t)d_in_add) & 15) == 0)
     hipLaunchKernelGGL((k_bn_bwd_apply4<T>), dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, d_in, out,
@@ -617,8 +635,8 @@ extern "C" int aabr_bn_backward(const float *in, float *d_in, const float *out, 
 }
 
 // d_in = BatchNorm gradient + d_in_add: the gradient sum of a tensor with a second consumer (the identity branch of
-// a residual block, a lateral connection) folded into the apply pass; fp32 only (a + b is commutative bit for bit,
-// in bf16 storage the separate add would round twice)
+// a residual block, a lateral connection) folded into the apply pass (a + b is commutative bit for bit; in bf16 storage
+// the BatchNorm gradient is rounded before the sum, as the separate add would have read it: aabr_bn_backward_add_bf16)
 extern "C" int aabr_bn_backward_add(const float *in, float *d_in, const float *out, const float *d_out,
                                     int64_t rows, int planes, const float *save_mean, const float *save_invstd,
                                     const float *weight, const float *bias, float *d_weight, float *d_bias,
@@ -670,4 +688,19 @@ extern "C" int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const u
                                reinterpret_cast<const __bf16 *>(out), reinterpret_cast<const __bf16 *>(d_out),
                                rows, planes, save_mean, save_invstd, weight, bias, d_weight, d_bias, leakiness,
                                scratch, stream_);
+}
+
+// bf16 storage: d_in = bf16(bf16(BatchNorm gradient) + d_in_add) -- the gradient sum of a tensor with a second consumer in
+// the apply pass, bit for bit what aabr_bn_backward_bf16 followed by aabr_add(bf16) stores; `parts` / `nparts` as
+// aabr_bn_backward_parts_bf16, or NULL / 0 for statistics of its own
+extern "C" int aabr_bn_backward_add_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out, const uint16_t *d_out,
+                                         int64_t rows, int planes, const float *save_mean, const float *save_invstd,
+                                         const float *weight, const float *bias, float *d_weight, float *d_bias,
+                                         float leakiness, const double *parts, int nparts, float *scratch,
+                                         const uint16_t *d_in_add, void *stream_) {
+  AABR_CHECK_ARG((parts != nullptr) == (nparts > 0), "partials");
+  return bn_backward_t<__bf16>(reinterpret_cast<const __bf16 *>(in), reinterpret_cast<__bf16 *>(d_in),
+                               reinterpret_cast<const __bf16 *>(out), reinterpret_cast<const __bf16 *>(d_out), rows,
+                               planes, save_mean, save_invstd, weight, bias, d_weight, d_bias, leakiness, scratch,
+                               stream_, reinterpret_cast<const __bf16 *>(d_in_add), parts, nparts);
 }

@@ -252,13 +252,35 @@ __global__ __launch_bounds__(256) void k_brick_remap_points(const int32_t *__res
 //                      the same first_pt / cnt_extra / head / nxt the mean and backward kernels of voxel_scatter.hip read.
 // (a few hundred workgroups stride over the points: the extent costs one atomic per workgroup and axis at most -- one per
 // WAVE of a point-per-thread launch was 20 k same-address atomics, 280 us at 320 k points)
+constexpr int kPrepItems = 4;      // points per thread, their loads issued together (a grid-stride loop of dependent
+                                   // iterations at 1.2 workgroups per CU took 23 us for 15 MB at 320 k points)
 __global__ __launch_bounds__(256) void k_points_prepare(const int64_t *__restrict__ coords, int64_t n, int ncols,
-                                                        int4 *__restrict__ pc, int32_t *meta) {
+                                                        int4 *__restrict__ pc, int32_t *meta, int32_t *__restrict__ first_pt,
+                                                        int32_t *__restrict__ cnt_extra, int32_t *__restrict__ head,
+                                                        int vec16) {
   int ext[4] = {-1, -1, -1, -1};
   bool bad = false;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t *c = coords + i * ncols;
-    const int64_t x = c[0], y = c[1], z = c[2], b = ncols == 4 ? c[3] : 0;
+  const int64_t base = (int64_t)blockIdx.x * (256 * kPrepItems) + threadIdx.x;
+  int64_t cx[kPrepItems], cy[kPrepItems], cz[kPrepItems], cb[kPrepItems];
+#pragma unroll
+  for (int q = 0; q < kPrepItems; ++q) {
+    const int64_t i = base + q * 256;
+    cx[q] = cy[q] = cz[q] = -1; cb[q] = 0;
+    if (i < n) {
+      const int64_t *c = coords + i * ncols;
+      if (vec16) {             // ncols == 4 and a 16-byte aligned list: 32 bytes per point in two 16-byte loads
+        const longlong2 a = *reinterpret_cast<const longlong2 *>(c), b2 = *reinterpret_cast<const longlong2 *>(c + 2);
+        cx[q] = a.x; cy[q] = a.y; cz[q] = b2.x; cb[q] = b2.y;
+      } else {
+        cx[q] = c[0]; cy[q] = c[1]; cz[q] = c[2]; cb[q] = ncols == 4 ? c[3] : 0;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kPrepItems; ++q) {
+    const int64_t i = base + q * 256;
+    if (i >= n) continue;
+    const int64_t x = cx[q], y = cy[q], z = cz[q], b = cb[q];
     int4 o = make_int4(-1, -1, -1, 0);
     if (x == -1 && y == -1 && z == -1) {
       // dropped by aabr_quantize_points (outside FULL_SCALE): skipped silently
@@ -270,6 +292,7 @@ __global__ __launch_bounds__(256) void k_points_prepare(const int64_t *__restric
       ext[2] = o.z > ext[2] ? o.z : ext[2]; ext[3] = o.w > ext[3] ? o.w : ext[3];
     }
     pc[i] = o;
+    if (first_pt) { first_pt[i] = -1; cnt_extra[i] = 0; head[i] = -1; }   // the starting values aabr_points_sites wants
   }
   __shared__ int s_ext[4][4];
 #pragma unroll
@@ -463,23 +486,26 @@ extern "C" int aabr_brick_convolution_tables(const int32_t *in_coords, int64_t V
   return AABR_OK;
 }
 
-extern "C" int aabr_points_prepare(const int64_t *coords, int64_t n, int ncols, int32_t *pc, int32_t *meta, void *stream_) {
+extern "C" int aabr_points_prepare(const int64_t *coords, int64_t n, int ncols, int32_t *pc, int32_t *meta,
+                                   int32_t *first_pt, int32_t *cnt_extra, int32_t *head, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(n >= 0 && n < (1ll << 31) - 65536 && (ncols == 3 || ncols == 4), "0 <= n < 2^31, ncols in {3,4}");
   AABR_CHECK_ARG(meta && (n == 0 || (coords && pc)) && ((uintptr_t)pc & 15) == 0, "null / misaligned pointer");
+  AABR_CHECK_ARG((first_pt != nullptr) == (cnt_extra != nullptr) && (first_pt != nullptr) == (head != nullptr),
+                 "first_pt / cnt_extra / head: all three or none");
   AABR_CHECK_HIP(hipMemsetAsync(meta, 0xFF, AABR_META_WORDS * sizeof(int32_t), st));
   if (n > 0)
-    hipLaunchKernelGGL(k_points_prepare, dim3((unsigned)(ceil_div(n, 1024) < 512 ? ceil_div(n, 1024) : 512)), dim3(256), 0, st,
-                       coords, n, ncols, (int4 *)pc, meta);
+    hipLaunchKernelGGL(k_points_prepare, dim3((unsigned)ceil_div(n, 256 * kPrepItems)), dim3(256), 0, st, coords, n, ncols,
+                       (int4 *)pc, meta, first_pt, cnt_extra, head, (ncols == 4 && ((uintptr_t)coords & 15) == 0) ? 1 : 0);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
 
 extern "C" int aabr_points_sites(const int32_t *pc, int64_t n, const int32_t *dims_host, const void *dir, const void *bricks,
                                  int32_t *point_site, int32_t *first_pt, int32_t *cnt_extra, int32_t *head, int32_t *nxt,
-                                 int32_t *meta, void *stream_) {
+                                 int32_t *meta, int flags, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  AABR_CHECK_ARG(n >= 0, "bad n");
+  AABR_CHECK_ARG(n >= 0 && (flags & ~1) == 0, "bad n / flags");
   BrickLevel L;
   AABR_CHECK_ARG(make_dims(dims_host, L.d) == 0, "bad dims");
   if (n == 0) return AABR_OK;
@@ -487,13 +513,15 @@ extern "C" int aabr_points_sites(const int32_t *pc, int64_t n, const int32_t *di
   L.dir = (const uint4 *)dir;
   L.bricks = (const uint4 *)bricks;
   // first_pt and head start at all ones (no first point yet / empty chain), cnt_extra at 0
-  if (head == first_pt + n)
+  if (flags & 1) {
+    // aabr_points_prepare wrote them (three fills fewer)
+  } else if (head == first_pt + n)
     AABR_CHECK_HIP(hipMemsetAsync(first_pt, 0xFF, (size_t)2 * n * sizeof(int32_t), st));
   else {
     AABR_CHECK_HIP(hipMemsetAsync(first_pt, 0xFF, (size_t)n * sizeof(int32_t), st));
     AABR_CHECK_HIP(hipMemsetAsync(head, 0xFF, (size_t)n * sizeof(int32_t), st));
   }
-  AABR_CHECK_HIP(hipMemsetAsync(cnt_extra, 0, (size_t)n * sizeof(int32_t), st));
+  if (!(flags & 1)) AABR_CHECK_HIP(hipMemsetAsync(cnt_extra, 0, (size_t)n * sizeof(int32_t), st));
   hipLaunchKernelGGL(k_points_sites, grid1(n, 256), dim3(256), 0, st, (const int4 *)pc, n, L, point_site,
                      (uint32_t *)first_pt, meta);
   hipLaunchKernelGGL(k_points_chains, grid1(n, 256), dim3(256), 0, st, n, (const int32_t *)point_site,

@@ -17,7 +17,7 @@ void set_error(const char *fmt, ...);
 #define AABR_KNOB_LIST(X)                                                                                            \
   X(CONV_WLDS) X(CONV_SMALL) X(CONV_NBW) X(CONV_WPB) X(WIDE_ROWS) X(CONV_WIDE) X(WIDE_NBUF) X(CONV_WIDE_BF16)         \
   X(VOXEL_MEAN) X(WIDE_NCB) X(BN_SMALL) X(WIDE_PRIO) X(PLAN_SIDE_BATCH) X(PLAN_SIDE_PRIO) X(SMALL_WPB) X(SMALL_MAX)   \
-  X(WIDE_SPLIT) X(SPLIT_TARGET) X(SPLIT_NBUF) X(SPLIT_MIN_ITEMS) X(CONV_NARROW) X(DW_FULL) X(DW_FULL_MIN) X(DW_FULL_WGS) X(SPLIT_ROWS)
+  X(WIDE_SPLIT) X(SPLIT_TARGET) X(SPLIT_NBUF) X(SPLIT_MIN_ITEMS) X(CONV_NARROW) X(DW_FULL) X(DW_FULL_MIN) X(DW_FULL_WGS) X(SPLIT_ROWS) X(GEOM_JOBS)
 #define AABR_KNOB_ENUM(n) K_##n,
 enum Knob { AABR_KNOB_LIST(AABR_KNOB_ENUM) K_COUNT };
 #undef AABR_KNOB_ENUM
@@ -125,6 +125,43 @@ __device__ inline uint32_t grid_insert(GridEnt *g, uint64_t mask, uint64_t key) 
     h = grid_next(h, mask, t);
   }
 }
+
+// ---- stream builders over MANY rule books in one launch (round 6) ----------------------------------------------------
+// A pass compiles every gather table into its streaming forms: wide tile blocks (conv_wide.hip), 64-row tile blocks and
+// the offset-major pair list of the weight gradient (conv.hip).  Round 5 issued them book by book -- 4 launches x ~45
+// books of 2.5-14 us each, a third of a step's launches.  A job list hands up to kStreamJobsMax books to ONE launch:
+// block b of the grid serves job j with first[j] <= b < first[j + 1].  Same per-book code, bit-identical words.
+constexpr int kStreamJobsMax = 48;
+struct StreamJob {
+  const int32_t *table;    // gather table [vol][V]
+  const int32_t *counts;   // per-256-row hit counts [vol][ceil(V / 256)] (pair lists only)
+  int32_t *words;          // the stream being built
+  int64_t V;
+  int32_t vol, T;          // T: rows per wide tile (wide blocks only)
+};
+struct StreamJobs {
+  StreamJob j[kStreamJobsMax];
+  uint32_t first[kStreamJobsMax + 1];   // first block of job j; first[n] = grid size
+  int n;
+};
+// job of block b (wave-uniform: a linear walk over <= 48 prefix entries held in SGPRs)
+__device__ inline int stream_job_of(const StreamJobs &js, unsigned b) {
+  int j = 0;
+  while (j + 1 < js.n && b >= js.first[j + 1]) ++j;
+  return j;
+}
+int launch_wide_blocks_jobs(const StreamJob *jobs, int n, hipStream_t st);     // conv_wide.hip
+int launch_tile_blocks_jobs(const StreamJob *jobs, int n, hipStream_t st);     // conv.hip
+int launch_offset_pairs_jobs(const StreamJob *jobs, int n, hipStream_t st);    // conv.hip
+// per-sample row offsets of many levels in one launch (geometry.hip k_sample_offsets: one 64-thread block per level)
+constexpr int kSampleJobsMax = 32;
+struct SampleJob {
+  const int32_t *sc, *meta;
+  int32_t *out;
+  int64_t V_max;
+  int32_t max_samples;
+};
+int launch_sample_offsets_jobs(const SampleJob *jobs, int n, hipStream_t st);  // geometry.hip
 
 inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

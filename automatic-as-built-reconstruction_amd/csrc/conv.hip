@@ -186,10 +186,14 @@ __global__ __launch_bounds__(256) void k_pack_weights_jobs(const PackJob *__rest
 __host__ __device__ inline int64_t tb_ntiles(int64_t V) { return (V + 63) / 64; }
 __host__ __device__ inline int tb_maxb(int vol) { return 4 * vol; }
 
-__global__ __launch_bounds__(256) void k_build_tile_blocks(const int32_t *__restrict__ table, int64_t V,
-                                                           int vol, int32_t *__restrict__ words) {
+__global__ __launch_bounds__(256) void k_build_tile_blocks(const StreamJobs js) {      // common.h: one launch, many books
+  const int job = stream_job_of(js, blockIdx.x);
+  const int32_t *__restrict__ table = js.j[job].table;
+  int32_t *__restrict__ words = js.j[job].words;
+  const int64_t V = js.j[job].V;
+  const int vol = js.j[job].vol;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t ntiles = tb_ntiles(V), tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t ntiles = tb_ntiles(V), tile = (int64_t)(blockIdx.x - js.first[job]) * 4 + wave;
   if (tile >= ntiles) return;
   const int maxb = tb_maxb(vol);
   int32_t *nblk = words;
@@ -1447,11 +1451,15 @@ __host__ __device__ inline int64_t op_hdr(int vol) { return (int64_t)vol + 2 * (
 __host__ __device__ inline int64_t op_nb256(int64_t V) { return (V + 255) / 256; }
 
 // one block per offset: exclusive scan of the per-256-row hit counts
-__global__ __launch_bounds__(256) void k_offset_bases(const int32_t *__restrict__ counts, int64_t nb,
-                                                      int vol, int32_t *__restrict__ words) {
+__global__ __launch_bounds__(256) void k_offset_bases(const StreamJobs js) {            // common.h: one launch, many books
   __shared__ int ws[4];
   __shared__ int carry_s;
-  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int job = stream_job_of(js, blockIdx.x);
+  const int32_t *__restrict__ counts = js.j[job].counts;
+  int32_t *__restrict__ words = js.j[job].words;
+  const int64_t nb = op_nb256(js.j[job].V);
+  const int vol = js.j[job].vol;
+  const int k = blockIdx.x - js.first[job], lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int32_t *bases = words + op_hdr(vol) + (int64_t)k * nb;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
@@ -1476,15 +1484,21 @@ __global__ __launch_bounds__(256) void k_offset_bases(const int32_t *__restrict_
 }
 
 
-__global__ __launch_bounds__(256) void k_fill_offset_pairs(const int32_t *__restrict__ table, int64_t V,
-                                                           int vol, int32_t *__restrict__ words) {
+__global__ __launch_bounds__(256) void k_fill_offset_pairs(const StreamJobs js) {       // common.h: one launch, many books
   __shared__ int ws[4];
-  const int k = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int job = stream_job_of(js, blockIdx.x);
+  const int32_t *__restrict__ table = js.j[job].table;
+  int32_t *__restrict__ words = js.j[job].words;
+  const int64_t V = js.j[job].V;
+  const int vol = js.j[job].vol;
   const int64_t nb = op_nb256(V);
-  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned lb = blockIdx.x - js.first[job];            // block of this book: (row block, offset), offset-major
+  const unsigned bx = (unsigned)(lb % (unsigned)nb);
+  const int k = (int)(lb / (unsigned)nb), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)bx * 256 + threadIdx.x;
   // chunk layouts (one thread of the grid): offset k owns chunks [cstart[k], cstart[k+1]) of 1024 resp. 256
   // pairs each; the R_k were written by k_offset_bases, the previous launch on this stream
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (lb == 0 && threadIdx.x == 0) {
     int c = 0, c4 = 0;
     for (int kk = 0; kk < vol; ++kk) {
       words[vol + kk] = c;
@@ -1499,7 +1513,7 @@ __global__ __launch_bounds__(256) void k_fill_offset_pairs(const int32_t *__rest
   const unsigned long long m = __ballot(t >= 0);
   if (lane == 0) ws[wave] = (int)__popcll(m);
   __syncthreads();
-  int pre = words[op_hdr(vol) + (int64_t)k * nb + blockIdx.x];
+  int pre = words[op_hdr(vol) + (int64_t)k * nb + bx];
   for (int j = 0; j < wave; ++j) pre += ws[j];
   if (t >= 0) {
     int pos = pre + (int)__popcll(m & ((1ull << lane) - 1ull));
@@ -2221,10 +2235,45 @@ extern "C" int aabr_build_tile_blocks(const int32_t *table, int64_t V, int vol, 
   AABR_CHECK_ARG(V < (1ll << 25), "more than 2^25 sites per grid are not supported");
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(table && blocks, "null pointer");
-  hipLaunchKernelGGL(k_build_tile_blocks, dim3((unsigned)ceil_div(tb_ntiles(V), 4)), dim3(256), 0,
-                     (hipStream_t)stream_, table, V, vol, blocks);
+  const StreamJob job{table, nullptr, blocks, V, vol, 0};
+  return launch_tile_blocks_jobs(&job, 1, (hipStream_t)stream_);
+}
+
+// job lists: the grid of a launch = the blocks of all its books back to back (StreamJobs::first)
+template <typename F>
+static int launch_stream_jobs(const StreamJob *jobs, int n, F blocks_of, void (*kernel)(const StreamJobs), hipStream_t st) {
+  for (int j0 = 0; j0 < n;) {
+    StreamJobs js;
+    uint64_t blocks = 0;
+    int m = 0;
+    while (j0 + m < n && m < kStreamJobsMax) {
+      const uint64_t b = (uint64_t)blocks_of(jobs[j0 + m]);
+      if (m && blocks + b >= (1ull << 31)) break;
+      js.j[m] = jobs[j0 + m];
+      js.first[m] = (uint32_t)blocks;
+      blocks += b;
+      ++m;
+    }
+    js.n = m;
+    js.first[m] = (uint32_t)blocks;
+    AABR_CHECK_ARG(blocks < (1ull << 31), "too many blocks in one job list");
+    if (blocks) hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), 0, st, js);
+    j0 += m;
+  }
   AABR_CHECK_LAUNCH();
   return AABR_OK;
+}
+
+int aabr::launch_tile_blocks_jobs(const StreamJob *jobs, int n, hipStream_t st) {
+  return launch_stream_jobs(jobs, n, [](const StreamJob &j) { return ceil_div(tb_ntiles(j.V), 4); }, k_build_tile_blocks, st);
+}
+
+// the pair lists of n books: ONE scan launch (a block per book and offset), then ONE fill launch (the fill reads the
+// R_k the scan wrote: stream order)
+int aabr::launch_offset_pairs_jobs(const StreamJob *jobs, int n, hipStream_t st) {
+  int rc = launch_stream_jobs(jobs, n, [](const StreamJob &j) { return (int64_t)j.vol; }, k_offset_bases, st);
+  if (rc != AABR_OK) return rc;
+  return launch_stream_jobs(jobs, n, [](const StreamJob &j) { return op_nb256(j.V) * j.vol; }, k_fill_offset_pairs, st);
 }
 
 extern "C" int64_t aabr_offset_pairs_words(int64_t V, int vol) {
@@ -2240,11 +2289,8 @@ extern "C" int aabr_build_offset_pairs(const int32_t *table, const int32_t *bloc
     return AABR_OK;
   }
   AABR_CHECK_ARG(table && block_counts, "null pointer");
-  hipLaunchKernelGGL(k_offset_bases, dim3((unsigned)vol), dim3(256), 0, st, block_counts, op_nb256(V), vol, pairs);
-  hipLaunchKernelGGL(k_fill_offset_pairs, dim3((unsigned)op_nb256(V), (unsigned)vol), dim3(256), 0, st, table, V,
-                     vol, pairs);
-  AABR_CHECK_LAUNCH();
-  return AABR_OK;
+  const StreamJob job{table, block_counts, pairs, V, vol, 0};
+  return launch_offset_pairs_jobs(&job, 1, st);
 }
 
 extern "C" int aabr_conv_forward(const float *in_feats, int n_in, int64_t rows_in, float *out_feats, int n_out,

@@ -40,8 +40,13 @@ constexpr int kMaxVol = 63;  // vol + 1 prefix entries live in the lanes of one 
 //   entry = (partner_row << 8) | local_row; padding entries repeat the block's first pair with bit 31 set.
 // Pairs of one offset are in ascending local-row order (deterministic).
 // T = rows per tile (a multiple of 16, <= 128); the workgroup has ceil(T/64) waves
-__global__ __launch_bounds__(256) void k_build_tileT(const int32_t *__restrict__ table, int64_t V, int vol, int T,
-                                                      int32_t *__restrict__ words) {
+// (one launch serves the books of a job list that need the same number of waves per tile, common.h StreamJobs)
+__global__ __launch_bounds__(256) void k_build_tileT(const StreamJobs js) {
+  const int job = stream_job_of(js, blockIdx.x);
+  const int32_t *__restrict__ table = js.j[job].table;
+  int32_t *__restrict__ words = js.j[job].words;
+  const int64_t V = js.j[job].V;
+  const int vol = js.j[job].vol, T = js.j[job].T;
   const int kT = T;
   const int NWV = (T + 63) / 64;
   __shared__ int s_cnt[4][kMaxVol];
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256) void k_build_tileT(const int32_t *__restrict__
   __shared__ int s_tot[kMaxVol];
   __shared__ int s_first[kMaxVol];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t ntiles = (V + T - 1) / T, tile = blockIdx.x;
+  const int64_t ntiles = (V + T - 1) / T, tile = blockIdx.x - js.first[job];
   const int maxb = (T / 16) * vol;
   int32_t *pre = words + tile * (vol + 1);
   int32_t *ent = words + ntiles * (vol + 1) + tile * (int64_t)maxb * 16;
@@ -501,8 +506,17 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 3) void k_conv_cs(const float 
       v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
     }
     if (res) { // out = conv + res: the residual / lateral add of the consumer folded into the write-out
-      const f32x4 rr = *reinterpret_cast<const f32x4 *>(res + (row0 + r) * co + nb0 * 16 + q * 4);
-      v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+      if (BF) {
+        // bf16 storage: the separate add would read the convolution's STORED value -- round it first, add the stored
+        // residual in fp32, round once more below: bit for bit what k_add2<bf16> / torch's bf16 add give
+        const bf16x4w rr = *reinterpret_cast<const bf16x4w *>(reinterpret_cast<const __bf16 *>(res) + (row0 + r) * co +
+                                                              nb0 * 16 + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)(__bf16)v[j] + (float)rr[j];
+      } else {
+        const f32x4 rr = *reinterpret_cast<const f32x4 *>(res + (row0 + r) * co + nb0 * 16 + q * 4);
+        v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+      }
     }
     if (BF) {
       bf16x4w o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -570,9 +584,37 @@ extern "C" int aabr_build_wide_blocks(const int32_t *table, int64_t V, int vol, 
   AABR_CHECK_ARG(tile_rows >= 16 && tile_rows <= kMaxTileRows && (tile_rows & 15) == 0, "tile_rows: multiple of 16, <= 240");
   if (V == 0) return AABR_OK;
   AABR_CHECK_ARG(table && blocks, "null pointer");
-  const unsigned nt = (unsigned)((V + tile_rows - 1) / tile_rows);
-  hipLaunchKernelGGL(k_build_tileT, dim3(nt), dim3(64 * ((tile_rows + 63) / 64)), 0, (hipStream_t)stream_, table, V, vol,
-                     tile_rows, blocks);
+  const StreamJob job{table, nullptr, blocks, V, vol, tile_rows};
+  return launch_wide_blocks_jobs(&job, 1, (hipStream_t)stream_);
+}
+
+int aabr::launch_wide_blocks_jobs(const StreamJob *jobs, int n, hipStream_t st) {
+  // one launch per workgroup size: a tile of T rows needs ceil(T / 64) waves, and waves beyond that would walk the whole
+  // offset loop for nothing (T = 64 and T = 96..128 are what the dispatch rules produce: two launches per list)
+  for (int nwv = 1; nwv <= 4; ++nwv) {
+    StreamJobs js;
+    js.n = 0;
+    uint64_t blocks = 0;
+    auto flush = [&]() -> int {
+      if (js.n == 0 || blocks == 0) { js.n = 0; blocks = 0; return AABR_OK; }
+      js.first[js.n] = (uint32_t)blocks;
+      hipLaunchKernelGGL(k_build_tileT, dim3((unsigned)blocks), dim3(64 * nwv), 0, st, js);
+      js.n = 0;
+      blocks = 0;
+      return AABR_OK;
+    };
+    for (int j = 0; j < n; ++j) {
+      if ((jobs[j].T + 63) / 64 != nwv) continue;
+      const uint64_t b = (uint64_t)((jobs[j].V + jobs[j].T - 1) / jobs[j].T);
+      if (js.n == kStreamJobsMax || blocks + b >= (1ull << 31)) flush();
+      AABR_CHECK_ARG(b < (1ull << 31), "too many tiles in one rule book");
+      js.j[js.n] = jobs[j];
+      js.first[js.n] = (uint32_t)blocks;
+      blocks += b;
+      ++js.n;
+    }
+    flush();
+  }
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }
@@ -766,8 +808,14 @@ __global__ __launch_bounds__(256) void k_split_reduce(const float *__restrict__ 
     v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3];
   }
   if (res) {
-    const f32x4 rr = reinterpret_cast<const f32x4 *>(res)[i];
-    v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+    if (BF) {      // the sum of two stored bf16 values (see k_conv_cs' write-out)
+      const bf16x4w rr = reinterpret_cast<const bf16x4w *>(res)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (float)(__bf16)v[j] + (float)rr[j];
+    } else {
+      const f32x4 rr = reinterpret_cast<const f32x4 *>(res)[i];
+      v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+    }
   }
   if (BF) {
     bf16x4w o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -910,14 +958,35 @@ extern "C" int aabr_conv_forward_wide_bf16(const uint16_t *in_feats, int n_in, i
 
 static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
                             int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias, int flags,
-                            const uint16_t *wpack, double *stats, BnBwdStats bn, void *stream_);
+                            const uint16_t *wpack, const uint16_t *residual, double *stats, BnBwdStats bn, void *stream_);
 
 extern "C" int aabr_conv_forward_wide_bf16_stats(const uint16_t *in_feats, int n_in, int64_t rows_in,
                                                  uint16_t *out_feats, int n_out, int64_t V_out, const int32_t *blocks,
                                                  int tile_rows, int vol, const float *bias, int flags,
                                                  const uint16_t *wpack, double *stats, void *stream_) {
   return wide_launch_bf16(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias, flags, wpack,
-                          stats, BnBwdStats{}, stream_);
+                          nullptr, stats, BnBwdStats{}, stream_);
+}
+
+// the general bf16-storage form behind the compiled pass: optional residual (out = conv + residual, both rounded as
+// stored: see the write-out), optional statistics of the following BatchNorm (bn_in NULL) or backward statistics of the
+// BatchNorm whose d_out this launch writes (bn_in, bn_out, save_mean, leakiness as aabr_conv_forward_wide_bf16_bwd_stats)
+extern "C" int aabr_conv_forward_wide_bf16_res(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
+                                               int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                               const float *bias, int flags, const uint16_t *wpack,
+                                               const uint16_t *residual, double *stats, const uint16_t *bn_in,
+                                               const uint16_t *bn_out, const float *save_mean, float leakiness,
+                                               void *stream_) {
+  AABR_CHECK_ARG(((uintptr_t)residual & 7) == 0, "residual must be 8-byte aligned");
+  BnBwdStats bn{};
+  if (bn_in) {
+    AABR_CHECK_ARG(stats && bn_out && save_mean, "null pointer");
+    AABR_CHECK_ARG((((uintptr_t)bn_in | (uintptr_t)bn_out) & 7) == 0, "the BatchNorm's input / output must be 8-byte aligned");
+    bn = BnBwdStats{reinterpret_cast<const float *>(bn_in), save_mean, nullptr, nullptr, nullptr, leakiness,
+                    reinterpret_cast<const float *>(bn_out)};
+  }
+  return wide_launch_bf16(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias, flags, wpack,
+                          residual, stats, bn, stream_);
 }
 
 extern "C" int aabr_conv_forward_wide_bf16_bwd_stats(const uint16_t *in_feats, int n_in, int64_t rows_in,
@@ -931,12 +1000,12 @@ extern "C" int aabr_conv_forward_wide_bf16_bwd_stats(const uint16_t *in_feats, i
   BnBwdStats bn{reinterpret_cast<const float *>(bn_in), save_mean, nullptr, nullptr, nullptr, leakiness,
                 reinterpret_cast<const float *>(bn_out)};
   return wide_launch_bf16(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias, flags, wpack,
-                          stats, bn, stream_);
+                          nullptr, stats, bn, stream_);
 }
 
 static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
                             int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias, int flags,
-                            const uint16_t *wpack, double *stats, BnBwdStats bn, void *stream_) {
+                            const uint16_t *wpack, const uint16_t *residual, double *stats, BnBwdStats bn, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
   AABR_CHECK_ARG(!stats || (tile_rows >= 64 && ((uintptr_t)stats & 7) == 0), "statistics need tiles of >= 64 rows");
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 63) == 0 && (n_out & 63) == 0, "plane counts: n_in % 64, n_out % 64");
@@ -964,6 +1033,7 @@ static int wide_launch_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in,
   }
   const float *in_f = reinterpret_cast<const float *>(in_feats), *wp_f = reinterpret_cast<const float *>(wpack);
   float *out_f = reinterpret_cast<float *>(out_feats);
+  const float *res_f = reinterpret_cast<const float *>(residual);
 constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: measured slower, 100 -> 112 us)
 #define AABR_WIDE_BF(KG, NB, NCB) AABR_WIDE_BF_S(KG, NB, NCB, ((KG) <= 2 ? kBfSets : 2))
 #define AABR_WIDE_BF_D(KG, NB, NCB, D)                                                                              \
@@ -973,7 +1043,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
     hipLaunchKernelGGL((k_conv_cs<KG, D, NB, true, NCB, kBfSets>), grid, dim3(256),                                \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr, stats, bn);                                                      \
+                       tile_rows, res_f, stats, bn);                                                      \
   } while (0)
 #define AABR_WIDE_BF_S(KG, NB, NCB, NS) AABR_WIDE_BF_L(KG, NB, NCB, NS)
 #define AABR_WIDE_BF_L(KG, NB, NCB, NS)                                                                            \
@@ -984,7 +1054,7 @@ constexpr int kBfSets = 2;   // gather register sets of the bf16 launches (4: me
     hipLaunchKernelGGL((k_conv_cs<KG, 0, NB, true, NCB, NS>), grid, dim3(256),                   \
                        (size_t)((tile_rows + 1) * kWS * NCB + NB * 2 * 16 * KG * 32) * sizeof(float), st, in_f,    \
                        n_in, in_bytes, out_f, n_out, V_out, blocks, words_bytes, vol, flip, wp_f, wp_bytes, bias,  \
-                       tile_rows, (const float *)nullptr, stats, bn);                                              \
+                       tile_rows, res_f, stats, bn);                                              \
   } while (0)
 #define AABR_WIDE_BF_K(KG)                                                                                         \
   do {                                                                                                             \
@@ -1046,11 +1116,26 @@ extern "C" int aabr_conv_wide_split_bf16(int n_in, int n_out, int64_t rows_in, i
   return (P << 16) | T;
 }
 
+extern "C" int aabr_conv_forward_wide_split_bf16_res(const uint16_t *in_feats, int n_in, int64_t rows_in,
+                                                     uint16_t *out_feats, int n_out, int64_t V_out, const int32_t *blocks,
+                                                     int tile_rows, int vol, const float *bias, int flags,
+                                                     const uint16_t *wpack, int parts, float *scratch,
+                                                     const uint16_t *residual, void *stream_);
 extern "C" int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
                                                  int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
                                                  const float *bias, int flags, const uint16_t *wpack, int parts,
                                                  float *scratch, void *stream_) {
+  return aabr_conv_forward_wide_split_bf16_res(in_feats, n_in, rows_in, out_feats, n_out, V_out, blocks, tile_rows, vol, bias,
+                                               flags, wpack, parts, scratch, nullptr, stream_);
+}
+
+extern "C" int aabr_conv_forward_wide_split_bf16_res(const uint16_t *in_feats, int n_in, int64_t rows_in,
+                                                     uint16_t *out_feats, int n_out, int64_t V_out, const int32_t *blocks,
+                                                     int tile_rows, int vol, const float *bias, int flags,
+                                                     const uint16_t *wpack, int parts, float *scratch,
+                                                     const uint16_t *residual, void *stream_) {
   hipStream_t st = (hipStream_t)stream_;
+  AABR_CHECK_ARG(((uintptr_t)residual & 7) == 0, "residual must be 8-byte aligned");
   AABR_CHECK_ARG(parts >= 2 && parts <= 32 && parts <= vol && scratch && ((uintptr_t)scratch & 15) == 0,
                  "2 <= parts <= min(32, vol) and a 16-byte aligned scratch of parts x V_out x n_out floats");
   AABR_CHECK_ARG(n_in > 0 && n_out > 0 && (n_in & 63) == 0 && (n_out & 63) == 0, "plane counts: n_in % 64, n_out % 64");
@@ -1085,7 +1170,7 @@ extern "C" int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n
 #undef AABR_SPLIT_BF
   const int64_t n4 = V_out * n_out / 4;
   hipLaunchKernelGGL((k_split_reduce<true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, scratch, parts, n4,
-                     n_out / 4, bias, (const float *)nullptr, (void *)out_feats);
+                     n_out / 4, bias, reinterpret_cast<const float *>(residual), (void *)out_feats);
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

@@ -256,8 +256,13 @@ __global__ __launch_bounds__(256) void k_spatial_locations(const int32_t *__rest
 // Metadata.h:24-33): out[0] = V, out[1 + b] = first row whose batch index is >= b (b = 0 .. max_samples), so
 // sample b owns rows [out[1+b], out[2+b]).  V is read from device memory (meta[0] of the grid builder), so the
 // launch can follow the builder without a host read in between.
-__global__ __launch_bounds__(64) void k_sample_offsets(const int32_t *__restrict__ sc, const int32_t *__restrict__ meta,
-                                                       int64_t V_max, int max_samples, int32_t *__restrict__ out) {
+struct SampleJobs { SampleJob j[kSampleJobsMax]; };
+__global__ __launch_bounds__(64) void k_sample_offsets(const SampleJobs js) {      // block = level (common.h SampleJob)
+  const int32_t *__restrict__ sc = js.j[blockIdx.x].sc;
+  const int32_t *__restrict__ meta = js.j[blockIdx.x].meta;
+  int32_t *__restrict__ out = js.j[blockIdx.x].out;
+  const int64_t V_max = js.j[blockIdx.x].V_max;
+  const int max_samples = js.j[blockIdx.x].max_samples;
   int64_t V = meta[0];
   if (V > V_max) V = V_max;
   if (V < 0) V = 0;
@@ -434,8 +439,17 @@ extern "C" int aabr_spatial_locations(const int32_t *site_coords, int64_t V, int
 extern "C" int aabr_sample_offsets(const int32_t *site_coords, const int32_t *meta, int64_t V_max, int max_samples,
                                    int32_t *out, void *stream_) {
   AABR_CHECK_ARG(site_coords && meta && out && V_max >= 0 && max_samples >= 1 && max_samples <= 4096, "bad arguments");
-  hipLaunchKernelGGL(k_sample_offsets, dim3(1), dim3(64), 0, (hipStream_t)stream_, site_coords, meta, V_max,
-                     max_samples, out);
+  const SampleJob job{site_coords, meta, out, V_max, max_samples};
+  return launch_sample_offsets_jobs(&job, 1, (hipStream_t)stream_);
+}
+
+int aabr::launch_sample_offsets_jobs(const SampleJob *jobs, int n, hipStream_t st) {
+  for (int j0 = 0; j0 < n; j0 += kSampleJobsMax) {
+    SampleJobs js;
+    const int m = n - j0 < kSampleJobsMax ? n - j0 : kSampleJobsMax;
+    for (int j = 0; j < m; ++j) js.j[j] = jobs[j0 + j];
+    hipLaunchKernelGGL(k_sample_offsets, dim3((unsigned)m), dim3(64), 0, st, js);
+  }
   AABR_CHECK_LAUNCH();
   return AABR_OK;
 }

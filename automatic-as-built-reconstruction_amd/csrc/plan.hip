@@ -56,6 +56,33 @@ __global__ __launch_bounds__(256) void k_cast(const TI *__restrict__ in, TO *__r
   }
 }
 
+// a run of storage casts in one launch (the fp32 copies of the returned maps at the end of a bf16-storage forward list, the
+// bf16 copies of their gradients at the head of the backward list: 10 records each): block b serves job j with
+// first[j] <= b < first[j + 1]
+constexpr int kCastJobsMax = 16;
+struct CastJobs {
+  const void *in[kCastJobsMax];
+  void *out[kCastJobsMax];
+  int64_t n[kCastJobsMax];
+  uint32_t first[kCastJobsMax + 1];
+  int count;
+};
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_cast_jobs(const CastJobs js) {
+  int j = 0;
+  while (j + 1 < js.count && blockIdx.x >= js.first[j + 1]) ++j;
+  const TI *__restrict__ in = reinterpret_cast<const TI *>(js.in[j]);
+  TO *__restrict__ out = reinterpret_cast<TO *>(js.out[j]);
+  const int64_t n = js.n[j];
+  const int64_t i = ((int64_t)(blockIdx.x - js.first[j]) * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[i + q] = (TO)(float)in[i + q];
+  } else {
+    for (int64_t q = i; q < n; ++q) out[q] = (TO)(float)in[q];
+  }
+}
+
 // rule totals of many rule books in one launch: job j sums n[j] int32 counts into the float64 slot out[j]
 struct SumJobs {
   const int32_t *c[64];
@@ -135,6 +162,32 @@ extern "C" int aabr_cast_storage(const void *in, void *out, int64_t n, int to_bf
   return AABR_OK;
 }
 
+// records ops[j .. j + m) are storage casts in the same direction on the caller's stream: one launch
+static int plan_cast_run(const AabrPlanOp *ops, int m, void *st) {
+  CastJobs js;
+  uint64_t blocks = 0;
+  int c = 0;
+  for (int j = 0; j < m; ++j) {
+    const AabrPlanOp &o = ops[j];
+    AABR_CHECK_ARG(o.i64[0] >= 0 && (o.i64[0] == 0 || (o.p[0] && o.p[1])), "cast record: bad size / null pointer");
+    if (o.i64[0] == 0) continue;
+    js.in[c] = o.p[0]; js.out[c] = o.p[1]; js.n[c] = o.i64[0];
+    js.first[c] = (uint32_t)blocks;
+    blocks += (uint64_t)((o.i64[0] + 1023) / 1024);
+    ++c;
+  }
+  AABR_CHECK_ARG(blocks < (1ull << 31), "too many elements");
+  if (c == 0) return AABR_OK;
+  js.first[c] = (uint32_t)blocks;
+  js.count = c;
+  if (ops[0].flags & AABR_PLAN_TO_BF16)
+    hipLaunchKernelGGL((k_cast_jobs<float, __bf16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, js);
+  else
+    hipLaunchKernelGGL((k_cast_jobs<__bf16, float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, js);
+  AABR_CHECK_LAUNCH();
+  return AABR_OK;
+}
+
 // One record = one library call; the field use per kind is listed in include/aabr_hip.h (AabrPlanOp).
 static_assert(sizeof(AabrPlanOp) == 176, "AabrPlanOp layout is part of the C ABI");
 
@@ -177,11 +230,12 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
     break;
   case AABR_PLAN_CONV_WIDE:
     if (o.i32[5] == 1) { // the write-out forms the BACKWARD statistics of the BatchNorm whose d_out it produces
-      if (bf) {          // p7 the BatchNorm's input, p9 its stored output (the sign), p8 save_mean
-        rc = aabr_conv_forward_wide_bf16_bwd_stats((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
-                                                   o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4],
-                                                   o.i32[3], (const uint16_t *)p[5], (double *)p[6], (const uint16_t *)p[7],
-                                                   (const uint16_t *)p[9], (const float *)p[8], o.f32[0], st);
+      if (bf) {          // p7 the BatchNorm's input, p9 its stored output (the sign), p8 save_mean; p3 = residual or NULL
+        rc = aabr_conv_forward_wide_bf16_res((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
+                                             o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4],
+                                             o.i32[3], (const uint16_t *)p[5], (const uint16_t *)p[3], (double *)p[6],
+                                             (const uint16_t *)p[7], (const uint16_t *)p[9], (const float *)p[8], o.f32[0],
+                                             st);
         break;
       }
       rc = aabr_conv_forward_wide_bwd_stats((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
@@ -191,17 +245,19 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
                                             (const float *)p[10], (const float *)p[11], o.f32[0], st);
       break;
     }
-    rc = bf ? aabr_conv_forward_wide_bf16_stats((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
-                                                o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2],
-                                                (const float *)p[4], o.i32[3], (const uint16_t *)p[5], (double *)p[6], st)
+    rc = bf ? aabr_conv_forward_wide_bf16_res((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
+                                              o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4],
+                                              o.i32[3], (const uint16_t *)p[5], (const uint16_t *)p[3], (double *)p[6],
+                                              nullptr, nullptr, nullptr, 0.0f, st)
             : aabr_conv_forward_wide_stats((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
                                            (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
                                            (const float *)p[5], (const float *)p[3], (double *)p[6], st);
     break;
   case AABR_PLAN_CONV_WIDE_SPLIT:
-    rc = bf ? aabr_conv_forward_wide_split_bf16((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1], o.i32[1],
-                                                o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4],
-                                                o.i32[3], (const uint16_t *)p[5], o.i32[5], (float *)p[6], st)
+    rc = bf ? aabr_conv_forward_wide_split_bf16_res((const uint16_t *)p[0], o.i32[0], o.i64[0], (uint16_t *)p[1],
+                                                    o.i32[1], o.i64[1], (const int32_t *)p[2], o.i32[4], o.i32[2],
+                                                    (const float *)p[4], o.i32[3], (const uint16_t *)p[5], o.i32[5],
+                                                    (float *)p[6], (const uint16_t *)p[3], st)
             : aabr_conv_forward_wide_split((const float *)p[0], o.i32[0], o.i64[0], (float *)p[1], o.i32[1], o.i64[1],
                                            (const int32_t *)p[2], o.i32[4], o.i32[2], (const float *)p[4], o.i32[3],
                                            (const float *)p[5], (const float *)p[3], o.i32[5], (float *)p[6], st);
@@ -255,6 +311,14 @@ static int plan_dispatch(const AabrPlanOp &o, void *st) {
                               o.f32[1], o.i32[1], o.f32[2], (float *)p[8], st);
     break;
   case AABR_PLAN_BN_BWD:
+    if (bf && p[11]) { // bf16 storage with the gradient sum folded in (p11); statistics given (i64[1], i32[1]) or its own
+      rc = aabr_bn_backward_add_bf16((const uint16_t *)p[0], (uint16_t *)p[1], (const uint16_t *)p[2],
+                                     (const uint16_t *)p[3], o.i64[0], o.i32[0], (const float *)p[4], (const float *)p[5],
+                                     (const float *)p[6], (const float *)p[10], (float *)p[7], (float *)p[8], o.f32[2],
+                                     (const double *)(uintptr_t)o.i64[1], o.i32[1], (float *)p[9], (const uint16_t *)p[11],
+                                     st);
+      break;
+    }
     if (o.i64[1]) { // the statistics' partial sums came with the producing convolution (i64[1] = address, i32[1] of them)
       if (bf) {
         rc = aabr_bn_backward_parts_bf16((const uint16_t *)p[0], (uint16_t *)p[1], (const uint16_t *)p[2],
@@ -360,6 +424,37 @@ static int plan_run_part(const AabrPlanOp *ops, int n_ops, void *st_, int hold) 
         if (rc != AABR_OK) return fail(rc);
       }
       continue;
+    }
+    if (o.kind == AABR_PLAN_CAST) {        // a run of casts in one direction: one launch (plan_cast_run)
+      // The records of a list mean "one after the other": a pass whose arena is packed by liveness hands a cast's input
+      // on to a LATER record's output.  A record joins the run only if what it writes overlaps nothing an earlier
+      // record of the run reads or writes.
+      const size_t es_in = (o.flags & AABR_PLAN_TO_BF16) ? 4 : 2, es_out = (o.flags & AABR_PLAN_TO_BF16) ? 2 : 4;
+      auto overlaps = [](const void *a, size_t na, const void *b, size_t nb) {
+        const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+        return a0 < b0 + nb && b0 < a0 + na;
+      };
+      int m = 1;
+      while (j + m < n_ops && m < kCastJobsMax && ops[j + m].kind == AABR_PLAN_CAST &&
+             !(ops[j + m].flags & (AABR_PLAN_SIDE | AABR_PLAN_JOIN)) &&
+             ((ops[j + m].flags ^ o.flags) & AABR_PLAN_TO_BF16) == 0) {
+        const AabrPlanOp &c = ops[j + m];
+        bool clash = false;
+        for (int q = 0; q < m && !clash; ++q) {
+          const AabrPlanOp &e = ops[j + q];
+          clash = overlaps(c.p[1], (size_t)c.i64[0] * es_out, e.p[0], (size_t)e.i64[0] * es_in) ||
+                  overlaps(c.p[1], (size_t)c.i64[0] * es_out, e.p[1], (size_t)e.i64[0] * es_out) ||
+                  overlaps(c.p[0], (size_t)c.i64[0] * es_in, e.p[1], (size_t)e.i64[0] * es_out);
+        }
+        if (clash) break;
+        ++m;
+      }
+      if (m > 1) {
+        const int rc = plan_cast_run(ops + j, m, st_);
+        if (rc != AABR_OK) return fail(rc);
+        j += m - 1;
+        continue;
+      }
     }
     const int rc = plan_dispatch(o, st_);
     if (rc != AABR_OK) return fail(rc);
@@ -507,6 +602,12 @@ static inline int64_t dir_bytes(const int32_t dims[4]) { return (int64_t)dims[0]
 
 extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
   AABR_CHECK_ARG(n_ops >= 0 && (ops || n_ops == 0), "bad plan");
+  // The stream builders (tile blocks, wide tile blocks, pair lists) read finished gather tables and feed nothing else in
+  // the list: they are collected here and issued behind the last record as ONE launch per kind over all the books of the
+  // list (common.h StreamJobs) instead of one to two launches per book -- same words, a third of a step's launches gone.
+  std::vector<StreamJob> tile_jobs, wide_jobs, pair_jobs;
+  std::vector<SampleJob> sample_jobs;      // the per-sample row offsets of the levels built in this list: read by the host only
+  const bool per_book = knob(K_GEOM_JOBS) == 0;     // A/B knob: 0 = issue every builder where it stands, book by book (round 5)
   for (int j = 0; j < n_ops; ++j) {
     const AabrGeomOp &o = ops[j];
     void *const *p = o.p;
@@ -523,20 +624,36 @@ extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
                                     (int32_t *)p[7], st);
       break;
     case AABR_GEOM_TILE_BLOCKS:
-      rc = aabr_build_tile_blocks((const int32_t *)p[0], o.i64[0], o.i32[0], (int32_t *)p[1], st);
+      AABR_CHECK_ARG(o.i64[0] >= 0 && o.i64[0] < (1ll << 25) && o.i32[0] > 0 && o.i32[0] <= 4096, "tile blocks: bad sizes");
+      if (o.i64[0] == 0) break;
+      AABR_CHECK_ARG(p[0] && p[1], "tile blocks: null pointer");
+      if (per_book) { rc = aabr_build_tile_blocks((const int32_t *)p[0], o.i64[0], o.i32[0], (int32_t *)p[1], st); break; }
+      tile_jobs.push_back(StreamJob{(const int32_t *)p[0], nullptr, (int32_t *)p[1], o.i64[0], o.i32[0], 0});
       break;
     case AABR_GEOM_WIDE_BLOCKS:
-      rc = aabr_build_wide_blocks((const int32_t *)p[0], o.i64[0], o.i32[0], o.i32[1], (int32_t *)p[1], st);
+      AABR_CHECK_ARG(o.i64[0] >= 0 && o.i32[0] > 0 && o.i32[0] <= 63, "wide blocks: bad sizes (vol <= 63)");
+      AABR_CHECK_ARG(o.i32[1] >= 16 && o.i32[1] <= 240 && (o.i32[1] & 15) == 0, "wide blocks: tile_rows a multiple of 16, <= 240");
+      if (o.i64[0] == 0) break;
+      AABR_CHECK_ARG(p[0] && p[1], "wide blocks: null pointer");
+      if (per_book) { rc = aabr_build_wide_blocks((const int32_t *)p[0], o.i64[0], o.i32[0], o.i32[1], (int32_t *)p[1], st); break; }
+      wide_jobs.push_back(StreamJob{(const int32_t *)p[0], nullptr, (int32_t *)p[1], o.i64[0], o.i32[0], o.i32[1]});
       break;
     case AABR_GEOM_OFFSET_PAIRS:
-      rc = aabr_build_offset_pairs((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st);
+      if (o.i64[0] <= 0 || per_book) {   // an empty book: its header is cleared at once
+        rc = aabr_build_offset_pairs((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st);
+        break;
+      }
+      AABR_CHECK_ARG(o.i32[0] > 0 && o.i32[0] <= 65535 && p[0] && p[1] && p[2], "pair list: bad arguments");
+      pair_jobs.push_back(StreamJob{(const int32_t *)p[0], (const int32_t *)p[1], (int32_t *)p[2], o.i64[0], o.i32[0], 0});
       break;
     case AABR_GEOM_CONV_SITES:
       rc = aabr_convolution_sites((const int32_t *)p[0], o.i64[0], &o.i32[0], &o.i32[3], &o.i32[6], (uint64_t *)p[1],
                                   o.i64[1], (int32_t *)p[2], (int32_t *)p[3], (int32_t *)p[4], st);
       break;
     case AABR_GEOM_SAMPLE_OFFSETS:
-      rc = aabr_sample_offsets((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st);
+      AABR_CHECK_ARG(p[0] && p[1] && p[2] && o.i64[0] >= 0 && o.i32[0] >= 1 && o.i32[0] <= 4096, "sample offsets: bad arguments");
+      if (per_book) { rc = aabr_sample_offsets((const int32_t *)p[0], (const int32_t *)p[1], o.i64[0], o.i32[0], (int32_t *)p[2], st); break; }
+      sample_jobs.push_back(SampleJob{(const int32_t *)p[0], (const int32_t *)p[1], (int32_t *)p[2], o.i64[0], o.i32[0]});
       break;
     case AABR_GEOM_BRICK_BUILD: {
       int32_t dims[4];
@@ -571,7 +688,12 @@ extern "C" int aabr_geom_run(const AabrGeomOp *ops, int n_ops, void *st) {
     }
     if (rc != AABR_OK) return rc;
   }
-  return AABR_OK;
+  int rc = AABR_OK;
+  if (!sample_jobs.empty()) rc = launch_sample_offsets_jobs(sample_jobs.data(), (int)sample_jobs.size(), (hipStream_t)st);
+  if (rc == AABR_OK && !wide_jobs.empty()) rc = launch_wide_blocks_jobs(wide_jobs.data(), (int)wide_jobs.size(), (hipStream_t)st);
+  if (rc == AABR_OK && !tile_jobs.empty()) rc = launch_tile_blocks_jobs(tile_jobs.data(), (int)tile_jobs.size(), (hipStream_t)st);
+  if (rc == AABR_OK && !pair_jobs.empty()) rc = launch_offset_pairs_jobs(pair_jobs.data(), (int)pair_jobs.size(), (hipStream_t)st);
+  return rc;
 }
 
 // ---- mailbox: a small result handed to the host WITHOUT a stream / event wait ----------------------------------------

@@ -736,7 +736,9 @@ class Metadata_3(object):
         buf = torch.empty(tot + 4, dtype=torch.int32, device=device)
         piece = {name: buf[offs[name]:offs[name] + sz] for name, sz in names}
         meta = piece["meta"]
-        check(lib.aabr_points_prepare(ptr(coords), n, ncols, piece["pc"].data_ptr(), meta.data_ptr(), stream()))
+        # (the per-site arrays' starting values ride in this pass: aabr_points_sites(flags = 1) then fills nothing)
+        check(lib.aabr_points_prepare(ptr(coords), n, ncols, piece["pc"].data_ptr(), meta.data_ptr(),
+                                      ptr(piece["first_pt"]), ptr(piece["cnt_extra"]), ptr(piece["head"]), stream()))
         host = ev = None
         if asynchronous:
             host, ev = _pinned_pool.pop() if _pinned_pool else (
@@ -754,17 +756,25 @@ class Metadata_3(object):
         """the launches of the brick-native scatter behind the extent read: input level from the points, then every point's
         row / first point / chain (no host read in here -- bench.py times exactly this)"""
         lib = _hip.load()
-        rows = self._brick_rows = torch.empty((_BK_MAX_LEVELS, _BK_ROW), dtype=torch.int32, device=dev)
+        # the rows of every level's read-back block (sample offsets + meta) start at zero: ONE fill here covers the meta words
+        # of the input level and of the pyramid built later (round 5: a memset per level build + a fill per pyramid)
+        rows = self._brick_rows = torch.zeros((_BK_MAX_LEVELS, _BK_ROW), dtype=torch.int32, device=dev)
+        self._brick_rows_clean = True
         self._brick_nrows = 1
-        bk = _Brick([e + 1 for e in extent[:3]], extent[3] + 1, n, n, dev, rows[0, 64:64 + _hip.META_WORDS])
+        bk = _Brick([e + 1 for e in extent[:3]], extent[3] + 1, n, n, dev, rows[0, 64:64 + _hip.META_WORDS], alloc=False)
+        # ONE allocation and ONE fill for the directory, the bricks and the scan's scratch (round 5: two memsets)
+        lw = 4 * (bk.nw + bk.nb_cap)
+        sw = (int(lib.aabr_brick_scratch_words(bk.nw, bk.nb_cap)) + 3) // 4 * 4
+        arena = torch.zeros(lw + sw, dtype=torch.int32, device=dev)
+        bk.level = arena[:lw]
         # the level is clamped to the EXTENT of the points, not to the layer's spatial size: a coordinate beyond
         # spatial_size (<= 65534) is a site here as it is for the hash form and the reference's InputLayer
         out_sp = tuple(max(int(k), int(e) + 1) for k, e in zip(key, extent[:3]))
-        scratch = _brick_build(piece["pc"], n, 0, (1, 1, 1), (1, 1, 1), out_sp, bk)
+        scratch = _brick_build(piece["pc"], n, 0, (1, 1, 1), (1, 1, 1), out_sp, bk, 1, arena[lw:])
         flush_geom()
         check(lib.aabr_points_sites(piece["pc"].data_ptr(), n, bk.dims_c(), bk.dir_ptr(), bk.bricks_ptr(),
                                     ptr(piece["point_site"]), ptr(piece["first_pt"]), ptr(piece["cnt_extra"]),
-                                    ptr(piece["head"]), ptr(piece["nxt"]), bk.meta.data_ptr(), stream()))
+                                    ptr(piece["head"]), ptr(piece["nxt"]), bk.meta.data_ptr(), 1, stream()))
         return bk, scratch
 
     def _finish_brick_scatter(self, pend):
@@ -944,7 +954,8 @@ class Metadata_3(object):
             offs.append((words, lw, sw))
             words += lw + sw
         arena = torch.zeros(max(words, 4), dtype=torch.int32, device=dev)
-        self._brick_rows[first_row:self._brick_nrows].zero_()
+        if not self.__dict__.get("_brick_rows_clean"):      # (rows allocated zeroed by the brick-native scatter: nothing to do)
+            self._brick_rows[first_row:self._brick_nrows].zero_()
         self._brick_keep.append(arena)
         for (osz, bs, size, stride, bk, row), (o, lw, sw) in zip(plan, offs):
             bk.level = arena[o:o + lw]

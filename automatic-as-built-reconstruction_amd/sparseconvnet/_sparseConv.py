@@ -99,7 +99,7 @@ class SparseConvFunction(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, metadata, kind, geom):
-        ctx.metadata, ctx.kind, ctx.geom = metadata, kind, geom
+        ctx.scn_md, ctx.kind, ctx.geom = metadata, kind, geom
         # the input-gradient layout of the weights is packed in the forward pack's launch when a backward pass through
         # this layer will want it
         ctx.pack_t = [] if ctx.needs_input_grad[0] else None
@@ -114,5 +114,5 @@ class SparseConvFunction(Function):
         x, weight, bias = ctx.saved_tensors
         need = ctx.needs_input_grad[0]
         dx, dw, db = dy.new(), torch.empty_like(weight), torch.zeros_like(bias)
-        KINDS[ctx.kind].bwd(ctx.geom, ctx.metadata, x, dx, dy.contiguous(), weight, dw, db, ctx.pack_t, need)
+        KINDS[ctx.kind].bwd(ctx.geom, ctx.scn_md, x, dx, dy.contiguous(), weight, dw, db, ctx.pack_t, need)
         return (dx if need else None), dw, optionalTensorReturn(db), None, None, None

@@ -58,6 +58,8 @@ lateral_side_stream = os.environ.get("AABR_PLAN_LATERAL_SIDE", "0") != "0"
 fuse_adds = os.environ.get("AABR_PLAN_FUSE_ADDS", "1") != "0"
 # a training-mode BatchNorm right behind a wide-kernel convolution takes its statistics' partial sums from that
 # convolution's write-out (aabr_conv_forward_wide_stats -> aabr_bn_forward_parts): one pass over the matrix less
+# ... the same in bf16 storage (round 6; forward adds, and the gradient sums of the backward list)
+fuse_adds_bf16 = os.environ.get("AABR_PLAN_FUSE_ADDS_BF16", "1") != "0"
 conv_bn_stats = os.environ.get("AABR_PLAN_CONV_BN_STATS", "1") != "0"
 # ... and a BatchNorm backward right behind the wide-kernel input-gradient launch that produced its d_out takes its
 # statistics from that launch's write-out (aabr_conv_forward_wide[_bf16]_bwd_stats -> aabr_bn_backward_parts[_bf16])
@@ -143,9 +145,11 @@ class _Template(object):
         stats["templates"] += 1
 
     def _fusable_adds(self):
-        """{id(conv op): (add op, other operand)}: an fp32 convolution whose only reader is an add with an operand
-        that exists before the convolution runs -- the add can ride in the convolution's write-out when the pass
-        dispatches it to the wide kernel (`aabr_conv_forward_wide_res`; a + b == b + a bit for bit)"""
+        """{id(conv op): (add op, other operand)}: a convolution whose only reader is an add with an operand that
+        exists before the convolution runs -- the add can ride in the convolution's write-out when the pass dispatches it
+        to the wide kernel or the offset split (`aabr_conv_forward_wide_res`, `aabr_conv_forward_wide_bf16_res`, the
+        split's second stage; a + b == b + a bit for bit, and in bf16 storage the write-out rounds the convolution's
+        value before the sum exactly as the separate add would have read it)"""
         uses, prod = {}, {0: -1}
         for i, op in enumerate(self.fops):
             ins = (op[1], op[2]) if op[0] == "add" else (op[1],)
@@ -156,7 +160,7 @@ class _Template(object):
             uses[b] = uses.get(b, 0) + 1
         out = {}
         for i, op in enumerate(self.fops):
-            if op[0] != "add" or op[6]:
+            if op[0] != "add" or (op[6] and not fuse_adds_bf16):
                 continue
             for conv_b, other in ((op[2], op[1]), (op[1], op[2])):
                 j = prod.get(conv_b, -1)
@@ -391,9 +395,9 @@ class _Template(object):
                 gx = gnew(lvl, planes, self.fbufs[x][2])
                 pw = pslot(m.weight) if m.affine and m.weight.requires_grad else -1
                 pb = pslot(m.bias) if m.affine and m.bias.requires_grad else -1
-                res = acc.get(x) if (fuse and not flg) else None
+                res = acc.get(x) if (fuse and (not flg or fuse_adds_bf16)) else None
                 ops.append(("bn", x, gx, y, gy, lvl, planes, flg, leak, st, p_w, pw, pb, p_b, res))
-                if res is not None:      # fp32: the sum with what has arrived so far rides in the apply pass
+                if res is not None:      # the sum with what has arrived so far rides in the apply pass
                     acc[x] = gx
                 else:
                     arrive(x, gx)
@@ -406,7 +410,7 @@ class _Template(object):
                 flg = F_BF16 if dt == BF16 else 0
                 if x != 0 or need_dx:
                     gx = gnew(lvl, n_in, dt)
-                    res = acc.get(x) if (fuse and not flg) else None
+                    res = acc.get(x) if (fuse and (not flg or fuse_adds_bf16)) else None
                     tmp = gnew(lvl, n_in, dt) if res is not None else None   # used when the launch is not a wide one
                     # the launch reads d_out (n_out planes) and writes d_in (n_in planes)
                     ops.append(("din", gy, gx, lo, lvl, n_out, n_in, book, side_din, din_flags, p_w, pt, flg, res,
@@ -469,10 +473,11 @@ class _Pass(object):
             v = self._wide[key] = SCN.wide_split(n_in, n_out, rows_in, rows_out, vol, bf) or ()
         return v or None
 
-    def res_ok(self, n_in, n_out, rows_in, rows_out, vol):
-        """an fp32 launch that can add a residual in its write-out: the wide kernel, or the offset split (its second
-        stage, k_split_reduce, adds it)"""
-        return bool(self.wide_rows(n_in, n_out, rows_in, rows_out, vol) or self.split_of(n_in, n_out, rows_in, rows_out, vol))
+    def res_ok(self, n_in, n_out, rows_in, rows_out, vol, bf=False):
+        """a launch that can add a residual in its write-out: the wide kernel, or the offset split (its second stage,
+        k_split_reduce, adds it)"""
+        return bool(self.wide_rows(n_in, n_out, rows_in, rows_out, vol, bf) or
+                    self.split_of(n_in, n_out, rows_in, rows_out, vol, bf))
 
     def conv_launch(self, pack, buf, off, src, rows_in, n_in, dst, rows_out, n_out, gather, p_w, p_pack, flags, bf,
                     xf=0, res=0):
@@ -490,7 +495,7 @@ class _Pass(object):
         T = self.wide_rows(n_in, n_out, rows_in, rows_out, gather.vol, bf)
         self._lw = T
         sp = None if T else self.split_of(n_in, n_out, rows_in, rows_out, gather.vol, bf)
-        assert T or (sp and not bf) or not res
+        assert T or sp or not res
         if T:
             pack(buf, off, K_WIDE, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, T, 0, 0.0, 0.0, 0.0,
                  0.0, rows_in, rows_out, 0, 0, src, dst, gather.blocks_wide(T).data_ptr(), res, 0, p_pack, 0, 0, 0, 0,
@@ -504,7 +509,7 @@ class _Pass(object):
             self._tmp.append(tmp)
             ws = tmp.data_ptr()
             pack(buf, off, K_WSPLIT, xf | (F_BF16 if bf else 0), n_in, n_out, gather.vol, flags & 3, Ts, P, 0.0, 0.0, 0.0, 0.0, rows_in, rows_out,
-                 0, 0, src, dst, gather.blocks_wide(Ts).data_ptr(), 0 if bf else res, 0, p_pack, ws, 0, 0, 0, 0, 0)
+                 0, 0, src, dst, gather.blocks_wide(Ts).data_ptr(), res, 0, p_pack, ws, 0, 0, 0, 0, 0)
         else:
             pack(buf, off, K_CONV, (F_BF16 if bf else 0) | xf, n_in, n_out, gather.vol, flags | 4, 0, 0, 0.0, 0.0, 0.0, 0.0,
                  rows_in, rows_out, 0, 0, src, dst, gather.blocks().data_ptr(), p_w, 0, p_pack, 0, 0, 0, 0, 0, 0)
@@ -524,7 +529,8 @@ class _Pass(object):
             if kind == "conv":
                 x, y, lvl, lo, n_in, n_out, book, side = op[1:9]
                 fz = fuse.get(id(op))
-                if fz is not None and V[lo] and self.res_ok(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
+                if fz is not None and V[lo] and self.res_ok(n_in, n_out, V[lvl], V[lo], books[book][side].vol,
+                                                            fbufs[x][2] == BF16):
                     add_op, other = fz
                     skip.add(id(add_op))
                     steps.append(((x, other), add_op[3]))
@@ -625,12 +631,13 @@ class _Pass(object):
             if kind == "conv":
                 x, y, lvl, lo, n_in, n_out, book, side, p_w, pf = op[1:11]
                 fz = fuse.get(id(op))
-                if fz is not None and V[lo] and self.res_ok(n_in, n_out, V[lvl], V[lo], books[book][side].vol):
+                bfx = fbufs[x][2] == BF16
+                if fz is not None and V[lo] and self.res_ok(n_in, n_out, V[lvl], V[lo], books[book][side].vol, bfx):
                     add_op, other = fz           # out = conv + other, written where the add would have written
                     skip.add(id(add_op))
                     off0 = off
                     off = self.conv_launch(pack, buf, off, A[x], V[lvl], n_in, A[add_op[3]], V[lo], n_out,
-                                           books[book][side], p_w, pf, 0, False, xf, A[other])
+                                           books[book][side], p_w, pf, 0, bfx, xf, A[other])
                     last[sk] = (add_op[3], off0, self._lw, n_out) if (self._lw >= 64 or self._lw < 0) else None
                 else:
                     off0 = off
@@ -779,16 +786,16 @@ class _Pass(object):
                                            n_out, g, p_w, pt, flags, flg == F_BF16)
                     if (self._lw >= 64 or self._lw < 0) and off > off0:
                         last_din = (gx, off0, self._lw, n_out)
-                elif V[lvl] and self.res_ok(n_in, n_out, V[lo], V[lvl], g.vol):
+                elif V[lvl] and self.res_ok(n_in, n_out, V[lo], V[lvl], g.vol, flg == F_BF16):
                     off0 = off
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[gx[0]][gx[1]], V[lvl],
-                                           n_out, g, p_w, pt, flags, False, 0, AD[res[0]][res[1]])
+                                           n_out, g, p_w, pt, flags, flg == F_BF16, 0, AD[res[0]][res[1]])
                     if (self._lw >= 64 or self._lw < 0) and off > off0:
                         last_din = (gx, off0, self._lw, n_out)
                 else:                    # not a wide launch: d_in into the spare buffer, then the sum
                     off = self.conv_launch(pack, buf, off, AD[gy[0]][gy[1]], V[lo], n_in, AD[tmp[0]][tmp[1]], V[lvl],
-                                           n_out, g, p_w, pt, flags, False)
-                    pack(buf, off, K_ADD, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * n_out, 0, 0, 0,
+                                           n_out, g, p_w, pt, flags, flg == F_BF16)
+                    pack(buf, off, K_ADD, flg, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, V[lvl] * n_out, 0, 0, 0,
                          AD[res[0]][res[1]], AD[tmp[0]][tmp[1]], AD[gx[0]][gx[1]], 0, 0, 0, 0, 0, 0, 0, 0, 0)
                     off += 176
             elif kind == "dw":

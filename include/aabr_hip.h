@@ -39,7 +39,7 @@ const char *aabr_last_error(void);
 int aabr_version(void);
 /* Tuning knobs for experiments and tests (no counterpart in the reference; the defaults are what ships): CONV_WIDE,
  * CONV_WIDE_BF16 (0 = never / 1 = whenever supported), WIDE_ROWS, WIDE_NBUF, CONV_WLDS,
- * CONV_SMALL, CONV_NBW, CONV_WPB, VOXEL_MEAN.  A knob takes its value from the environment variable AABR_<NAME>,
+ * CONV_SMALL, CONV_NBW, CONV_WPB, VOXEL_MEAN, GEOM_JOBS (0: aabr_geom_run issues its stream builders book by book).  A knob takes its value from the environment variable AABR_<NAME>,
  * read ONCE at its first use in the process; aabr_set_knob overrides it (unset != 0: back to "no value").  No entry
  * point reads the environment on its launch path.                                                              */
 int aabr_set_knob(const char *name, int value, int unset);
@@ -193,14 +193,18 @@ int aabr_brick_renumber(const int32_t *old_coords, int64_t V, const int32_t *dim
  * level's aabr_brick_build (size = stride = 1), a voxel's row follows from where it lies.
  *   aabr_points_prepare: coords int64 [n, ncols] -> pc int32 [n,4] (x, y, z, batch; x = -1: a point the layer skips),
  *     meta (AABR_META_WORDS, starts at all ones): meta[2] == 0: a coordinate outside [0, 65534]; meta[8..11] = largest
- *     x, y, z, batch index of the valid points (-1: none) -- the extent the directory is sized by.
+ *     x, y, z, batch index of the valid points (-1: none) -- the extent the directory is sized by.  first_pt / cnt_extra /
+ *     head (each n words; all three or none, may be NULL): set to their starting values (-1, 0, -1) in the same pass, so
+ *     aabr_points_sites (flags bit 0) need not fill them.
  *   aabr_points_sites (after aabr_brick_build(pc, n, ..)): point_site[i] = row of point i's voxel (-1: skipped),
  *     first_pt[row] = lowest point index of the voxel, cnt_extra[row] = its further points, head / nxt = their chain --
- *     the arrays aabr_input_layer_forward / _backward / _rule_table read; sized n (rows < V are meaningful).        */
-int aabr_points_prepare(const int64_t *coords, int64_t n, int ncols, int32_t *pc, int32_t *meta, void *stream);
+ *     the arrays aabr_input_layer_forward / _backward / _rule_table read; sized n (rows < V are meaningful).
+ *     flags bit 0: first_pt / cnt_extra / head already hold their starting values (aabr_points_prepare wrote them).   */
+int aabr_points_prepare(const int64_t *coords, int64_t n, int ncols, int32_t *pc, int32_t *meta, int32_t *first_pt,
+                        int32_t *cnt_extra, int32_t *head, void *stream);
 int aabr_points_sites(const int32_t *pc, int64_t n, const int32_t *dims_host, const void *dir, const void *bricks,
                       int32_t *point_site, int32_t *first_pt, int32_t *cnt_extra, int32_t *head, int32_t *nxt,
-                      int32_t *meta, void *stream);
+                      int32_t *meta, int flags, void *stream);
 /* aabr_submanifold_table / aabr_convolution_tables2 over brick levels: same tables, same block counts
  * (Metadata.cpp:429-443,484-510; SubmanifoldConvolutionRules.h:26-45; ConvolutionRules.h:11-34).                       */
 int aabr_brick_submanifold_table(const int32_t *site_coords, int64_t V, const int32_t *dims_host, const void *dir,
@@ -334,6 +338,16 @@ int aabr_conv_forward_wide_bf16_bwd_stats(const uint16_t *in_feats, int n_in, in
                                           const float *bias, int flags, const uint16_t *wpack, double *stats,
                                           const uint16_t *bn_in, const uint16_t *bn_out, const float *save_mean,
                                           float leakiness, void *stream);
+/* The general bf16-storage launch of the compiled pass: aabr_conv_forward_wide_bf16 with an optional `residual` (bf16
+ * [V_out, n_out]: out = bf16(bf16(conv + bias) + residual) -- the residual / lateral add, or the gradient sum of a tensor
+ * with a second consumer, folded into the write-out, bit for bit what the separate bf16 add stores), optional `stats`
+ * of the stored values (as aabr_conv_forward_wide_bf16_stats; bn_in NULL) or, with bn_in / bn_out / save_mean /
+ * leakiness, the backward statistics of aabr_conv_forward_wide_bf16_bwd_stats.                                        */
+int aabr_conv_forward_wide_bf16_res(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
+                                    int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
+                                    int flags, const uint16_t *wpack, const uint16_t *residual, double *stats,
+                                    const uint16_t *bn_in, const uint16_t *bn_out, const float *save_mean, float leakiness,
+                                    void *stream);
 int aabr_bn_backward_parts_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out, const uint16_t *d_out,
                                 int64_t rows, int planes, const float *save_mean, const float *save_invstd,
                                 const float *weight, const float *bias, float *d_weight, float *d_bias, float leakiness,
@@ -454,6 +468,12 @@ int aabr_bn_backward_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *ou
                           const uint16_t *d_out, int64_t rows, int planes, const float *save_mean,
                           const float *save_invstd, const float *weight, const float *bias, float *d_weight,
                           float *d_bias, float leakiness, float *scratch, void *stream);
+/* aabr_bn_backward_add for bf16 storage: d_in = bf16(bf16(BatchNorm gradient) + d_in_add); parts / nparts as
+ * aabr_bn_backward_parts_bf16, or NULL / 0.                                                                        */
+int aabr_bn_backward_add_bf16(const uint16_t *in, uint16_t *d_in, const uint16_t *out, const uint16_t *d_out,
+                              int64_t rows, int planes, const float *save_mean, const float *save_invstd,
+                              const float *weight, const float *bias, float *d_weight, float *d_bias, float leakiness,
+                              const double *parts, int nparts, float *scratch, const uint16_t *d_in_add, void *stream);
 
 /* ---- the proposal stage of a whole batch (extension) --------------------------------------------
  * The reference's RPNPostProcessor loops over the examples in Python (rpn/inference_3d.py:95-149).
@@ -502,6 +522,12 @@ int aabr_conv_wide_split_bf16(int n_in, int n_out, int64_t rows_in, int64_t V_ou
 int aabr_conv_forward_wide_split_bf16(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats, int n_out,
                                       int64_t V_out, const int32_t *blocks, int tile_rows, int vol, const float *bias,
                                       int flags, const uint16_t *wpack, int parts, float *scratch, void *stream);
+/* ... with `residual` (bf16 [V_out, n_out], may be NULL): out = bf16(bf16(sum of the parts + bias) + residual), what the
+ * separate bf16 add of the consumer would have stored.                                                                */
+int aabr_conv_forward_wide_split_bf16_res(const uint16_t *in_feats, int n_in, int64_t rows_in, uint16_t *out_feats,
+                                          int n_out, int64_t V_out, const int32_t *blocks, int tile_rows, int vol,
+                                          const float *bias, int flags, const uint16_t *wpack, int parts, float *scratch,
+                                          const uint16_t *residual, void *stream);
 
 /* 32 -> 32 plane layers (the finest scales; csrc/conv_narrow.hip): the same sum as aabr_conv_forward (Convolution.cpp:
  * 117-185), read from the GATHER TABLE `table` [vol][V_out] (input row of output row o at offset k, or -1 -- what

@@ -274,6 +274,6 @@ def test_knob_registry_rejects_unknown_names_and_takes_known_ones():
         assert lib.aabr_set_knob(gone, 1, 0) != 0
     assert b"unknown knob" in lib.aabr_last_error()
     for name in ("CONV_WIDE", "WIDE_NBUF", "BN_SMALL", "WIDE_PRIO", "PLAN_SIDE_BATCH", "PLAN_SIDE_PRIO", "VOXEL_MEAN",
-                 "WIDE_NCB", "CONV_NARROW", "DW_FULL", "DW_FULL_MIN", "DW_FULL_WGS", "SPLIT_ROWS"):
+                 "WIDE_NCB", "CONV_NARROW", "DW_FULL", "DW_FULL_MIN", "DW_FULL_WGS", "SPLIT_ROWS", "GEOM_JOBS"):
         assert lib.aabr_set_knob(name.encode(), 1, 0) == 0
         assert lib.aabr_set_knob(name.encode(), 0, 1) == 0                       # back to "unset"

@@ -270,3 +270,102 @@ def test_parameter_update_between_forward_and_backward_is_refused():
     rpn, _ = net([l, f])
     sum(m.features.square().mean() for m in rpn).backward()  # the regular order works
     assert sum(p.grad is not None for p in net.parameters()) > 100
+
+
+def test_runs_of_cast_records_go_out_as_one_launch_with_the_same_bits():
+    """round 6: consecutive storage-cast records of one direction on the caller's stream are served by ONE job-list launch
+    (csrc/plan.hip plan_cast_run; up to 16 records per launch): 19 casts fp32 -> bf16 of odd sizes followed by 5 back,
+    against torch's conversion, bit for bit; a lone record keeps the single-launch path."""
+    _hip, lib = _lib()
+    torch.manual_seed(3)
+    K_CAST, F_TO_BF16 = 7, 2
+    sizes = [1, 3, 4, 5, 1023, 1024, 1025, 4097, 100003, 7, 8, 9, 2048, 2047, 31, 33, 65536, 12345, 2]
+    src = [torch.randn(n, device=DEV) * 10 ** (i % 5 - 2) for i, n in enumerate(sizes)]
+    dst = [torch.empty(n, dtype=torch.bfloat16, device=DEV) for n in sizes]
+    back = [torch.empty(n, dtype=torch.float32, device=DEV) for n in sizes[:5]]
+    recs = b"".join(_rec(K_CAST, F_TO_BF16, i64=(s.numel(),), ps=(s.data_ptr(), d.data_ptr())) for s, d in zip(src, dst))
+    recs += b"".join(_rec(K_CAST, 0, i64=(d.numel(),), ps=(d.data_ptr(), b.data_ptr())) for d, b in zip(dst, back))
+    _hip.check(lib.aabr_plan_run(recs, len(sizes) + 5, _hip.stream()))
+    for s, d in zip(src, dst):
+        assert torch.equal(d, s.to(torch.bfloat16))
+    for d, b in zip(dst, back):
+        assert torch.equal(b, d.float())
+    # the records of a list mean "one after the other": a cast whose OUTPUT reuses the memory of an earlier cast's INPUT
+    # (what a liveness-packed inference arena does) must not share a launch with it
+    n = 50000
+    a1, a2 = torch.randn(n, device=DEV), torch.randn(n // 2, device=DEV)
+    a1_orig = a1.clone()
+    b1 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    b2 = a1.view(torch.bfloat16)[:n // 2]                     # lives in a1's bytes
+    recs = _rec(K_CAST, F_TO_BF16, i64=(n,), ps=(a1.data_ptr(), b1.data_ptr())) + \
+        _rec(K_CAST, F_TO_BF16, i64=(n // 2,), ps=(a2.data_ptr(), b2.data_ptr()))
+    _hip.check(lib.aabr_plan_run(recs, 2, _hip.stream()))
+    assert torch.equal(b1, a1_orig.to(torch.bfloat16)) and torch.equal(b2, a2.to(torch.bfloat16))
+    one = torch.empty(sizes[8], dtype=torch.bfloat16, device=DEV)
+    _hip.check(lib.aabr_plan_run(_rec(K_CAST, F_TO_BF16, i64=(sizes[8],), ps=(src[8].data_ptr(), one.data_ptr())), 1,
+                                 _hip.stream()))
+    assert torch.equal(one, dst[8])
+
+
+def test_job_list_stream_builders_equal_book_by_book_builds():
+    """round 6: inside a geometry list the tile-block, wide-block and pair-list builders of ALL its rule books go out as one
+    launch per kind (csrc/common.h StreamJobs; aabr_geom_run defers them behind the list's last record).  Every stream must
+    be word for word what the single-book entry points build: three submanifold books of different sizes and a strided book
+    (both sides), wide blocks at two tile sizes, over hash grids and over brick grids."""
+    import sparseconvnet as scn
+    from sparseconvnet import SCN
+    for order in ("first_seen", "brick"):
+        tables = []
+        for seed, npts in ((5, 3000), (6, 20000), (7, 60000)):
+            locs, feats = S.make_batch(2, npts, seed, 20)
+            layer = scn.InputLayer(3, list(S.FULL_SCALE), mode=4)
+            layer.site_order = order
+            x = layer([torch.as_tensor(locs).to(DEV), torch.as_tensor(feats).to(DEV)])
+            md = x.metadata
+            tb = md.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+            tables.append(tb.out)
+            if seed == 7:
+                osz = (x.spatial_size - 2) // 2 + 1
+                st = md.getRuleBook(x.spatial_size, osz, torch.LongTensor([2, 2, 2]), torch.LongTensor([2, 2, 2]))
+                tables += [st.out, st.inn]
+        SCN.flush_geom()
+
+        def fresh(g):
+            return SCN._Gather(g.table, g._ensure_counts(), g.vol, g.rows)
+
+        def meaningful(g, words, kind, T=0):
+            """the words a builder defines (a stream's buffer is sized for the worst case; the tail of a tile's entry
+            region, and of an offset's pair list, is never written or read)"""
+            w = words.cpu().numpy()
+            V, vol = g.rows, g.vol
+            if kind == "wide":
+                nt, maxb = (V + T - 1) // T, (T // 16) * vol
+                pre = w[:nt * (vol + 1)].reshape(nt, vol + 1)
+                ent = w[nt * (vol + 1):nt * (vol + 1) + nt * maxb * 16].reshape(nt, maxb * 16)
+                return pre, np.where(np.arange(maxb * 16)[None] < pre[:, vol:vol + 1] * 16, ent, 0)
+            if kind == "tile":
+                nt, maxb = (V + 63) // 64, 4 * vol
+                nblk = w[:nt]
+                bk = w[nt:nt + nt * maxb].reshape(nt, maxb)
+                ent = w[nt + nt * maxb:nt + nt * maxb + nt * maxb * 16].reshape(nt, maxb * 16)
+                return (nblk, np.where(np.arange(maxb)[None] < nblk[:, None], bk, 0),
+                        np.where(np.arange(maxb * 16)[None] < nblk[:, None] * 16, ent, 0))
+            hdr, nb = vol + 2 * (vol + 1), (V + 255) // 256
+            pr = w[hdr + vol * nb:hdr + vol * nb + 2 * vol * V].reshape(vol, V, 2)
+            return w[:hdr + vol * nb], np.where(np.arange(V)[None, :, None] < w[:vol][:, None, None], pr, 0)
+
+        def streams(gs):
+            return [[meaningful(g, g.blocks(), "tile"), meaningful(g, g.blocks_wide(128), "wide", 128),
+                     meaningful(g, g.blocks_wide(64), "wide", 64), meaningful(g, g.pairs(), "pairs")] for g in gs]
+
+        want = streams([fresh(g) for g in tables])       # outside a plan: one launch (a one-job list) per call
+        listed = [fresh(g) for g in tables]
+        with SCN.geom_plan():
+            for g in listed:                             # recorded: the list's builders go out as one launch per kind
+                g.blocks(), g.blocks_wide(128), g.blocks_wide(64), g.pairs()
+        got = streams(listed)                            # (cached now: nothing is rebuilt)
+        for g, w_, g_ in zip(tables, want, got):
+            assert g.rows > 0
+            for a, b in zip(w_, g_):
+                for x_, y_ in zip(a, b):
+                    assert x_.shape == y_.shape and (x_ == y_).all(), (order, g.rows, g.vol)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage (GPU box, repo root): bash tools/tools_pmc_config4.sh -- FETCH_SIZE and WRITE_SIZE in separate --pmc passes over
 # `bench.py --config 4` (one 1.5 M-point scene, bf16); per-kernel averages by tools/tools_pmc_summary.py-style reading
+set -u
+: "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets it)}"
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -36,4 +38,5 @@ with open(os.path.join(root, "gpurun_out", "pmc4_summary.txt"), "w") as fh:
         fh.write("%-70s launches %4d  FETCH_SIZE %10.1f KB  WRITE_SIZE %10.1f KB  2F+W %8.1f MB\n" % (k, f[1], fa, wa, (2 * fa + wa) / 1024))
 print(open(os.path.join(root, "gpurun_out", "pmc4_summary.txt")).read()[:3000])
 PY
-rm -rf $root/gpurun_out/pmc4_FETCH_SIZE $root/gpurun_out/pmc4_WRITE_SIZE
+# KEEP=1: leave the raw passes for `tools_pmc_summary.py <tag> merge-c4`
+[ "${KEEP:-0}" = 1 ] || rm -rf $root/gpurun_out/pmc4_FETCH_SIZE $root/gpurun_out/pmc4_WRITE_SIZE

@@ -43,5 +43,5 @@ for d in ("f32", "bf16"):
 json.dump({"note": "rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS over "
                    "`bench.py --dtype {f32,bf16} --batches 1 --steps 4 --warmup 1 ...` (tools/tools_pmc_lds.sh); per (kernel, grid): "
                    "lds_active_frac = SQ_LDS_IDX_ACTIVE / (256 CUs x elapsed cycles) (rocprofv3's LdsUtil), mfma_busy_frac = MFMA busy "
-                   "cycles / (1024 SIMDs x elapsed cycles)", "kernels": out}, open("gpurun_out/r05_pmc_lds_conv_kernels.json", "w"), indent=1)
+                   "cycles / (1024 SIMDs x elapsed cycles)", "kernels": out}, open("gpurun_out/r06_pmc_lds_conv_kernels.json", "w"), indent=1)
 PY

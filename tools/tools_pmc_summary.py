@@ -27,6 +27,25 @@ def agg(pat, counter=None):
     return d
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "merge-c4":
+    # instances of the `--config 4` passes (tools/tools_pmc_config4.sh, run with KEEP=1) that the profile does not have:
+    # `bench.py --config 4` looks its dominant instance's traffic up in the same file
+    path = "profiles/%s_pmc_fetch_write_per_kernel.json" % TAG
+    doc = json.load(open(path))
+    fb = agg("gpurun_out/pmc4_FETCH_SIZE/**/*counter_collection.csv")
+    wb = agg("gpurun_out/pmc4_WRITE_SIZE/**/*counter_collection.csv")
+    added = 0
+    for k, v in fb.items():
+        if k in doc["kernels"]:
+            continue
+        wv = wb.get(k, [0.0])
+        doc["kernels"][k] = {"launches": len(v), "FETCH_SIZE_KB_avg": round(sum(v) / len(v), 1),
+                             "WRITE_SIZE_KB_avg": round(sum(wv) / len(wv), 1), "from": "bench.py --config 4"}
+        added += 1
+    doc["note"] += "  Entries marked `from: bench.py --config 4` come from the same passes over the configs[4] line."
+    json.dump(doc, open(path, "w"), indent=1)
+    print("added", added, "config-4 instances")
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "merge-bf16":
     # instances of the `--dtype bf16` passes (tools/tools_pmc_bf16.sh) that the fp32 profile does not have
     path = "profiles/%s_pmc_fetch_write_per_kernel.json" % TAG
