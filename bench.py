@@ -1052,6 +1052,14 @@ def main():
     import dp
     head_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     wl = Workload(scn, torch, dp, dev, head_dtype, rank, world, args.batches)
+    # The step's own stream -- forward, backward, update -- runs at HIGH queue priority: the kernels of the critical chain are
+    # preferred over the geometry / proposal / weight-gradient streams they share the CUs with.  Measured on one box, two
+    # runs each (profiles/r06_switches_ab.txt): fp32 12.72 -> 12.67 ms, bf16 unchanged (host-bound); AABR_BENCH_MAIN_PRIORITY=0
+    # puts the step back on the default stream
+    main_prio = os.environ.get("AABR_BENCH_MAIN_PRIORITY", "1") == "1"
+    if main_prio:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     el, tinfo = timed_steps(torch, dist, wl, args.steps, args.warmup, world, dev,
                             min_timed_s=args.min_timed_s, prewarm=not args.no_prewarm)
     n_timed = args.steps
