@@ -21,11 +21,13 @@ namespace aabr {
 #endif
 
 constexpr int kMaxParts = 512;
-// finalize: FP planes x 256 / FP slices of the partial list per 256-thread block.  8 x 32 for short lists; 2 x 128 for
-// long ones (the statistics a wide convolution's write-out leaves: one part per tile, 2,502 parts x 64 planes at the
-// 282 k-row level -- eight blocks walked 78 dependent steps each, 12 us; 32 blocks walk 20: round 6)
-constexpr int kFinLongList = 96;
-__host__ __device__ constexpr int fin_planes(int nparts) { return nparts > kFinLongList ? 2 : 8; }
+// finalize: 8 planes x 32 slices of the partial list per 256-thread block (a wave-load reads 64-byte segments of 8 planes).
+// Round 6 measured two wider forms on the long lists a wide convolution's write-out leaves (2,502 parts x 64 planes at the
+// 282 k-row level, 12 us): 2 planes x 128 slices in 4 x the blocks (16-byte segments: 13.4 us) and 8 planes x 128 slices in
+// 1,024-thread blocks (16.4 us; backward 21-40 us): both slower -- the launch is bound by its ~10 dependent batches of
+// strided loads and a wider block only adds lines per load or barrier weight.  Kept as it was.
+constexpr int kFinSlices = 32;
+constexpr int kFinPlanes = 8;
 
 // feature element access: fp32 (reference precision) or bf16 storage (extension, fp32/fp64 maths)
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -140,10 +142,8 @@ __global__ __launch_bounds__(256) void k_bn_partials(const T *__restrict__ x, co
 
 // sum the per-block partials of one plane: 32 threads take interleaved slices of the list (loads
 // in flight instead of one dependent chain), then a fixed-order combine => deterministic.
-template <int kFinPlanes>
 __device__ inline void reduce_partials(const double *__restrict__ part, int nparts, int planes, int p,
                                        double &s0, double &s1) {
-  constexpr int kFinSlices = 256 / kFinPlanes;
   __shared__ double ra[kFinSlices][kFinPlanes], rb[kFinSlices][kFinPlanes];
   const int pl = threadIdx.x % kFinPlanes, sl = threadIdx.x / kFinPlanes;
   double a = 0.0, b = 0.0;
@@ -161,7 +161,6 @@ __device__ inline void reduce_partials(const double *__restrict__ part, int npar
 }
 
 // forward finalize (CPU/BatchNormalization.cpp:33-48): coef[p] = {w, b} with y = x*w + b.
-template <int kFinPlanes>
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const double *__restrict__ part, int nparts,
                                                          int64_t rows, int planes, float *save_mean,
                                                          float *save_invstd, float *running_mean,
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const double *__restric
   AABR_BN_SETPRIO();
   const int p = blockIdx.x * kFinPlanes + (threadIdx.x % kFinPlanes);
   double s = 0.0, ss = 0.0;
-  if (train) reduce_partials<kFinPlanes>(part, nparts, planes, p, s, ss);
+  if (train) reduce_partials(part, nparts, planes, p, s, ss);
   if (p >= planes || threadIdx.x >= kFinPlanes) return;
   float mean, invstd;
   if (train) {
@@ -223,7 +222,6 @@ __global__ __launch_bounds__(256) void k_bn_fwd_apply1(const T *__restrict__ x, 
 }
 
 // backward finalize (CPU/BatchNormalization.cpp:85-90,103-106): coef = {gradMean, k, invstd*w}
-template <int kFinPlanes>
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double *__restrict__ part, int nparts,
                                                          int64_t rows, int planes, const float *save_invstd,
                                                          const float *weight, float *d_weight, float *d_bias,
@@ -231,7 +229,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double *__restric
   AABR_BN_SETPRIO();
   const int p = blockIdx.x * kFinPlanes + (threadIdx.x % kFinPlanes);
   double s, dp;
-  reduce_partials<kFinPlanes>(part, nparts, planes, p, s, dp);
+  reduce_partials(part, nparts, planes, p, s, dp);
   if (p >= planes || threadIdx.x >= kFinPlanes) return;
   float is = save_invstd[p];
   if (d_bias) d_bias[p] = (float)s;
@@ -521,12 +519,9 @@ static int bn_forward_t(const T *in, T *out, int64_t rows, int planes, float *sa
       hipLaunchKernelGGL((k_bn_partials<0, 1, T>), dim3(nparts), dim3(256), 0, st, in, (const T *)nullptr,
                          (const T *)nullptr, (const float *)nullptr, 0.0f, rows, planes, part);
   }
-  if (fin_planes(nparts) == 2)
-    hipLaunchKernelGGL(k_bn_fwd_finalize<2>, dim3((unsigned)ceil_div(planes, 2)), dim3(256), 0, st, part, nparts, rows,
-                       planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, train, coef);
-  else
-    hipLaunchKernelGGL(k_bn_fwd_finalize<8>, dim3((unsigned)ceil_div(planes, 8)), dim3(256), 0, st, part, nparts, rows,
-                       planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps, momentum, train, coef);
+  hipLaunchKernelGGL(k_bn_fwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, part, nparts,
+                     rows, planes, save_mean, save_invstd, running_mean, running_var, weight, bias, eps,
+                     momentum, train, coef);
   int64_t total = rows * planes;
   if ((planes & 3) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
     hipLaunchKernelGGL((k_bn_fwd_apply<T>), dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, out,
@@ -579,12 +574,8 @@ static int bn_backward_t(const T *in, T *d_in, const T *out, const T *d_out, int
   else
     hipLaunchKernelGGL((k_bn_partials<1, 1, T>), dim3(nparts), dim3(256), 0, st, in, out, d_out, save_mean,
                        leakiness, rows, planes, part, save_invstd, weight, bias, recompute);
-  if (fin_planes(nparts) == 2)
-    hipLaunchKernelGGL(k_bn_bwd_finalize<2>, dim3((unsigned)ceil_div(planes, 2)), dim3(256), 0, st, fin_part, nparts, rows,
-                       planes, save_invstd, weight, d_weight, d_bias, coef);
-  else
-    hipLaunchKernelGGL(k_bn_bwd_finalize<8>, dim3((unsigned)ceil_div(planes, 8)), dim3(256), 0, st, fin_part, nparts, rows,
-                       planes, save_invstd, weight, d_weight, d_bias, coef);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((unsigned)ceil_div(planes, kFinPlanes)), dim3(256), 0, st, fin_part, nparts,
+                     rows, planes, save_invstd, weight, d_weight, d_bias, coef);
   int64_t total = rows * planes;
   if (v4 && (((uintptr_t)d_in | (uintptr_t)save_mean | (uintptr_t)d_in_add) & 15) == 0)
     hipLaunchKernelGGL((k_bn_bwd_apply4<T>), dim3((unsigned)ceil_div(total / 4, 256)), dim3(256), 0, st, in, d_in, out,

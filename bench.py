@@ -59,7 +59,7 @@ N_GT = 40                       # ground-truth walls per scene (label generation
 # cfg.MODEL.RPN.LABEL_AUG_THICKNESS_{Y,Z}_TAR_ANC (config/defaults.py:161-162; rpn/loss_3d.py:351)
 LABEL_AUG = {"target_Y": 0.4, "anchor_Y": 0.0, "target_Z": 0.8, "anchor_Z": 0.0}
 MIN_TIMED_S = 0.2               # a timed region shorter than this is reported as such (`timed_region_short`)
-PMC_PROFILE = "r05_pmc_fetch_write_per_kernel.json"   # committed --pmc passes of this command (tools/tools_pmc.sh)
+PMC_PROFILE = "r06_pmc_fetch_write_per_kernel.json"   # committed --pmc passes of this command (tools/tools_pmc.sh)
 
 # RPN constants of the reference config (defaults.py:127-131,159-181)
 ANCHOR_SIZES_3D = [[0.4, 1.5, 1.5], [1.5, 1.5, 1.0], [4, 4, 1.5], [0.2, 0.5, 3], [0.4, 1.5, 3], [0.6, 2.5, 3]]
