@@ -612,3 +612,82 @@ def test_wide_bf16_write_out_backward_statistics_feed_batchnorm_backward(nIn, nO
         _hip.set_knob("BN_SMALL", None)
         _hip.set_knob("CONV_WIDE_BF16", None)
 
+
+
+@pytest.mark.parametrize("nIn,nOut,npts", [(64, 64, 3000), (128, 128, 2500), (128, 64, 900), (256, 128, 1200)])
+def test_bf16_residual_in_the_write_out_equals_store_then_add(request, nIn, nOut, npts):
+    """round 6: aabr_conv_forward_wide_bf16_res / aabr_conv_forward_wide_split_bf16_res / aabr_bn_backward_add_bf16 fold the
+    consumer's bf16 add into the producing write-out.  The separate form stores bf16(conv) and then bf16(float(a) +
+    float(b)) -- two roundings -- and the fused write-outs round their own value before the sum: the results must be EQUAL,
+    bit for bit, to "unfused launch + aabr_add(bf16)" (which tests/test_gpu_plan.py holds equal to torch's bf16 add), also
+    with the forward statistics of the stored values riding along."""
+    import _hip
+    from _hip import ptr, stream, check
+    scn = _scn()
+    lib = _hip.load()
+    rng = np.random.default_rng(nIn * 3 + nOut + npts)
+    coords, _ = _scene(rng, npts, (12, 11, 5), 2, 1)
+    x = scn.InputLayer(3, [16, 16, 8], mode=4)([_t(coords), _t(np.zeros((npts, 1), np.float32))])
+    tb = x.metadata.getSubmanifoldRuleBook(x.spatial_size, torch.LongTensor([3, 3, 3]))
+    ga, V, vol = tb.out, tb.V_out, tb.vol
+    Wd = _t((rng.standard_normal((vol, 1, nIn, nOut)) * 0.1).astype(np.float32))
+    n = int(lib.aabr_conv_wpack_bf16_elems(vol, nIn, nOut))
+    pf = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    pt = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    check(lib.aabr_conv_pack_weights2_bf16(ptr(Wd), vol, nIn, nOut, ptr(pf), ptr(pt), stream()))
+    f = torch.as_tensor(rng.standard_normal((V, nIn)).astype(np.float32)).to(DEV).bfloat16()
+    res = torch.as_tensor(rng.standard_normal((V, nOut)).astype(np.float32) * 3).to(DEV).bfloat16()
+    # ---- wide kernel
+    _hip.set_knob("CONV_WIDE_BF16", 1)
+    request.addfinalizer(lambda: _hip.set_knob("CONV_WIDE_BF16", None))
+    T = lib.aabr_conv_wide_tile_rows_bf16(nIn, nOut, V, V, vol)
+    assert T >= 64
+    blocks = ga.blocks_wide(T)
+    plain = torch.empty((V, nOut), dtype=torch.bfloat16, device=DEV)
+    check(lib.aabr_conv_forward_wide_bf16(ptr(f), nIn, V, ptr(plain), nOut, V, ptr(blocks), T, vol, None, 0, ptr(pf), stream()))
+    want = torch.empty_like(plain)
+    check(lib.aabr_add(ptr(plain), ptr(res), ptr(want), V * nOut, 1, stream()))
+    assert torch.equal(want, plain + res)
+    ntile = (V + T - 1) // T
+    stats = torch.zeros(ntile * 2 * nOut, dtype=torch.float64, device=DEV)
+    got = torch.empty_like(plain)
+    check(lib.aabr_conv_forward_wide_bf16_res(ptr(f), nIn, V, ptr(got), nOut, V, ptr(blocks), T, vol, None, 0, ptr(pf),
+                                              ptr(res), ptr(stats), None, None, None, 0.0, stream()))
+    assert torch.equal(got, want)
+    s = stats.view(ntile, 2, nOut).sum(0)                      # the statistics are those of the STORED sums
+    np.testing.assert_allclose(s[0].cpu().numpy(), want.double().sum(0).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(s[1].cpu().numpy(), want.double().square().sum(0).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    # ---- offset split (second stage adds the residual)
+    _hip.set_knob("SPLIT_MIN_ITEMS", 1)
+    request.addfinalizer(lambda: _hip.set_knob("SPLIT_MIN_ITEMS", None))
+    P, Ts = 5, 64
+    scratch = torch.empty(int(lib.aabr_conv_wide_split_scratch_floats(V, nOut, P)), device=DEV)
+    sp_plain = torch.empty_like(plain)
+    check(lib.aabr_conv_forward_wide_split_bf16(ptr(f), nIn, V, ptr(sp_plain), nOut, V, ptr(ga.blocks_wide(Ts)), Ts, vol,
+                                                None, 0, ptr(pf), P, ptr(scratch), stream()))
+    sp_got = torch.empty_like(plain)
+    check(lib.aabr_conv_forward_wide_split_bf16_res(ptr(f), nIn, V, ptr(sp_got), nOut, V, ptr(ga.blocks_wide(Ts)), Ts, vol,
+                                                    None, 0, ptr(pf), P, ptr(scratch), ptr(res), stream()))
+    assert torch.equal(sp_got, sp_plain + res)
+    # ---- BatchNorm backward with the gradient sum of a second consumer (planes = nOut; large and small-map kernels)
+    for rows in (V, min(V, 700)):
+        xb, dy, add = f[:rows, :min(nIn, nOut)].contiguous(), None, None
+        planes = xb.shape[1]
+        xb = torch.as_tensor(rng.standard_normal((rows, planes)).astype(np.float32)).to(DEV).bfloat16()
+        dy = torch.as_tensor(rng.standard_normal((rows, planes)).astype(np.float32)).to(DEV).bfloat16()
+        add = torch.as_tensor(rng.standard_normal((rows, planes)).astype(np.float32)).to(DEV).bfloat16()
+        w_ = torch.rand(planes, device=DEV) + 0.5
+        b_ = torch.randn(planes, device=DEV)
+        rm, rv = torch.zeros(planes, device=DEV), torch.ones(planes, device=DEV)
+        mean, inv = torch.empty(planes, device=DEV), torch.empty(planes, device=DEV)
+        yb = torch.empty_like(xb)
+        ws = torch.empty(int(lib.aabr_bn_scratch_floats(planes)), device=DEV)
+        check(lib.aabr_bn_forward_bf16(ptr(xb), ptr(yb), rows, planes, ptr(mean), ptr(inv), ptr(rm), ptr(rv), ptr(w_), ptr(b_),
+                                       1e-4, 0.9, 1, 0.2, ptr(ws), stream()))
+        dx0, dw0, db0 = torch.empty_like(xb), torch.empty(planes, device=DEV), torch.empty(planes, device=DEV)
+        check(lib.aabr_bn_backward_bf16(ptr(xb), ptr(dx0), ptr(yb), ptr(dy), rows, planes, ptr(mean), ptr(inv), ptr(w_), ptr(b_),
+                                        ptr(dw0), ptr(db0), 0.2, ptr(ws), stream()))
+        dx1, dw1, db1 = torch.empty_like(xb), torch.empty(planes, device=DEV), torch.empty(planes, device=DEV)
+        check(lib.aabr_bn_backward_add_bf16(ptr(xb), ptr(dx1), ptr(yb), ptr(dy), rows, planes, ptr(mean), ptr(inv), ptr(w_),
+                                            ptr(b_), ptr(dw1), ptr(db1), 0.2, None, 0, ptr(ws), ptr(add), stream()))
+        assert torch.equal(dx1, dx0 + add) and torch.equal(dw1, dw0) and torch.equal(db1, db0)
