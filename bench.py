@@ -558,10 +558,11 @@ def pmc_traffic(kernel_name, grid_threads):
         "committed profile profiles/%s, entry %s (%d launches)" % (name, key, v["launches"])
 
 
-def pmc_kernels_traffic(prefixes):
+def pmc_kernels_traffic(prefixes, source=None):
     """sum over the committed PMC profile's entries whose kernel name starts with one of `prefixes` of the bytes moved
     per launch (2 x FETCH + WRITE), largest grid of each kernel -- the voxel-scatter stage's HBM traffic; None when
-    the profile is missing"""
+    the profile is missing.  `source`: only entries of that command (None = the default command's own passes; the profile
+    also carries the instances of `--dtype bf16` and `--config 4`, marked `from`)"""
     try:
         pm = json.load(open(os.path.join(REPO, "profiles", PMC_PROFILE)))["kernels"]
     except Exception:
@@ -569,7 +570,7 @@ def pmc_kernels_traffic(prefixes):
     best = {}
     for k, v in pm.items():
         nm, _, g = k.partition("|grid=")
-        if not any(nm.startswith(p) for p in prefixes) or "backward" in nm:
+        if not any(nm.startswith(p) for p in prefixes) or "backward" in nm or v.get("from") != source:
             continue
         if nm not in best or int(g) > best[nm][0]:
             best[nm] = (int(g), (2.0 * v["FETCH_SIZE_KB_avg"] + v["WRITE_SIZE_KB_avg"]) * 1024)
@@ -1125,8 +1126,7 @@ def main():
             # (brick-native scatter: the level build's mark / scan kernels run for every level of the pyramid too -- the
             # profile's LARGEST grid of each is the input level's launch; the fills are hipMemsetAsync, not in the sum)
             prefixes = ("k_points_", "k_brick_mark", "k_brick_scan", "k_voxel_mean") if native else ("aabr::k_voxel", "k_voxel")
-            tr, src = pmc_kernels_traffic(prefixes) if args.config == 2 else \
-                (None, "the committed PMC passes are over the --config 2 command")
+            tr, src = pmc_kernels_traffic(prefixes, None if args.config == 2 else "bench.py --config 4")
             vs["traffic"], vs["traffic_source"] = tr, src
             if tr:
                 vs["traffic_over_algorithmic"] = round(tr / vs["bytes"], 2)

@@ -1,12 +1,17 @@
 #!/bin/bash
 # The four bench lines a round keeps under profiles/ (run on the GPU box from the repo root):
-#   default command, the driver's command, bf16 storage, configs[4].
+#   default command, the driver's command, bf16 storage, configs[4].   usage: tools_bench_lines.sh [tag] [first|second|all]
 R=${1:-r06}
+W=${2:-all}
 mkdir -p gpurun_out
-timeout -k 10 500 python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
-timeout -k 10 500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_line_driver_command.json 2> gpurun_out/${R}_bench_line_driver_command.err
-timeout -k 10 500 python bench.py --dtype bf16 > gpurun_out/${R}_bench_line_bf16.json 2> gpurun_out/${R}_bench_line_bf16.err
-timeout -k 10 500 python bench.py --config 4 > gpurun_out/${R}_bench_line_config4.json 2> gpurun_out/${R}_bench_line_config4.err
+if [ "$W" != second ]; then
+timeout -k 10 560 python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
+timeout -k 10 560 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_line_driver_command.json 2> gpurun_out/${R}_bench_line_driver_command.err
+fi
+if [ "$W" != first ]; then
+timeout -k 10 560 python bench.py --dtype bf16 > gpurun_out/${R}_bench_line_bf16.json 2> gpurun_out/${R}_bench_line_bf16.err
+timeout -k 10 560 python bench.py --config 4 > gpurun_out/${R}_bench_line_config4.json 2> gpurun_out/${R}_bench_line_config4.err
+fi
 python - <<PY
 import json
 for f in ["", "_driver_command", "_bf16", "_config4"]:
