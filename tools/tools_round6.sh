@@ -57,6 +57,14 @@ if has pmc; then
   echo "pmc done"
 fi
 if has soak; then
-  timeout -k 10 600 python tools/tools_soak.py > gpurun_out/r06_determinism_soak.txt 2>&1; echo "soak rc=$?"
+  out=gpurun_out/r06_determinism_soak.txt
+  (echo "# tools/tools_soak.py 60 {f32,bf16} (round 6 end): the bench step in brick-major site order (job-list builders, bf16 adds in the"
+   echo "# write-outs, cast runs), 60 times from fixed seeds in separate processes; then the reference row order; then configs[4] x2") > $out
+  for d in f32 f32 f32 bf16 bf16 bf16; do timeout -k 10 200 python tools/tools_soak.py 60 $d 2>/dev/null | grep "^steps" >> $out; done
+  echo "# AABR_BENCH_SITE_ORDER=first_seen" >> $out
+  for d in f32 f32; do AABR_BENCH_SITE_ORDER=first_seen timeout -k 10 200 python tools/tools_soak.py 60 $d 2>/dev/null | grep "^steps" >> $out; done
+  echo "# configs[4]" >> $out
+  for d in bf16 bf16; do timeout -k 10 300 python tools/tools_soak.py 40 $d config4 2>/dev/null | grep "^steps" >> $out; done
+  echo "soak done"
 fi
 echo "all done"
