@@ -42,7 +42,9 @@ def _worker(rank, world, port, q):
     local2 = fp.flat_grad.clone()
     fp.start_allreduce()
     assert fp.finish_update(0.1, world) is True and fp.finish_update(0.1, world) is False
-    q.put((rank, mine, local, g_mean, w_before, local2, fp.flat.clone()))
+    # numpy: plain pickles (a torch tensor would share its storage through a listener of a process that may be gone
+    # by the time the parent reads the queue)
+    q.put((rank, mine) + tuple(t.detach().numpy().copy() for t in (local, g_mean, w_before, local2, fp.flat)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,7 +60,8 @@ def test_two_rank_gloo_allreduce_and_sharding():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, s0, l0, g0, w0, m0, v0), (_, s1, l1, g1, w1, m1, v1) = res
+    (_, s0, *t0), (_, s1, *t1) = res
+    (l0, g0, w0, m0, v0), (l1, g1, w1, m1, v1) = ([torch.from_numpy(a) for a in t] for t in (t0, t1))
     assert sorted(s0 + s1) == list(range(6)) and not set(s0) & set(s1)
     # balanced by size: 60+30+20 vs 50+40+10
     assert s0 == [1, 4, 2] and s1 == [3, 5, 0]
