@@ -2,6 +2,7 @@
 # usage (GPU box, repo root): bash tools/tools_pmc.sh   -- FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes over
 # the default bench command (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2: not one pass); then
 # the MFMA-pipe counters in a third pass.  No trace domains in a --pmc run.
+: "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets it)}"
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): bash tools/tools_pmc_lds.sh  -- LDS-pipe counters beside the MFMA-pipe ones for the convolution
 # kernels, fp32 and bf16 storage (own --pmc passes, no trace domains): is the bf16 wide kernel LDS-bound?
+: "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets it)}"
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for d in f32 bf16; do

@@ -2,6 +2,7 @@
 # usage (on the GPU box, from the repo root): bash tools/tools_profile.sh <tag> [bench args...]
 # runs the GPU tests, a rocprofv3 kernel-trace of bench.py and an un-profiled bench line
 tag=$1; shift
+: "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets it)}"
 root=$GRAFT_REPO_ROOT
 mkdir -p $root/gpurun_out
 timeout -k 10 600 python -m pytest $root/tests -q -m gpu --timeout 300 > $root/gpurun_out/gpu_tests.log 2>&1; echo "pytest rc=$?"; tail -3 $root/gpurun_out/gpu_tests.log

@@ -2,6 +2,7 @@
 # usage (GPU box, repo root): bash tools/tools_profile_cmd.sh <tag> <python script> [args...]
 # rocprofv3 kernel trace of one python tool; per-kernel and per-(kernel, grid) totals through tools/rocpd_stats.py
 tag=$1; shift
+: "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets it)}"
 root=$GRAFT_REPO_ROOT
 script=$root/$1; shift
 mkdir -p $root/gpurun_out

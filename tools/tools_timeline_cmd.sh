@@ -3,6 +3,7 @@
 # rocprofv3 kernel trace of one python tool, then tools/rocpd_timeline.py over the second half of the trace: per-stream
 # busy time, union of busy intervals, the gaps on the busiest stream
 tag=$1; shift
+: "${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun sets it)}"
 root=$GRAFT_REPO_ROOT
 script=$root/$1; shift
 mkdir -p $root/gpurun_out
